@@ -1,0 +1,192 @@
+/* resel_hip.h - C ABI of the MI355X (gfx950) kernels behind the `offpolicy_rnn` layer/operator interface.
+ *
+ * Drop-in boundary for the full-trajectory recurrent SAC/TD3 update of FanmingL/Recurrent-Offpolicy-RL.
+ * The reference has no native code of its own: its GPU path binds Triton kernels and three un-vendored
+ * CUDA extensions from Python.  Each entry point below names the reference interface it replaces
+ * (path:line in the reference checkout).  The Python binding is recurrent-offpolicy-rl_amd/offpolicy_rnn/hip/_lib.py
+ * (ctypes); INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch's caching allocator); nothing is
+ *     allocated, freed or synchronised inside; all work is enqueued on `stream` (a hipStream_t);
+ *   - activations are TOKEN-MAJOR: logical [B, L, C] with channel stride 1, token index tok = b*L + t and an
+ *     explicit token stride `ld_*` in ELEMENTS (so column slices of a wider row-major matrix are passed
+ *     without copies); per-token flags are dense [B*L] fp32; base pointers and ld must be 16-byte aligned
+ *     (ld % 4 == 0) where noted;
+ *   - fp32 everywhere unless a name says bf16; no float atomics: results are bitwise reproducible;
+ *   - return value: 0 = enqueued, <0 = RESEL_E* (nothing enqueued).  Scratch is caller-provided; its size
+ *     comes from the matching *_workspace_bytes() function.
+ */
+#ifndef RESEL_HIP_H
+#define RESEL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RESEL_OK 0
+#define RESEL_EINVAL (-1)   /* unsupported shape / null pointer / misalignment */
+#define RESEL_ELAUNCH (-2)  /* hipLaunchKernel reported an error */
+
+typedef void* resel_stream_t; /* hipStream_t */
+
+/* Library / device identification (used by the binding to fail loudly when the wrong build is loaded). */
+int resel_abi_version(void);            /* bumps when a signature changes */
+const char* resel_build_info(void);     /* "gfx950 <date> ..." */
+
+/* ------------------------------------------------------------------------------------------------------
+ * smamba selective scan.  Replaces `selective_scan_cuda.fwd / .bwd` (modified Mamba CUDA extension with the
+ * extra `start` reset input) bound at offpolicy_rnn/models/smamba/mamba_ssm/ops/selective_scan_interface_new.py:47
+ * and :72; arithmetic spec = `selective_scan_ref`, same file :96-166.
+ *   delta' = softplus(delta + delta_bias)            (softplus iff delta_softplus != 0)
+ *   h_t    = exp(delta'_t * A) * (1 - start_t) * h_{t-1} + delta'_t * Bm_t * u_t          h: [Di, N]
+ *   out_t  = (<Cm_t, h_t> + D * u_t) * silu(z_t)     (gate skipped when z == NULL, skip term when D == NULL)
+ * u, delta, z, out: [B*L, Di] (ld_u, ld_delta, ld_z, ld_out; 16-byte aligned); A: [Di, N] dense;
+ * Bm, Cm: [B*L, N] (ld_b, ld_c); D, delta_bias: [Di]; start: [B*L] or NULL.
+ * Supported: Di % 4 == 0, N in {4, 8, 16, 32, 64}.
+ * ckpt (optional, for the backward): state checkpoints every RESEL_SSCAN_CKPT steps,
+ *   resel_selective_scan_ckpt_bytes(B, L, Di, N) bytes.  last_state (optional): [B, Di, N].
+ */
+#define RESEL_SSCAN_CKPT 64
+size_t resel_selective_scan_ckpt_bytes(int B, int L, int Di, int N);
+int resel_selective_scan_fwd(const float* u, int64_t ld_u, const float* delta, int64_t ld_delta,
+                             const float* z, int64_t ld_z, const float* A,
+                             const float* Bm, int64_t ld_b, const float* Cm, int64_t ld_c,
+                             const float* D, const float* delta_bias, const float* start,
+                             float* out, int64_t ld_out, float* ckpt, float* last_state,
+                             int B, int L, int Di, int N, int delta_softplus, resel_stream_t stream);
+
+/* Backward of the above.  dout: [B*L, Di] (ld_dout).  Outputs: du, ddelta, dz: [B*L, Di] (dz may be NULL iff
+ * z is NULL); dBm, dCm: [B*L, N]; dA: [Di, N]; dD, ddelta_bias: [Di] (NULL iff the input was NULL).
+ * All outputs are overwritten (not accumulated).  workspace: resel_selective_scan_bwd_workspace_bytes(). */
+size_t resel_selective_scan_bwd_workspace_bytes(int B, int L, int Di, int N);
+int resel_selective_scan_bwd(const float* u, int64_t ld_u, const float* delta, int64_t ld_delta,
+                             const float* z, int64_t ld_z, const float* A,
+                             const float* Bm, int64_t ld_b, const float* Cm, int64_t ld_c,
+                             const float* D, const float* delta_bias, const float* start,
+                             const float* dout, int64_t ld_dout, const float* ckpt,
+                             float* du, int64_t ld_du, float* ddelta, int64_t ld_ddelta, float* dz, int64_t ld_dz,
+                             float* dBm, int64_t ld_db, float* dCm, int64_t ld_dc,
+                             float* dA, float* dD, float* ddelta_bias, void* workspace,
+                             int B, int L, int Di, int N, int delta_softplus, resel_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * smamba depthwise causal conv1d + bias + SiLU on the masked input.  Replaces `causal_conv1d_cuda.causal_conv1d_fwd/bwd`
+ * (selective_scan_interface_new.py:199,273) and the nn.Conv1d(groups=d_inner) + SiLU branch taken for d_conv > 4
+ * (offpolicy_rnn/models/smamba/mamba.py:75-83, 210-212).
+ *   y[tok, d] = silu(bias[d] + sum_k w[d, k] * mask[tok'] * x[tok', d]),  tok' = tok - (K-1) + k within the row b
+ * x, y: [B*L, Di] (ld_x, ld_y); w: [Di, K] dense; bias: [Di] or NULL; mask: [B*L] or NULL.  1 <= K <= 32.
+ * Backward: dx [B*L, Di] (ld_dx), dw [Di, K], dbias [Di]; workspace resel_causal_conv1d_bwd_workspace_bytes().
+ */
+int resel_causal_conv1d_fwd(const float* x, int64_t ld_x, const float* w, const float* bias, const float* mask,
+                            float* y, int64_t ld_y, int B, int L, int Di, int K, int silu, resel_stream_t stream);
+size_t resel_causal_conv1d_bwd_workspace_bytes(int B, int L, int Di, int K);
+int resel_causal_conv1d_bwd(const float* x, int64_t ld_x, const float* w, const float* bias, const float* mask,
+                            const float* dy, int64_t ld_dy, float* dx, int64_t ld_dx, float* dw, float* dbias,
+                            void* workspace, int B, int L, int Di, int K, int silu, resel_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Fused residual add + LayerNorm / RMSNorm.  Replaces the Triton kernels `_layer_norm_fwd_1pass_kernel` /
+ * `_layer_norm_bwd_kernel` (offpolicy_rnn/models/smamba/mamba_ssm/ops/triton/layernorm.py:65,196; CPU spec
+ * layernorm_cpu.py:6-35).  rows M, width C (C % 4 == 0, C <= 8192), all dense [M, C].
+ *   res_out = x (+ residual) ; y = (res_out - mean) * rstd * w + b      (rms: y = res_out * rstd * w (+ b))
+ * residual / res_out / bias may be NULL.  stats: [M, 2] (mean, rstd) saved for the backward.
+ * Backward: dres_in (optional, [M, C]) is the gradient arriving at res_out from downstream; dx receives the
+ * gradient w.r.t. x (== w.r.t. residual).  dw, db: [C]; workspace resel_add_layernorm_bwd_workspace_bytes().
+ */
+int resel_add_layernorm_fwd(const float* x, const float* residual, const float* w, const float* b,
+                            float* y, float* res_out, float* stats, int M, int C, float eps, int rms,
+                            resel_stream_t stream);
+size_t resel_add_layernorm_bwd_workspace_bytes(int M, int C);
+int resel_add_layernorm_bwd(const float* dy, const float* dres_in, const float* res, const float* w,
+                            const float* stats, float* dx, float* dw, float* db, void* workspace,
+                            int M, int C, int rms, int has_bias, resel_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Linear-recurrence scans (gilr, lru).  Replace the Triton kernels
+ *   fwd_sequential_scan / bwd_sequential_scan          offpolicy_rnn/models/gilr/scan_triton/real_rnn_tie_input_gate.py:9,67
+ *   fwd_sequential_scan_complex / bwd_...               offpolicy_rnn/models/lru/scan_triton/complex_rnn.py:44,91
+ * (CPU specs real_rnn_tie_input_gate_cpu.py:4-14, complex_rnn_cpu.py:4-26) with a time-parallel chunked scan.
+ * real:    v' = act ? tanh(v) : v ; f' = (act ? sigmoid(f) : f) * (1 - start) ; h_t = f'_t h_{t-1} + (1 - f'_t) v'_t
+ * complex: h_t = lambda (1 - start_t) h_{t-1} + gamma * (vr_t + i vi_t)       (lambda, gamma per channel)
+ * v, f, h, vr, vi, hr, hi: dense [B, L, C]; start: [B*L] or NULL; h0*: [B, C] or NULL (zeros).
+ * Backward outputs are gradients w.r.t. the PRE-activation v, f (real) / vr, vi, lambda, gamma (complex;
+ * dlam_re, dlam_im, dgamma: [C], reduced over B and L).  No gradient flows into h0 (reference: complex_rnn.py:242).
+ */
+int resel_linrec_real_fwd(const float* v, const float* f, const float* start, const float* h0, float* h,
+                          int B, int L, int C, int fuse_act, resel_stream_t stream);
+int resel_linrec_real_bwd(const float* v, const float* f, const float* start, const float* h0, const float* h,
+                          const float* dh, float* dv, float* df, int B, int L, int C, int fuse_act,
+                          resel_stream_t stream);
+int resel_linrec_complex_fwd(const float* vr, const float* vi, const float* lam_re, const float* lam_im,
+                             const float* gamma, const float* start, const float* h0r, const float* h0i,
+                             float* hr, float* hi, int B, int L, int C, resel_stream_t stream);
+size_t resel_linrec_complex_bwd_workspace_bytes(int B, int L, int C);
+int resel_linrec_complex_bwd(const float* vr, const float* vi, const float* lam_re, const float* lam_im,
+                             const float* gamma, const float* start, const float* h0r, const float* h0i,
+                             const float* hr, const float* hi, const float* dhr, const float* dhi,
+                             float* dvr, float* dvi, float* dlam_re, float* dlam_im, float* dgamma,
+                             void* workspace, int B, int L, int C, resel_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * GRU recurrence on a hoisted input projection.  Replaces cuDNN/MIOpen GRU reached through
+ * torch.nn.GRU(batch_first=True) (offpolicy_rnn/models/rnn_base.py:59,247; called at :453-454).
+ * gi = x W_ih^T + b_ih: [B, L, 3H] dense (r, z, n blocks); w_hh: [3H, H]; b_hh: [3H]; h0: [B, H] or NULL.
+ *   r = sig(gi_r + W_hr h + b_hr) ; z = sig(gi_z + W_hz h + b_hz) ; n = tanh(gi_n + r * (W_hn h + b_hn))
+ *   h' = (1 - z) n + z h ;  h_all: [B, L, H].  gates (optional, training): [B, L, 4H] saves r, z, n and
+ *   (W_hn h + b_hn) for the backward.  Supported: H % 16 == 0, H <= 1024.
+ * The recurrence is T-sequential; each step is one launch (grid = H/16 unit slices x ceil(B/16) row groups)
+ * enqueued back-to-back from C.  workspace: resel_gru_workspace_bytes() (re-laid-out W_hh slices, carry).
+ * Backward returns the pre-activation gradients of BOTH projections: dgi [B, L, 3H] (w.r.t. gi) and
+ * dgh [B, L, 3H] (w.r.t. W_hh h + b_hh); the caller finishes dW_hh = dgh^T h_prev and db_hh = sum dgh with one
+ * library GEMM (they are plain GEMM/reduction shapes over B*L rows).  No gradient is produced for h0.
+ */
+size_t resel_gru_workspace_bytes(int B, int L, int H);
+int resel_gru_seq_fwd(const float* gi, const float* w_hh, const float* b_hh, const float* h0,
+                      float* h_all, float* gates, void* workspace, int B, int L, int H, resel_stream_t stream);
+int resel_gru_seq_bwd(const float* w_hh, const float* h0, const float* h_all, const float* gates,
+                      const float* dh_all, float* dgi, float* dgh, void* workspace,
+                      int B, int L, int H, resel_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * SAC / TD3 head, target and loss arithmetic + optimizer tail (the "fusions" of SURVEY.md section 8 row a16-a18).
+ */
+/* tanh-Gaussian head: contextual_sac_policy_single_head.py:109-123.  out2: [M, 2A] = (logstd | mean) as produced
+ * by the actor's last Linear; noise: [M, A].  action_mean, action_sample: [M, A]; logp: [M].
+ * Backward: d_out2 [M, 2A] from d_sample [M, A] and d_logp [M] (action_mean carries no gradient in the update). */
+int resel_tanh_gaussian_fwd(const float* out2, const float* noise, float* action_mean, float* action_sample,
+                            float* logp, int M, int A, resel_stream_t stream);
+int resel_tanh_gaussian_bwd(const float* out2, const float* noise, const float* d_sample, const float* d_logp,
+                            float* d_out2, int M, int A, resel_stream_t stream);
+
+/* REDQ target: sac_full_length_rnn_redq.py:28-33 / td3_full_length_rnn_redq.py:29-35, clamp = QValueGuard
+ * (utility/q_value_guard.py:22-38).  q: [E, M]; subset: m ensemble indices; next_logp: [M] or NULL (TD3);
+ * done (already timeout-corrected), reward, mask: [M].  guard: device fp32[4] = {min, max, initialised, decay}:
+ *   if !initialised: min/max <- extrema of v (first call, q_value_guard.py:23-26);  y = r + (1-d) gamma clamp(v)
+ *   then the running update of q_value_guard.py:29-38 with y*mask - all on device, no host sync.
+ * target: [M].  stats (optional) fp32[2]: max |target|, sum(mask). */
+int resel_sac_target(const float* q, const int32_t* subset, int m, const float* next_logp, const float* log_alpha,
+                     const float* reward, const float* done, const float* mask, float gamma, float* guard,
+                     float* target, float* stats, void* workspace, int E, int M, resel_stream_t stream);
+size_t resel_sac_target_workspace_bytes(int M);
+
+/* Flat-buffer optimizer tail.  All parameter / gradient / moment tensors of one network live in ONE fp32 buffer.
+ * soft update: rnn_base.py:490-491   target <- tau * target + (1 - tau) * online
+ * adamw: torch.optim.AdamW (sac.py:61) with a per-segment learning rate table (RESeL groups,
+ *        sac_full_length_rnn_redq_sep_optim.py:49-66): seg_end[i] = one-past-last element of segment i,
+ *        seg_lr[i], seg_wd[i]; grad_scale multiplies the gradient first (1/valid_num or 1/world).
+ * sumsq: out[0] = sum(x^2)  (l2_norm_square, rnn_base.py:531-532), deterministic two-stage reduction. */
+int resel_soft_update(float* target, const float* online, float tau, int64_t n, resel_stream_t stream);
+int resel_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, const int64_t* seg_end,
+                     const float* seg_lr, const float* seg_wd, int nseg, float beta1, float beta2, float eps,
+                     int step, const float* grad_scale, resel_stream_t stream);
+size_t resel_sumsq_workspace_bytes(int64_t n);
+int resel_sumsq(const float* x, int64_t n, float* out, void* workspace, resel_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RESEL_HIP_H */

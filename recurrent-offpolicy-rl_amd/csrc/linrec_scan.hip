@@ -1,0 +1,306 @@
+// Linear-recurrence scans for gilr (real, gated) and lru (complex diagonal), dense [B, L, C] - forward and backward.
+//
+// The reference runs these as strictly sequential Triton loops over L with one program per (b, 256 channels)
+// (real_rnn_tie_input_gate.py:9-34, complex_rnn.py:44-87): at B = 16, T' = 2003 that is 16 programs.  Here the
+// time axis itself is parallel: a workgroup owns (row b, 64 channels), its 16 waves own 16 contiguous time
+// segments, lanes are channels (every access is a fully used 256-byte segment).  Pass 1 reduces each segment to
+// the affine map h_out = a * h_in + c, the 16 maps are composed through LDS, pass 2 replays the segment from
+// its true incoming state and writes the result.  The composition is exact algebra on the same fp32
+// operations, start-resets are folded into the gate (f := 0), and nothing is atomic.
+#include "resel_common.h"
+
+namespace {
+using namespace resel;
+
+constexpr int NSEG = 16;            // waves (= time segments) per workgroup
+constexpr int TILE_C = 64;
+
+__device__ __forceinline__ float tanhf_(float x) {
+    const float e = fast_exp(-2.0f * fabsf(x));                 // tanh|x| = (1 - e) / (1 + e)
+    const float t = (1.0f - e) * fast_rcp(1.0f + e);
+    return copysignf(t, x);
+}
+
+struct Seg {
+    int t0, t1;
+};
+__device__ __forceinline__ Seg segment(int w, int L) {
+    const int len = (L + NSEG - 1) / NSEG;
+    Seg s;
+    s.t0 = min(L, w * len);
+    s.t1 = min(L, s.t0 + len);
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------ real (gilr)
+__device__ __forceinline__ void gilr_gate(float vraw, float fraw, float keep, int act, float& v, float& fe) {
+    v = act ? tanhf_(vraw) : vraw;
+    fe = (act ? sigmoidf_(fraw) : fraw) * keep;
+}
+
+__global__ __launch_bounds__(NSEG * 64) void linrec_real_fwd_kernel(const float* __restrict__ v, const float* __restrict__ f,
+                                                                    const float* __restrict__ start, const float* __restrict__ h0,
+                                                                    float* __restrict__ h, int B, int L, int C, int act) {
+    __shared__ float s_a[NSEG][TILE_C], s_c[NSEG][TILE_C];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int b = blockIdx.y, c = blockIdx.x * TILE_C + lane;
+    const bool ok = c < C;
+    const int64_t base = (int64_t)b * L * C + c;
+    const Seg sg = segment(w, L);
+    float a = 1.f, hl = 0.f;
+    if (ok) {
+#pragma unroll 4
+        for (int t = sg.t0; t < sg.t1; ++t) {
+            const float keep = start ? 1.f - start[(int64_t)b * L + t] : 1.f;
+            float vv, fe;
+            gilr_gate(v[base + (int64_t)t * C], f[base + (int64_t)t * C], keep, act, vv, fe);
+            hl = __builtin_fmaf(fe, hl - vv, vv);                 // f h + (1 - f) v
+            a *= fe;
+        }
+    }
+    s_a[w][lane] = a;
+    s_c[w][lane] = hl;
+    __syncthreads();
+    float hin = (h0 && ok) ? h0[(int64_t)b * C + c] : 0.f;
+    for (int ww = 0; ww < w; ++ww) hin = __builtin_fmaf(s_a[ww][lane], hin, s_c[ww][lane]);
+    if (ok) {
+        float hc = hin;
+#pragma unroll 4
+        for (int t = sg.t0; t < sg.t1; ++t) {
+            const float keep = start ? 1.f - start[(int64_t)b * L + t] : 1.f;
+            float vv, fe;
+            gilr_gate(v[base + (int64_t)t * C], f[base + (int64_t)t * C], keep, act, vv, fe);
+            hc = __builtin_fmaf(fe, hc - vv, vv);
+            h[base + (int64_t)t * C] = hc;
+        }
+    }
+}
+
+// g_t = dh_t + f_{t+1} g_{t+1} ;  dv_t = g_t (1 - f_t) ;  df_t = g_t (h_{t-1} - v_t)   (then through tanh / sigmoid)
+__global__ __launch_bounds__(NSEG * 64) void linrec_real_bwd_kernel(const float* __restrict__ v, const float* __restrict__ f,
+                                                                    const float* __restrict__ start, const float* __restrict__ h0,
+                                                                    const float* __restrict__ h, const float* __restrict__ dh,
+                                                                    float* __restrict__ dv, float* __restrict__ df,
+                                                                    int B, int L, int C, int act) {
+    __shared__ float s_a[NSEG][TILE_C], s_c[NSEG][TILE_C];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int b = blockIdx.y, c = blockIdx.x * TILE_C + lane;
+    const bool ok = c < C;
+    const int64_t base = (int64_t)b * L * C + c;
+    const Seg sg = segment(w, L);
+    auto gate_f = [&](int t) -> float {                          // effective gate f_t (0 beyond the row end)
+        if (t >= L) return 0.f;
+        const float keep = start ? 1.f - start[(int64_t)b * L + t] : 1.f;
+        const float fr = f[base + (int64_t)t * C];
+        return (act ? sigmoidf_(fr) : fr) * keep;
+    };
+    float a = 1.f, gl = 0.f;
+    if (ok && sg.t1 > sg.t0) {
+        float fnext = gate_f(sg.t1);
+        for (int t = sg.t1 - 1; t >= sg.t0; --t) {
+            gl = __builtin_fmaf(fnext, gl, dh[base + (int64_t)t * C]);
+            a *= fnext;
+            fnext = gate_f(t);
+        }
+    }
+    s_a[w][lane] = a;
+    s_c[w][lane] = gl;
+    __syncthreads();
+    float gin = 0.f;                                              // g just right of this segment
+    for (int ww = NSEG - 1; ww > w; --ww) gin = __builtin_fmaf(s_a[ww][lane], gin, s_c[ww][lane]);
+    if (ok && sg.t1 > sg.t0) {
+        float g = gin;
+        float fnext = gate_f(sg.t1);
+        for (int t = sg.t1 - 1; t >= sg.t0; --t) {
+            g = __builtin_fmaf(fnext, g, dh[base + (int64_t)t * C]);
+            const float keep = start ? 1.f - start[(int64_t)b * L + t] : 1.f;
+            const float vraw = v[base + (int64_t)t * C], fraw = f[base + (int64_t)t * C];
+            const float vv = act ? tanhf_(vraw) : vraw;
+            const float sg_ = act ? sigmoidf_(fraw) : fraw;
+            const float fe = sg_ * keep;
+            const float hprev = t > 0 ? h[base + (int64_t)(t - 1) * C] : (h0 ? h0[(int64_t)b * C + c] : 0.f);
+            float gv = g * (1.f - fe);
+            float gf = g * (hprev - vv) * keep;
+            if (act) {
+                gv *= (1.f - vv * vv);
+                gf *= sg_ * (1.f - sg_);
+            }
+            dv[base + (int64_t)t * C] = gv;
+            df[base + (int64_t)t * C] = gf;
+            fnext = fe;
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------- complex (lru)
+__global__ __launch_bounds__(NSEG * 64) void linrec_complex_fwd_kernel(const float* __restrict__ vr, const float* __restrict__ vi,
+                                                                       const float* __restrict__ lam_re, const float* __restrict__ lam_im,
+                                                                       const float* __restrict__ gamma, const float* __restrict__ start,
+                                                                       const float* __restrict__ h0r, const float* __restrict__ h0i,
+                                                                       float* __restrict__ hr, float* __restrict__ hi, int B, int L, int C) {
+    __shared__ float s_ar[NSEG][TILE_C], s_ai[NSEG][TILE_C], s_cr[NSEG][TILE_C], s_ci[NSEG][TILE_C];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int b = blockIdx.y, c = blockIdx.x * TILE_C + lane;
+    const bool ok = c < C;
+    const int64_t base = (int64_t)b * L * C + c;
+    const Seg sg = segment(w, L);
+    const float lr = ok ? lam_re[c] : 0.f, li = ok ? lam_im[c] : 0.f, gm = (ok && gamma) ? gamma[c] : 1.f;
+    float ar = 1.f, ai = 0.f, cr = 0.f, ci = 0.f;
+    if (ok) {
+#pragma unroll 4
+        for (int t = sg.t0; t < sg.t1; ++t) {
+            const float keep = start ? 1.f - start[(int64_t)b * L + t] : 1.f;
+            const float fr = lr * keep, fi = li * keep;
+            const float xr = gm * vr[base + (int64_t)t * C], xi = gm * vi[base + (int64_t)t * C];
+            const float nr = cr * fr - ci * fi + xr, ni = cr * fi + ci * fr + xi;
+            cr = nr; ci = ni;
+            const float pr = ar * fr - ai * fi, pi = ar * fi + ai * fr;
+            ar = pr; ai = pi;
+        }
+    }
+    s_ar[w][lane] = ar; s_ai[w][lane] = ai; s_cr[w][lane] = cr; s_ci[w][lane] = ci;
+    __syncthreads();
+    float xr0 = (h0r && ok) ? h0r[(int64_t)b * C + c] : 0.f, xi0 = (h0i && ok) ? h0i[(int64_t)b * C + c] : 0.f;
+    for (int ww = 0; ww < w; ++ww) {
+        const float pr = s_ar[ww][lane], pi = s_ai[ww][lane];
+        const float nr = pr * xr0 - pi * xi0 + s_cr[ww][lane], ni = pr * xi0 + pi * xr0 + s_ci[ww][lane];
+        xr0 = nr; xi0 = ni;
+    }
+    if (ok) {
+        float cr2 = xr0, ci2 = xi0;
+#pragma unroll 4
+        for (int t = sg.t0; t < sg.t1; ++t) {
+            const float keep = start ? 1.f - start[(int64_t)b * L + t] : 1.f;
+            const float fr = lr * keep, fi = li * keep;
+            const float xr = gm * vr[base + (int64_t)t * C], xi = gm * vi[base + (int64_t)t * C];
+            const float nr = cr2 * fr - ci2 * fi + xr, ni = cr2 * fi + ci2 * fr + xi;
+            cr2 = nr; ci2 = ni;
+            hr[base + (int64_t)t * C] = cr2;
+            hi[base + (int64_t)t * C] = ci2;
+        }
+    }
+}
+
+// g_t = dh_t + conj(f_{t+1}) g_{t+1} ; dv = gamma g ; dgamma += Re(g conj(v_raw)) ; dlambda += (1 - s_t) g conj(h_{t-1})
+__global__ __launch_bounds__(NSEG * 64) void linrec_complex_bwd_kernel(const float* __restrict__ vr, const float* __restrict__ vi,
+                                                                       const float* __restrict__ lam_re, const float* __restrict__ lam_im,
+                                                                       const float* __restrict__ gamma, const float* __restrict__ start,
+                                                                       const float* __restrict__ h0r, const float* __restrict__ h0i,
+                                                                       const float* __restrict__ hr, const float* __restrict__ hi,
+                                                                       const float* __restrict__ dhr, const float* __restrict__ dhi,
+                                                                       float* __restrict__ dvr, float* __restrict__ dvi,
+                                                                       float* __restrict__ part, int B, int L, int C) {
+    __shared__ float s_ar[NSEG][TILE_C], s_ai[NSEG][TILE_C], s_cr[NSEG][TILE_C], s_ci[NSEG][TILE_C];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int b = blockIdx.y, c = blockIdx.x * TILE_C + lane;
+    const bool ok = c < C;
+    const int64_t base = (int64_t)b * L * C + c;
+    const Seg sg = segment(w, L);
+    const float lr = ok ? lam_re[c] : 0.f, li = ok ? lam_im[c] : 0.f, gm = (ok && gamma) ? gamma[c] : 1.f;
+    auto keep_at = [&](int t) -> float { return t >= L ? 0.f : (start ? 1.f - start[(int64_t)b * L + t] : 1.f); };
+    float ar = 1.f, ai = 0.f, gr = 0.f, gi = 0.f;
+    if (ok && sg.t1 > sg.t0) {
+        float kn = keep_at(sg.t1);
+        for (int t = sg.t1 - 1; t >= sg.t0; --t) {
+            const float fr = lr * kn, fi = -li * kn;                 // conj(f_{t+1})
+            const float nr = gr * fr - gi * fi + dhr[base + (int64_t)t * C], ni = gr * fi + gi * fr + dhi[base + (int64_t)t * C];
+            gr = nr; gi = ni;
+            const float pr = ar * fr - ai * fi, pi = ar * fi + ai * fr;
+            ar = pr; ai = pi;
+            kn = keep_at(t);
+        }
+    }
+    s_ar[w][lane] = ar; s_ai[w][lane] = ai; s_cr[w][lane] = gr; s_ci[w][lane] = gi;
+    __syncthreads();
+    float xr0 = 0.f, xi0 = 0.f;
+    for (int ww = NSEG - 1; ww > w; --ww) {
+        const float pr = s_ar[ww][lane], pi = s_ai[ww][lane];
+        const float nr = pr * xr0 - pi * xi0 + s_cr[ww][lane], ni = pr * xi0 + pi * xr0 + s_ci[ww][lane];
+        xr0 = nr; xi0 = ni;
+    }
+    float dlr = 0.f, dli = 0.f, dgm = 0.f;
+    if (ok && sg.t1 > sg.t0) {
+        float g_r = xr0, g_i = xi0;
+        float kn = keep_at(sg.t1);
+        for (int t = sg.t1 - 1; t >= sg.t0; --t) {
+            const float fr = lr * kn, fi = -li * kn;
+            const float nr = g_r * fr - g_i * fi + dhr[base + (int64_t)t * C], ni = g_r * fi + g_i * fr + dhi[base + (int64_t)t * C];
+            g_r = nr; g_i = ni;
+            const float kt = keep_at(t);
+            const float pr = t > 0 ? hr[base + (int64_t)(t - 1) * C] : (h0r ? h0r[(int64_t)b * C + c] : 0.f);
+            const float pi = t > 0 ? hi[base + (int64_t)(t - 1) * C] : (h0i ? h0i[(int64_t)b * C + c] : 0.f);
+            dlr += kt * (g_r * pr + g_i * pi);                      // d/d lam_re : g . h_prev
+            dli += kt * (g_i * pr - g_r * pi);                      // d/d lam_im
+            dgm += g_r * vr[base + (int64_t)t * C] + g_i * vi[base + (int64_t)t * C];
+            dvr[base + (int64_t)t * C] = gm * g_r;
+            dvi[base + (int64_t)t * C] = gm * g_i;
+            kn = kt;
+        }
+    }
+    // per-(b, segment) partials of the per-channel parameter gradients: [B, NSEG, 3, C]
+    if (ok) {
+        float* o = part + (((int64_t)b * NSEG + w) * 3) * C + c;
+        o[0] = dlr; o[(int64_t)C] = dli; o[2 * (int64_t)C] = dgm;
+    }
+}
+
+__global__ void linrec_complex_reduce_kernel(const float* part, int nrow, int C, float* dlr, float* dli, float* dgm) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float a = 0.f, b = 0.f, g = 0.f;
+    for (int r = 0; r < nrow; ++r) {
+        const float* p = part + (int64_t)r * 3 * C + c;
+        a += p[0]; b += p[C]; g += p[2 * (int64_t)C];
+    }
+    dlr[c] = a; dli[c] = b;
+    if (dgm) dgm[c] = g;
+}
+
+}  // namespace
+
+extern "C" int resel_linrec_real_fwd(const float* v, const float* f, const float* start, const float* h0, float* h,
+                                     int B, int L, int C, int fuse_act, resel_stream_t stream) {
+    if (!v || !f || !h || B <= 0 || L <= 0 || C <= 0) return RESEL_EINVAL;
+    hipLaunchKernelGGL(linrec_real_fwd_kernel, dim3((C + TILE_C - 1) / TILE_C, B), dim3(NSEG * 64), 0, (hipStream_t)stream,
+                       v, f, start, h0, h, B, L, C, fuse_act);
+    return launch_status();
+}
+
+extern "C" int resel_linrec_real_bwd(const float* v, const float* f, const float* start, const float* h0, const float* h,
+                                     const float* dh, float* dv, float* df, int B, int L, int C, int fuse_act,
+                                     resel_stream_t stream) {
+    if (!v || !f || !h || !dh || !dv || !df || B <= 0 || L <= 0 || C <= 0) return RESEL_EINVAL;
+    hipLaunchKernelGGL(linrec_real_bwd_kernel, dim3((C + TILE_C - 1) / TILE_C, B), dim3(NSEG * 64), 0, (hipStream_t)stream,
+                       v, f, start, h0, h, dh, dv, df, B, L, C, fuse_act);
+    return launch_status();
+}
+
+extern "C" int resel_linrec_complex_fwd(const float* vr, const float* vi, const float* lam_re, const float* lam_im,
+                                        const float* gamma, const float* start, const float* h0r, const float* h0i,
+                                        float* hr, float* hi, int B, int L, int C, resel_stream_t stream) {
+    if (!vr || !vi || !lam_re || !lam_im || !hr || !hi || B <= 0 || L <= 0 || C <= 0) return RESEL_EINVAL;
+    hipLaunchKernelGGL(linrec_complex_fwd_kernel, dim3((C + TILE_C - 1) / TILE_C, B), dim3(NSEG * 64), 0, (hipStream_t)stream,
+                       vr, vi, lam_re, lam_im, gamma, start, h0r, h0i, hr, hi, B, L, C);
+    return launch_status();
+}
+
+extern "C" size_t resel_linrec_complex_bwd_workspace_bytes(int B, int L, int C) {
+    (void)L;
+    return (size_t)B * NSEG * 3 * C * sizeof(float);
+}
+
+extern "C" int resel_linrec_complex_bwd(const float* vr, const float* vi, const float* lam_re, const float* lam_im,
+                                        const float* gamma, const float* start, const float* h0r, const float* h0i,
+                                        const float* hr, const float* hi, const float* dhr, const float* dhi,
+                                        float* dvr, float* dvi, float* dlam_re, float* dlam_im, float* dgamma,
+                                        void* workspace, int B, int L, int C, resel_stream_t stream) {
+    if (!vr || !vi || !lam_re || !lam_im || !hr || !hi || !dhr || !dhi || !dvr || !dvi || !dlam_re || !dlam_im || !workspace ||
+        B <= 0 || L <= 0 || C <= 0)
+        return RESEL_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(linrec_complex_bwd_kernel, dim3((C + TILE_C - 1) / TILE_C, B), dim3(NSEG * 64), 0, s,
+                       vr, vi, lam_re, lam_im, gamma, start, h0r, h0i, hr, hi, dhr, dhi, dvr, dvi, (float*)workspace, B, L, C);
+    hipLaunchKernelGGL(linrec_complex_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)workspace, B * NSEG, C,
+                       dlam_re, dlam_im, dgamma);
+    return launch_status();
+}

@@ -1,0 +1,53 @@
+// Shared device helpers for the gfx950 kernels (CDNA4: wave64, 160 KiB LDS/CU, 256 CUs in 8 XCDs).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/resel_hip.h"
+
+#define RESEL_LOG2E 1.4426950408889634f
+#define RESEL_LN2 0.6931471805599453f
+
+namespace resel {
+
+// Scalar (SMEM) loads: a wave-uniform address in the constant address space becomes s_load_dword*,
+// so per-step coefficients shared by all 64 lanes cost no VALU/LDS bandwidth and feed v_fma directly
+// as SGPR operands.
+typedef const float __attribute__((address_space(4)))* cfloat_p;
+__device__ __forceinline__ cfloat_p as_uniform(const float* p) {
+    return (cfloat_p)(uintptr_t)p;
+}
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * RESEL_LOG2E); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+__device__ __forceinline__ float sigmoidf_(float x) { return fast_rcp(1.0f + fast_exp(-x)); }
+__device__ __forceinline__ float siluf_(float x) { return x * fast_rcp(1.0f + fast_exp(-x)); }
+// d/dx [x * sigmoid(x)] = s * (1 + x * (1 - s))
+__device__ __forceinline__ float dsiluf_(float x) {
+    float s = sigmoidf_(x);
+    return s * (1.0f + x * (1.0f - s));
+}
+// torch.nn.functional.softplus (beta = 1, threshold = 20) as max(x, 0) + log1p(exp(-|x|)) on v_exp/v_log:
+// for e = exp(-|x|) < 1e-4 the series e - e^2/2 replaces log(1 + e) (keeps relative accuracy of tiny deltas);
+// at x > 20 the correction term is < 2.1e-9 and rounds away, matching torch's threshold branch.
+__device__ __forceinline__ float softplusf_(float x) {
+    const float e = fast_exp(-fabsf(x));
+    const float l = e < 1e-4f ? e - 0.5f * e * e : __logf(1.0f + e);
+    return fmaxf(x, 0.0f) + l;
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// full-wave (64 lane) sum, result in every lane
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+inline int launch_status() { return hipGetLastError() == hipSuccess ? RESEL_OK : RESEL_ELAUNCH; }
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace resel

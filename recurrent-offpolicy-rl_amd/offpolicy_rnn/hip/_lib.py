@@ -1,0 +1,80 @@
+"""ctypes binding of the C-ABI library `libresel_hip.so` (include/resel_hip.h).
+
+The product path has NO CPU fallback: every op in `ops.py` goes through `lib()`, which raises a loud
+RuntimeError when the shared library is missing or was built against another ABI.
+"""
+import ctypes
+import os
+from ctypes import c_float, c_int, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libresel_hip.so')
+ABI_VERSION = 1
+_lib = None
+
+P, I, L, F, S = c_void_p, c_int, c_int64, c_float, c_void_p
+
+# name -> (restype, argtypes); order and types mirror include/resel_hip.h
+SIGNATURES = {
+    'resel_abi_version': (c_int, []),
+    'resel_build_info': (ctypes.c_char_p, []),
+    'resel_selective_scan_ckpt_bytes': (c_size_t, [I, I, I, I]),
+    'resel_selective_scan_fwd': (c_int, [P, L, P, L, P, L, P, P, L, P, L, P, P, P, P, L, P, P, I, I, I, I, I, S]),
+    'resel_selective_scan_bwd_workspace_bytes': (c_size_t, [I, I, I, I]),
+    'resel_selective_scan_bwd': (c_int, [P, L, P, L, P, L, P, P, L, P, L, P, P, P, P, L, P,
+                                         P, L, P, L, P, L, P, L, P, L, P, P, P, P, I, I, I, I, I, S]),
+    'resel_causal_conv1d_fwd': (c_int, [P, L, P, P, P, P, L, I, I, I, I, I, S]),
+    'resel_causal_conv1d_bwd_workspace_bytes': (c_size_t, [I, I, I, I]),
+    'resel_causal_conv1d_bwd': (c_int, [P, L, P, P, P, P, L, P, L, P, P, P, I, I, I, I, I, S]),
+    'resel_add_layernorm_fwd': (c_int, [P, P, P, P, P, P, P, I, I, F, I, S]),
+    'resel_add_layernorm_bwd_workspace_bytes': (c_size_t, [I, I]),
+    'resel_add_layernorm_bwd': (c_int, [P, P, P, P, P, P, P, P, P, I, I, I, I, S]),
+    'resel_linrec_real_fwd': (c_int, [P, P, P, P, P, I, I, I, I, S]),
+    'resel_linrec_real_bwd': (c_int, [P, P, P, P, P, P, P, P, I, I, I, I, S]),
+    'resel_linrec_complex_fwd': (c_int, [P, P, P, P, P, P, P, P, P, P, I, I, I, S]),
+    'resel_linrec_complex_bwd_workspace_bytes': (c_size_t, [I, I, I]),
+    'resel_linrec_complex_bwd': (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, S]),
+    'resel_gru_workspace_bytes': (c_size_t, [I, I, I]),
+    'resel_gru_seq_fwd': (c_int, [P, P, P, P, P, P, P, I, I, I, S]),
+    'resel_gru_seq_bwd': (c_int, [P, P, P, P, P, P, P, P, I, I, I, S]),
+    'resel_tanh_gaussian_fwd': (c_int, [P, P, P, P, P, I, I, S]),
+    'resel_tanh_gaussian_bwd': (c_int, [P, P, P, P, P, I, I, S]),
+    'resel_sac_target': (c_int, [P, P, I, P, P, P, P, P, F, P, P, P, P, I, I, S]),
+    'resel_sac_target_workspace_bytes': (c_size_t, [I]),
+    'resel_soft_update': (c_int, [P, P, F, L, S]),
+    'resel_adamw_flat': (c_int, [P, P, P, P, L, P, P, P, I, F, F, F, I, P, S]),
+    'resel_sumsq_workspace_bytes': (c_size_t, [L]),
+    'resel_sumsq': (c_int, [P, L, P, P, S]),
+}
+
+
+class ReselHipUnavailable(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the C-ABI library; fail loudly if it is missing or stale."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ReselHipUnavailable(
+            f'RESeL-HIP: {LIB_PATH} not found. The MI355X kernels are the only implementation of the hot path; '
+            f'build them with `python -c "import __graft_entry__ as g; g.build()"` (or `make -C recurrent-offpolicy-rl_amd/csrc`).')
+    handle = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(handle, name, None)
+        if fn is None:
+            raise ReselHipUnavailable(f'RESeL-HIP: symbol {name} missing from {LIB_PATH} (stale build?)')
+        fn.restype = res
+        fn.argtypes = args
+    if handle.resel_abi_version() != ABI_VERSION:
+        raise ReselHipUnavailable(f'RESeL-HIP: ABI {handle.resel_abi_version()} != expected {ABI_VERSION}; rebuild the library')
+    _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError(f'RESeL-HIP: {what} failed with code {rc} '
+                           f'({ {-1: "RESEL_EINVAL (shape/alignment/null)", -2: "RESEL_ELAUNCH"}.get(rc, "?")})')

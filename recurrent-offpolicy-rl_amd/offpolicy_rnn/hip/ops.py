@@ -1,0 +1,406 @@
+"""torch.autograd wrappers over the C-ABI kernels (include/resel_hip.h).
+
+Every function here requires CUDA (ROCm) tensors and the in-tree `libresel_hip.so`; there is deliberately NO
+CPU / eager fallback - a missing library or a CPU tensor raises.  PyTorch only provides device memory, the
+current stream and autograd bookkeeping.
+
+Layout: activations are token-major `[B, L, C]` (channel stride 1).  Column slices of a wider row-major
+tensor (e.g. the `x` / `z` halves of `in_proj`'s output) are passed by stride, never copied.
+"""
+import ctypes
+from typing import Optional
+
+import torch
+
+from ._lib import check, lib
+
+
+def _need_cuda(name, *ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(f'RESeL-HIP: {name} needs CUDA tensors (got a {t.device} tensor); the HIP kernels are the '
+                               f'only implementation of this op - there is no CPU fallback.')
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _tok_major(t: torch.Tensor) -> torch.Tensor:
+    """Return a [B, L, C] view/copy with channel stride 1, batch stride L*ld, ld % 4 == 0 and a 16-byte aligned base."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    B, L, C = t.shape
+    ok = (C == 1 or t.stride(2) == 1) and t.stride(1) % 4 == 0 and (B == 1 or t.stride(0) == L * t.stride(1)) \
+        and t.data_ptr() % 16 == 0 and t.stride(1) >= C
+    return t if ok else t.contiguous()
+
+
+def _flags(t: Optional[torch.Tensor], B: int, L: int) -> Optional[torch.Tensor]:
+    """[B, L] / [B, L, 1] float flags -> dense fp32 [B*L]."""
+    if t is None:
+        return None
+    return t.reshape(B, L).to(torch.float32).contiguous()
+
+
+def _ws(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+# ---------------------------------------------------------------------------------------------- selective scan
+class SelectiveScanFn(torch.autograd.Function):
+    """Token-major selective scan with start resets.  Interface counterpart of the reference's
+    `SelectiveScanFn` (mamba_ssm/ops/selective_scan_interface_new.py:19-84)."""
+
+    @staticmethod
+    def forward(ctx, u, delta, A, Bm, Cm, D, z, delta_bias, start, delta_softplus, return_last_state):
+        _need_cuda('selective_scan', u, delta, A, Bm, Cm)
+        u, delta, Bm, Cm = _tok_major(u), _tok_major(delta), _tok_major(Bm), _tok_major(Cm)
+        z = None if z is None else _tok_major(z)
+        A = A.float().contiguous()
+        D = None if D is None else D.float().contiguous()
+        delta_bias = None if delta_bias is None else delta_bias.float().contiguous()
+        Bsz, L, Di = u.shape
+        N = A.shape[1]
+        start = _flags(start, Bsz, L)
+        out = torch.empty(Bsz, L, Di, dtype=torch.float32, device=u.device)
+        need_grad = any(ctx.needs_input_grad)
+        ck = None
+        if need_grad:
+            ck = _ws(lib().resel_selective_scan_ckpt_bytes(Bsz, L, Di, N), u.device)
+        last = torch.empty(Bsz, Di, N, dtype=torch.float32, device=u.device) if return_last_state else None
+        check(lib().resel_selective_scan_fwd(
+            _p(u), u.stride(1), _p(delta), delta.stride(1), _p(z), 0 if z is None else z.stride(1), _p(A),
+            _p(Bm), Bm.stride(1), _p(Cm), Cm.stride(1), _p(D), _p(delta_bias), _p(start),
+            _p(out), out.stride(1), _p(ck), _p(last), Bsz, L, Di, N, int(bool(delta_softplus)), _stream()),
+            'selective_scan_fwd')
+        ctx.save_for_backward(u, delta, A, Bm, Cm, D, z, delta_bias, start, ck)
+        ctx.softplus = bool(delta_softplus)
+        if return_last_state:
+            ctx.mark_non_differentiable(last)
+            return out, last
+        return out
+
+    @staticmethod
+    def backward(ctx, dout, *_):
+        u, delta, A, Bm, Cm, D, z, delta_bias, start, ck = ctx.saved_tensors
+        Bsz, L, Di = u.shape
+        N = A.shape[1]
+        dout = _tok_major(dout)
+        dev = u.device
+        du = torch.empty(Bsz, L, Di, dtype=torch.float32, device=dev)
+        ddelta = torch.empty_like(du)
+        dz = torch.empty_like(du) if z is not None else None
+        dB = torch.empty(Bsz, L, N, dtype=torch.float32, device=dev)
+        dC = torch.empty_like(dB)
+        dA = torch.empty(Di, N, dtype=torch.float32, device=dev)
+        dD = torch.empty(Di, dtype=torch.float32, device=dev) if D is not None else None
+        dbias = torch.empty(Di, dtype=torch.float32, device=dev) if delta_bias is not None else None
+        ws = _ws(lib().resel_selective_scan_bwd_workspace_bytes(Bsz, L, Di, N), dev)
+        check(lib().resel_selective_scan_bwd(
+            _p(u), u.stride(1), _p(delta), delta.stride(1), _p(z), 0 if z is None else z.stride(1), _p(A),
+            _p(Bm), Bm.stride(1), _p(Cm), Cm.stride(1), _p(D), _p(delta_bias), _p(start),
+            _p(dout), dout.stride(1), _p(ck),
+            _p(du), du.stride(1), _p(ddelta), ddelta.stride(1), _p(dz), 0 if dz is None else dz.stride(1),
+            _p(dB), dB.stride(1), _p(dC), dC.stride(1), _p(dA), _p(dD), _p(dbias), _p(ws),
+            Bsz, L, Di, N, int(ctx.softplus), _stream()), 'selective_scan_bwd')
+        return du, ddelta, dA, dB, dC, dD, dz, dbias, None, None, None
+
+
+def selective_scan_tm(u, delta, A, Bm, Cm, D=None, z=None, delta_bias=None, start=None, delta_softplus=True,
+                      return_last_state=False):
+    """Token-major entry: u, delta, z [B, L, Di]; Bm, Cm [B, L, N]; start [B, L] or [B, L, 1]."""
+    return SelectiveScanFn.apply(u, delta, A, Bm, Cm, D, z, delta_bias, start, delta_softplus, return_last_state)
+
+
+def selective_scan_fn(u, delta, A, B, C, start, D=None, z=None, delta_bias=None, delta_softplus=False,
+                      return_last_state=False):
+    """Reference signature (selective_scan_interface_new.py:87-93): u, delta, z, start (B, D, L); B, C (B, N, L).
+    Channel-major VIEWS of token-major storage are accepted without copies; anything else is re-laid-out."""
+    tm = lambda t: None if t is None else t.transpose(1, 2)
+    st = None if start is None else start[:, 0, :]
+    res = selective_scan_tm(tm(u), tm(delta), A, tm(B), tm(C), D, tm(z), delta_bias, st, delta_softplus, return_last_state)
+    if return_last_state:
+        return res[0].transpose(1, 2), res[1]
+    return res.transpose(1, 2)
+
+
+# ---------------------------------------------------------------------------------------------- causal conv1d
+class CausalConv1dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, mask, activation):
+        _need_cuda('causal_conv1d', x, weight)
+        x = _tok_major(x)
+        Bsz, L, Di = x.shape
+        w = weight.float().reshape(Di, -1).contiguous()
+        K = w.shape[1]
+        bias = None if bias is None else bias.float().contiguous()
+        mask = _flags(mask, Bsz, L)
+        y = torch.empty(Bsz, L, Di, dtype=torch.float32, device=x.device)
+        check(lib().resel_causal_conv1d_fwd(_p(x), x.stride(1), _p(w), _p(bias), _p(mask), _p(y), y.stride(1),
+                                            Bsz, L, Di, K, int(bool(activation)), _stream()), 'causal_conv1d_fwd')
+        ctx.save_for_backward(x, w, bias, mask)
+        ctx.act = bool(activation)
+        ctx.wshape = weight.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, bias, mask = ctx.saved_tensors
+        Bsz, L, Di = x.shape
+        K = w.shape[1]
+        dy = _tok_major(dy)
+        dx = torch.empty(Bsz, L, Di, dtype=torch.float32, device=x.device)
+        dw = torch.empty(Di, K, dtype=torch.float32, device=x.device)
+        db = torch.empty(Di, dtype=torch.float32, device=x.device) if bias is not None else None
+        ws = _ws(lib().resel_causal_conv1d_bwd_workspace_bytes(Bsz, L, Di, K), x.device)
+        check(lib().resel_causal_conv1d_bwd(_p(x), x.stride(1), _p(w), _p(bias), _p(mask), _p(dy), dy.stride(1),
+                                            _p(dx), dx.stride(1), _p(dw), _p(db), _p(ws), Bsz, L, Di, K, int(ctx.act),
+                                            _stream()), 'causal_conv1d_bwd')
+        return dx, dw.reshape(ctx.wshape), db, None, None
+
+
+def causal_conv1d_fn(x, weight, bias=None, mask=None, activation=True):
+    """x [B, L, Di] token-major; weight [Di, K] or Conv1d's [Di, 1, K]; mask [B, L(,1)]: y = silu(conv(mask * x) + b)."""
+    return CausalConv1dFn.apply(x, weight, bias, mask, activation)
+
+
+# ---------------------------------------------------------------------------------------------- add + norm
+class AddNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, residual, weight, bias, eps, rms, prenorm):
+        _need_cuda('add_layernorm', x, weight)
+        shape = x.shape
+        C = shape[-1]
+        x2 = x.float().reshape(-1, C).contiguous()
+        r2 = None if residual is None else residual.float().reshape(-1, C).contiguous()
+        M = x2.shape[0]
+        w = weight.float().contiguous()
+        b = None if bias is None else bias.float().contiguous()
+        y = torch.empty_like(x2)
+        need_res = residual is not None or prenorm
+        res_out = torch.empty_like(x2) if need_res else None
+        stats = torch.empty(M, 2, dtype=torch.float32, device=x.device)
+        check(lib().resel_add_layernorm_fwd(_p(x2), _p(r2), _p(w), _p(b), _p(y), _p(res_out), _p(stats), M, C, float(eps),
+                                            int(bool(rms)), _stream()), 'add_layernorm_fwd')
+        ctx.save_for_backward(res_out if res_out is not None else x2, w, stats)
+        ctx.rms, ctx.has_bias, ctx.has_res, ctx.prenorm, ctx.shape = bool(rms), b is not None, residual is not None, prenorm, shape
+        if prenorm:
+            return y.reshape(shape), res_out.reshape(shape)
+        return y.reshape(shape)
+
+    @staticmethod
+    def backward(ctx, dy, dres=None):
+        res, w, stats = ctx.saved_tensors
+        M, C = res.shape
+        dy2 = dy.float().reshape(M, C).contiguous()
+        dr2 = None if (dres is None or not ctx.prenorm) else dres.float().reshape(M, C).contiguous()
+        dx = torch.empty_like(res)
+        dw = torch.empty(C, dtype=torch.float32, device=res.device)
+        db = torch.empty(C, dtype=torch.float32, device=res.device) if ctx.has_bias else None
+        ws = _ws(lib().resel_add_layernorm_bwd_workspace_bytes(M, C), res.device)
+        check(lib().resel_add_layernorm_bwd(_p(dy2), _p(dr2), _p(res), _p(w), _p(stats), _p(dx), _p(dw), _p(db), _p(ws),
+                                            M, C, int(ctx.rms), int(ctx.has_bias), _stream()), 'add_layernorm_bwd')
+        dx = dx.reshape(ctx.shape)
+        return dx, (dx if ctx.has_res else None), dw, db, None, None, None
+
+
+def layer_norm_fn(x, weight, bias, residual=None, eps=1e-6, prenorm=False, residual_in_fp32=False):
+    """Signature of the reference's fused add+LayerNorm (mamba_ssm/ops/triton/layernorm.py `layer_norm_fn`)."""
+    return AddNormFn.apply(x, residual, weight, bias, eps, False, prenorm)
+
+
+def rms_norm_fn(x, weight, bias, residual=None, eps=1e-6, prenorm=False, residual_in_fp32=False):
+    return AddNormFn.apply(x, residual, weight, bias, eps, True, prenorm)
+
+
+# ---------------------------------------------------------------------------------------------- linear recurrences
+class GilrScanFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, v, f, start, h0, fuse_act):
+        _need_cuda('linrec_real', v, f)
+        v, f = v.float().contiguous(), f.float().contiguous()
+        Bsz, L, C = v.shape
+        start = _flags(start, Bsz, L)
+        h0 = None if h0 is None else h0.float().reshape(Bsz, C).contiguous()
+        h = torch.empty_like(v)
+        check(lib().resel_linrec_real_fwd(_p(v), _p(f), _p(start), _p(h0), _p(h), Bsz, L, C, int(bool(fuse_act)), _stream()),
+              'linrec_real_fwd')
+        ctx.save_for_backward(v, f, start, h0, h)
+        ctx.act = bool(fuse_act)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        v, f, start, h0, h = ctx.saved_tensors
+        Bsz, L, C = v.shape
+        dh = dh.float().contiguous()
+        dv, df = torch.empty_like(v), torch.empty_like(f)
+        check(lib().resel_linrec_real_bwd(_p(v), _p(f), _p(start), _p(h0), _p(h), _p(dh), _p(dv), _p(df), Bsz, L, C,
+                                          int(ctx.act), _stream()), 'linrec_real_bwd')
+        return dv, df, None, None, None
+
+
+def gilr_scan(v, f, start=None, h0=None, fuse_act=True):
+    """h_t = f'_t h_{t-1} + (1 - f'_t) v'_t with v' = tanh(v), f' = sigmoid(f) (1 - start) when fuse_act."""
+    return GilrScanFn.apply(v, f, start, h0, fuse_act)
+
+
+def real_scan_tie_input_gate(v, f):
+    """Reference name (gilr/scan_triton/real_rnn_tie_input_gate.py:170-214): post-activation v, f; zero initial state."""
+    return GilrScanFn.apply(v, f, None, None, False)
+
+
+class LruScanFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, vr, vi, lam_re, lam_im, gamma, start, h0r, h0i):
+        _need_cuda('linrec_complex', vr, vi, lam_re, lam_im)
+        vr, vi = vr.float().contiguous(), vi.float().contiguous()
+        Bsz, L, C = vr.shape
+        lam_re, lam_im = lam_re.float().contiguous(), lam_im.float().contiguous()
+        gamma = None if gamma is None else gamma.float().contiguous()
+        start = _flags(start, Bsz, L)
+        h0r = None if h0r is None else h0r.float().reshape(Bsz, C).contiguous()
+        h0i = None if h0i is None else h0i.float().reshape(Bsz, C).contiguous()
+        hr, hi = torch.empty_like(vr), torch.empty_like(vi)
+        check(lib().resel_linrec_complex_fwd(_p(vr), _p(vi), _p(lam_re), _p(lam_im), _p(gamma), _p(start), _p(h0r), _p(h0i),
+                                             _p(hr), _p(hi), Bsz, L, C, _stream()), 'linrec_complex_fwd')
+        ctx.save_for_backward(vr, vi, lam_re, lam_im, gamma, start, h0r, h0i, hr, hi)
+        return hr, hi
+
+    @staticmethod
+    def backward(ctx, dhr, dhi):
+        vr, vi, lam_re, lam_im, gamma, start, h0r, h0i, hr, hi = ctx.saved_tensors
+        Bsz, L, C = vr.shape
+        dhr, dhi = dhr.float().contiguous(), dhi.float().contiguous()
+        dvr, dvi = torch.empty_like(vr), torch.empty_like(vi)
+        dlr, dli = torch.empty_like(lam_re), torch.empty_like(lam_im)
+        dg = torch.empty_like(lam_re) if gamma is not None else None
+        ws = _ws(lib().resel_linrec_complex_bwd_workspace_bytes(Bsz, L, C), vr.device)
+        check(lib().resel_linrec_complex_bwd(_p(vr), _p(vi), _p(lam_re), _p(lam_im), _p(gamma), _p(start), _p(h0r), _p(h0i),
+                                             _p(hr), _p(hi), _p(dhr), _p(dhi), _p(dvr), _p(dvi), _p(dlr), _p(dli), _p(dg),
+                                             _p(ws), Bsz, L, C, _stream()), 'linrec_complex_bwd')
+        return dvr, dvi, dlr, dli, dg, None, None, None
+
+
+def complex_scan(vr, vi, lam_re, lam_im, gamma=None, start=None, h0r=None, h0i=None):
+    """h_t = lambda (1 - start_t) h_{t-1} + gamma (vr_t + i vi_t); lambda, gamma per channel [C]."""
+    return LruScanFn.apply(vr, vi, lam_re, lam_im, gamma, start, h0r, h0i)
+
+
+# ---------------------------------------------------------------------------------------------- GRU
+class GruSeqFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gi, w_hh, b_hh, h0):
+        _need_cuda('gru_seq', gi, w_hh, b_hh)
+        gi = gi.float().contiguous()
+        Bsz, L, H3 = gi.shape
+        H = H3 // 3
+        w_hh, b_hh = w_hh.float().contiguous(), b_hh.float().contiguous()
+        h0 = None if h0 is None else h0.float().reshape(Bsz, H).contiguous()
+        need_grad = any(ctx.needs_input_grad)
+        h_all = torch.empty(Bsz, L, H, dtype=torch.float32, device=gi.device)
+        gates = torch.empty(Bsz, L, 4 * H, dtype=torch.float32, device=gi.device) if need_grad else None
+        ws = _ws(lib().resel_gru_workspace_bytes(Bsz, L, H), gi.device)
+        check(lib().resel_gru_seq_fwd(_p(gi), _p(w_hh), _p(b_hh), _p(h0), _p(h_all), _p(gates), _p(ws), Bsz, L, H, _stream()),
+              'gru_seq_fwd')
+        ctx.save_for_backward(w_hh, h0, h_all, gates)
+        return h_all
+
+    @staticmethod
+    def backward(ctx, dh_all):
+        w_hh, h0, h_all, gates = ctx.saved_tensors
+        Bsz, L, H = h_all.shape
+        dh_all = dh_all.float().contiguous()
+        dgi = torch.empty(Bsz, L, 3 * H, dtype=torch.float32, device=h_all.device)
+        dgh = torch.empty_like(dgi)
+        ws = _ws(lib().resel_gru_workspace_bytes(Bsz, L, H), h_all.device)
+        check(lib().resel_gru_seq_bwd(_p(w_hh), _p(h0), _p(h_all), _p(gates), _p(dh_all), _p(dgi), _p(dgh), _p(ws),
+                                      Bsz, L, H, _stream()), 'gru_seq_bwd')
+        # dW_hh = dgh^T h_prev and db_hh = sum dgh: plain GEMM / reduction over B*L rows (library GEMM, see resel_hip.h)
+        h_prev = torch.cat((torch.zeros(Bsz, 1, H, device=h_all.device) if h0 is None else h0.unsqueeze(1), h_all[:, :-1]), dim=1)
+        dw_hh = dgh.reshape(-1, 3 * H).t() @ h_prev.reshape(-1, H)
+        db_hh = dgh.sum(dim=(0, 1))
+        return dgi, dw_hh, db_hh, None
+
+
+def gru_seq(gi, w_hh, b_hh, h0=None):
+    """gi = x W_ih^T + b_ih [B, L, 3H] -> all hidden states [B, L, H] (torch.nn.GRU gate order / formula)."""
+    return GruSeqFn.apply(gi, w_hh, b_hh, h0)
+
+
+# ---------------------------------------------------------------------------------------------- SAC / TD3 arithmetic
+class TanhGaussianFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, out2, noise):
+        _need_cuda('tanh_gaussian', out2, noise)
+        shape = out2.shape
+        A = shape[-1] // 2
+        o2 = out2.float().reshape(-1, 2 * A).contiguous()
+        nz = noise.float().reshape(-1, A).contiguous()
+        M = o2.shape[0]
+        mean, samp = torch.empty_like(nz), torch.empty_like(nz)
+        logp = torch.empty(M, dtype=torch.float32, device=o2.device)
+        check(lib().resel_tanh_gaussian_fwd(_p(o2), _p(nz), _p(mean), _p(samp), _p(logp), M, A, _stream()), 'tanh_gaussian_fwd')
+        ctx.save_for_backward(o2, nz)
+        ctx.shape = shape
+        ctx.mark_non_differentiable(mean)
+        out_shape = shape[:-1] + (A,)
+        return mean.reshape(out_shape), samp.reshape(out_shape), logp.reshape(shape[:-1] + (1,))
+
+    @staticmethod
+    def backward(ctx, _dmean, dsamp, dlogp):
+        o2, nz = ctx.saved_tensors
+        M, A = nz.shape
+        ds = None if dsamp is None else dsamp.float().reshape(M, A).contiguous()
+        dl = None if dlogp is None else dlogp.float().reshape(M).contiguous()
+        d2 = torch.empty_like(o2)
+        check(lib().resel_tanh_gaussian_bwd(_p(o2), _p(nz), _p(ds), _p(dl), _p(d2), M, A, _stream()), 'tanh_gaussian_bwd')
+        return d2.reshape(ctx.shape), None
+
+
+def tanh_gaussian(out2, noise):
+    """(logstd | mean) [..., 2A], noise [..., A] -> tanh(mean) (no grad), tanh(sample), log_prob [..., 1]."""
+    return TanhGaussianFn.apply(out2, noise)
+
+
+@torch.no_grad()
+def sac_target(q, subset, next_logp, log_alpha, reward, done, mask, gamma, guard, stats=None):
+    """q [E, ...]; subset int32 [m] (device); guard fp32[4] device state {min, max, initialised, decay}."""
+    _need_cuda('sac_target', q, reward, done, guard)
+    E = q.shape[0]
+    M = reward.numel()
+    qf = q.float().reshape(E, M).contiguous()
+    target = torch.empty(M, dtype=torch.float32, device=q.device)
+    ws = _ws(lib().resel_sac_target_workspace_bytes(M), q.device)
+    f = lambda t: None if t is None else t.float().reshape(-1).contiguous()
+    nl, rw, dn, mk = f(next_logp), f(reward), f(done), f(mask)
+    check(lib().resel_sac_target(_p(qf), _p(subset), int(subset.numel()), _p(nl), _p(log_alpha), _p(rw), _p(dn), _p(mk),
+                                 float(gamma), _p(guard), _p(target), _p(stats), _p(ws), E, M, _stream()), 'sac_target')
+    return target.reshape(reward.shape)
+
+
+@torch.no_grad()
+def soft_update_(target_flat, online_flat, tau):
+    _need_cuda('soft_update', target_flat, online_flat)
+    check(lib().resel_soft_update(_p(target_flat), _p(online_flat), float(tau), target_flat.numel(), _stream()), 'soft_update')
+
+
+@torch.no_grad()
+def adamw_flat_(p, g, m, v, seg_end, seg_lr, seg_wd, step, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=None):
+    _need_cuda('adamw_flat', p, g, m, v, seg_end, seg_lr, seg_wd)
+    check(lib().resel_adamw_flat(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(seg_end), _p(seg_lr), _p(seg_wd), int(seg_end.numel()),
+                                 float(beta1), float(beta2), float(eps), int(step), _p(grad_scale), _stream()), 'adamw_flat')
+
+
+@torch.no_grad()
+def sumsq(x, out=None):
+    _need_cuda('sumsq', x)
+    out = torch.empty(1, dtype=torch.float32, device=x.device) if out is None else out
+    ws = _ws(lib().resel_sumsq_workspace_bytes(x.numel()), x.device)
+    check(lib().resel_sumsq(_p(x), x.numel(), _p(out), _p(ws), _stream()), 'sumsq')
+    return out

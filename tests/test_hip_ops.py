@@ -1,0 +1,319 @@
+"""Parity of every C-ABI kernel (through the ctypes binding) against the CPU oracle.  GPU box only.
+
+Tolerances: fp32 kernels against an fp32 CPU restatement of the same arithmetic - rtol 1e-4 (north_star's fp32 bar),
+with an absolute floor that scales with the magnitude of the compared tensor (reductions over thousands of terms).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import kernels as K
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from offpolicy_rnn.hip import ops as o
+    return o
+
+
+def close(got, ref, rtol=1e-4, atol_scale=2e-5, name=''):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float()
+    scale = max(ref.abs().max().item(), 1e-6)
+    err = (got - ref).abs().max().item()
+    assert torch.isfinite(got).all(), f'{name}: non-finite output'
+    assert err <= rtol * scale + atol_scale * scale, f'{name}: max err {err:.3e} vs scale {scale:.3e}'
+
+
+def rnd(*shape, g=None, scale=1.0):
+    return torch.randn(*shape, generator=g) * scale
+
+
+def make_start(B, L, g, p=0.03):
+    s = (torch.rand(B, L, generator=g) < p).float()
+    s[:, 0] = 1
+    return s
+
+
+# ------------------------------------------------------------------------------------------------ selective scan
+@pytest.mark.parametrize('B,L,Di,N', [(2, 37, 64, 8), (3, 150, 96, 16), (2, 129, 128, 32), (1, 70, 64, 64), (2, 64, 64, 32), (1, 5, 8, 4)])
+@pytest.mark.parametrize('with_z', [True, False])
+def test_selective_scan_fwd_bwd(ops, B, L, Di, N, with_z):
+    g = torch.Generator().manual_seed(B * 1000 + L + N)
+    # strided operands: x | z halves of one [B, L, 2Di] tensor; delta_r | B | C slices of one [B, L, R+2N] tensor
+    xz = rnd(B, L, 2 * Di, g=g)
+    R = 8
+    xdbl = rnd(B, L, R + 2 * N, g=g)
+    delta = rnd(B, L, Di, g=g, scale=0.5)
+    A = -torch.exp(rnd(Di, N, g=g, scale=0.4))
+    D, db = rnd(Di, g=g), rnd(Di, g=g, scale=0.2)
+    start = make_start(B, L, g)
+    dout = rnd(B, L, Di, g=g)
+
+    def run(dev, fn):
+        ts = [t.clone().to(dev).requires_grad_(True) for t in (xz, xdbl, delta, A, D, db)]
+        xz_, xdbl_, delta_, A_, D_, db_ = ts
+        u, z = xz_[..., :Di], (xz_[..., Di:] if with_z else None)
+        Bm, Cm = xdbl_[..., R:R + N], xdbl_[..., R + N:]
+        out, last = fn(u, delta_, A_, Bm, Cm, D_, z, db_, start.to(dev))
+        (out * dout.to(dev)).sum().backward()
+        return out, last, [t.grad for t in ts]
+
+    o_ref, l_ref, g_ref = run('cpu', lambda u, d, A_, Bm, Cm, D_, z, db_, s: K.selective_scan_ref(u, d, A_, Bm, Cm, D_, z, db_, s, True))
+    o_gpu, l_gpu, g_gpu = run('cuda', lambda u, d, A_, Bm, Cm, D_, z, db_, s: ops.selective_scan_tm(u, d, A_, Bm, Cm, D_, z, db_, s, True, True))
+    close(o_gpu, o_ref, name='out')
+    close(l_gpu, l_ref, name='last_state')
+    for nm, a, b in zip(('dxz', 'dxdbl', 'ddelta', 'dA', 'dD', 'ddelta_bias'), g_gpu, g_ref):
+        close(a, b, rtol=2e-4, atol_scale=5e-5, name=nm)
+
+
+def test_selective_scan_golden_reference_vectors(ops):
+    """The reference's own selective_scan_ref outputs (tests/golden/selective_scan.npz), channel-major signature."""
+    gold = load_golden('selective_scan.npz')
+    for case in ('n16', 'n32', 'n64'):
+        T = lambda k: torch.from_numpy(gold[f'{case}|{k}']).cuda()
+        u, delta, z, Bm, Cm = [T(k).requires_grad_(True) for k in ('u', 'delta', 'z', 'Bm', 'Cm')]
+        A, D, db = [T(k).requires_grad_(True) for k in ('A', 'D', 'delta_bias')]
+        start = T('start')[:, None, :].expand(-1, u.shape[1], -1)
+        out, last = ops.selective_scan_fn(u, delta, A, Bm, Cm, start, D, z, db, True, True)
+        close(out, torch.from_numpy(gold[f'{case}|out']), name=f'{case} out')
+        close(last, torch.from_numpy(gold[f'{case}|last_state']), name=f'{case} last')
+        (out * T('dout')).sum().backward()
+        for k, t in dict(u=u, delta=delta, z=z, Bm=Bm, Cm=Cm, A=A, D=D, delta_bias=db).items():
+            close(t.grad, torch.from_numpy(gold[f'{case}|d{k}']), rtol=3e-4, atol_scale=1e-4, name=f'{case} d{k}')
+
+
+def test_selective_scan_reset_isolation(ops):
+    """Size-independent property at BASELINE config-2 width: outputs after a reset do not depend on inputs before it."""
+    g = torch.Generator().manual_seed(3)
+    B, L, Di, N = 2, 300, 512, 32
+    mk = lambda *s: rnd(*s, g=g).cuda()
+    u, delta, z, Bm, Cm = mk(B, L, Di), mk(B, L, Di) * 0.5, mk(B, L, Di), mk(B, L, N), mk(B, L, N)
+    A = -torch.exp(mk(Di, N) * 0.3)
+    start = torch.zeros(B, L, device='cuda')
+    start[:, 0] = 1
+    start[:, 170] = 1
+    o1 = ops.selective_scan_tm(u, delta, A, Bm, Cm, None, z, None, start, True)
+    u2 = u.clone()
+    u2[:, :170] += 5.0
+    o2 = ops.selective_scan_tm(u2, delta, A, Bm, Cm, None, z, None, start, True)
+    assert torch.equal(o1[:, 170:], o2[:, 170:])
+    assert not torch.equal(o1[:, :170], o2[:, :170])
+    # bitwise reproducible (no atomics)
+    assert torch.equal(o1, ops.selective_scan_tm(u, delta, A, Bm, Cm, None, z, None, start, True))
+
+
+# ------------------------------------------------------------------------------------------------ conv1d
+@pytest.mark.parametrize('B,L,Di,Kw', [(2, 50, 64, 4), (3, 130, 96, 16), (1, 70, 128, 3), (2, 65, 64, 8), (1, 200, 64, 20)])
+def test_causal_conv1d_fwd_bwd(ops, B, L, Di, Kw):
+    g = torch.Generator().manual_seed(L + Kw)
+    xz = rnd(B, L, 2 * Di, g=g)
+    w, b = rnd(Di, 1, Kw, g=g, scale=0.3), rnd(Di, g=g, scale=0.2)
+    mask = (torch.rand(B, L, generator=g) > 0.2).float()
+    dy = rnd(B, L, Di, g=g)
+
+    def run(dev, fn):
+        ts = [t.clone().to(dev).requires_grad_(True) for t in (xz, w, b)]
+        y = fn(ts[0][..., :Di], ts[1], ts[2], mask.to(dev))
+        (y * dy.to(dev)).sum().backward()
+        return y, [t.grad for t in ts]
+
+    y_ref, g_ref = run('cpu', lambda x, w_, b_, m: K.causal_conv1d_silu_ref(x, w_[:, 0], b_, m))
+    y_gpu, g_gpu = run('cuda', lambda x, w_, b_, m: ops.causal_conv1d_fn(x, w_, b_, m, True))
+    close(y_gpu, y_ref, name='y')
+    for nm, a, b_ in zip(('dx', 'dw', 'db'), g_gpu, g_ref):
+        close(a, b_, rtol=2e-4, atol_scale=5e-5, name=nm)
+
+
+# ------------------------------------------------------------------------------------------------ add + norm
+@pytest.mark.parametrize('M,C', [(37, 256), (100, 64), (9, 512), (5, 1024)])
+@pytest.mark.parametrize('rms', [False, True])
+@pytest.mark.parametrize('prenorm', [True, False])
+def test_add_layernorm_fwd_bwd(ops, M, C, rms, prenorm):
+    g = torch.Generator().manual_seed(M + C)
+    x, r = rnd(2, M, C, g=g), rnd(2, M, C, g=g)
+    w, b = 1 + rnd(C, g=g, scale=0.1), rnd(C, g=g, scale=0.1)
+    dy, dr = rnd(2, M, C, g=g), rnd(2, M, C, g=g)
+
+    def run(dev, fn):
+        ts = [t.clone().to(dev).requires_grad_(True) for t in (x, r, w, b)]
+        y, res = fn(ts[0], ts[1], ts[2], None if rms else ts[3])
+        loss = (y * dy.to(dev)).sum()
+        if prenorm:
+            loss = loss + (res * dr.to(dev)).sum()
+        loss.backward()
+        return y, res, [t.grad for t in (ts[:3] if rms else ts)]
+
+    y_ref, res_ref, g_ref = run('cpu', lambda x_, r_, w_, b_: K.add_layernorm_ref(x_, r_, w_, b_, 1e-8, rms))
+
+    def gpu_fn(x_, r_, w_, b_):
+        f = ops.rms_norm_fn if rms else ops.layer_norm_fn
+        out = f(x_, w_, b_, residual=r_, eps=1e-8, prenorm=prenorm, residual_in_fp32=True)
+        return out if prenorm else (out, x_ + r_)
+
+    y_gpu, res_gpu, g_gpu = run('cuda', gpu_fn)
+    close(y_gpu, y_ref, name='y')
+    close(res_gpu, res_ref, name='res')
+    for i, (a, b_) in enumerate(zip(g_gpu, g_ref)):
+        close(a, b_, rtol=2e-4, atol_scale=5e-5, name=f'grad{i}')
+
+
+# ------------------------------------------------------------------------------------------------ linear recurrences
+@pytest.mark.parametrize('B,L,C', [(2, 33, 64), (3, 500, 96), (1, 2003, 256), (2, 7, 32)])
+@pytest.mark.parametrize('fuse', [True, False])
+def test_gilr_scan_fwd_bwd(ops, B, L, C, fuse):
+    g = torch.Generator().manual_seed(L + C)
+    v, f = rnd(B, L, C, g=g), rnd(B, L, C, g=g)
+    if not fuse:
+        f = torch.sigmoid(f)
+    start = make_start(B, L, g)
+    h0 = rnd(B, C, g=g)
+    dh = rnd(B, L, C, g=g)
+
+    def run(dev, fn):
+        ts = [t.clone().to(dev).requires_grad_(True) for t in (v, f)]
+        h = fn(ts[0], ts[1], start.to(dev), h0.to(dev))
+        (h * dh.to(dev)).sum().backward()
+        return h, [t.grad for t in ts]
+
+    h_ref, g_ref = run('cpu', lambda v_, f_, s, h: K.linrec_real_ref(v_, f_, s, h, fuse)[0])
+    h_gpu, g_gpu = run('cuda', lambda v_, f_, s, h: ops.gilr_scan(v_, f_, s, h, fuse))
+    close(h_gpu, h_ref, name='h')
+    close(g_gpu[0], g_ref[0], rtol=2e-4, atol_scale=5e-5, name='dv')
+    close(g_gpu[1], g_ref[1], rtol=2e-4, atol_scale=5e-5, name='df')
+
+
+@pytest.mark.parametrize('B,L,C', [(2, 33, 64), (3, 500, 96), (1, 2003, 256)])
+def test_lru_scan_fwd_bwd(ops, B, L, C):
+    g = torch.Generator().manual_seed(L + C + 1)
+    vr, vi = rnd(B, L, C, g=g), rnd(B, L, C, g=g)
+    mag, th = 0.9 + 0.099 * torch.rand(C, generator=g), 6.28 * torch.rand(C, generator=g)
+    lr, li = mag * torch.cos(th), mag * torch.sin(th)
+    gamma = torch.sqrt(1 - mag ** 2)
+    start = make_start(B, L, g)
+    dhr, dhi = rnd(B, L, C, g=g), rnd(B, L, C, g=g)
+
+    def run(dev, fn):
+        ts = [t.clone().to(dev).requires_grad_(True) for t in (vr, vi, lr, li, gamma)]
+        hr, hi = fn(*ts, start.to(dev))
+        ((hr * dhr.to(dev)).sum() + (hi * dhi.to(dev)).sum()).backward()
+        return hr, hi, [t.grad for t in ts]
+
+    r_ref = run('cpu', lambda a, b, c, d, e, s: K.linrec_complex_ref(a, b, c, d, s, gamma=e))
+    r_gpu = run('cuda', lambda a, b, c, d, e, s: ops.complex_scan(a, b, c, d, e, s))
+    close(r_gpu[0], r_ref[0], name='hr')
+    close(r_gpu[1], r_ref[1], name='hi')
+    for nm, a, b in zip(('dvr', 'dvi', 'dlam_re', 'dlam_im', 'dgamma'), r_gpu[2], r_ref[2]):
+        close(a, b, rtol=3e-4, atol_scale=1e-4, name=nm)
+
+
+# ------------------------------------------------------------------------------------------------ GRU
+@pytest.mark.parametrize('B,L,H', [(3, 20, 64), (18, 40, 256), (2, 130, 32)])
+def test_gru_seq_fwd_bwd_vs_aten(ops, B, L, H):
+    """Against torch.nn.GRU on CPU (the reference's GRU layer is exactly that module, rnn_base.py:59)."""
+    g = torch.Generator().manual_seed(H + L)
+    gru = torch.nn.GRU(H, H, batch_first=True)
+    with torch.no_grad():
+        for p in gru.parameters():
+            p.copy_(rnd(*p.shape, g=g, scale=1 / math.sqrt(H)))
+    x = rnd(B, L, H, g=g)
+    dy = rnd(B, L, H, g=g)
+    xr = x.clone().requires_grad_(True)
+    y_ref, _ = gru(xr)
+    (y_ref * dy).sum().backward()
+    ps = {n: p.detach().clone().cuda().requires_grad_(True) for n, p in gru.named_parameters()}
+    xg = x.clone().cuda().requires_grad_(True)
+    gi = torch.nn.functional.linear(xg, ps['weight_ih_l0'], ps['bias_ih_l0'])
+    y = ops.gru_seq(gi, ps['weight_hh_l0'], ps['bias_hh_l0'])
+    (y * dy.cuda()).sum().backward()
+    close(y, y_ref, name='h_all')
+    close(xg.grad, xr.grad, rtol=2e-4, atol_scale=5e-5, name='dx')
+    for n, p in gru.named_parameters():
+        close(ps[n].grad, p.grad, rtol=3e-4, atol_scale=1e-4, name=n)
+    # the oracle's explicit-formula GRU agrees with ATen too
+    y_or = K.gru_seq_ref(torch.nn.functional.linear(x, gru.weight_ih_l0, gru.bias_ih_l0), gru.weight_hh_l0, gru.bias_hh_l0)
+    close(y, y_or.detach(), name='h_all vs oracle')
+
+
+# ------------------------------------------------------------------------------------------------ SAC arithmetic
+def test_tanh_gaussian_fwd_bwd(ops):
+    g = torch.Generator().manual_seed(1)
+    out2 = rnd(5, 33, 12, g=g, scale=2.0)
+    out2[0, 0, :6] = 5.0       # clamped log-std (no gradient through the clamp)
+    out2[0, 1, :6] = -30.0
+    noise = rnd(5, 33, 6, g=g)
+    ds, dl = rnd(5, 33, 6, g=g), rnd(5, 33, 1, g=g)
+
+    def run(dev, fn):
+        o = out2.clone().to(dev).requires_grad_(True)
+        mean, samp, logp = fn(o, noise.to(dev))
+        ((samp * ds.to(dev)).sum() + (logp * dl.to(dev)).sum()).backward()
+        return mean, samp, logp, o.grad
+
+    ref = run('cpu', lambda o, n: K.tanh_gaussian_ref(o[..., 6:], o[..., :6], n))
+    got = run('cuda', ops.tanh_gaussian)
+    for nm, a, b in zip(('mean', 'sample', 'logp', 'dout2'), got, ref):
+        close(a, b, rtol=2e-4, atol_scale=5e-5, name=nm)
+
+
+def test_sac_target_and_guard(ops):
+    g = torch.Generator().manual_seed(2)
+    E, R, L = 8, 6, 50
+    q = rnd(E, R, L, 1, g=g, scale=3.0)
+    logp, reward = rnd(R, L, 1, g=g), rnd(R, L, 1, g=g)
+    done = (torch.rand(R, L, 1, generator=g) < 0.05).float()
+    mask = (torch.rand(R, L, 1, generator=g) < 0.8).float()
+    log_alpha = torch.tensor([-0.3])
+    guard = torch.tensor([1e6, -1e6, 0.0, 1 - 1e-3]).cuda()
+    stats = torch.zeros(2).cuda()
+    gmin = gmax = None
+    for it in range(3):
+        idx = torch.randperm(E, generator=g)[:2]
+        v = q[idx].min(dim=0).values - log_alpha.exp() * logp
+        if gmin is None:
+            gmin, gmax = v.min().item(), v.max().item()
+        ref = K.sac_target_ref(q[idx], logp, reward, done, log_alpha.exp(), 0.99, gmin, gmax)
+        got = ops.sac_target(q.cuda(), idx.int().cuda(), logp.cuda(), log_alpha.cuda(), reward.cuda(), done.cuda(), mask.cuda(),
+                             0.99, guard, stats)
+        close(got, ref, name=f'target[{it}]')
+        ym = ref * mask                                   # q_value_guard.py:29-38
+        gmin, gmax = min(gmin, ym.min().item()), max(gmax, ym.max().item())
+        gmin = (1 - 1e-3) * gmin + 1e-3 * ym.min().item()
+        gmax = (1 - 1e-3) * gmax + 1e-3 * ym.max().item()
+        gd = guard.cpu()
+        assert gd[0].item() == pytest.approx(gmin, rel=1e-5, abs=1e-5) and gd[1].item() == pytest.approx(gmax, rel=1e-5, abs=1e-5)
+        st = stats.cpu()
+        assert st[0].item() == pytest.approx(ref.abs().max().item(), rel=1e-5)
+        assert st[1].item() == mask.sum().item()
+        q = q + 0.1 * rnd(E, R, L, 1, g=g)
+
+
+def test_flat_optimizer_tail(ops):
+    g = torch.Generator().manual_seed(4)
+    n = 10007
+    p0, gr = rnd(n, g=g), rnd(n, g=g)
+    tgt = rnd(n, g=g)
+    t2 = tgt.clone().cuda()
+    ops.soft_update_(t2, p0.cuda(), 0.995)
+    close(t2, K.soft_update_ref(tgt, p0, 0.995), name='soft_update')
+    close(ops.sumsq(p0.cuda()), (p0 ** 2).sum().reshape(1), name='sumsq')
+    # AdamW with two learning-rate segments against torch.optim.AdamW
+    cut = 4001
+    a, b = p0[:cut].clone().requires_grad_(True), p0[cut:].clone().requires_grad_(True)
+    opt = torch.optim.AdamW([{'params': [a], 'lr': 1e-2, 'weight_decay': 0.0}, {'params': [b], 'lr': 3e-3, 'weight_decay': 0.01}])
+    pg, m, v = p0.clone().cuda(), torch.zeros(n).cuda(), torch.zeros(n).cuda()
+    seg_end = torch.tensor([cut, n], dtype=torch.int64).cuda()
+    seg_lr, seg_wd = torch.tensor([1e-2, 3e-3]).cuda(), torch.tensor([0.0, 0.01]).cuda()
+    for step in range(1, 4):
+        gstep = gr * step
+        a.grad, b.grad = gstep[:cut].clone(), gstep[cut:].clone()
+        opt.step()
+        ops.adamw_flat_(pg, gstep.cuda(), m, v, seg_end, seg_lr, seg_wd, step)
+    close(pg, torch.cat((a, b)).detach(), rtol=1e-5, atol_scale=1e-6, name='adamw')
