@@ -1,0 +1,260 @@
+"""Full-trajectory recurrent SAC with an ensemble critic: `train_one_batch()` - THE hot path
+(reference offpolicy_rnn/algorithm/sac_full_length_rnn_ensembleQ.py:297-467).
+
+Same contract (no arguments, returns the log dict with the reference's keys, `grad_num` gates the actor step) and the
+same arithmetic per update:
+    sample packed trajectories -> [no grad] actor + target critics on (s', s, a) -> REDQ / min target with the
+    Q-guard clamp -> critic step -> soft target update -> actor step (+ alpha step) on the live critics.
+What is organised differently for the MI355X:
+  * the sampled batch crosses PCIe ONCE as a single fp32 array (all fields, validity and the derived reset /
+    validity flags are columns of it); field tensors are column views on the device;
+  * target, Q-guard state and the running extrema stay on the device (`ops.sac_target`);
+  * losses are back-propagated as masked SUMS; the 1 / valid_num normalisation is applied inside the flat AdamW
+    kernel from a device scalar that rides in the gradient buffer - which is what makes the data-parallel version a
+    single all-reduce (parallel/data_parallel.py) with a global normalisation identical to the reference's;
+  * the actor step back-propagates only into the actor (`backward(inputs=...)`), skipping the critic weight gradients
+    that the reference computes and throws away;
+  * every scalar of the log dict is gathered on the device and fetched with one transfer at the end.
+"""
+from typing import Dict, List
+
+import numpy as np
+import torch
+
+from ..buffers.transition_buffer.nested_replay_memory import NestedMemoryArray as NestedTransitionMemoryArray
+from ..hip import ops
+from ..parallel.data_parallel import GradSync
+from ..policy_value_models.make_models import make_policy_model
+from ..utility.q_value_guard import QValueGuard
+from .sac import SAC
+
+FIELDS = ('state', 'last_state', 'action', 'last_action', 'next_state', 'done', 'mask', 'reward', 'reward_input', 'timeout', 'start')
+
+
+class SACFullLengthRNNEnsembleQ(SAC):
+    def __init__(self, parameter):
+        super().__init__(parameter)
+        assert self.parameter.value_net_num == 1
+        for item in self.parameter.value_layer_type:
+            assert item.startswith('e'), 'the critic MLP must be an ensemble (efc-<E>) stack'
+        for net in (self.values[0].embedding_network.layer_list + self.target_values[0].embedding_network.layer_list
+                    + self.values[0].uni_network.layer_list + self.target_values[0].uni_network.layer_list):
+            if hasattr(net, 'desire_ndim'):
+                net.desire_ndim = 4
+            if hasattr(net, 'in_proj') and hasattr(net.in_proj, 'desire_ndim'):
+                net.in_proj.desire_ndim = 4
+        self.logger(f'replay buffer skip len: {self._get_skip_len()}')
+        self.amp_scalar = self.amp_scalar_critic = None            # fp32 / bf16 paths need no loss scaling
+        self.replay_buffer = NestedTransitionMemoryArray(self.parameter.max_buffer_transition_num, self.env_info['max_trajectory_len'],
+                                                         additional_history_len=self._get_skip_len())
+        self.Q_guard = QValueGuard(guard_min=True, guard_max=True, decay_ratio=1.0 if self.discrete_env else 1 - 1e-3,
+                                   device=self.device)
+        # kept for API parity: built, hard-copied, never updated; only the non-REDQ TD3 trainer reads it
+        self.target_policy = make_policy_model(self.policy_args, self.base_algorithm, self.discrete_env)
+        self.target_policy.to(self.device)
+        self.target_policy.copy_weight_from(self.policy, tau=0.0)
+        self.target_policy.eval()
+        self.grad_sync = GradSync()
+        self._pinned = None
+        self._needs_seq_table = False
+        self._stats = torch.zeros(2, dtype=torch.float32, device=self.device)
+
+    step = property(lambda self: self.train_one_batch)          # north_star's "algorithm.step()" alias
+
+    def _get_skip_len(self):
+        skip = 0
+        for net in (self.values[0].uni_network, self.values[0].embedding_network, self.policy.uni_network, self.policy.embedding_network):
+            for i, lid in enumerate(net.layer_type):
+                if 'smamba' in lid:
+                    skip = max(net.layer_list[i].d_conv, skip)
+        return skip + 1
+
+    def _get_whether_require_amp(self):
+        return False
+
+    def _mask_mean(self, data: torch.Tensor, mask: torch.Tensor, valid_num) -> torch.Tensor:
+        return (data * mask).sum() / valid_num
+
+    # ------------------------------------------------------------------------------------------ batch
+    def _upload_batch(self, batch, valid, table):
+        """Host fix-ups + ONE host->device copy.  Returns dict of device views."""
+        arr = self.replay_buffer._last_batch_array                   # (rows, T', W) fp32: every field is a column range
+        rows, T, W = arr.shape
+        R = self.replay_buffer.name2range
+        need = rows * T * (W + 3)
+        if self._pinned is None or self._pinned.numel() < need:
+            cap = max(need, rows * self.replay_buffer.max_traj_step * (W + 3))
+            self._pinned = torch.empty(cap, dtype=torch.float32)
+            if self.device.type == 'cuda':
+                self._pinned = self._pinned.pin_memory()
+        staged = self._pinned[:need].view(rows, T, W + 3)
+        host = staged.numpy()
+        host[..., :W] = arr
+        start = arr[..., R['start'][0]]
+        v = valid[..., 0]
+        # flag surgery (reference :338-342): the target pass sees the slot before each sequence as valid / not-start
+        tv = v.copy()
+        tv[:, :-1][np.diff(v, axis=1) == 1] = 1
+        ts = start.copy()
+        ts[:, :-1][np.diff(start, axis=1) == -1] = 0
+        host[..., W], host[..., W + 1], host[..., W + 2] = v, tv, ts
+        d0, t0 = R['done'][0], R['timeout'][0]
+        host[..., d0][arr[..., t0] > 0] = 0                          # time-limit terminations bootstrap
+        dev = staged.to(self.device, non_blocking=True)
+        out = {name: dev[..., R[name][0]:R[name][1]] for name in FIELDS}
+        out['valid'], out['total_valid'], out['total_start'] = dev[..., W:W + 1], dev[..., W + 1:W + 2], dev[..., W + 2:W + 3]
+        # per-row sequence-length tables (reference :358-366) are consumed by attention layers only
+        out['attention_mask'] = out['target_attention_mask'] = None
+        if self._needs_seq_table:
+            am = np.zeros((rows, T), dtype=np.int32)
+            am[:, :table.shape[1]] = table
+            tam = np.concatenate((am[:, 1:], np.zeros((rows, 1), dtype=np.int32)), axis=1)
+            out['attention_mask'], out['target_attention_mask'] = torch.from_numpy(am).to(self.device), torch.from_numpy(tam).to(self.device)
+        return out
+
+    def _make_hidden(self, model, rows, start, mask, attn):
+        if self.parameter.randomize_first_hidden:
+            h = model.make_rnd_init_state(rows, device=self.device)
+        else:
+            h = model.make_init_state(rows, device=self.device)
+        h.set_rnn_start(start)
+        h.set_mask(mask)
+        h.set_attention_concat_mask(attn)
+        return h
+
+    # ------------------------------------------------------------------------------------------ target
+    def _next_action(self, b, hidden):
+        """(a', log pi(a'|s')) on the shifted inputs (s', s, a); TD3 trainers override."""
+        _, _, sample, logp, _, _ = self.policy.forward(b['next_state'], b['state'], b['action'], hidden, b['reward'])
+        return sample, logp
+
+    def _select_target_ensemble(self, num_ensemble: int) -> np.ndarray:
+        return np.arange(num_ensemble)                               # plain ensemble-min (REDQ trainers override)
+
+    def get_target_Q(self, b, policy_hidden, target_hiddens, stats):
+        with torch.no_grad():
+            sample, logp = self._next_action(b, policy_hidden)
+            q = self.target_values[0].forward(b['next_state'], b['state'], b['action'], sample, target_hiddens[0], b['reward'])[0]
+            idx = torch.from_numpy(np.ascontiguousarray(self._select_target_ensemble(q.shape[0]))).to(torch.int32).to(self.device)
+            return ops.sac_target(q, idx, logp if self.base_algorithm == 'sac' else None, self.log_sac_alpha.detach(), b['reward'],
+                                  b['done'], b['mask'], self.parameter.gamma, self.Q_guard.state, stats)
+
+    # ------------------------------------------------------------------------------------------ losses
+    def _q_for_policy(self, qs: torch.Tensor) -> torch.Tensor:
+        return qs.min(dim=0).values                                  # (REDQ trainers use the ensemble mean)
+
+    def _actor_objective(self, alpha, logp, q_pi):
+        return alpha * logp - q_pi                                   # (TD3 trainers drop the entropy term)
+
+    def _clip(self, store, model, max_norm, emb_max, scale):
+        """Optional gradient clipping on the *normalised* gradient (reference :239-250, 274-287)."""
+        gnorm = 0.0
+        if max_norm is None and emb_max is None:
+            return gnorm
+        store.grad[:store.numel].mul_(scale)
+        scale.fill_(1.0)
+        if max_norm is not None:
+            gnorm = torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm, norm_type=2)
+        if emb_max is not None:
+            torch.nn.utils.clip_grad_value_(model.embedding_network.parameters(), emb_max)
+            for layer in model.embedding_network.layer_list:
+                for sub in getattr(layer, 'layers', []):
+                    if hasattr(sub, 'mixer'):
+                        torch.nn.utils.clip_grad_value_([sub.mixer.A_log], 1e-3)
+            gnorm = 0.0
+        return gnorm
+
+    def _finish_step(self, optimizer, store, local_count):
+        """Exchange (sum) the flat gradient + the local valid count, then AdamW with grad / global count."""
+        store.grad[store.numel] = local_count
+        self.grad_sync.all_reduce_(store.grad)
+        return 1.0 / store.grad[store.numel:store.numel + 1]
+
+    # ------------------------------------------------------------------------------------------ the update
+    def train_one_batch(self) -> Dict:
+        par = self.parameter
+        self.policy.to(self.device)
+        self.optimizer_policy.to(self.device)
+        policy_update_cnt = 0
+        scal: Dict[str, torch.Tensor] = {}
+        host: Dict[str, float] = {}
+        for utd_idx in range(par.utd):
+            self.timer.register_point(tag='sample_trajs', level=2)
+            batch, batch_size, valid, table = self.replay_buffer.sample_trajs(
+                par.sac_batch_size, None, randomize_mask=par.randomize_mask, valid_number_post_randomized=par.valid_number_post_randomized,
+                equalize_data_of_each_traj=True, random_trunc_traj=par.random_trunc_traj, nest_stack_trajs=self.allow_nest_stack)
+            self.timer.register_end(level=2)
+            b = self._upload_batch(batch, valid, table)
+            rows = b['state'].shape[0]
+            value, target_value = self.values[0], self.target_values[0]
+            # hidden states + side channels: the target pass uses the one-slot-earlier flags (reference :368-378)
+            target_policy_hidden = self._make_hidden(self.policy, rows, b['total_start'], b['total_valid'], b['target_attention_mask'])
+            target_hiddens = [self._make_hidden(target_value, rows, b['total_start'], b['total_valid'], b['target_attention_mask'])]
+            value_hiddens = [self._make_hidden(value, rows, b['start'], b['valid'], b['attention_mask'])]
+            policy_hidden = self._make_hidden(self.policy, rows, b['start'], b['valid'], b['attention_mask'])
+            alpha_detach = self.log_sac_alpha.exp().detach()
+            mask = b['mask']
+
+            # 1. target (no grad); guard clamp/update + max|target| + sum(mask) happen inside the fused kernel
+            self.policy.eval()
+            target_Q = self.get_target_Q(b, target_policy_hidden, target_hiddens, self._stats)
+            valid_num = self._stats[1]
+
+            # 2. critic step
+            value.train()
+            q = value.forward(b['state'], b['last_state'], b['last_action'], b['action'], value_hiddens[0], b['reward_input'])[0]
+            q_loss_sum = ((q - target_Q.unsqueeze(0)).pow(2).sum(dim=0) * mask).sum()
+            self.optimizer_value.zero_grad()
+            q_loss_sum.backward()
+            scale = self._finish_step(self.optimizer_value, value.store, valid_num)
+            q_grad_norm = self._clip(value.store, value, par.value_max_gradnorm, par.value_embedding_max_gradnorm, scale)
+            self.optimizer_value.step(grad_scale=scale)
+            scal['critic_loss'] = q_loss_sum.detach() / valid_num
+            host['value_grad_norm'] = q_grad_norm
+
+            # 3. soft target update: one kernel over the flat buffers
+            self._value_update(tau=par.sac_tau)
+            value.eval()
+            self.policy.train()
+
+            # 4. actor (+ alpha) step
+            if self.grad_num % par.policy_update_per == 0 and (utd_idx + 1) / par.utd * par.policy_utd > policy_update_cnt:
+                action_mean, _, act_sample, log_prob, _, _ = self.policy.forward(b['state'], b['last_state'], b['last_action'],
+                                                                                policy_hidden, b['reward_input'])
+                act_in = act_sample if self.base_algorithm == 'sac' else action_mean
+                q_pi = value.forward(b['state'], b['last_state'], b['last_action'], act_in, value_hiddens[0], b['reward_input'],
+                                     detach_embedding=True)[0]
+                actor_sum = (self._actor_objective(alpha_detach, log_prob, self._q_for_policy(q_pi)) * mask).sum()
+                self.optimizer_policy.zero_grad()
+                actor_sum.backward(inputs=self.policy.parameters())
+                pstore = self.policy.store
+                tune_alpha = not par.no_alpha_auto_tune
+                if tune_alpha:     # d/d log_alpha of -sum(mask * log_alpha * (logp + H)) rides in the second spare slot
+                    pstore.grad[pstore.numel + 1] = -((log_prob.detach() + self.target_entropy) * mask).sum()
+                scale = self._finish_step(self.optimizer_policy, pstore, valid_num)
+                pi_grad_norm = self._clip(pstore, self.policy, par.policy_max_gradnorm, par.policy_embedding_max_gradnorm, scale)
+                self.optimizer_policy.step(grad_scale=scale)
+                if tune_alpha:
+                    g_alpha = pstore.grad[pstore.numel + 1:pstore.numel + 2] / pstore.grad[pstore.numel:pstore.numel + 1]
+                    scal['alpha_loss'] = (self.log_sac_alpha.detach() * g_alpha)[0]
+                    self.log_sac_alpha.grad = g_alpha.clone()
+                    self.optimizer_alpha.step()
+                    with torch.no_grad():
+                        self.log_sac_alpha.clamp_max_(1)
+                scal['log_prob'] = (log_prob.detach() * mask).sum() / valid_num
+                scal['actor_loss'] = actor_sum.detach() / valid_num
+                scal['policy_l2_norm_square'] = self.policy.l2_norm_square()
+                host['policy_grad_norm'] = pi_grad_norm
+                policy_update_cnt += 1
+        self.policy.to(self.sample_device)
+        scal.update(log_alpha=self.log_sac_alpha.detach()[0], target_q_max=self._stats[0], clip_min=self.Q_guard.state[0],
+                    clip_max=self.Q_guard.state[1], q1_l2_norm_square=self.values[0].l2_norm_square())
+        keys = list(scal)
+        vals = torch.stack([scal[k].reshape(()).float() for k in keys]).cpu().tolist()      # the only device->host sync
+        log = dict(zip(keys, vals))
+        if 'actor_loss' in log:
+            log['actor_loss'] = (log['actor_loss'],)            # a 1-tuple upstream (reference :430); kept
+        log.update({k: float(v) for k, v in host.items()})
+        log.update(real_batch_size=batch_size, real_batch_traj_num=rows, average_traj_len=self.replay_buffer.size / len(self.replay_buffer),
+                   amp_scalar_pi=0, amp_scalar_q=0)
+        return log

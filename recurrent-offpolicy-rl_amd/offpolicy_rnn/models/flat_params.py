@@ -1,0 +1,72 @@
+"""One contiguous fp32 buffer per network (MI355X-first parameter layout).
+
+Every nn.Parameter of a ContextualModel becomes a view into `flat`, every `.grad` a view into `grad`, in the
+contractual module / parameter order.  That turns the per-tensor Python loops of the
+reference into single HBM-bound kernels:
+    soft target update (rnn_base.py:490-491)        -> ops.soft_update_(target.flat, online.flat, tau)
+    AdamW with RESeL lr groups (…_sep_optim.py:49-66) -> ops.adamw_flat_(flat, grad, m, v, segment table)
+    l2_norm_square (rnn_base.py:531-532)            -> ops.sumsq(flat[prefix])
+    data-parallel gradient exchange                 -> ONE RCCL all-reduce of `grad`, no bucketing copies.
+Each tensor starts on a 16-byte boundary (kernels take float4 loads of D / delta_bias / norm weights)."""
+from collections import OrderedDict
+from typing import Dict, List, Tuple
+
+import torch
+
+
+class FlatParameterStore:
+    ALIGN = 4          # elements
+
+    def __init__(self, modules: 'OrderedDict[str, torch.nn.Module]', extra: int = 4):
+        """`extra` trailing fp32 slots ride along with the gradient buffer (e.g. the local valid-transition count and
+        the entropy-coefficient gradient), so that one all-reduce carries everything a step needs."""
+        self.modules = modules
+        self.slices: List[Tuple[torch.nn.Parameter, int, int]] = []
+        self.module_range: Dict[str, Tuple[int, int]] = {}
+        off = 0
+        for name, mod in modules.items():
+            begin = off
+            for p in mod.parameters(True):
+                n = p.numel()
+                self.slices.append((p, off, n))
+                off += (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+            self.module_range[name] = (begin, off)
+        self.numel = off
+        self.extra = extra
+        dev = self.slices[0][0].device if self.slices else torch.device('cpu')
+        self.flat = torch.zeros(off + extra, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(off + extra, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, o, n in self.slices:
+                self.flat[o:o + n].copy_(p.detach().reshape(-1))
+        self._repoint()
+
+    def _repoint(self):
+        for p, o, n in self.slices:
+            p.data = self.flat[o:o + n].view(p.shape)
+            p.grad = self.grad[o:o + n].view(p.shape)
+
+    def to(self, device):
+        if self.flat.device != torch.device(device):
+            self.flat = self.flat.to(device)
+            self.grad = self.grad.to(device)
+            self._repoint()
+        return self
+
+    def zero_grad(self):
+        self.grad.zero_()
+        for p, o, n in self.slices:          # autograd accumulates in place as long as .grad stays a view
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
+                p.grad = self.grad[o:o + n].view(p.shape)
+
+    def segments(self, lr_of_module, wd_of_module):
+        """-> (seg_end int64[n], seg_lr[n], seg_wd[n]) tensors on the buffer's device, one segment per module."""
+        ends, lrs, wds = [], [], []
+        for name, (a, b) in self.module_range.items():
+            if b > a:
+                ends.append(b)
+                lrs.append(lr_of_module(name))
+                wds.append(wd_of_module(name))
+        dev = self.flat.device
+        return (torch.tensor(ends, dtype=torch.int64, device=dev), torch.tensor(lrs, dtype=torch.float32, device=dev),
+                torch.tensor(wds, dtype=torch.float32, device=dev))

@@ -1,0 +1,50 @@
+"""`gilr` layer - gated input linear RNN (reference offpolicy_rnn/models/gilr/gilr.py:13-81).
+
+h_t = f_t h_{t-1} + (1 - f_t) v_t with v = tanh(.), f = sigmoid(.) (1 - rnn_start): the activations, the reset
+folding and the recurrence run in ONE time-parallel HIP kernel (`ops.gilr_scan`); the reference needs three
+element-wise passes plus a sequential Triton scan for the same thing."""
+import torch
+import torch.nn as nn
+
+from ..ensemble_linear_model import EnsembleLinear
+from ...hip import ops
+
+
+class PositionWiseFeedForward(nn.Module):
+    def __init__(self, d_model, dropout=0.1, eps=1e-5):
+        super().__init__()
+        self.w_1 = nn.Linear(d_model, d_model)
+        self.w_2 = nn.Linear(d_model, d_model)
+        self.activation = nn.GELU()
+        self.dropout = nn.Dropout(dropout)
+        self.layer_norm = nn.LayerNorm(d_model, eps=eps)
+
+    def forward(self, x):
+        y = self.dropout(self.activation(self.w_1(x)))
+        return self.layer_norm(self.dropout(self.w_2(y)) + x)
+
+
+class GILRLayer(nn.Module):
+    def __init__(self, input_dim, output_dim, factor=1, dropout=0.0, use_ff=True, batch_first=True):
+        super().__init__()
+        assert batch_first
+        self.d_model = output_dim
+        self.in_proj = EnsembleLinear(input_dim, self.d_model * factor, 2, desire_ndim=4)
+        self.out_proj = nn.Linear(self.d_model * factor, self.d_model * factor)
+        self.dropout = nn.Dropout(dropout)
+        self.layer_norm = nn.LayerNorm(factor * self.d_model)      # constructed (state_dict parity) but unused, as upstream
+        self.use_ff = use_ff
+        if use_ff:
+            self.ff = PositionWiseFeedForward(self.d_model, dropout)
+
+    def rnn_parameters(self):
+        return list(self.parameters(True))
+
+    def forward(self, x, hidden=None, rnn_start=None):
+        u = self.in_proj(x)                                         # [2, B, T, C]
+        h0 = None if hidden is None else hidden[0]
+        h = ops.gilr_scan(u[0], u[1], rnn_start, h0, True)
+        out = self.out_proj(h)
+        if self.use_ff:
+            out = self.ff(out)
+        return out, h[:, -1:, :].transpose(0, 1)

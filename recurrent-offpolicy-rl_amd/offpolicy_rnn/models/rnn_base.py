@@ -1,0 +1,235 @@
+"""RNNBase: a stack of layers selected by layer-id strings, with a per-layer (norm, activation) tail
+(reference offpolicy_rnn/models/rnn_base.py:31-532).
+
+Layer-id grammar kept from the reference (:101-247): `fc`, `efc-<E>`, `gru`, `gilr`, `lru`,
+`smamba[_s<N>][_c<K>][_b<blocks>][_n<ln|...>][_ff]`.  Ids of reference layers that are outside the MI355X hot path
+(`lstm`, `mamba*`, `gilr_lstm`, `conv1d*`, `e<rnn>-<E>`, `gpt*`, `cgpt*`, `transformer*`) are recognised and rejected
+with an explicit message.  Module / parameter naming (`layer_list.<i>.…`, `activation_list.<i>.0.…`) matches the
+reference so that its per-module checkpoints load."""
+import copy
+import os
+from typing import List, Optional, Tuple, Union
+
+import torch
+
+from .RNNHidden import RNNHidden
+from .ensemble_linear_model import EnsembleLinear
+from .gilr.gilr import GILRLayer
+from .gru import GRU
+from .lru.lru import LRULayer
+from .smamba.mamba import BlockList as MambaBlockList
+
+ACTIVATIONS = {'tanh': torch.nn.Tanh, 'relu': torch.nn.ReLU, 'sigmoid': torch.nn.Sigmoid, 'leaky_relu': torch.nn.LeakyReLU,
+               'linear': torch.nn.Identity, 'elu': torch.nn.ELU, 'gelu': torch.nn.GELU}
+_UNSUPPORTED_PREFIXES = ('lstm', 'mamba', 'gilr_lstm', 'conv1d', 'econv1d', 'gpt', 'cgpt', 'transformer', 'cgru', 'elru', 'egilr')
+
+
+def parse_smamba_id(layer_id: str) -> dict:
+    cfg = dict(d_conv=4, d_state=16, block_num=2, rms_norm=True, use_ff=False)
+    for tok in layer_id.split('_')[1:]:
+        if tok.startswith('s'):
+            cfg['d_state'] = int(tok[1:])
+        elif tok.startswith('c'):
+            cfg['d_conv'] = int(tok[1:])
+        elif tok.startswith('b'):
+            cfg['block_num'] = int(tok[1:])
+        elif tok.startswith('n'):
+            cfg['rms_norm'] = tok[1:] != 'ln'
+        elif tok.startswith('f'):
+            cfg['use_ff'] = cfg['use_ff'] or tok[1:] == 'f'
+        else:
+            raise ValueError(f'Pattern {tok} has not been implemented!')
+    return cfg
+
+
+def is_rnn_layer(layer_id: str) -> bool:
+    return layer_id != 'fc' and not layer_id.startswith('efc')
+
+
+class RNNBase(torch.nn.Module):
+    def __init__(self, input_size: int, output_size: int, hidden_size_list: List[int], activation: List[str],
+                 layer_type: List[str]):
+        super().__init__()
+        assert len(activation) - 1 == len(hidden_size_list), 'number of activation should be larger by 1 than size of hidden layers.'
+        assert len(activation) == len(layer_type), 'number of layer type should equal to the activate'
+        self.activation_dict = ACTIVATIONS
+        self.check_is_rnn = is_rnn_layer
+        self.layer_type = copy.deepcopy(layer_type)
+        self.activation_type = copy.deepcopy(activation)
+        self.layer_list = torch.nn.ModuleList()
+        self.activation_list = torch.nn.ModuleList()
+        self.rnn_hidden_state_input_size, self.rnn_layer_type = [], []
+        self.rnn_num = 0
+        self.input_size = input_size
+        width_in = input_size
+        for ind, width in enumerate(list(hidden_size_list) + [output_size]):
+            lid = self.layer_type[ind]
+            layer, hidden_width = self._make_layer(lid, width_in, width)
+            self.layer_list.append(layer)
+            if hidden_width is not None:
+                self.rnn_num += 1
+                self.rnn_hidden_state_input_size.append(hidden_width)
+                self.rnn_layer_type.append(lid)
+            self.activation_list.append(self._make_activation(activation[ind], width))
+            width_in = width
+        self.xavier_initialize_weights()
+
+    @staticmethod
+    def _make_layer(lid: str, n_in: int, n_out: int):
+        if lid == 'fc':
+            return torch.nn.Linear(n_in, n_out), None
+        if lid.startswith('efc'):
+            return EnsembleLinear(n_in, n_out, int(lid.split('-')[-1])), None
+        if lid == 'gru':
+            return GRU(n_in, n_out, batch_first=True), n_out
+        if lid == 'gilr':
+            return GILRLayer(n_in, n_out, batch_first=True), n_out
+        if lid == 'lru':
+            return LRULayer(n_in, n_out, batch_first=True), n_out * 2
+        if lid.startswith('smamba'):
+            cfg = parse_smamba_id(lid)
+            assert n_in == n_out, f'mamba_simple require input_dim == output_dim, while got {n_in} and {n_out}'
+            layer = MambaBlockList(cfg['block_num'], n_in, d_conv=cfg['d_conv'], d_state=cfg['d_state'], rms_norm=cfg['rms_norm'],
+                                   use_ff=cfg['use_ff'])
+            return layer, layer.desired_hidden_dim
+        if lid.startswith(_UNSUPPORTED_PREFIXES):
+            raise NotImplementedError(f'layer id {lid!r} exists in the reference but is outside the MI355X hot path of this build '
+                                      f'(supported: fc, efc-<E>, gru, gilr, lru, smamba_*)')
+        raise NotImplementedError(f'unknown layer id {lid!r}')
+
+    @staticmethod
+    def _make_activation(spec: str, width: int):
+        if '+' not in spec:
+            return ACTIVATIONS[spec]()
+        norm, act = spec.split('+')
+        if norm.startswith('eln'):
+            shape = [int(norm.split('-')[-1]), width]
+        elif norm == 'ln':
+            shape = width
+        else:
+            raise NotImplementedError(f'norm {norm}')
+        return torch.nn.ModuleList([torch.nn.LayerNorm(shape), ACTIVATIONS[act]()])
+
+    def xavier_initialize_weights(self):
+        """Xavier-uniform weights / zero biases for the plain layers; smamba keeps its own init (reference :267-354)."""
+        def xavier_ensemble(efc):
+            with torch.no_grad():
+                for i in range(efc.weight.shape[0]):
+                    torch.nn.init.xavier_uniform_(efc.weight[i].transpose(0, 1))
+                if getattr(efc, 'bias', None) is not None:
+                    efc.bias.zero_()
+        for m in self.layer_list:
+            if isinstance(m, torch.nn.Linear):
+                torch.nn.init.xavier_uniform_(m.weight)
+                if m.bias is not None:
+                    torch.nn.init.constant_(m.bias, 0)
+            elif isinstance(m, EnsembleLinear):
+                xavier_ensemble(m)
+            elif isinstance(m, LRULayer):
+                xavier_ensemble(m.in_proj)
+                xavier_ensemble(m.middle_proj)
+            elif isinstance(m, GILRLayer):
+                torch.nn.init.xavier_uniform_(m.out_proj.weight)
+                torch.nn.init.constant_(m.out_proj.bias, 0)
+                xavier_ensemble(m.in_proj)
+            elif isinstance(m, MambaBlockList):
+                pass
+            else:
+                for name, param in m.named_parameters():
+                    if 'weight' in name:
+                        torch.nn.init.xavier_uniform_(param.data)
+                    elif 'bias' in name:
+                        torch.nn.init.constant_(param.data, 0)
+
+    def rnn_parameters(self, recursive=True):
+        out = []
+        for lid, layer in zip(self.layer_type, self.layer_list):
+            if is_rnn_layer(lid):
+                out += list(layer.rnn_parameters()) if hasattr(layer, 'rnn_parameters') else list(layer.parameters(recursive))
+        return out
+
+    # ------------------------------------------------------------------------------------------ hidden state
+    def _make_state(self, batch_size, device, random: bool) -> RNNHidden:
+        st = RNNHidden(self.rnn_num, self.rnn_layer_type, device)
+        for width, lid in zip(self.rnn_hidden_state_input_size, self.rnn_layer_type):
+            make = st.init_random_hidden_by_type if random else st.init_hidden_by_type
+            st.append(make(lid, batch_size, width, device))
+        return st
+
+    def make_init_state(self, batch_size: int, device: Union[str, torch.device] = torch.device('cpu')) -> RNNHidden:
+        return self._make_state(batch_size, device, False)
+
+    def make_rnd_init_state(self, batch_size: int, device: Union[str, torch.device] = torch.device('cpu')) -> RNNHidden:
+        return self._make_state(batch_size, device, True)
+
+    # ------------------------------------------------------------------------------------------ forward
+    def meta_forward(self, x: torch.Tensor, hidden_state: Optional[RNNHidden] = None, require_full_hidden: bool = False
+                     ) -> Tuple[torch.Tensor, RNNHidden, Optional[RNNHidden]]:
+        assert x.shape[-1] == self.input_size, f'inputting size does not match!!!! input is {x.shape[-1]}, expected: {self.input_size}'
+        if hidden_state is None:
+            hidden_state = self.make_init_state(x.shape[0], x.device)
+        assert len(hidden_state) == self.rnn_num, f'rnn num does not match, input is {len(hidden_state)}, expected: {self.rnn_num}'
+        squeeze = x.dim() == 2 and self.rnn_num > 0
+        if squeeze:
+            x = x.unsqueeze(0)
+        out_state = RNNHidden(self.rnn_num, self.rnn_layer_type, device=x.device, batch_first=False)
+        full = RNNHidden(self.rnn_num, self.rnn_layer_type, device=x.device, batch_first=True) if require_full_hidden else None
+        k = 0
+        for ind, layer in enumerate(self.layer_list):
+            lid = self.layer_type[ind]
+            if is_rnn_layer(lid):
+                if lid == 'gilr':
+                    x, h = layer(x, hidden_state[k], hidden_state.rnn_start)
+                elif lid == 'lru':
+                    x, h = layer(x, hidden_state[k], hidden_state.rnn_start, hidden_state.grad_detach)
+                elif lid.startswith('smamba'):
+                    x, h = layer(x, hidden_state[k], hidden_state.rnn_start, hidden_state.mask)
+                else:                                   # gru: no reset / mask handling (reference :453-454)
+                    x, h = layer(x, hidden_state[k])
+                k += 1
+                out_state.append(h)
+                if require_full_hidden:
+                    full.append(x)
+            else:
+                x = layer(x)
+            act = self.activation_list[ind]
+            if isinstance(act, torch.nn.ModuleList):
+                if self.activation_type[ind].startswith('eln'):
+                    x = act[0](x.transpose(-2, 0)).transpose(-2, 0)
+                else:
+                    x = act[0](x)
+                x = act[1](x)
+            else:
+                x = act(x)
+        if squeeze:
+            x = x.squeeze(0)
+        return x, out_state, full
+
+    # ------------------------------------------------------------------------------------------ weights
+    @staticmethod
+    def _copy_weight_from(dst_net: torch.nn.Module, src_net: torch.nn.Module, tau: float):
+        """dst <- tau * dst + (1 - tau) * src  (tau = 0: hard copy).  Per-tensor form; ContextualModel overrides this
+        with one flat-buffer kernel for whole networks."""
+        with torch.no_grad():
+            if tau == 0.0:
+                dst_net.load_state_dict(src_net.state_dict())
+                return
+            if tau == 1.0:
+                return
+            src, dst = list(src_net.parameters(True)), list(dst_net.parameters(True))
+            assert len(src) == len(dst), 'parameter number show be equal!'
+            for s, d in zip(src, dst):
+                d.data.mul_(tau).add_(s.data, alpha=1 - tau)
+
+    def copy_weight_from(self, src_net: 'RNNBase', tau: float):
+        RNNBase._copy_weight_from(self, src_net, tau)
+
+    def save(self, path):
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        torch.save(self.state_dict(), path)
+
+    def load(self, path, **kwargs):
+        self.load_state_dict(torch.load(path, map_location=kwargs.get('map_location')))
+
+    def l2_norm_square(self) -> torch.Tensor:
+        return sum(torch.sum(p ** 2) for p in self.parameters(True))

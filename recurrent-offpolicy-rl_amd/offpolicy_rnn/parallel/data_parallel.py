@@ -1,0 +1,44 @@
+"""Batch-row data parallelism: one process per GPU, identical parameters everywhere, each rank trains on its own
+rows, ONE all-reduce (sum) of the flat gradient buffer per optimizer step (RCCL over xGMI; `gloo` in the CPU tests).
+
+The buffer's trailing slots carry the rank-local valid-transition count (and the entropy-coefficient gradient for the
+actor step), so the global normalisation `sum_r g_r / sum_r n_r` - exactly the reference's `/ valid_num`
+(sac_full_length_rnn_ensembleQ.py:80-81,391) over the global batch - needs no second collective and no host sync.
+The reference itself has no distributed code; this is new design."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+class GradSync:
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
+
+    def all_reduce_(self, flat_grad: torch.Tensor):
+        if self.world > 1:
+            dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+
+    def broadcast_(self, flat: torch.Tensor, src=0):
+        if self.world > 1:
+            dist.broadcast(flat, src=src, group=self.group)
+
+    def all_reduce_max_(self, t: torch.Tensor):
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+
+
+def init_from_env(backend=None):
+    """torchrun-style initialisation (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*).  Returns (rank, world, local_rank)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local

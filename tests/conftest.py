@@ -34,3 +34,10 @@ def nested(d, prefix):
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture
+def oracle_ops(monkeypatch):
+    """Swap the HIP op table for the CPU oracle (host-logic tests only; see tests/oracle_backend.py)."""
+    import oracle_backend
+    return oracle_backend.install(monkeypatch)

@@ -1,0 +1,104 @@
+"""Test-only kernel stand-ins: route `offpolicy_rnn.hip.ops` to the CPU oracle so that the HOST logic of the product
+(buffers -> trainer orchestration -> optimizer / DP plumbing) can be exercised in the GPU-less container.
+
+This is test infrastructure: the product never imports it, and on a GPU box the real HIP kernels run instead
+(tests/test_hip_ops.py, tests/test_trainer_gpu.py).  Installed by the `oracle_ops` fixture in conftest.py."""
+import math
+
+import torch
+
+from oracle import kernels as K
+
+
+def _flag(t, B, L):
+    return None if t is None else t.reshape(B, L)
+
+
+def selective_scan_tm(u, delta, A, Bm, Cm, D=None, z=None, delta_bias=None, start=None, delta_softplus=True, return_last_state=False):
+    out, last = K.selective_scan_ref(u, delta, A, Bm, Cm, D, z, delta_bias, _flag(start, *u.shape[:2]), delta_softplus)
+    return (out, last) if return_last_state else out
+
+
+def causal_conv1d_fn(x, weight, bias=None, mask=None, activation=True):
+    return K.causal_conv1d_silu_ref(x, weight.reshape(x.shape[-1], -1), bias, _flag(mask, *x.shape[:2]), activation)
+
+
+def _norm(rms):
+    def fn(x, weight, bias, residual=None, eps=1e-6, prenorm=False, residual_in_fp32=False):
+        y, res = K.add_layernorm_ref(x, residual, weight, bias, eps, rms)
+        return (y, res) if prenorm else y
+    return fn
+
+
+def gilr_scan(v, f, start=None, h0=None, fuse_act=True):
+    return K.linrec_real_ref(v, f, _flag(start, *v.shape[:2]), h0, fuse_act)[0]
+
+
+def complex_scan(vr, vi, lam_re, lam_im, gamma=None, start=None, h0r=None, h0i=None):
+    h0r = None if h0r is None else h0r.reshape(vr.shape[0], -1)
+    h0i = None if h0i is None else h0i.reshape(vr.shape[0], -1)
+    return K.linrec_complex_ref(vr, vi, lam_re, lam_im, _flag(start, *vr.shape[:2]), h0r, h0i, gamma)
+
+
+def gru_seq(gi, w_hh, b_hh, h0=None):
+    return K.gru_seq_ref(gi, w_hh, b_hh, h0)
+
+
+def tanh_gaussian(out2, noise):
+    A = out2.shape[-1] // 2
+    mean, samp, logp = K.tanh_gaussian_ref(out2[..., A:], out2[..., :A], noise)
+    return mean.detach(), samp, logp
+
+
+@torch.no_grad()
+def sac_target(q, subset, next_logp, log_alpha, reward, done, mask, gamma, guard, stats=None):
+    idx = subset.long()
+    v = q[idx].min(dim=0).values
+    if next_logp is not None:
+        v = v - log_alpha.exp() * next_logp
+    if guard[2] == 0:
+        guard[0], guard[1], guard[2] = v.min(), v.max(), 1.0
+    y = reward + (1 - done) * gamma * v.clamp(min=guard[0].item(), max=guard[1].item())
+    ym = y * mask
+    lo, hi = torch.minimum(guard[0], ym.min()), torch.maximum(guard[1], ym.max())
+    decay = guard[3]
+    if decay < 1:
+        lo, hi = decay * lo + (1 - decay) * ym.min(), decay * hi + (1 - decay) * ym.max()
+    guard[0], guard[1] = lo, hi
+    if stats is not None:
+        stats[0], stats[1] = y.abs().max(), mask.sum()
+    return y
+
+
+@torch.no_grad()
+def soft_update_(target_flat, online_flat, tau):
+    target_flat.copy_(K.soft_update_ref(target_flat, online_flat, tau))
+
+
+@torch.no_grad()
+def adamw_flat_(p, g, m, v, seg_end, seg_lr, seg_wd, step, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=None):
+    gs = g if grad_scale is None else g * grad_scale
+    a = 0
+    for e, lr, wd in zip(seg_end.tolist(), seg_lr.tolist(), seg_wd.tolist()):
+        pn, mn, vn = K.adamw_ref(p[a:e], gs[a:e], m[a:e], v[a:e], step, lr, beta1, beta2, eps, wd)
+        p[a:e], m[a:e], v[a:e] = pn, mn, vn
+        a = e
+
+
+@torch.no_grad()
+def sumsq(x, out=None):
+    r = (x.float() ** 2).sum().reshape(1)
+    if out is not None:
+        out.copy_(r)
+        return out
+    return r
+
+
+def install(monkeypatch):
+    from offpolicy_rnn.hip import ops
+    table = dict(selective_scan_tm=selective_scan_tm, causal_conv1d_fn=causal_conv1d_fn, layer_norm_fn=_norm(False),
+                 rms_norm_fn=_norm(True), gilr_scan=gilr_scan, complex_scan=complex_scan, gru_seq=gru_seq, tanh_gaussian=tanh_gaussian,
+                 sac_target=sac_target, soft_update_=soft_update_, adamw_flat_=adamw_flat_, sumsq=sumsq)
+    for k, fn in table.items():
+        monkeypatch.setattr(ops, k, fn)
+    return ops
