@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""bench.py - env-steps/sec trained by the full-trajectory recurrent SAC update on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]            (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one `train_one_batch()` (sample B trajectories -> H2D -> target -> critic step -> soft update -> actor +
+alpha step) on synthetic Gaussian trajectories.  Workload at N = 1 = BASELINE.json configs[1]:
+smamba_s32_c16_b2_nln SAC, B=64, T=1024, obs=17, act=6, published RESeL architecture (D=256, efc-8 critic).
+N > 1 keeps B=64 rows per GPU (weak scaling; N = 8 is configs[3]'s global B=512) with ONE RCCL all-reduce of the flat
+gradient buffer per optimizer step.  Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, 'recurrent-offpolicy-rl_amd')):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np
+import torch
+
+OBS, ACT = 17, 6
+
+
+def make_parameter(rnn, B, T, D=256, algo='sac'):
+    argv, sys.argv = sys.argv, ['bench']
+    from offpolicy_rnn import Parameter
+    p = Parameter()
+    sys.argv = argv
+    p.alg_name = ('sac' if algo == 'sac' else 'td3') + '_rnn_full_horizon_redQ_sep_optim'
+    p.env_name = f'synthetic-o{OBS}-a{ACT}-T{T}'
+    p.value_net_num, p.cuda_inference = 1, True
+    for w in ('value', 'policy'):                       # gen_tmuxp_mamba_pomdp.py:43-86 with the RNN id swapped
+        setattr(p, f'{w}_embedding_layer_type', ['fc', rnn, 'fc'])
+        setattr(p, f'{w}_embedding_activations', ['elu', 'elu', 'linear'])
+        setattr(p, f'{w}_embedding_hidden_size', [D, D])
+        setattr(p, f'{w}_hidden_size', [D, D])
+        setattr(p, f'{w}_activations', ['elu', 'elu', 'linear'])
+        setattr(p, f'{w}_embedding_dim', 128)
+        setattr(p, f'{w}_uni_model_input_mapping_dim', 128)
+    p.value_layer_type, p.policy_layer_type = ['efc-8'] * 3, ['fc'] * 3
+    p.state_action_encoder = p.last_state_input = True
+    p.alpha_lr, p.policy_update_per = 1e-4, 1          # every update identical (SURVEY.md 8(d) metric 1)
+    p.sac_batch_size = B * T - 1                        # exactly B trajectories per batch
+    p.max_buffer_transition_num = 4 * B * T
+    return p
+
+
+def fill_synthetic(alg, n_traj, T, seed):
+    rs = np.random.RandomState(seed)
+    for _ in range(n_traj):
+        obs = rs.randn(T + 1, OBS)
+        act = np.tanh(rs.randn(T, ACT))
+        rew = rs.randn(T, 1)
+        last = np.zeros((T, 1))
+        last[-1] = 1
+        first = np.zeros((T, 1))
+        first[0] = 1
+        alg.replay_buffer.push_trajectory(dict(
+            state=obs[:-1], last_state=np.vstack((np.zeros((1, OBS)), obs[:-2])), last_action=np.vstack((np.zeros((1, ACT)), act[:-1])),
+            action=act, next_state=obs[1:], reward=rew, logp=None, mask=np.ones((T, 1)), start=first, done=last,
+            reward_input=np.vstack((np.zeros((1, 1)), rew[:-1])), timeout=last))
+
+
+def build_trainer(rnn, B, T, seed=0, algo='sac'):
+    from offpolicy_rnn import alg_init
+    alg = alg_init(make_parameter(rnn, B, T, algo=algo))
+    fill_synthetic(alg, 2 * B, T, seed)
+    return alg
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--rnn', default='smamba_s32_c16_b2_nln')
+    ap.add_argument('--rows', type=int, default=64, help='trajectories per GPU per update')
+    ap.add_argument('--horizon', type=int, default=1024)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    from offpolicy_rnn.parallel.data_parallel import init_from_env
+    import torch.distributed as dist
+    rank, world, local = init_from_env()
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    torch.cuda.set_device(local)
+    torch.manual_seed(1234 + rank)
+    np.random.seed(1234 + rank)                         # each rank samples its own rows
+    alg = build_trainer(args.rnn, args.rows, args.horizon, seed=rank)
+    alg.grad_sync.__init__()                            # pick up the process group
+    if world > 1:
+        for net in [alg.policy] + alg.values + alg.target_values:
+            alg.grad_sync.broadcast_(net.store.flat)
+    from offpolicy_rnn.hip import ops
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        alg.train_one_batch()
+        alg.grad_num += 1
+    ops.profile_enable(True)                            # HIP event pair bound to each scan dispatch, timed region only
+    sync()
+    t0 = time.perf_counter()
+    trained = 0
+    for _ in range(args.steps):
+        trained += alg.train_one_batch()['real_batch_size']
+        alg.grad_num += 1
+    sync()
+    dt = time.perf_counter() - t0
+    prof = ops.profile_collect()
+    ops.profile_enable(False)
+    stat = torch.tensor([dt, float(trained)], dtype=torch.float64, device='cuda')
+    if world > 1:
+        tmax = stat[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tot = stat[1:].clone()
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dt, trained = tmax.item(), tot.item()
+    if rank != 0:
+        return
+    Bsz, Tp = args.rows, alg.replay_buffer._last_batch_array.shape[1]
+    kern = {name: dict(launches=n, avg_us=avg) for name, (n, avg) in prof.items()}
+    out = {
+        'metric': 'env-steps/sec trained', 'value': trained / dt, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'{args.rnn} SAC-REDQ full-trajectory update, B={Bsz}/GPU, T={args.horizon} (row length {Tp}), obs={OBS}, act={ACT}, '
+                               f'D=256, efc-8 critic (BASELINE configs[1]; N=8 is configs[3])',
+                   'global_rows': Bsz * world, 'parallelism': f'dp{world}'},
+    }
+    if 'sscan_fwd_kernel' in kern and args.rnn.startswith('smamba'):
+        Di, N = 512, int(args.rnn.split('_s')[1].split('_')[0])
+        fwd_bytes = 4 * Bsz * Di * Tp * 4 + 4 * Bsz * N * Tp * 2 + Bsz * Tp      # u, delta, z, out + B, C + start(u8)
+        bwd_bytes = 4 * Bsz * Di * Tp * 7 + 4 * Bsz * N * Tp * 4
+        a = fwd_bytes / (kern['sscan_fwd_kernel']['avg_us'] * 1e-6) / 1e9
+        out['roofline'] = {'kernel': 'sscan_fwd_kernel', 'bound': 'hbm', 'achieved': a, 'peak': 8000.0, 'unit': 'GB/s', 'frac': a / 8000.0,
+                           'traffic': None, 'avg_us': kern['sscan_fwd_kernel']['avg_us'], 'algorithmic_bytes': fwd_bytes}
+        if 'sscan_bwd_kernel' in kern:
+            ab = bwd_bytes / (kern['sscan_bwd_kernel']['avg_us'] * 1e-6) / 1e9
+            out['roofline_bwd'] = {'kernel': 'sscan_bwd_kernel', 'bound': 'hbm', 'achieved': ab, 'peak': 8000.0, 'unit': 'GB/s',
+                                   'frac': ab / 8000.0, 'avg_us': kern['sscan_bwd_kernel']['avg_us'], 'algorithmic_bytes': bwd_bytes}
+    out['kernels'] = kern
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle.trainer import time_cpu_baseline
+        cores = min(32, os.cpu_count() or 1)      # more threads run the T-sequential ATen GRU slower on the 2x64-core host
+        base = time_cpu_baseline('gru', B=64, T=1024, updates=1, warmup=0, threads=cores)
+        out['cpu_baseline'] = {'value': base['value'], 'unit': 'env-steps/s', 'cores': base['cores'], 'kind': 'port',
+                               'sample': base['sample'] + f'; {base["seconds_per_update"]:.2f} s/update'}
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

@@ -37,6 +37,13 @@ typedef void* resel_stream_t; /* hipStream_t */
 int resel_abi_version(void);            /* bumps when a signature changes */
 const char* resel_build_info(void);     /* "gfx950 <date> ..." */
 
+/* Diagnostics for bench.py (off by default; the only global state of the library).  While enabled, the selective-scan
+ * kernels are dispatched with a (start, stop) HIP event pair bound to each dispatch on its own stream;
+ * resel_profile_collect() synchronises those events, returns their summed duration and count and clears them.
+ * kernel_id: 0 = sscan_fwd_kernel, 1 = sscan_bwd_kernel. */
+int resel_profile_enable(int on);
+int resel_profile_collect(int kernel_id, double* total_us, int* launches);
+
 /* ------------------------------------------------------------------------------------------------------
  * smamba selective scan.  Replaces `selective_scan_cuda.fwd / .bwd` (modified Mamba CUDA extension with the
  * extra `start` reset input) bound at offpolicy_rnn/models/smamba/mamba_ssm/ops/selective_scan_interface_new.py:47
@@ -91,7 +98,7 @@ int resel_causal_conv1d_bwd(const float* x, int64_t ld_x, const float* w, const 
 /* ------------------------------------------------------------------------------------------------------
  * Fused residual add + LayerNorm / RMSNorm.  Replaces the Triton kernels `_layer_norm_fwd_1pass_kernel` /
  * `_layer_norm_bwd_kernel` (offpolicy_rnn/models/smamba/mamba_ssm/ops/triton/layernorm.py:65,196; CPU spec
- * layernorm_cpu.py:6-35).  rows M, width C (C % 4 == 0, C <= 8192), all dense [M, C].
+ * layernorm_cpu.py:6-35).  rows M, width C (C % 4 == 0, C <= 2048), all dense [M, C].
  *   res_out = x (+ residual) ; y = (res_out - mean) * rstd * w + b      (rms: y = res_out * rstd * w (+ b))
  * residual / res_out / bias may be NULL.  stats: [M, 2] (mean, rstd) saved for the backward.
  * Backward: dres_in (optional, [M, C]) is the gradient arriving at res_out from downstream; dx receives the

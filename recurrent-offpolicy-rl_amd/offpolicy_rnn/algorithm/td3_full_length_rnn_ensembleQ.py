@@ -2,6 +2,7 @@
 deterministic actor, clipped-noise target smoothing, no entropy term, no alpha tuning."""
 import torch
 
+from ..utility import rng
 from .sac_full_length_rnn_ensembleQ import SACFullLengthRNNEnsembleQ
 
 
@@ -16,7 +17,7 @@ class TD3FullLengthRNNEnsembleQ(SACFullLengthRNNEnsembleQ):
         net = self.policy if self.target_from_live_policy else self.target_policy
         mean = net.forward(b['next_state'], b['state'], b['action'], hidden, b['reward'])[0]
         par = self.parameter
-        noise = torch.clamp(torch.randn_like(mean) * par.target_action_noise_std, -par.target_action_noise_clip, par.target_action_noise_clip)
+        noise = torch.clamp(rng.randn_like(mean) * par.target_action_noise_std, -par.target_action_noise_clip, par.target_action_noise_clip)
         return torch.clamp(mean + noise, -1, 1), None
 
     def _actor_objective(self, alpha, logp, q_pi):

@@ -116,6 +116,32 @@ class MemoryArray:
         if self.ptr >= self.max_transition_num:
             self.ptr = 0
 
+    def push_trajectory(self, fields: dict):
+        """Bulk insert of one finished trajectory given per-field arrays of shape [n, width] (same result as n
+        `mem_push` calls; used to load synthetic / pre-recorded data without a Python loop per transition)."""
+        n = len(next(iter(fields.values())))
+        if self.memory_buffer is None:
+            self._init_memory_buffer(Transition(*[None if fields.get(k) is None else np.asarray(fields[k]).reshape(n, -1)[0] for k in tuplenames]))
+        drop, count = 0, self.transition_count
+        while count + n > self.max_transition_num:
+            count -= self.trajectory_length[drop]
+            drop += 1
+        if drop:
+            self.transition_count = count
+            del self.trajectory_start[:drop]
+            del self.trajectory_length[:drop]
+        rows = self.memory_buffer[self.ptr:self.ptr + n]
+        for name in tuplenames:
+            a, b = self.name2range[name]
+            if b > a:
+                rows[:, a:b] = np.asarray(fields[name], dtype=np.float64).reshape(n, -1)
+        self.trajectory_start.append(self.ptr)
+        self.trajectory_length.append(n)
+        self.transition_count += n
+        self.ptr += n
+        if self.ptr >= self.max_transition_num:
+            self.ptr = 0
+
     # ------------------------------------------------------------------ sampling
     @property
     def available_traj_num(self):

@@ -18,6 +18,8 @@ P, I, L, F, S = c_void_p, c_int, c_int64, c_float, c_void_p
 SIGNATURES = {
     'resel_abi_version': (c_int, []),
     'resel_build_info': (ctypes.c_char_p, []),
+    'resel_profile_enable': (c_int, [I]),
+    'resel_profile_collect': (c_int, [I, P, P]),
     'resel_selective_scan_ckpt_bytes': (c_size_t, [I, I, I, I]),
     'resel_selective_scan_fwd': (c_int, [P, L, P, L, P, L, P, P, L, P, L, P, P, P, P, L, P, P, I, I, I, I, I, S]),
     'resel_selective_scan_bwd_workspace_bytes': (c_size_t, [I, I, I, I]),

@@ -51,6 +51,22 @@ def _ws(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
 
+def profile_enable(on: bool):
+    """Bind a (start, stop) HIP event pair to every selective-scan dispatch (bench.py's roofline measurement)."""
+    check(lib().resel_profile_enable(int(bool(on))), 'profile_enable')
+
+
+def profile_collect():
+    """-> {kernel: (launches, avg_us)} for the dispatches recorded since the last call."""
+    out = {}
+    for kid, name in ((0, 'sscan_fwd_kernel'), (1, 'sscan_bwd_kernel')):
+        tot, n = ctypes.c_double(0.0), ctypes.c_int(0)
+        check(lib().resel_profile_collect(kid, ctypes.byref(tot), ctypes.byref(n)), 'profile_collect')
+        if n.value:
+            out[name] = (n.value, tot.value / n.value)
+    return out
+
+
 # ---------------------------------------------------------------------------------------------- selective scan
 class SelectiveScanFn(torch.autograd.Function):
     """Token-major selective scan with start resets.  Interface counterpart of the reference's

@@ -8,6 +8,7 @@ from ..hip import ops
 from ..models.RNNHidden import RNNHidden
 from ..models.contextual_model import ContextualModel
 from . import _inputs
+from ..utility import rng
 from .utils import nearest_power_of_two, nearest_power_of_two_half
 
 
@@ -52,7 +53,7 @@ class ContextualSACPolicySingleHead(ContextualModel):
     def process_model_out(self, out2, noise=None):
         """out2 = (logstd | mean).  noise defaults to a fresh N(0, I) draw (torch generator of out2's device)."""
         if noise is None:
-            noise = torch.randn(out2.shape[:-1] + (out2.shape[-1] // 2,), device=out2.device, dtype=out2.dtype)
+            noise = rng.randn(out2.shape[:-1] + (out2.shape[-1] // 2,), out2.device, out2.dtype)
         return ops.tanh_gaussian(out2, noise)
 
     def forward_embedding(self, state, lst_state, lst_action, rnn_memory, reward):

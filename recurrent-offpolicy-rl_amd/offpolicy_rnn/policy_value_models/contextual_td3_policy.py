@@ -1,6 +1,7 @@
 """Deterministic TD3 actor (reference offpolicy_rnn/policy_value_models/contextual_td3_policy.py:6-36)."""
 import torch
 
+from ..utility import rng
 from .contextual_sac_policy import ContextualSACPolicy
 
 
@@ -18,5 +19,5 @@ class ContextualTD3Policy(ContextualSACPolicy):
         emb_in = self.get_embedding_input(state, lst_state, lst_action, reward)
         out, rnn_memory, emb, full = self.meta_forward(emb_in, state, rnn_memory, detach_embedding)
         action_mean = torch.tanh(out)
-        action_sample = torch.clamp(action_mean + torch.randn_like(out) * self.sample_std, -1, 1)
+        action_sample = torch.clamp(action_mean + rng.randn_like(out) * self.sample_std, -1, 1)
         return action_mean, emb, action_sample, torch.zeros_like(action_sample), rnn_memory, full
