@@ -57,7 +57,7 @@ int resel_profile_collect(int kernel_id, double* total_us, int* launches);
  * ckpt (optional, for the backward): state checkpoints every RESEL_SSCAN_CKPT steps,
  *   resel_selective_scan_ckpt_bytes(B, L, Di, N) bytes.  last_state (optional): [B, Di, N].
  */
-#define RESEL_SSCAN_CKPT 64
+#define RESEL_SSCAN_CKPT 16
 size_t resel_selective_scan_ckpt_bytes(int B, int L, int Di, int N);
 int resel_selective_scan_fwd(const float* u, int64_t ld_u, const float* delta, int64_t ld_delta,
                              const float* z, int64_t ld_z, const float* A,

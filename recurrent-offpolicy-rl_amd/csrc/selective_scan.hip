@@ -13,10 +13,14 @@
 //   * block id -> (b, channel tile) is XCD-aware: blocks are dealt round-robin over the 8 XCDs, so the
 //     Di/64 channel tiles of one row b are given ids that differ by multiples of 8 and share one L2 for the
 //     B_t / C_t rows they all read (speed only; any placement is correct).
-// Backward: reverse-time recurrence with two-level recomputation - the forward leaves a state checkpoint
-// every 64 steps, the backward rebuilds 16-step sub-checkpoints (registers) and then a 16-step state history
-// (registers) per sub-chunk.  Reductions over channels (dB, dC) use an in-wave multi-value butterfly plus
-// per-tile partial slabs summed by a second kernel: no float atomics, bitwise reproducible.
+// Backward: reverse-time recurrence with recomputation - the forward leaves a state checkpoint every 16 steps
+// (free: the forward is VALU-bound, not HBM-bound), the backward stages one 16-step interval in LDS, replays it from
+// the checkpoint in two 8-step halves whose (state, decay) history lives in registers, and sweeps each half in
+// reverse.  Reductions over channels (dB, dC) use an in-wave multi-value butterfly (DPP) plus per-tile partial
+// slabs summed by a second kernel: no float atomics, bitwise reproducible.
+// Rates that shape both kernels (tools/micro/valu_rate.hip, MI355X): wave64 v_fma/v_mul_f32 = 4 cycles per SIMD,
+// v_pk_fma/v_pk_mul_f32 = 5.6 (two results), v_exp_f32 = 8 - the per-state arithmetic is therefore written on
+// float2 pairs, and with N = 32 states the kernels are VALU-bound well below the HBM roofline.
 #include "resel_common.h"
 #include <hip/hip_ext.h>
 #include <vector>
@@ -44,16 +48,16 @@ void launch_maybe_timed(int slot, K kernel, dim3 grid, dim3 block, hipStream_t s
 }
 
 constexpr int TILE_C = 64;            // channels per workgroup
-constexpr int TC = 32;                // time steps per LDS chunk (forward)
 constexpr int CKS = RESEL_SSCAN_CKPT; // checkpoint stride
-constexpr int SC = 16;                // backward sub-chunk (state history kept in registers)
-constexpr int NSUB = CKS / SC;
+constexpr int SC = 16;                // backward sub-chunk = one checkpoint interval staged in LDS
+constexpr int SCH = 8;                // steps of (h, dA) history kept in registers
+static_assert(CKS == SC, "the backward replays one checkpoint interval per sub-chunk");
 
 struct FwdParams {
     const float *u, *delta, *z, *A, *Bm, *Cm, *D, *delta_bias, *start;
     float *out, *ckpt, *last_state;
     int64_t ld_u, ld_delta, ld_z, ld_b, ld_c, ld_out;
-    int B, L, Di, N, nck, softplus, nd;
+    int B, L, Di, N, nck, softplus, nd, bc_vec;
 };
 
 template <int NS>
@@ -70,13 +74,64 @@ __device__ __forceinline__ bool decode_block(int id, int nd, int B, int& b, int&
     return b < B;
 }
 
-template <int NS, int NW>
+// NS wave-uniform coefficients from LDS (every lane reads the same address: one broadcast ds_read_b128 / b64 / b32)
+template <int NS>
+__device__ __forceinline__ void lds_coef(const float* p, float (&dst)[NS]) {
+    if constexpr (NS % 4 == 0) {
+#pragma unroll
+        for (int j = 0; j < NS; j += 4) {
+            const float4 v = ld4(p + j);
+            dst[j] = v.x; dst[j + 1] = v.y; dst[j + 2] = v.z; dst[j + 3] = v.w;
+        }
+    } else if constexpr (NS == 2) {
+        const float2 v = *reinterpret_cast<const float2*>(p);
+        dst[0] = v.x; dst[1] = v.y;
+    } else {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) dst[j] = p[j];
+    }
+}
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// the same as float2 pairs (NS odd: the upper lane of the last pair is zero)
+template <int NS>
+__device__ __forceinline__ void lds_coef2(const float* p, f2 (&dst)[(NS + 1) / 2]) {
+    if constexpr (NS % 4 == 0) {
+#pragma unroll
+        for (int j = 0; j < NS; j += 4) {
+            const float4 v = ld4(p + j);
+            dst[j / 2] = f2{v.x, v.y};
+            dst[j / 2 + 1] = f2{v.z, v.w};
+        }
+    } else if constexpr (NS == 2) {
+        const float2 v = *reinterpret_cast<const float2*>(p);
+        dst[0] = f2{v.x, v.y};
+    } else {
+        dst[0] = f2{p[0], 0.f};
+    }
+}
+
+// 4 consecutive floats of a [tok, N] coefficient matrix with token stride ld (vector load when the layout allows it)
+__device__ __forceinline__ float4 load_bc4(const float* base, int64_t tok, int64_t ld, int c, bool vec) {
+    const float* q = base + tok * ld + c;
+    if (vec) return ld4(q);
+    return make_float4(q[0], q[1], q[2], q[3]);
+}
+
+template <int NS, int NW, int TC>
 __global__ __launch_bounds__(NW * 64) void sscan_fwd_kernel(FwdParams p) {
     constexpr int NT = NW * 64;
-    constexpr int PER_T = (TC * 16) / NT;          // float4 tile items per thread
+    constexpr int N = NS * NW;
+    constexpr int PER_T = (TC * 16 + NT - 1) / NT; // float4 tile items per thread (u / delta / z / out)
+    constexpr int BC_ITEMS = TC * N / 4;           // float4 items of a [TC][N] coefficient tile
+    constexpr int PER_BC = (BC_ITEMS + NT - 1) / NT;
     __shared__ __attribute__((aligned(16))) float s_dl[TC][TILE_C];
     __shared__ __attribute__((aligned(16))) float s_du[TC][TILE_C];
     __shared__ __attribute__((aligned(16))) float s_y[NW][TC][TILE_C];
+    __shared__ __attribute__((aligned(16))) float s_B[TC][N];
+    __shared__ __attribute__((aligned(16))) float s_C[TC][N];
+    __shared__ float s_st[TC];
 
     int b, dt;
     if (!decode_block(blockIdx.x, p.nd, p.B, b, dt)) return;
@@ -86,16 +141,22 @@ __global__ __launch_bounds__(NW * 64) void sscan_fwd_kernel(FwdParams p) {
     const int d0 = dt * TILE_C;
     const int d = d0 + lane;
     const bool d_ok = d < p.Di;
-    const int N = NS * NW;
     const int64_t tok0 = (int64_t)b * p.L;
 
     // per-lane recurrence constants: A (pre-scaled for exp2; clamped below zero so that the reset trick
     // delta := +inf always yields exp2(-inf) = 0) for this lane's channel and this wave's states
-    float A2[NS], h[NS];
+    constexpr int NP = (NS + 1) / 2;                // states are processed as float2 pairs (odd NS: padded lane is inert)
+    f2 A2p[NP], hp[NP];
 #pragma unroll
-    for (int j = 0; j < NS; ++j) {
-        A2[j] = d_ok ? fminf(p.A[(int64_t)d * N + w * NS + j] * RESEL_LOG2E, -1e-30f) : -1.f;
-        h[j] = 0.f;
+    for (int k = 0; k < NP; ++k) {
+        float a[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int j = 2 * k + e;
+            a[e] = (d_ok && j < NS) ? fminf(p.A[(int64_t)d * N + w * NS + j] * RESEL_LOG2E, -1e-30f) : -1.f;
+        }
+        A2p[k] = f2{a[0], a[1]};
+        hp[k] = f2{0.f, 0.f};
     }
     const int tc4 = (tid & 15) * 4;
     const int tr0 = tid >> 4;                       // first tile row of this thread
@@ -106,26 +167,40 @@ __global__ __launch_bounds__(NW * 64) void sscan_fwd_kernel(FwdParams p) {
         if (p.delta_bias) bv = ld4(p.delta_bias + d0 + tc4);
     }
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 pu[PER_T], pd[PER_T], pz[PER_T];         // register prefetch of the NEXT chunk's tile
+    float4 pu[PER_T], pd[PER_T], pz[PER_T];         // register prefetch of the NEXT chunk's tiles
+    float4 pB[PER_BC], pC[PER_BC];
+    float pst = 0.f;
     float4 u_r[PER_T], z_r[PER_T];
 
     auto prefetch = [&](int c0) {
 #pragma unroll
         for (int i = 0; i < PER_T; ++i) {
-            const int t = c0 + tr0 + i * (NT / 16);
+            const int r = tr0 + i * (NT / 16);
+            const int t = c0 + r;
             pu[i] = zero4; pd[i] = zero4; pz[i] = zero4;
-            if (t < p.L && c_ok) {
+            if (r < TC && t < p.L && c_ok) {
                 const int64_t tok = tok0 + t;
                 pu[i] = ld4(p.u + tok * p.ld_u + d0 + tc4);
                 pd[i] = ld4(p.delta + tok * p.ld_delta + d0 + tc4);
                 if (p.z) pz[i] = ld4(p.z + tok * p.ld_z + d0 + tc4);
             }
         }
+#pragma unroll
+        for (int i = 0; i < PER_BC; ++i) {
+            const int it = tid + i * NT;
+            const int t = c0 + it / (N / 4), c = (it % (N / 4)) * 4;
+            pB[i] = zero4; pC[i] = zero4;
+            if (it < BC_ITEMS && t < p.L) {
+                pB[i] = load_bc4(p.Bm, tok0 + t, p.ld_b, c, p.bc_vec);
+                pC[i] = load_bc4(p.Cm, tok0 + t, p.ld_c, c, p.bc_vec);
+            }
+        }
+        pst = (p.start && tid < TC && c0 + tid < p.L) ? p.start[tok0 + c0 + tid] : 0.f;
     };
     prefetch(0);
 
     for (int c0 = 0; c0 < p.L; c0 += TC) {
-        // ---- stage: softplus(delta + bias), delta * u -> LDS; u and z stay in registers for the output phase
+        // ---- stage: softplus(delta + bias), delta * u, B_t / C_t / start_t -> LDS; u and z stay in registers
 #pragma unroll
         for (int i = 0; i < PER_T; ++i) {
             const int r = tr0 + i * (NT / 16);
@@ -137,50 +212,72 @@ __global__ __launch_bounds__(NW * 64) void sscan_fwd_kernel(FwdParams p) {
             }
             u_r[i] = uv;
             z_r[i] = pz[i];
-            st4(&s_dl[r][tc4], dv);
-            st4(&s_du[r][tc4], make_float4(dv.x * uv.x, dv.y * uv.y, dv.z * uv.z, dv.w * uv.w));
+            if (r < TC) {
+                st4(&s_dl[r][tc4], dv);
+                st4(&s_du[r][tc4], make_float4(dv.x * uv.x, dv.y * uv.y, dv.z * uv.z, dv.w * uv.w));
+            }
         }
+#pragma unroll
+        for (int i = 0; i < PER_BC; ++i) {
+            const int it = tid + i * NT;
+            if (it < BC_ITEMS) {
+                st4(&s_B[0][0] + it * 4, pB[i]);
+                st4(&s_C[0][0] + it * 4, pC[i]);
+            }
+        }
+        if (tid < TC) s_st[tid] = pst;
         __syncthreads();
         if (c0 + TC < p.L) prefetch(c0 + TC);        // in flight during the whole scan phase
 
-        // ---- scan: lane = channel, wave = state group, sequential in time; B_t / C_t / start_t are scalar loads
+        // ---- scan: lane = channel, wave = state group, sequential in time; B_t / C_t / start_t broadcast from LDS,
+        //      fetched one step ahead of their use
         const int nst = min(TC, p.L - c0);
-        float Bc[NS], Cc[NS];
-        {
-            const int64_t tok = tok0 + c0;
-            load_coef<NS>(as_uniform(p.Bm + tok * p.ld_b + w * NS), Bc);
-            load_coef<NS>(as_uniform(p.Cm + tok * p.ld_c + w * NS), Cc);
-        }
-        float sflag = p.start ? as_uniform(p.start + tok0 + c0)[0] : 0.f;
-        float dl = s_dl[0][lane], du = s_du[0][lane];
-        for (int t = 0; t < nst; ++t) {
-            // prefetch the next step's coefficients (clamped: the last prefetch of a chunk is a harmless re-read)
-            const int tn = min(t + 1, nst - 1);
-            const int64_t tokn = tok0 + c0 + tn;
-            float Bn[NS], Cn[NS];
-            load_coef<NS>(as_uniform(p.Bm + tokn * p.ld_b + w * NS), Bn);
-            load_coef<NS>(as_uniform(p.Cm + tokn * p.ld_c + w * NS), Cn);
-            const float sn = p.start ? as_uniform(p.start + tokn)[0] : 0.f;
-            const float dln = s_dl[tn][lane], dun = s_du[tn][lane];
-
-            const float dle = (sflag != 0.f) ? __builtin_inff() : dl;   // reset: exp2(-inf) = 0 wipes h_{t-1}
-            float y = 0.f;
+        // ping-pong operand sets: while step t is computed from set 0, the LDS reads of step t+1 fill set 1 (and vice
+        // versa) - issued first in each half-iteration and pinned there with sched_barrier, so that their latency
+        // hides behind the VALU work instead of stalling the loop head.
+        // The per-state arithmetic is written on float2 pairs: on gfx950 a wave64 v_fma_f32 / v_mul_f32 issues every
+        // 4 cycles per SIMD and v_pk_fma_f32 / v_pk_mul_f32 every ~5.6 (tools/micro/valu_rate.hip), i.e. packed math
+        // is ~1.4x the scalar rate; v_exp_f32 (8 cycles) stays scalar.
+        f2 B0[NP], C0[NP], B1[NP], C1[NP];
+        float sf0, dl0, du0, sf1, dl1, du1;
+        auto fetch = [&](int t, f2 (&Bq)[NP], f2 (&Cq)[NP], float& sf, float& dlq, float& duq) {
+            lds_coef2<NS>(&s_B[t][w * NS], Bq);
+            lds_coef2<NS>(&s_C[t][w * NS], Cq);
+            sf = s_st[t];
+            dlq = s_dl[t][lane];
+            duq = s_du[t][lane];
+        };
+        auto step = [&](int t, const f2 (&Bq)[NP], const f2 (&Cq)[NP], float sf, float dlq, float duq) {
+            const float dle = (sf != 0.f) ? __builtin_inff() : dlq;    // reset: exp2(-inf) = 0 wipes h_{t-1}
+            const f2 dle2 = {dle, dle}, du2 = {duq, duq};
+            f2 yacc = {0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < NS; ++j) {
-                const float dA = fast_exp2(dle * A2[j]);
-                h[j] = __builtin_fmaf(dA, h[j], du * Bc[j]);
-                y = __builtin_fmaf(Cc[j], h[j], y);
+            for (int k = 0; k < NP; ++k) {
+                const f2 arg = dle2 * A2p[k];
+                f2 dA;
+                dA.x = fast_exp2(arg.x);
+                dA.y = fast_exp2(arg.y);
+                hp[k] = __builtin_elementwise_fma(dA, hp[k], du2 * Bq[k]);
+                yacc = __builtin_elementwise_fma(Cq[k], hp[k], yacc);
             }
-            s_y[w][t][lane] = y;
+            s_y[w][t][lane] = yacc.x + yacc.y;
             const int tabs = c0 + t + 1;
             if (p.ckpt != nullptr && (tabs % CKS) == 0 && tabs < p.L && d_ok) {
                 float* ck = p.ckpt + (((int64_t)b * p.nck + (tabs / CKS - 1)) * N + w * NS) * p.Di + d;
 #pragma unroll
-                for (int j = 0; j < NS; ++j) ck[(int64_t)j * p.Di] = h[j];
+                for (int j = 0; j < NS; ++j) ck[(int64_t)j * p.Di] = (j & 1) ? hp[j / 2].y : hp[j / 2].x;
             }
-#pragma unroll
-            for (int j = 0; j < NS; ++j) { Bc[j] = Bn[j]; Cc[j] = Cn[j]; }
-            sflag = sn; dl = dln; du = dun;
+        };
+        fetch(0, B0, C0, sf0, dl0, du0);
+        for (int t = 0; t < nst; t += 2) {
+            fetch(min(t + 1, TC - 1), B1, C1, sf1, dl1, du1);
+            __builtin_amdgcn_sched_barrier(0);
+            step(t, B0, C0, sf0, dl0, du0);
+            if (t + 1 < nst) {
+                fetch(min(t + 2, TC - 1), B0, C0, sf0, dl0, du0);
+                __builtin_amdgcn_sched_barrier(0);
+                step(t + 1, B1, C1, sf1, dl1, du1);
+            }
         }
         __syncthreads();
 
@@ -189,7 +286,7 @@ __global__ __launch_bounds__(NW * 64) void sscan_fwd_kernel(FwdParams p) {
         for (int i = 0; i < PER_T; ++i) {
             const int r = tr0 + i * (NT / 16);
             const int t = c0 + r;
-            if (t < p.L && c_ok) {
+            if (r < TC && t < p.L && c_ok) {
                 float4 y = ld4(&s_y[0][r][tc4]);
 #pragma unroll
                 for (int ww = 1; ww < NW; ++ww) {
@@ -206,12 +303,13 @@ __global__ __launch_bounds__(NW * 64) void sscan_fwd_kernel(FwdParams p) {
                 st4(p.out + (tok0 + t) * p.ld_out + d0 + tc4, y);
             }
         }
-        // no barrier needed here: the next stage only writes s_dl/s_du (last read before the barrier above),
-        // and s_y is rewritten only after the barrier that follows that stage.
+        // no barrier needed here: the next stage only writes s_dl/s_du/s_B/s_C/s_st (last read before the barrier
+        // above), and s_y is rewritten only after the barrier that follows that stage.
     }
     if (p.last_state != nullptr && d_ok) {
 #pragma unroll
-        for (int j = 0; j < NS; ++j) p.last_state[((int64_t)b * p.Di + d) * N + w * NS + j] = h[j];
+        for (int j = 0; j < NS; ++j)
+            p.last_state[((int64_t)b * p.Di + d) * N + w * NS + j] = (j & 1) ? hp[j / 2].y : hp[j / 2].x;
     }
 }
 
@@ -223,7 +321,7 @@ struct BwdParams {
     float *du, *ddelta, *dz;
     float *dB_part, *dC_part, *dA_part, *dD_part, *dbias_part;     // workspace slabs
     int64_t ld_u, ld_delta, ld_z, ld_b, ld_c, ld_dout, ld_du, ld_ddelta, ld_dz;
-    int B, L, Di, N, nck, softplus, nd;
+    int B, L, Di, N, nck, softplus, nd, bc_vec;
 };
 
 // value held by lane (l ^ K), DPP where the pairing stays inside a 16-lane row
@@ -247,61 +345,65 @@ __device__ __forceinline__ float lane_xor(float v) {
     return __builtin_bit_cast(float, r);
 }
 
-// Sum v[0..NS) over the 64 lanes of the wave with a multi-value butterfly: each of the first log2(NS) stages
-// halves the number of values a lane carries.  On return v[0] of lane l is the wave total of the state
-// j = state_of_lane<NS>(l) (all 64 lanes hold a total; lanes l < NS cover every j exactly once).
-template <int NS>
-__device__ __forceinline__ float butterfly_sum(float (&v)[NS], int lane) {
-    if constexpr (NS >= 8) {
-        const bool hi = lane & 1;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float send = hi ? v[i] : v[i + 4];
-            const float keep = hi ? v[i + 4] : v[i];
-            v[i] = keep + lane_xor<1>(send);
-        }
-    }
-    if constexpr (NS >= 4) {
-        constexpr int K = NS >= 8 ? 2 : 1;
+// Sum v[0..V) over the 64 lanes of the wave with a multi-value butterfly: stage s (lane bit s) halves the number of
+// values a lane carries - lanes with the bit clear keep the lower half and receive the partner's lower half.  On
+// return lane l holds (in every lane) the wave total of value index value_of_lane<V>(l); lanes l < V cover every
+// index exactly once.  V in {1, 2, 4, 8, 16}.
+template <int V, int K = 1>
+__device__ __forceinline__ float butterfly_sum(float (&v)[V > 0 ? V : 1], int lane) {
+    if constexpr (V > 1) {
+        constexpr int H = V / 2;
         const bool hi = lane & K;
+        float nv[H];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const float send = hi ? v[i] : v[i + 2];
-            const float keep = hi ? v[i + 2] : v[i];
-            v[i] = keep + lane_xor<K>(send);
+        for (int i = 0; i < H; ++i) {
+            const float send = hi ? v[i] : v[i + H];
+            const float keep = hi ? v[i + H] : v[i];
+            nv[i] = keep + lane_xor<K>(send);
         }
+        return butterfly_sum<H, K * 2>(nv, lane);
+    } else {
+        float r = v[0];
+        if constexpr (K <= 1) r += lane_xor<1>(r);
+        if constexpr (K <= 2) r += lane_xor<2>(r);
+        if constexpr (K <= 4) r += lane_xor<4>(r);
+        if constexpr (K <= 8) r += lane_xor<8>(r);
+        if constexpr (K <= 16) r += lane_xor<16>(r);
+        r += lane_xor<32>(r);
+        return r;
     }
-    if constexpr (NS >= 2) {
-        constexpr int K = NS >= 8 ? 4 : (NS >= 4 ? 2 : 1);
-        const bool hi = lane & K;
-        const float send = hi ? v[0] : v[1];
-        const float keep = hi ? v[1] : v[0];
-        v[0] = keep + lane_xor<K>(send);
-    }
-    float r = v[0];
-    if constexpr (NS < 2) r += lane_xor<1>(r);
-    if constexpr (NS < 4) r += lane_xor<2>(r);
-    if constexpr (NS < 8) r += lane_xor<4>(r);
-    r += lane_xor<8>(r);
-    r += lane_xor<16>(r);
-    r += lane_xor<32>(r);
-    return r;
 }
-template <int NS>
-__device__ __forceinline__ int state_of_lane(int lane) {
-    if constexpr (NS == 8) return ((lane & 1) << 2) | (lane & 2) | ((lane >> 2) & 1);
-    if constexpr (NS == 4) return ((lane & 1) << 1) | ((lane >> 1) & 1);
-    if constexpr (NS == 2) return lane & 1;
-    return 0;
+template <int V>
+__device__ __forceinline__ int value_of_lane(int lane) {
+    int idx = 0, h = V / 2;
+#pragma unroll
+    for (int bit = 1; bit < V; bit <<= 1) {
+        if (lane & bit) idx += h;
+        h >>= 1;
+    }
+    return idx;
 }
 
+// One workgroup = (row b, 64-channel tile); NW waves x NS states; time in 16-step sub-chunks, last to first.
+// Per sub-chunk: tile stage (softplus, delta*u, gated dout, B/C/start rows -> LDS) | forward replay from the
+// checkpoint with the state AND decay history of the 16 steps in registers | reverse sweep | epilogue on the tile.
 template <int NS, int NW>
 __global__ __launch_bounds__(NW * 64) void sscan_bwd_kernel(BwdParams p) {
     constexpr int NT = NW * 64;
-    __shared__ __attribute__((aligned(16))) float s_dl[SC][TILE_C];
-    __shared__ __attribute__((aligned(16))) float s_du[SC][TILE_C];
-    __shared__ __attribute__((aligned(16))) float s_dy[SC][TILE_C];
+    constexpr int N = NS * NW;
+    constexpr int NP = (NS + 1) / 2;
+    constexpr int BC_ITEMS = SC * N / 4;
+    constexpr int PER_BC = (BC_ITEMS + NT - 1) / NT;
+    // everything a sub-chunk needs lives in LDS, so that the 16-step (h, dA) history can own the register file
+    __shared__ __attribute__((aligned(16))) float s_dl[SC][TILE_C];     // softplus(delta + bias)
+    __shared__ __attribute__((aligned(16))) float s_u[SC][TILE_C];
+    __shared__ __attribute__((aligned(16))) float s_dy[SC][TILE_C];     // dout * silu(z)
+    __shared__ __attribute__((aligned(16))) float s_z[SC][TILE_C];
+    __shared__ __attribute__((aligned(16))) float s_do[SC][TILE_C];
     __shared__ __attribute__((aligned(16))) float s_part[3][NW][SC][TILE_C];
+    __shared__ __attribute__((aligned(16))) float s_B[SC][N];
+    __shared__ __attribute__((aligned(16))) float s_C[SC][N];
+    __shared__ float s_st[SC];
 
     int b, dt;
     if (!decode_block(blockIdx.x, p.nd, p.B, b, dt)) return;
@@ -311,218 +413,247 @@ __global__ __launch_bounds__(NW * 64) void sscan_bwd_kernel(BwdParams p) {
     const int d0 = dt * TILE_C;
     const int d = d0 + lane;
     const bool d_ok = d < p.Di;
-    const int N = NS * NW;
     const int64_t tok0 = (int64_t)b * p.L;
     const bool tile_thr = tid < SC * 16;            // threads that own one float4 of the [SC][64] tile
     const int tc4 = (tid & 15) * 4;
     const int tr = (tid >> 4) & (SC - 1);
     const bool c_ok = tile_thr && (d0 + tc4) < p.Di;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // per-thread element offsets inside a sub-chunk tile (32-bit; the sub-chunk base pointers are wave-uniform)
+    const int o_u = tr * (int)p.ld_u + tc4, o_dl = tr * (int)p.ld_delta + tc4, o_z = tr * (int)p.ld_z + tc4;
+    const int o_do = tr * (int)p.ld_dout + tc4;
 
-    float A2[NS], Aj[NS], dh[NS], dAacc[NS];
+    f2 A2p[NP], Ap[NP], dh[NP], dAacc[NP];
 #pragma unroll
-    for (int j = 0; j < NS; ++j) {
-        const float a = d_ok ? p.A[(int64_t)d * N + w * NS + j] : -1.f;
-        Aj[j] = a;
-        A2[j] = fminf(a * RESEL_LOG2E, -1e-30f);
-        dh[j] = 0.f;
-        dAacc[j] = 0.f;
-    }
-    float4 Dv = zero4, bv = zero4, dDacc = zero4, dbacc = zero4;
-    if (c_ok) {
-        if (p.D) Dv = ld4(p.D + d0 + tc4);
-        if (p.delta_bias) bv = ld4(p.delta_bias + d0 + tc4);
-    }
-
-    const int nchunk = (p.L + CKS - 1) / CKS;
-    for (int k = nchunk - 1; k >= 0; --k) {
-        const int tbase = k * CKS;
-        const int cl = min(CKS, p.L - tbase);
-        const int nsub = (cl + SC - 1) / SC;
-        float hs[NSUB][NS];
+    for (int k = 0; k < NP; ++k) {
+        float a[2];
 #pragma unroll
-        for (int j = 0; j < NS; ++j) {
-            hs[0][j] = (k > 0 && d_ok)
-                           ? p.ckpt[(((int64_t)b * p.nck + (k - 1)) * N + w * NS + j) * p.Di + d] : 0.f;
+        for (int e = 0; e < 2; ++e) {
+            const int j = 2 * k + e;
+            a[e] = (d_ok && j < NS) ? p.A[(int64_t)d * N + w * NS + j] : -1.f;
         }
-        // ---------------- phase A: rebuild the sub-checkpoints hs[1..nsub-1] ----------------
+        Ap[k] = f2{a[0], a[1]};
+        A2p[k] = f2{fminf(a[0] * RESEL_LOG2E, -1e-30f), fminf(a[1] * RESEL_LOG2E, -1e-30f)};
+        dh[k] = f2{0.f, 0.f};
+        dAacc[k] = f2{0.f, 0.f};
+    }
+    float4 dDacc = zero4, dbacc = zero4;
+
+    const int nsc = (p.L + SC - 1) / SC;
+    // register prefetch of the next sub-chunk's tile (issued while the current one is being processed)
+    float4 pu = zero4, pd = zero4, pz = zero4, pdo = zero4;
+    float4 pB[PER_BC], pC[PER_BC];
+    float pst = 0.f;
+    f2 ph0[NP];
+    auto prefetch = [&](int sc) {
+        pu = zero4; pd = zero4; pz = zero4; pdo = zero4;
+        const int ts = sc * SC;
+        if (c_ok && ts + tr < p.L) {
+            const int64_t tok = tok0 + ts;
+            pu = ld4(p.u + tok * p.ld_u + d0 + o_u);
+            pd = ld4(p.delta + tok * p.ld_delta + d0 + o_dl);
+            pdo = ld4(p.dout + tok * p.ld_dout + d0 + o_do);
+            if (p.z) pz = ld4(p.z + tok * p.ld_z + d0 + o_z);
+        }
 #pragma unroll
-        for (int s = 0; s < NSUB - 1; ++s) {
-            if (s < nsub - 1) {
-                __syncthreads();
-                if (tile_thr) {
-                    float4 dv = zero4, uv = zero4;
-                    const int t = tbase + s * SC + tr;       // always < L here (a later sub-chunk exists)
-                    if (c_ok) {
-                        uv = ld4(p.u + (tok0 + t) * p.ld_u + d0 + tc4);
-                        dv = ld4(p.delta + (tok0 + t) * p.ld_delta + d0 + tc4);
-                        dv.x += bv.x; dv.y += bv.y; dv.z += bv.z; dv.w += bv.w;
-                        if (p.softplus) {
-                            dv.x = softplusf_(dv.x); dv.y = softplusf_(dv.y);
-                            dv.z = softplusf_(dv.z); dv.w = softplusf_(dv.w);
-                        }
-                    }
-                    st4(&s_dl[tr][tc4], dv);
-                    st4(&s_du[tr][tc4], make_float4(dv.x * uv.x, dv.y * uv.y, dv.z * uv.z, dv.w * uv.w));
-                }
-                __syncthreads();
-                float h[NS];
-#pragma unroll
-                for (int j = 0; j < NS; ++j) h[j] = hs[s][j];
-                for (int i = 0; i < SC; ++i) {
-                    const int64_t tok = tok0 + tbase + s * SC + i;
-                    float Bc[NS];
-                    load_coef<NS>(as_uniform(p.Bm + tok * p.ld_b + w * NS), Bc);
-                    const float sf = p.start ? as_uniform(p.start + tok)[0] : 0.f;
-                    const float dl = s_dl[i][lane], du = s_du[i][lane];
-                    const float dle = (sf != 0.f) ? __builtin_inff() : dl;
-#pragma unroll
-                    for (int j = 0; j < NS; ++j) h[j] = __builtin_fmaf(fast_exp2(dle * A2[j]), h[j], du * Bc[j]);
-                }
-#pragma unroll
-                for (int j = 0; j < NS; ++j) hs[s + 1][j] = h[j];
+        for (int i = 0; i < PER_BC; ++i) {
+            const int it = tid + i * NT;
+            const int r = it / (N / 4), c = (it % (N / 4)) * 4;
+            pB[i] = zero4; pC[i] = zero4;
+            if (it < BC_ITEMS && ts + r < p.L) {
+                pB[i] = load_bc4(p.Bm, tok0 + ts + r, p.ld_b, c, p.bc_vec);
+                pC[i] = load_bc4(p.Cm, tok0 + ts + r, p.ld_c, c, p.bc_vec);
             }
         }
-        // ---------------- phase B: sub-chunks in reverse ----------------
+        pst = (p.start && tid < SC && ts + tid < p.L) ? p.start[tok0 + ts + tid] : 0.f;
+        // state at the start of the sub-chunk: checkpoint sc-1 (written by the forward after step sc*SC)
 #pragma unroll
-        for (int s = NSUB - 1; s >= 0; --s) {
-            if (s < nsub) {
-                const int sl = min(SC, cl - s * SC);          // steps in this sub-chunk
-                const int ts = tbase + s * SC;
-                __syncthreads();
-                float4 u4 = zero4, draw4 = zero4, z4 = zero4, do4 = zero4, dl4 = zero4, dy4 = zero4;
-                if (tile_thr) {
-                    if (c_ok && tr < sl) {
-                        const int64_t tok = tok0 + ts + tr;
-                        u4 = ld4(p.u + tok * p.ld_u + d0 + tc4);
-                        draw4 = ld4(p.delta + tok * p.ld_delta + d0 + tc4);
-                        do4 = ld4(p.dout + tok * p.ld_dout + d0 + tc4);
-                        if (p.z) z4 = ld4(p.z + tok * p.ld_z + d0 + tc4);
-                        draw4.x += bv.x; draw4.y += bv.y; draw4.z += bv.z; draw4.w += bv.w;
-                        dl4 = draw4;
-                        if (p.softplus) {
-                            dl4.x = softplusf_(dl4.x); dl4.y = softplusf_(dl4.y);
-                            dl4.z = softplusf_(dl4.z); dl4.w = softplusf_(dl4.w);
-                        }
-                        dy4 = do4;
-                        if (p.z) {
-                            dy4.x *= siluf_(z4.x); dy4.y *= siluf_(z4.y); dy4.z *= siluf_(z4.z); dy4.w *= siluf_(z4.w);
-                        }
-                    }
-                    st4(&s_dl[tr][tc4], dl4);
-                    st4(&s_du[tr][tc4], make_float4(dl4.x * u4.x, dl4.y * u4.y, dl4.z * u4.z, dl4.w * u4.w));
-                    st4(&s_dy[tr][tc4], dy4);
+        for (int k = 0; k < NP; ++k) {
+            float a[2] = {0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int j = 2 * k + e;
+                if (sc > 0 && d_ok && j < NS) a[e] = p.ckpt[(((int64_t)b * p.nck + (sc - 1)) * N + w * NS + j) * p.Di + d];
+            }
+            ph0[k] = f2{a[0], a[1]};
+        }
+    };
+    prefetch(nsc - 1);
+
+    for (int sc = nsc - 1; sc >= 0; --sc) {
+        const int ts = sc * SC;
+        const int sl = min(SC, p.L - ts);                 // steps in this sub-chunk
+        // ---------------- stage ----------------
+        __syncthreads();
+        if (tile_thr) {
+            float4 dl4 = zero4, dy4 = zero4;
+            if (c_ok && tr < sl) {
+                float4 bv = zero4;
+                if (p.delta_bias) bv = ld4(p.delta_bias + d0 + tc4);
+                dl4 = pd;
+                dl4.x += bv.x; dl4.y += bv.y; dl4.z += bv.z; dl4.w += bv.w;
+                if (p.softplus) {
+                    dl4.x = softplusf_(dl4.x); dl4.y = softplusf_(dl4.y); dl4.z = softplusf_(dl4.z); dl4.w = softplusf_(dl4.w);
                 }
-                __syncthreads();
-                // forward recomputation with the full state history in registers
-                float hist[SC][NS];
-                {
-                    float h[NS];
-#pragma unroll
-                    for (int j = 0; j < NS; ++j) h[j] = hs[s][j];
-#pragma unroll
-                    for (int i = 0; i < SC; ++i) {
-                        if (i < sl) {
-                            const int64_t tok = tok0 + ts + i;
-                            float Bc[NS];
-                            load_coef<NS>(as_uniform(p.Bm + tok * p.ld_b + w * NS), Bc);
-                            const float sf = p.start ? as_uniform(p.start + tok)[0] : 0.f;
-                            const float dl = s_dl[i][lane], du = s_du[i][lane];
-                            const float dle = (sf != 0.f) ? __builtin_inff() : dl;
-#pragma unroll
-                            for (int j = 0; j < NS; ++j) {
-                                h[j] = __builtin_fmaf(fast_exp2(dle * A2[j]), h[j], du * Bc[j]);
-                                hist[i][j] = h[j];
-                            }
-                            __builtin_amdgcn_sched_barrier(0);   // keep the unrolled steps in order (register pressure)
-                        }
-                    }
+                dy4 = pdo;
+                if (p.z) {
+                    dy4.x *= siluf_(pz.x); dy4.y *= siluf_(pz.y); dy4.z *= siluf_(pz.z); dy4.w *= siluf_(pz.w);
                 }
-                // reverse time
+            }
+            st4(&s_dl[tr][tc4], dl4);
+            st4(&s_u[tr][tc4], pu);
+            st4(&s_dy[tr][tc4], dy4);
+            st4(&s_z[tr][tc4], pz);
+            st4(&s_do[tr][tc4], pdo);
+        }
 #pragma unroll
-                for (int i = SC - 1; i >= 0; --i) {
-                    if (i < sl) {
-                        const int64_t tok = tok0 + ts + i;
-                        float Bc[NS], Cc[NS];
-                        load_coef<NS>(as_uniform(p.Bm + tok * p.ld_b + w * NS), Bc);
-                        load_coef<NS>(as_uniform(p.Cm + tok * p.ld_c + w * NS), Cc);
-                        const float sf = p.start ? as_uniform(p.start + tok)[0] : 0.f;
-                        const float dl = s_dl[i][lane], du = s_du[i][lane], dy = s_dy[i][lane];
-                        const float dle = (sf != 0.f) ? __builtin_inff() : dl;
-                        float P1 = 0.f, P2 = 0.f, P3 = 0.f;
-                        float dBv[NS], dCv[NS];
+        for (int i = 0; i < PER_BC; ++i) {
+            const int it = tid + i * NT;
+            if (it < BC_ITEMS) {
+                st4(&s_B[0][0] + it * 4, pB[i]);
+                st4(&s_C[0][0] + it * 4, pC[i]);
+            }
+        }
+        if (tid < SC) s_st[tid] = pst;
+        f2 h0[NP];
 #pragma unroll
-                        for (int j = 0; j < NS; ++j) {
-                            const float hj = hist[i][j];
-                            const float hp = (i == 0) ? hs[s][j] : hist[i > 0 ? i - 1 : 0][j];
-                            dh[j] = __builtin_fmaf(dy, Cc[j], dh[j]);
-                            P3 = __builtin_fmaf(Cc[j], hj, P3);
-                            const float dA = fast_exp2(dle * A2[j]);          // 0 at a reset step
-                            const float tmp = dh[j] * hp * dA;                // dL/d(dA) * dA
-                            P2 = __builtin_fmaf(tmp, Aj[j], P2);
-                            dAacc[j] = __builtin_fmaf(tmp, dl, dAacc[j]);
-                            dBv[j] = dh[j] * du;
-                            dCv[j] = dy * hj;
-                            P1 = __builtin_fmaf(dh[j], Bc[j], P1);
-                            dh[j] *= dA;
-                        }
-                        s_part[0][w][i][lane] = P1;
-                        s_part[1][w][i][lane] = P2;
-                        s_part[2][w][i][lane] = P3;
-                        const float rb = butterfly_sum<NS>(dBv, lane);
-                        const float rc = butterfly_sum<NS>(dCv, lane);
-                        if (lane < NS) {
-                            const int64_t o = ((int64_t)dt * p.B * p.L + tok) * N + w * NS + state_of_lane<NS>(lane);
-                            p.dB_part[o] = rb;
-                            p.dC_part[o] = rc;
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
+        for (int k = 0; k < NP; ++k) h0[k] = ph0[k];
+        __syncthreads();
+        if (sc > 0) prefetch(sc - 1);
+
+        // ---------------- replay + reverse, in two halves of SCH steps (later half first) ----------------
+        // The (h, dA) history of SCH = 8 steps x NS states lives in registers.  The second half starts from the state
+        // after step SCH-1, obtained by a plain replay of the first half (no history kept): the first half is thus
+        // replayed twice, which costs ~15 % of a half's work and lets a lane carry twice the states.
+        auto replay_step = [&](int i, f2 (&h)[NP], f2 (&dAo)[NP]) {
+            f2 Bq[NP];
+            lds_coef2<NS>(&s_B[i][w * NS], Bq);
+            const float sf = s_st[i];
+            const float dl = s_dl[i][lane], du = dl * s_u[i][lane];
+            const float dle = (sf != 0.f) ? __builtin_inff() : dl;
+            const f2 dle2 = {dle, dle}, du2 = {du, du};
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const f2 arg = dle2 * A2p[k];
+                dAo[k].x = fast_exp2(arg.x);
+                dAo[k].y = fast_exp2(arg.y);
+                h[k] = __builtin_elementwise_fma(dAo[k], h[k], du2 * Bq[k]);
+            }
+        };
+        auto half = [&](int base, int n, const f2 (&hstart)[NP]) {
+            f2 hist_h[SCH][NP], hist_a[SCH][NP];
+            {
+                f2 h[NP];
+#pragma unroll
+                for (int k = 0; k < NP; ++k) h[k] = hstart[k];
+#pragma unroll
+                for (int i = 0; i < SCH; ++i) {
+                    if (i < n) {
+                        f2 dA[NP];
+                        replay_step(base + i, h, dA);
+#pragma unroll
+                        for (int k = 0; k < NP; ++k) { hist_h[i][k] = h[k]; hist_a[i][k] = dA[k]; }
+                        __builtin_amdgcn_sched_barrier(0);        // keep the unrolled steps in order (register pressure)
                     }
                 }
-                __syncthreads();
-                // epilogue on the tile mapping
-                if (c_ok && tr < sl) {
-                    float4 P1 = zero4, P2 = zero4, P3 = zero4;
+            }
 #pragma unroll
-                    for (int ww = 0; ww < NW; ++ww) {
-                        const float4 a = ld4(&s_part[0][ww][tr][tc4]);
-                        const float4 bq = ld4(&s_part[1][ww][tr][tc4]);
-                        const float4 c = ld4(&s_part[2][ww][tr][tc4]);
-                        P1.x += a.x; P1.y += a.y; P1.z += a.z; P1.w += a.w;
-                        P2.x += bq.x; P2.y += bq.y; P2.z += bq.z; P2.w += bq.w;
-                        P3.x += c.x; P3.y += c.y; P3.z += c.z; P3.w += c.w;
+            for (int i = SCH - 1; i >= 0; --i) {
+                if (i < n) {
+                    const int r = base + i;
+                    f2 Bq[NP], Cq[NP];
+                    lds_coef2<NS>(&s_B[r][w * NS], Bq);
+                    lds_coef2<NS>(&s_C[r][w * NS], Cq);
+                    const float dl = s_dl[r][lane], dy = s_dy[r][lane];
+                    const float du = dl * s_u[r][lane];
+                    const f2 dl2 = {dl, dl}, du2 = {du, du}, dy2 = {dy, dy};
+                    f2 P1 = {0.f, 0.f}, P2 = P1, P3 = P1;
+                    float red[4 * NP];                     // [dB pairs | dC pairs] for the channel reduction
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) {
+                        const f2 hk = hist_h[i][k];
+                        const f2 hp = (i == 0) ? hstart[k] : hist_h[i > 0 ? i - 1 : 0][k];
+                        const f2 ak = hist_a[i][k];                                   // 0 at a reset step
+                        dh[k] = __builtin_elementwise_fma(dy2, Cq[k], dh[k]);
+                        P3 = __builtin_elementwise_fma(Cq[k], hk, P3);
+                        const f2 tmp = dh[k] * hp * ak;                               // dL/d(dA) * dA
+                        P2 = __builtin_elementwise_fma(tmp, Ap[k], P2);
+                        dAacc[k] = __builtin_elementwise_fma(tmp, dl2, dAacc[k]);
+                        const f2 gb = dh[k] * du2, gc = dy2 * hk;
+                        red[2 * k] = gb.x; red[2 * k + 1] = gb.y;
+                        red[2 * NP + 2 * k] = gc.x; red[2 * NP + 2 * k + 1] = gc.y;
+                        P1 = __builtin_elementwise_fma(dh[k], Bq[k], P1);
+                        dh[k] = dh[k] * ak;
                     }
-                    const int64_t tok = tok0 + ts + tr;
-                    float4 o;
-                    // du = delta' * sum_n dh B + D * dy
-                    o.x = dl4.x * P1.x + Dv.x * dy4.x; o.y = dl4.y * P1.y + Dv.y * dy4.y;
-                    o.z = dl4.z * P1.z + Dv.z * dy4.z; o.w = dl4.w * P1.w + Dv.w * dy4.w;
-                    st4(p.du + tok * p.ld_du + d0 + tc4, o);
-                    // d delta' = sum_n (dh h_prev dA) A + u * sum_n dh B ; chain through softplus
-                    float4 g;
-                    g.x = P2.x + u4.x * P1.x; g.y = P2.y + u4.y * P1.y; g.z = P2.z + u4.z * P1.z; g.w = P2.w + u4.w * P1.w;
-                    if (p.softplus) {
-                        g.x *= sigmoidf_(draw4.x); g.y *= sigmoidf_(draw4.y); g.z *= sigmoidf_(draw4.z); g.w *= sigmoidf_(draw4.w);
+                    s_part[0][w][r][lane] = P1.x + P1.y;
+                    s_part[1][w][r][lane] = P2.x + P2.y;
+                    s_part[2][w][r][lane] = P3.x + P3.y;
+                    const float tot = butterfly_sum<4 * NP>(red, lane);
+                    if (lane < 4 * NP) {
+                        const int vi = value_of_lane<4 * NP>(lane);                   // < 2NP: dB state vi ; else dC state vi - 2NP
+                        const int st = vi < 2 * NP ? vi : vi - 2 * NP;
+                        if (st < NS) {
+                            const int64_t o = ((int64_t)dt * p.B * p.L + tok0 + ts + r) * N + w * NS + st;
+                            (vi < 2 * NP ? p.dB_part : p.dC_part)[o] = tot;
+                        }
                     }
-                    st4(p.ddelta + tok * p.ld_ddelta + d0 + tc4, g);
-                    dbacc.x += g.x; dbacc.y += g.y; dbacc.z += g.z; dbacc.w += g.w;
-                    dDacc.x += dy4.x * u4.x; dDacc.y += dy4.y * u4.y; dDacc.z += dy4.z * u4.z; dDacc.w += dy4.w * u4.w;
-                    if (p.z) {
-                        float4 yy;                     // pre-gate output y = sum_n C h + D u
-                        yy.x = P3.x + Dv.x * u4.x; yy.y = P3.y + Dv.y * u4.y; yy.z = P3.z + Dv.z * u4.z; yy.w = P3.w + Dv.w * u4.w;
-                        float4 gz;
-                        gz.x = do4.x * yy.x * dsiluf_(z4.x); gz.y = do4.y * yy.y * dsiluf_(z4.y);
-                        gz.z = do4.z * yy.z * dsiluf_(z4.z); gz.w = do4.w * yy.w * dsiluf_(z4.w);
-                        st4(p.dz + tok * p.ld_dz + d0 + tc4, gz);
-                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+            }
+        };
+        if (sl > SCH) {
+            f2 hm[NP], scratch_a[NP];
+#pragma unroll
+            for (int k = 0; k < NP; ++k) hm[k] = h0[k];
+            for (int i = 0; i < SCH; ++i) replay_step(i, hm, scratch_a);
+            half(SCH, sl - SCH, hm);
+        }
+        half(0, min(sl, SCH), h0);
+        __syncthreads();
+        // ---------------- epilogue on the tile mapping (operands come back from LDS) ----------------
+        if (c_ok && tr < sl) {
+            float4 P1 = zero4, P2 = zero4, P3 = zero4;
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) {
+                const float4 a = ld4(&s_part[0][ww][tr][tc4]);
+                const float4 bq = ld4(&s_part[1][ww][tr][tc4]);
+                const float4 c = ld4(&s_part[2][ww][tr][tc4]);
+                P1.x += a.x; P1.y += a.y; P1.z += a.z; P1.w += a.w;
+                P2.x += bq.x; P2.y += bq.y; P2.z += bq.z; P2.w += bq.w;
+                P3.x += c.x; P3.y += c.y; P3.z += c.z; P3.w += c.w;
+            }
+            const float4 dl4 = ld4(&s_dl[tr][tc4]), u4 = ld4(&s_u[tr][tc4]), dy4 = ld4(&s_dy[tr][tc4]);
+            float4 Dv = zero4;
+            if (p.D) Dv = ld4(p.D + d0 + tc4);
+            const int64_t tok = tok0 + ts;
+            float4 o;                                   // du = delta' * sum_n dh B + D * dy
+            o.x = dl4.x * P1.x + Dv.x * dy4.x; o.y = dl4.y * P1.y + Dv.y * dy4.y;
+            o.z = dl4.z * P1.z + Dv.z * dy4.z; o.w = dl4.w * P1.w + Dv.w * dy4.w;
+            st4(p.du + tok * p.ld_du + d0 + tr * (int)p.ld_du + tc4, o);
+            float4 g;                                   // d delta' = sum_n (dh h_prev dA) A + u * sum_n dh B
+            g.x = P2.x + u4.x * P1.x; g.y = P2.y + u4.y * P1.y; g.z = P2.z + u4.z * P1.z; g.w = P2.w + u4.w * P1.w;
+            if (p.softplus) {                           // softplus'(x) = sigmoid(x) = 1 - exp(-softplus(x))
+                g.x *= 1.f - fast_exp(-dl4.x); g.y *= 1.f - fast_exp(-dl4.y); g.z *= 1.f - fast_exp(-dl4.z); g.w *= 1.f - fast_exp(-dl4.w);
+            }
+            st4(p.ddelta + tok * p.ld_ddelta + d0 + tr * (int)p.ld_ddelta + tc4, g);
+            dbacc.x += g.x; dbacc.y += g.y; dbacc.z += g.z; dbacc.w += g.w;
+            dDacc.x += dy4.x * u4.x; dDacc.y += dy4.y * u4.y; dDacc.z += dy4.z * u4.z; dDacc.w += dy4.w * u4.w;
+            if (p.z) {
+                const float4 z4 = ld4(&s_z[tr][tc4]), do4 = ld4(&s_do[tr][tc4]);
+                float4 yy;                              // pre-gate output y = sum_n C h + D u
+                yy.x = P3.x + Dv.x * u4.x; yy.y = P3.y + Dv.y * u4.y; yy.z = P3.z + Dv.z * u4.z; yy.w = P3.w + Dv.w * u4.w;
+                float4 gz;
+                gz.x = do4.x * yy.x * dsiluf_(z4.x); gz.y = do4.y * yy.y * dsiluf_(z4.y);
+                gz.z = do4.z * yy.z * dsiluf_(z4.z); gz.w = do4.w * yy.w * dsiluf_(z4.w);
+                st4(p.dz + tok * p.ld_dz + d0 + tr * (int)p.ld_dz + tc4, gz);
             }
         }
     }
     // ---- per-(b) partials of the parameter gradients
     if (d_ok) {
 #pragma unroll
-        for (int j = 0; j < NS; ++j) p.dA_part[((int64_t)b * p.Di + d) * N + w * NS + j] = dAacc[j];
+        for (int j = 0; j < NS; ++j)
+            p.dA_part[((int64_t)b * p.Di + d) * N + w * NS + j] = (j & 1) ? dAacc[j / 2].y : dAacc[j / 2].x;
     }
     __syncthreads();
     float* s_red = &s_part[0][0][0][0];               // [2][SC][64] scratch
@@ -563,10 +694,10 @@ __global__ void sscan_reduce_rows_kernel(const float* __restrict__ part, int B, 
     out[i] = acc;
 }
 
-template <int NS, int NW>
+template <int NS, int NW, int TC>
 int launch_fwd(const FwdParams& p, hipStream_t s) {
     const int bp = (p.B + 7) / 8 * 8;
-    launch_maybe_timed(0, sscan_fwd_kernel<NS, NW>, dim3(bp * p.nd), dim3(NW * 64), s, p);
+    launch_maybe_timed(0, sscan_fwd_kernel<NS, NW, TC>, dim3(bp * p.nd), dim3(NW * 64), s, p);
     return launch_status();
 }
 template <int NS, int NW>
@@ -635,14 +766,15 @@ extern "C" int resel_selective_scan_fwd(const float* u, int64_t ld_u, const floa
     if ((D && !aligned16(D)) || (delta_bias && !aligned16(delta_bias))) return RESEL_EINVAL;
     FwdParams p{u, delta, z, A, Bm, Cm, D, delta_bias, start, out, ckpt, last_state,
                 ld_u, ld_delta, ld_z, ld_b, ld_c, ld_out, B, L, Di, N, n_ckpt(L), delta_softplus,
-                (Di + TILE_C - 1) / TILE_C};
+                (Di + TILE_C - 1) / TILE_C,
+                (ld_b % 4 == 0 && ld_c % 4 == 0 && aligned16(Bm) && aligned16(Cm)) ? 1 : 0};
     hipStream_t s = (hipStream_t)stream;
     switch (N) {
-        case 4: return launch_fwd<1, 4>(p, s);
-        case 8: return launch_fwd<2, 4>(p, s);
-        case 16: return launch_fwd<4, 4>(p, s);
-        case 32: return launch_fwd<8, 4>(p, s);
-        case 64: return launch_fwd<8, 8>(p, s);
+        case 4: return launch_fwd<1, 4, 32>(p, s);
+        case 8: return launch_fwd<2, 4, 32>(p, s);
+        case 16: return launch_fwd<4, 4, 32>(p, s);
+        case 32: return launch_fwd<8, 4, 32>(p, s);
+        case 64: return launch_fwd<8, 8, 32>(p, s);
         default: return RESEL_EINVAL;
     }
 }
@@ -677,14 +809,15 @@ extern "C" int resel_selective_scan_bwd(const float* u, int64_t ld_u, const floa
                 (float*)(base + ws.dB), (float*)(base + ws.dC), (float*)(base + ws.dA), (float*)(base + ws.dD),
                 (float*)(base + ws.dbias),
                 ld_u, ld_delta, ld_z, ld_b, ld_c, ld_dout, ld_du, ld_ddelta, ld_dz,
-                B, L, Di, N, n_ckpt(L), delta_softplus, (Di + TILE_C - 1) / TILE_C};
+                B, L, Di, N, n_ckpt(L), delta_softplus, (Di + TILE_C - 1) / TILE_C,
+                (ld_b % 4 == 0 && ld_c % 4 == 0 && aligned16(Bm) && aligned16(Cm)) ? 1 : 0};
     hipStream_t s = (hipStream_t)stream;
     int rc;
     switch (N) {
         case 4: rc = launch_bwd<1, 4>(p, s); break;
         case 8: rc = launch_bwd<2, 4>(p, s); break;
         case 16: rc = launch_bwd<4, 4>(p, s); break;
-        case 32: rc = launch_bwd<4, 8>(p, s); break;     // 8 waves x 4 states: halves the register-resident history
+        case 32: rc = launch_bwd<8, 4>(p, s); break;     // 4 waves x 8 states: the 8-step (h, dA) history is 128 VGPRs
         case 64: rc = launch_bwd<8, 8>(p, s); break;
         default: return RESEL_EINVAL;
     }

@@ -29,6 +29,8 @@ fwd_bytes = 4 * B * Di * L * 4 + 4 * B * N * L * 2 + B * L
 bwd_bytes = 4 * B * Di * L * 7 + 4 * B * N * L * 4
 t = timeit(lambda: ops.selective_scan_tm(u, delta, A, Bm, Cm, Dp, z, db, start, True))
 res['sscan_fwd_us'] = t; res['sscan_fwd_GBs'] = fwd_bytes / t / 1e3
+if len(sys.argv) > 1 and sys.argv[1] == 'sscan_only':
+    print(json.dumps(res)); sys.exit(0)
 ins = [t_.clone().requires_grad_(True) for t_ in (xz, xdbl, delta, A, Dp, db)]
 def fb():
     for t_ in ins: t_.grad = None
