@@ -79,6 +79,7 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--rnn', default='smamba_s32_c16_b2_nln')
+    ap.add_argument('--algo', default='sac', choices=['sac', 'td3'])
     ap.add_argument('--rows', type=int, default=64, help='trajectories per GPU per update')
     ap.add_argument('--horizon', type=int, default=1024)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -91,7 +92,7 @@ def main():
     torch.cuda.set_device(local)
     torch.manual_seed(1234 + rank)
     np.random.seed(1234 + rank)                         # each rank samples its own rows
-    alg = build_trainer(args.rnn, args.rows, args.horizon, seed=rank)
+    alg = build_trainer(args.rnn, args.rows, args.horizon, seed=rank, algo=args.algo)
     alg.grad_sync.__init__()                            # pick up the process group
     if world > 1:
         for net in [alg.policy] + alg.values + alg.target_values:
@@ -133,7 +134,7 @@ def main():
         'metric': 'env-steps/sec trained', 'value': trained / dt, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': f'{args.rnn} SAC-REDQ full-trajectory update, B={Bsz}/GPU, T={args.horizon} (row length {Tp}), obs={OBS}, act={ACT}, '
+        'config': {'workload': f'{args.rnn} {args.algo.upper()}-REDQ full-trajectory update, B={Bsz}/GPU, T={args.horizon} (row length {Tp}), obs={OBS}, act={ACT}, '
                                f'D=256, efc-8 critic (BASELINE configs[1]; N=8 is configs[3])',
                    'global_rows': Bsz * world, 'parallelism': f'dp{world}'},
     }

@@ -159,6 +159,24 @@ int resel_gru_seq_bwd(const float* w_hh, const float* h0, const float* h_all, co
                       int B, int L, int H, resel_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------
+ * cgpt attention core: packed var-len causal attention with ALiBi, bf16 MFMA (v_mfma_f32_32x32x16_bf16), fp32 softmax.
+ * Replaces the flash-attn varlen kernels reached through `flash_attn.modules.mha.MHA(causal=True, use_alibi=True)`
+ * (offpolicy_rnn/models/flash_attention/TransformerFlashAttention.py:67-70, called under bf16 autocast at :80-81; packing
+ * :107-112).  *** flash_attn is an un-vendored dependency: semantics restated (softmax(q k^T * scale - slope_h (i - j)), j <= i),
+ * parity unpinned ***
+ * qkv: [T, 3, H, hd] bf16 packed tokens (q | k | v); cu_seqlens: int32 [S + 1] device; slopes: [H] fp32 or NULL;
+ * out: [T, H, hd] bf16; lse: [H, T] fp32 (base-2 log-sum-exp, saved for the backward).  hd in {32, 64}; max_seqlen bounds
+ * the grid.  Backward: dqkv [T, 3, H, hd] bf16 (fully overwritten); workspace resel_attn_varlen_bwd_workspace_bytes().
+ * No attention-probability dropout (the reference's published cgpt runs use p = 0.0).
+ */
+int resel_attn_varlen_fwd(const uint16_t* qkv, const int32_t* cu_seqlens, const float* slopes, uint16_t* out, float* lse,
+                          int T, int S, int H, int hd, int max_seqlen, float scale, resel_stream_t stream);
+size_t resel_attn_varlen_bwd_workspace_bytes(int T, int H, int hd);
+int resel_attn_varlen_bwd(const uint16_t* qkv, const int32_t* cu_seqlens, const float* slopes, const uint16_t* out,
+                          const float* lse, const uint16_t* dout, uint16_t* dqkv, void* workspace,
+                          int T, int S, int H, int hd, int max_seqlen, float scale, resel_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------
  * SAC / TD3 head, target and loss arithmetic + optimizer tail (the "fusions" of SURVEY.md section 8 row a16-a18).
  */
 /* tanh-Gaussian head: contextual_sac_policy_single_head.py:109-123.  out2: [M, 2A] = (logstd | mean) as produced

@@ -1,0 +1,390 @@
+// cgpt attention core for gfx950: packed variable-length causal attention with ALiBi, bf16 MFMA, fp32 softmax.
+//
+// Tokens of all sequences are packed [T, 3, H, hd] (q | k | v per token); cu_seqlens delimits the sequences.
+// All three kernels are built on v_mfma_f32_32x32x16_bf16 and keep the SCORE tile transposed so that softmax
+// statistics are per LANE (MFMA C/D layout: column = lane & 31, 16 rows in registers, row = (r&3) + 8(r>>2) + 4(lane>>5)):
+//   forward / dQ kernel : S^T[key][q] = K Q^T      -> column = query: running max / sum / lse / delta are one value per lane,
+//                         and the probability tile feeds the next product (O^T = V^T P^T, dQ^T = K^T dS^T) straight from
+//                         registers as the B operand (rows = summed index; k-order 16s + 8(j>>2) + 4h + (j&3)), while the
+//                         A operand (V^T / K^T) is read from a transposed LDS tile in that same k-order with two ds_read_b64;
+//   dK/dV kernel        : S[q][key] = Q K^T        -> column = key: dV^T = dO^T P and dK^T = Q^T dS sum over the row index q.
+// Arithmetic intensity is low for hd = 32 (4 MFMAs per 32x32 tile against ~16 exp2 per lane), so these kernels are
+// VALU/exp-bound rather than MFMA-bound; the whole attention share of a cgpt update is ~1 TFLOP.
+// Semantics restated from flash-attn's MHA(causal, alibi) - see oracle/kernels.py attention_alibi_varlen_ref: PARITY UNPINNED.
+#include "resel_common.h"
+
+namespace {
+using namespace resel;
+
+typedef __bf16 bf16_t;
+typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));
+typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
+typedef bf16_t bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr float NEG_BIG = -1e30f;
+constexpr int KT = 32;          // keys per tile
+constexpr int PADE = 8;         // bf16 elements of row padding in LDS tiles (16 bytes)
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+__device__ __forceinline__ bf16x8 zero8() {
+    bf16x8 z;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) z[i] = (bf16_t)0.f;
+    return z;
+}
+__device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// accumulator registers 8s .. 8s+7 -> bf16 B-operand fragment of k-step s
+__device__ __forceinline__ bf16x8 acc_to_frag(const f32x16& x, int s) {
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        const f32x2 v = {x[8 * s + j], x[8 * s + j + 1]};
+        const bf16x2 p = __builtin_convertvector(v, bf16x2);
+        r[j] = p[0];
+        r[j + 1] = p[1];
+    }
+    return r;
+}
+// A-operand fragment in the accumulator's k-order from a transposed LDS tile row: elements [16s + 4h, +4) and [16s + 8 + 4h, +4)
+__device__ __forceinline__ bf16x8 tr_frag(const bf16_t* row, int s, int hh) {
+    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(row + 16 * s + 4 * hh);
+    const bf16x4 hi = *reinterpret_cast<const bf16x4*>(row + 16 * s + 8 + 4 * hh);
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { r[j] = lo[j]; r[4 + j] = hi[j]; }
+    return r;
+}
+__device__ __forceinline__ int acc_row(int reg, int hh) { return (reg & 3) + 8 * (reg >> 2) + 4 * hh; }
+
+struct AttnParams {
+    const bf16_t* qkv;
+    const int32_t* cu;
+    const float* slopes;
+    bf16_t* out;
+    float* lse;                 // [H, T] base-2 log-sum-exp of the scaled + biased scores
+    const bf16_t* dout;
+    const float* delta;         // [H, T]
+    bf16_t* dqkv;
+    int T, S, H;
+    float scale;
+};
+
+// stage a [KT keys][HD] tile of K or V (which = 1 / 2) row-major and / or transposed into LDS
+template <int HD, bool ROW, bool TR>
+__device__ __forceinline__ void stage_kv(const AttnParams& p, int which, int t0, int len, int k0, int h,
+                                         bf16_t (*rowm)[HD + PADE], bf16_t (*trm)[KT + PADE], int tid, int nthr) {
+    for (int i = tid; i < KT * HD / 8; i += nthr) {
+        const int key = i / (HD / 8), c8 = (i % (HD / 8)) * 8;
+        bf16x8 v = zero8();
+        if (k0 + key < len) v = *reinterpret_cast<const bf16x8*>(p.qkv + (((int64_t)(t0 + k0 + key) * 3 + which) * p.H + h) * HD + c8);
+        if (ROW) *reinterpret_cast<bf16x8*>(&rowm[key][c8]) = v;
+        if (TR) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) trm[c8 + e][key] = v[e];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------- forward
+// MODE 0: forward (O, lse).  MODE 1: dQ (needs dout, lse, delta).
+template <int HD, int MODE>
+__global__ __launch_bounds__(256) void attn_q_kernel(AttnParams p) {
+    constexpr int KS = HD / 16, ND = HD / 32;
+    __shared__ __attribute__((aligned(16))) bf16_t k_lds[KT][HD + PADE];
+    __shared__ __attribute__((aligned(16))) bf16_t v_lds[MODE == 1 ? KT : 1][HD + PADE];          // row-major V (dQ only)
+    __shared__ __attribute__((aligned(16))) bf16_t tr_lds[HD][KT + PADE];                          // V^T (fwd) or K^T (dQ)
+    const int s = blockIdx.y, h = blockIdx.z;
+    const int t0 = p.cu[s], len = p.cu[s + 1] - t0;
+    const int qb0 = blockIdx.x * 128;
+    if (qb0 >= len) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int q = qb0 + w * 32 + r;
+    const bool q_ok = q < len;
+    const float c1 = p.scale * RESEL_LOG2E;
+    const float slope2 = (p.slopes ? p.slopes[h] : 0.f) * RESEL_LOG2E;
+    bf16x8 qf[KS], dof[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        qf[ks] = zero8();
+        dof[ks] = zero8();
+        if (q_ok) {
+            qf[ks] = *reinterpret_cast<const bf16x8*>(p.qkv + (((int64_t)(t0 + q) * 3 + 0) * p.H + h) * HD + 16 * ks + 8 * hh);
+            if (MODE == 1) dof[ks] = *reinterpret_cast<const bf16x8*>(p.dout + ((int64_t)(t0 + q) * p.H + h) * HD + 16 * ks + 8 * hh);
+        }
+    }
+    float m = NEG_BIG, l = 0.f;
+    float lse2 = 0.f, dlt = 0.f;
+    if (MODE == 1 && q_ok) {
+        lse2 = p.lse[(int64_t)h * p.T + t0 + q];
+        dlt = p.delta[(int64_t)h * p.T + t0 + q];
+    }
+    f32x16 acc[ND];
+#pragma unroll
+    for (int t = 0; t < ND; ++t) acc[t] = zero16();
+
+    const int q_hi = min(len, qb0 + 128) - 1;                    // last query of this block
+    const int ntile = q_hi / KT + 1;                             // causal: keys <= q_hi
+    const int wq_hi = qb0 + w * 32 + 31;                         // last query of this wave
+    for (int kt = 0; kt < ntile; ++kt) {
+        const int k0 = kt * KT;
+        __syncthreads();
+        stage_kv<HD, true, MODE == 1>(p, 1, t0, len, k0, h, k_lds, tr_lds, tid, 256);              // K (+ K^T for dQ)
+        if (MODE == 0) stage_kv<HD, false, true>(p, 2, t0, len, k0, h, nullptr, tr_lds, tid, 256); // V^T
+        else stage_kv<HD, true, false>(p, 2, t0, len, k0, h, v_lds, nullptr, tid, 256);            // V row-major
+        __syncthreads();
+        if (k0 > wq_hi) continue;                                // tile entirely in this wave's future (uniform per wave)
+        f32x16 st = zero16();
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            st = mfma(*reinterpret_cast<const bf16x8*>(&k_lds[r][16 * ks + 8 * hh]), qf[ks], st);
+        // scaled + biased + masked scores, base 2
+        float sc[16];
+        float mloc = NEG_BIG;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int key = k0 + acc_row(i, hh);
+            const bool ok = q_ok && key <= q;                    // (key <= q < len)
+            sc[i] = ok ? st[i] * c1 - slope2 * (float)(q - key) : NEG_BIG;
+            mloc = fmaxf(mloc, sc[i]);
+        }
+        f32x16 pt;
+        if (MODE == 0) {
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+            const float mnew = fmaxf(m, mloc);
+            const float alpha = fast_exp2(m - mnew);
+            float psum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float e = sc[i] > 0.5f * NEG_BIG ? fast_exp2(sc[i] - mnew) : 0.f;
+                pt[i] = e;
+                psum += e;
+            }
+            l = l * alpha + psum;
+            m = mnew;
+#pragma unroll
+            for (int t = 0; t < ND; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[t][i] *= alpha;
+        } else {
+            // dP^T = V dO^T ; dS^T = P^T (dP^T - delta) * scale
+            f32x16 dp = zero16();
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                dp = mfma(*reinterpret_cast<const bf16x8*>(&v_lds[r][16 * ks + 8 * hh]), dof[ks], dp);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float e = sc[i] > 0.5f * NEG_BIG ? fast_exp2(sc[i] - lse2) : 0.f;
+                pt[i] = e * (dp[i] - dlt) * p.scale;
+            }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8 bfr = acc_to_frag(pt, s2);
+#pragma unroll
+            for (int t = 0; t < ND; ++t) acc[t] = mfma(tr_frag(&tr_lds[32 * t + r][0], s2, hh), bfr, acc[t]);
+        }
+    }
+    // epilogue: acc[t][reg] = X^T[d = 32t + row(reg)][q]
+    float inv = 1.f;
+    if (MODE == 0) {
+        const float ltot = l + __shfl_xor(l, 32, 64);
+        inv = ltot > 0.f ? 1.f / ltot : 0.f;
+        if (q_ok && hh == 0) p.lse[(int64_t)h * p.T + t0 + q] = m + __log2f(fmaxf(ltot, 1e-37f));
+    }
+    if (q_ok) {
+        bf16_t* dst = MODE == 0 ? p.out + ((int64_t)(t0 + q) * p.H + h) * HD
+                                : p.dqkv + (((int64_t)(t0 + q) * 3 + 0) * p.H + h) * HD;
+#pragma unroll
+        for (int t = 0; t < ND; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = {acc[t][4 * g] * inv, acc[t][4 * g + 1] * inv, acc[t][4 * g + 2] * inv, acc[t][4 * g + 3] * inv};
+                *reinterpret_cast<bf16x4*>(dst + 32 * t + 8 * g + 4 * hh) = __builtin_convertvector(v, bf16x4);
+            }
+    }
+}
+
+// delta[h, tok] = sum_d dO * O
+template <int HD>
+__global__ void attn_delta_kernel(const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout, float* __restrict__ delta, int T, int H) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;         // over T * H
+    if (i >= T * H) return;
+    const int tok = i / H, h = i % H;
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < HD; c += 8) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(out + (int64_t)i * HD + c);
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(dout + (int64_t)i * HD + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc += (float)a[e] * (float)b[e];
+    }
+    delta[(int64_t)h * T + tok] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------- dK / dV
+template <int HD>
+__global__ __launch_bounds__(256) void attn_dkv_kernel(AttnParams p) {
+    constexpr int KS = HD / 16, ND = HD / 32;
+    __shared__ __attribute__((aligned(16))) bf16_t qT[4][HD][KT + PADE];       // per-wave transposed Q tile  [d][q]
+    __shared__ __attribute__((aligned(16))) bf16_t doT[4][HD][KT + PADE];      // per-wave transposed dO tile [d][q]
+    __shared__ float s_red[4][2 * ND][16][64];
+    const int s = blockIdx.y, h = blockIdx.z;
+    const int t0 = p.cu[s], len = p.cu[s + 1] - t0;
+    const int k0 = blockIdx.x * KT;
+    if (k0 >= len) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int key = k0 + r;
+    const bool k_ok = key < len;
+    const float c1 = p.scale * RESEL_LOG2E;
+    const float slope2 = (p.slopes ? p.slopes[h] : 0.f) * RESEL_LOG2E;
+    bf16x8 kf[KS], vf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        kf[ks] = zero8();
+        vf[ks] = zero8();
+        if (k_ok) {
+            kf[ks] = *reinterpret_cast<const bf16x8*>(p.qkv + (((int64_t)(t0 + key) * 3 + 1) * p.H + h) * HD + 16 * ks + 8 * hh);
+            vf[ks] = *reinterpret_cast<const bf16x8*>(p.qkv + (((int64_t)(t0 + key) * 3 + 2) * p.H + h) * HD + 16 * ks + 8 * hh);
+        }
+    }
+    f32x16 dkt[ND], dvt[ND];
+#pragma unroll
+    for (int t = 0; t < ND; ++t) { dkt[t] = zero16(); dvt[t] = zero16(); }
+    const int nqt = (len + KT - 1) / KT;
+    const int qt_first = k0 / KT;                                // first query tile that can see these keys
+    const int niter = (nqt - qt_first + 3) / 4;
+    for (int it = 0; it < niter; ++it) {
+        const int qt = qt_first + it * 4 + w;
+        const bool active = qt < nqt;
+        const int q0 = qt * KT;
+        const int qa = q0 + r;                                   // the query this lane loads as an A-operand row
+        bf16x8 qa_f[KS], doa_f[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qa_f[ks] = zero8();
+            doa_f[ks] = zero8();
+            if (active && qa < len) {
+                qa_f[ks] = *reinterpret_cast<const bf16x8*>(p.qkv + (((int64_t)(t0 + qa) * 3 + 0) * p.H + h) * HD + 16 * ks + 8 * hh);
+                doa_f[ks] = *reinterpret_cast<const bf16x8*>(p.dout + ((int64_t)(t0 + qa) * p.H + h) * HD + 16 * ks + 8 * hh);
+            }
+        }
+        __syncthreads();                                         // previous iteration's transposed tiles fully consumed
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                qT[w][16 * ks + 8 * hh + e][r] = qa_f[ks][e];
+                doT[w][16 * ks + 8 * hh + e][r] = doa_f[ks][e];
+            }
+        __syncthreads();
+        if (!active) continue;
+        f32x16 sacc = zero16(), dp = zero16();
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            sacc = mfma(qa_f[ks], kf[ks], sacc);                 // S[q][key]
+            dp = mfma(doa_f[ks], vf[ks], dp);                    // dP[q][key]
+        }
+        f32x16 pm, ds;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int qq = q0 + acc_row(i, hh);
+            const bool ok = k_ok && qq < len && key <= qq;
+            float e = 0.f, dl = 0.f;
+            if (ok) {
+                const float l2 = p.lse[(int64_t)h * p.T + t0 + qq];
+                dl = p.delta[(int64_t)h * p.T + t0 + qq];
+                e = fast_exp2(sacc[i] * c1 - slope2 * (float)(qq - key) - l2);
+            }
+            pm[i] = e;
+            ds[i] = e * (dp[i] - dl) * p.scale;
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8 pb = acc_to_frag(pm, s2), dsb = acc_to_frag(ds, s2);
+#pragma unroll
+            for (int t = 0; t < ND; ++t) {
+                dvt[t] = mfma(tr_frag(&doT[w][32 * t + r][0], s2, hh), pb, dvt[t]);     // dV^T[d][key] += dO^T[d][q] P[q][key]
+                dkt[t] = mfma(tr_frag(&qT[w][32 * t + r][0], s2, hh), dsb, dkt[t]);     // dK^T[d][key] += Q^T[d][q] dS[q][key]
+            }
+        }
+    }
+    // sum the four waves' partial accumulators, then store dK / dV rows
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < ND; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            s_red[w][t][i][lane] = dkt[t][i];
+            s_red[w][ND + t][i][lane] = dvt[t][i];
+        }
+    __syncthreads();
+    for (int pair = w; pair < 2 * ND; pair += 4) {
+        const int which = pair < ND ? 1 : 2, t = pair < ND ? pair : pair - ND;
+        if (!k_ok) continue;
+        bf16_t* dst = p.dqkv + (((int64_t)(t0 + key) * 3 + which) * p.H + h) * HD + 32 * t;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = 4 * g + e;
+                v[e] = (s_red[0][pair][i][lane] + s_red[1][pair][i][lane]) + (s_red[2][pair][i][lane] + s_red[3][pair][i][lane]);
+            }
+            *reinterpret_cast<bf16x4*>(dst + 8 * g + 4 * hh) = __builtin_convertvector(v, bf16x4);
+        }
+    }
+}
+
+inline bool attn_ok(int T, int S, int H, int hd, int max_seqlen) { return T > 0 && S > 0 && H > 0 && (hd == 32 || hd == 64) && max_seqlen > 0; }
+
+}  // namespace
+
+extern "C" int resel_attn_varlen_fwd(const uint16_t* qkv, const int32_t* cu_seqlens, const float* slopes, uint16_t* out, float* lse,
+                                     int T, int S, int H, int hd, int max_seqlen, float scale, resel_stream_t stream) {
+    if (!qkv || !cu_seqlens || !out || !lse || !attn_ok(T, S, H, hd, max_seqlen) || !aligned16(qkv) || !aligned16(out)) return RESEL_EINVAL;
+    AttnParams p{(const bf16_t*)qkv, cu_seqlens, slopes, (bf16_t*)out, lse, nullptr, nullptr, nullptr, T, S, H, scale};
+    dim3 grid((max_seqlen + 127) / 128, S, H);
+    hipStream_t s = (hipStream_t)stream;
+    if (hd == 32) hipLaunchKernelGGL((attn_q_kernel<32, 0>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((attn_q_kernel<64, 0>), grid, dim3(256), 0, s, p);
+    return launch_status();
+}
+
+extern "C" size_t resel_attn_varlen_bwd_workspace_bytes(int T, int H, int hd) {
+    (void)hd;
+    return (size_t)T * H * sizeof(float);
+}
+
+extern "C" int resel_attn_varlen_bwd(const uint16_t* qkv, const int32_t* cu_seqlens, const float* slopes, const uint16_t* out,
+                                     const float* lse, const uint16_t* dout, uint16_t* dqkv, void* workspace,
+                                     int T, int S, int H, int hd, int max_seqlen, float scale, resel_stream_t stream) {
+    if (!qkv || !cu_seqlens || !out || !lse || !dout || !dqkv || !workspace || !attn_ok(T, S, H, hd, max_seqlen)) return RESEL_EINVAL;
+    if (!aligned16(qkv) || !aligned16(out) || !aligned16(dout) || !aligned16(dqkv)) return RESEL_EINVAL;
+    float* delta = (float*)workspace;
+    AttnParams p{(const bf16_t*)qkv, cu_seqlens, slopes, nullptr, const_cast<float*>(lse), (const bf16_t*)dout, delta, (bf16_t*)dqkv, T, S, H, scale};
+    hipStream_t s = (hipStream_t)stream;
+    const int n = T * H;
+    dim3 gq((max_seqlen + 127) / 128, S, H), gk((max_seqlen + KT - 1) / KT, S, H);
+    if (hd == 32) {
+        hipLaunchKernelGGL(attn_delta_kernel<32>, dim3((n + 255) / 256), dim3(256), 0, s, (const bf16_t*)out, (const bf16_t*)dout, delta, T, H);
+        hipLaunchKernelGGL((attn_q_kernel<32, 1>), gq, dim3(256), 0, s, p);
+        hipLaunchKernelGGL(attn_dkv_kernel<32>, gk, dim3(256), 0, s, p);
+    } else {
+        hipLaunchKernelGGL(attn_delta_kernel<64>, dim3((n + 255) / 256), dim3(256), 0, s, (const bf16_t*)out, (const bf16_t*)dout, delta, T, H);
+        hipLaunchKernelGGL((attn_q_kernel<64, 1>), gq, dim3(256), 0, s, p);
+        hipLaunchKernelGGL(attn_dkv_kernel<64>, gk, dim3(256), 0, s, p);
+    }
+    return launch_status();
+}

@@ -23,6 +23,7 @@ import torch
 
 from ..buffers.transition_buffer.nested_replay_memory import NestedMemoryArray as NestedTransitionMemoryArray
 from ..hip import ops
+from ..models.flash_attention.TransformerFlashAttention import PackedSeqs
 from ..parallel.data_parallel import GradSync
 from ..policy_value_models.make_models import make_policy_model
 from ..utility.q_value_guard import QValueGuard
@@ -56,7 +57,9 @@ class SACFullLengthRNNEnsembleQ(SAC):
         self.target_policy.eval()
         self.grad_sync = GradSync()
         self._pinned = None
-        self._needs_seq_table = False
+        self._needs_seq_table = any(lid.startswith('cgpt') for net in (self.values[0].uni_network, self.values[0].embedding_network,
+                                                                       self.policy.uni_network, self.policy.embedding_network)
+                                    for lid in net.layer_type)
         self._stats = torch.zeros(2, dtype=torch.float32, device=self.device)
 
     step = property(lambda self: self.train_one_batch)          # north_star's "algorithm.step()" alias
@@ -109,7 +112,8 @@ class SACFullLengthRNNEnsembleQ(SAC):
             am = np.zeros((rows, T), dtype=np.int32)
             am[:, :table.shape[1]] = table
             tam = np.concatenate((am[:, 1:], np.zeros((rows, 1), dtype=np.int32)), axis=1)
-            out['attention_mask'], out['target_attention_mask'] = torch.from_numpy(am).to(self.device), torch.from_numpy(tam).to(self.device)
+            # built on the host (the table is host data anyway): token indices + cu_seqlens for the var-len attention kernel
+            out['attention_mask'], out['target_attention_mask'] = PackedSeqs(am, T, self.device), PackedSeqs(tam, T, self.device)
         return out
 
     def _make_hidden(self, model, rows, start, mask, attn):

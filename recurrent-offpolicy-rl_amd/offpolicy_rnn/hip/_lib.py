@@ -39,6 +39,9 @@ SIGNATURES = {
     'resel_gru_workspace_bytes': (c_size_t, [I, I, I]),
     'resel_gru_seq_fwd': (c_int, [P, P, P, P, P, P, P, I, I, I, S]),
     'resel_gru_seq_bwd': (c_int, [P, P, P, P, P, P, P, P, I, I, I, S]),
+    'resel_attn_varlen_fwd': (c_int, [P, P, P, P, P, I, I, I, I, I, F, S]),
+    'resel_attn_varlen_bwd_workspace_bytes': (c_size_t, [I, I, I]),
+    'resel_attn_varlen_bwd': (c_int, [P, P, P, P, P, P, P, P, I, I, I, I, I, F, S]),
     'resel_tanh_gaussian_fwd': (c_int, [P, P, P, P, P, I, I, S]),
     'resel_tanh_gaussian_bwd': (c_int, [P, P, P, P, P, I, I, S]),
     'resel_sac_target': (c_int, [P, P, I, P, P, P, P, P, F, P, P, P, P, I, I, S]),

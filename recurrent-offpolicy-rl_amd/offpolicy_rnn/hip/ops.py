@@ -349,6 +349,43 @@ def gru_seq(gi, w_hh, b_hh, h0=None):
     return GruSeqFn.apply(gi, w_hh, b_hh, h0)
 
 
+# ---------------------------------------------------------------------------------------------- attention (cgpt)
+class AttnVarlenFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, cu_seqlens, max_seqlen, slopes, scale):
+        _need_cuda('attn_varlen', qkv, cu_seqlens)
+        assert qkv.dtype == torch.bfloat16 and qkv.dim() == 4 and qkv.shape[1] == 3
+        qkv = qkv.contiguous()
+        T, _, H, hd = qkv.shape
+        cu = cu_seqlens.to(torch.int32).contiguous()
+        S = cu.numel() - 1
+        slopes = None if slopes is None else slopes.float().contiguous()
+        out = torch.empty(T, H, hd, dtype=torch.bfloat16, device=qkv.device)
+        lse = torch.empty(H, T, dtype=torch.float32, device=qkv.device)
+        check(lib().resel_attn_varlen_fwd(_p(qkv), _p(cu), _p(slopes), _p(out), _p(lse), T, S, H, hd, int(max_seqlen), float(scale),
+                                          _stream()), 'attn_varlen_fwd')
+        ctx.save_for_backward(qkv, cu, slopes, out, lse)
+        ctx.max_seqlen, ctx.scale = int(max_seqlen), float(scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, cu, slopes, out, lse = ctx.saved_tensors
+        T, _, H, hd = qkv.shape
+        dout = dout.to(torch.bfloat16).contiguous()
+        dqkv = torch.empty_like(qkv)
+        ws = _ws(lib().resel_attn_varlen_bwd_workspace_bytes(T, H, hd), qkv.device)
+        check(lib().resel_attn_varlen_bwd(_p(qkv), _p(cu), _p(slopes), _p(out), _p(lse), _p(dout), _p(dqkv), _p(ws), T, cu.numel() - 1, H, hd,
+                                          ctx.max_seqlen, ctx.scale, _stream()), 'attn_varlen_bwd')
+        return dqkv, None, None, None, None
+
+
+def attn_varlen(qkv, cu_seqlens, max_seqlen, slopes=None, scale=None):
+    """qkv [T, 3, H, hd] bf16 packed tokens -> out [T, H, hd] bf16: causal softmax(q k^T * scale - slope_h (i - j)) v per sequence."""
+    scale = qkv.shape[-1] ** -0.5 if scale is None else scale
+    return AttnVarlenFn.apply(qkv, cu_seqlens, max_seqlen, slopes, scale)
+
+
 # ---------------------------------------------------------------------------------------------- SAC / TD3 arithmetic
 class TanhGaussianFn(torch.autograd.Function):
     @staticmethod

@@ -100,10 +100,10 @@ class RNNHidden:
     def to_device(self, device) -> None:
         if self._device != device:
             self._device = device
-            self._data = [tuple(t.to(device) for t in d) if isinstance(d, tuple) else d.to(device) for d in self._data]
+            self._data = [tuple(t.to(device) for t in d) if isinstance(d, tuple) else (d.to(device) if torch.is_tensor(d) else d) for d in self._data]
 
     def hidden_detach_(self) -> None:
-        self._data = [tuple(t.detach() for t in d) if isinstance(d, tuple) else d.detach() for d in self._data]
+        self._data = [tuple(t.detach() for t in d) if isinstance(d, tuple) else (d.detach() if torch.is_tensor(d) else d) for d in self._data]
 
     def hidden_detach(self) -> 'RNNHidden':
         out = copy.deepcopy(self)
@@ -117,10 +117,10 @@ class RNNHidden:
 
     def __deepcopy__(self, memo):
         out = RNNHidden(self._rnn_num, self._rnn_types, self._device, self._batch_first)
-        out._data = [tuple(t.clone() for t in d) if isinstance(d, tuple) else d.clone() for d in self._data]
+        out._data = [tuple(t.clone() for t in d) if isinstance(d, tuple) else (d.clone() if torch.is_tensor(d) else copy.deepcopy(d)) for d in self._data]
         for k in ('_rnn_start', '_attention_concat_mask', '_mask', '_grad_detach'):
             v = getattr(self, k)
-            setattr(out, k, None if v is None else v.clone())
+            setattr(out, k, v.clone() if torch.is_tensor(v) else v)
         return out
 
     def __str__(self):

@@ -2,8 +2,8 @@
 (reference offpolicy_rnn/models/rnn_base.py:31-532).
 
 Layer-id grammar kept from the reference (:101-247): `fc`, `efc-<E>`, `gru`, `gilr`, `lru`,
-`smamba[_s<N>][_c<K>][_b<blocks>][_n<ln|...>][_ff]`.  Ids of reference layers that are outside the MI355X hot path
-(`lstm`, `mamba*`, `gilr_lstm`, `conv1d*`, `e<rnn>-<E>`, `gpt*`, `cgpt*`, `transformer*`) are recognised and rejected
+`smamba[_s<N>][_c<K>][_b<blocks>][_n<ln|...>][_ff]`, `cgpt[_h<H>][_l<L>][_p<drop>][_ml<M>][_rms]`.  Ids of reference layers
+that are outside the MI355X hot path (`lstm`, `mamba*`, `gilr_lstm`, `conv1d*`, `e<rnn>-<E>`, `gpt*`, `transformer*`) are recognised and rejected
 with an explicit message.  Module / parameter naming (`layer_list.<i>.…`, `activation_list.<i>.0.…`) matches the
 reference so that its per-module checkpoints load."""
 import copy
@@ -14,6 +14,7 @@ import torch
 
 from .RNNHidden import RNNHidden
 from .ensemble_linear_model import EnsembleLinear
+from .flash_attention.TransformerFlashAttention import InferenceParams, TransformerDecoder
 from .gilr.gilr import GILRLayer
 from .gru import GRU
 from .lru.lru import LRULayer
@@ -21,7 +22,7 @@ from .smamba.mamba import BlockList as MambaBlockList
 
 ACTIVATIONS = {'tanh': torch.nn.Tanh, 'relu': torch.nn.ReLU, 'sigmoid': torch.nn.Sigmoid, 'leaky_relu': torch.nn.LeakyReLU,
                'linear': torch.nn.Identity, 'elu': torch.nn.ELU, 'gelu': torch.nn.GELU}
-_UNSUPPORTED_PREFIXES = ('lstm', 'mamba', 'gilr_lstm', 'conv1d', 'econv1d', 'gpt', 'cgpt', 'transformer', 'cgru', 'elru', 'egilr')
+_UNSUPPORTED_PREFIXES = ('lstm', 'mamba', 'gilr_lstm', 'conv1d', 'econv1d', 'gpt', 'transformer', 'cgru', 'elru', 'egilr')
 
 
 def parse_smamba_id(layer_id: str) -> dict:
@@ -37,6 +38,24 @@ def parse_smamba_id(layer_id: str) -> dict:
             cfg['rms_norm'] = tok[1:] != 'ln'
         elif tok.startswith('f'):
             cfg['use_ff'] = cfg['use_ff'] or tok[1:] == 'f'
+        else:
+            raise ValueError(f'Pattern {tok} has not been implemented!')
+    return cfg
+
+
+def parse_cgpt_id(layer_id: str) -> dict:
+    cfg = dict(nhead=8, nlayer=4, pdrop=0.1, maxlength=1024, ln=True)
+    for tok in layer_id.split('_')[1:]:
+        if tok.startswith('h'):
+            cfg['nhead'] = int(tok[1:])
+        elif tok.startswith('l'):
+            cfg['nlayer'] = int(tok[1:])
+        elif tok.startswith('p'):
+            cfg['pdrop'] = float(tok[1:])
+        elif tok.startswith('ml'):
+            cfg['maxlength'] = int(tok[2:])
+        elif tok.startswith('rms'):
+            cfg['ln'] = False
         else:
             raise ValueError(f'Pattern {tok} has not been implemented!')
     return cfg
@@ -92,9 +111,12 @@ class RNNBase(torch.nn.Module):
             layer = MambaBlockList(cfg['block_num'], n_in, d_conv=cfg['d_conv'], d_state=cfg['d_state'], rms_norm=cfg['rms_norm'],
                                    use_ff=cfg['use_ff'])
             return layer, layer.desired_hidden_dim
+        if lid.startswith('cgpt'):
+            cfg = parse_cgpt_id(lid)
+            return TransformerDecoder(n_in, cfg['nhead'], 4 * n_in, cfg['nlayer'], cfg['pdrop'], cfg['ln']), cfg['maxlength']
         if lid.startswith(_UNSUPPORTED_PREFIXES):
             raise NotImplementedError(f'layer id {lid!r} exists in the reference but is outside the MI355X hot path of this build '
-                                      f'(supported: fc, efc-<E>, gru, gilr, lru, smamba_*)')
+                                      f'(supported: fc, efc-<E>, gru, gilr, lru, smamba_*, cgpt_*)')
         raise NotImplementedError(f'unknown layer id {lid!r}')
 
     @staticmethod
@@ -132,7 +154,7 @@ class RNNBase(torch.nn.Module):
                 torch.nn.init.xavier_uniform_(m.out_proj.weight)
                 torch.nn.init.constant_(m.out_proj.bias, 0)
                 xavier_ensemble(m.in_proj)
-            elif isinstance(m, MambaBlockList):
+            elif isinstance(m, (MambaBlockList, TransformerDecoder)):
                 pass
             else:
                 for name, param in m.named_parameters():
@@ -152,6 +174,9 @@ class RNNBase(torch.nn.Module):
     def _make_state(self, batch_size, device, random: bool) -> RNNHidden:
         st = RNNHidden(self.rnn_num, self.rnn_layer_type, device)
         for width, lid in zip(self.rnn_hidden_state_input_size, self.rnn_layer_type):
+            if lid.startswith('cgpt'):
+                st.append(InferenceParams(max_seqlen=width, max_batch_size=batch_size))
+                continue
             make = st.init_random_hidden_by_type if random else st.init_hidden_by_type
             st.append(make(lid, batch_size, width, device))
         return st
@@ -184,6 +209,11 @@ class RNNBase(torch.nn.Module):
                     x, h = layer(x, hidden_state[k], hidden_state.rnn_start, hidden_state.grad_detach)
                 elif lid.startswith('smamba'):
                     x, h = layer(x, hidden_state[k], hidden_state.rnn_start, hidden_state.mask)
+                elif lid.startswith('cgpt'):
+                    multi = x.dim() == 3 and x.shape[-2] > 1          # whole packed rows (training) vs one rollout step
+                    x = layer(x, inference_params=None if multi else hidden_state[k],
+                              seqlens=hidden_state.attention_concat_mask if multi else None)
+                    h = hidden_state[k]
                 else:                                   # gru: no reset / mask handling (reference :453-454)
                     x, h = layer(x, hidden_state[k])
                 k += 1

@@ -44,6 +44,11 @@ def gru_seq(gi, w_hh, b_hh, h0=None):
     return K.gru_seq_ref(gi, w_hh, b_hh, h0)
 
 
+def attn_varlen(qkv, cu_seqlens, max_seqlen, slopes=None, scale=None):
+    out = K.attention_alibi_varlen_ref(qkv[:, 0], qkv[:, 1], qkv[:, 2], cu_seqlens, slopes, scale)
+    return out.to(torch.bfloat16)
+
+
 def tanh_gaussian(out2, noise):
     A = out2.shape[-1] // 2
     mean, samp, logp = K.tanh_gaussian_ref(out2[..., A:], out2[..., :A], noise)
@@ -97,7 +102,7 @@ def sumsq(x, out=None):
 def install(monkeypatch):
     from offpolicy_rnn.hip import ops
     table = dict(selective_scan_tm=selective_scan_tm, causal_conv1d_fn=causal_conv1d_fn, layer_norm_fn=_norm(False),
-                 rms_norm_fn=_norm(True), gilr_scan=gilr_scan, complex_scan=complex_scan, gru_seq=gru_seq, tanh_gaussian=tanh_gaussian,
+                 rms_norm_fn=_norm(True), gilr_scan=gilr_scan, complex_scan=complex_scan, gru_seq=gru_seq, tanh_gaussian=tanh_gaussian, attn_varlen=attn_varlen,
                  sac_target=sac_target, soft_update_=soft_update_, adamw_flat_=adamw_flat_, sumsq=sumsq)
     for k, fn in table.items():
         monkeypatch.setattr(ops, k, fn)

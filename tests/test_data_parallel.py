@@ -22,10 +22,10 @@ class _Patch:
         setattr(obj, name, val)
 
 
-def _build(seed_data, same_noise_seed):
+def _build(seed_data, same_noise_seed, patcher=None):
     sys.path[:0] = [HERE, os.path.dirname(HERE), os.path.join(os.path.dirname(HERE), 'recurrent-offpolicy-rl_amd')]
     import oracle_backend
-    oracle_backend.install(_Patch())
+    oracle_backend.install(patcher or _Patch())      # worker processes patch for good; the pytest process uses monkeypatch
     from test_host_logic import _push, _synth, make_parameter
     from offpolicy_rnn import alg_init
     torch.manual_seed(0)
@@ -64,14 +64,14 @@ def _free_port():
 
 
 @pytest.mark.parametrize('same_data', [False, True])
-def test_two_rank_update(tmp_path, same_data):
+def test_two_rank_update(tmp_path, same_data, monkeypatch):
     mp.spawn(_worker, args=(2, _free_port(), same_data, str(tmp_path)), nprocs=2, join=True)
     r0, r1 = (torch.load(os.path.join(tmp_path, f'rank{i}.pt')) for i in range(2))
     for k in ('policy', 'value', 'alpha'):
         assert torch.equal(r0[k], r1[k]), f'{k} diverged across ranks'
     if same_data:
         sys.path[:0] = [HERE]
-        alg = _build(seed_data=3, same_noise_seed=11)          # single process, same rows, same noise
+        alg = _build(seed_data=3, same_noise_seed=11, patcher=monkeypatch)   # single process, same rows, same noise
         for _ in range(2):
             alg.train_one_batch()
             alg.grad_num += 1

@@ -317,3 +317,38 @@ def test_flat_optimizer_tail(ops):
         opt.step()
         ops.adamw_flat_(pg, gstep.cuda(), m, v, seg_end, seg_lr, seg_wd, step)
     close(pg, torch.cat((a, b)).detach(), rtol=1e-5, atol_scale=1e-6, name='adamw')
+
+
+# ------------------------------------------------------------------------------------------------ cgpt attention (bf16)
+@pytest.mark.parametrize('H,hd,lens', [(2, 32, [5]), (8, 32, [1, 130, 37, 64]), (4, 64, [200, 33]), (8, 32, [1027])])
+def test_attn_varlen_alibi_fwd_bwd(ops, H, hd, lens):
+    """bf16 MFMA attention vs the fp32 oracle on bf16-rounded inputs (north_star: 1e-2 for the bf16 path).
+    The oracle restates published flash-attn semantics (causal + ALiBi, bottom-right aligned = same-length q/k): parity unpinned."""
+    g = torch.Generator().manual_seed(sum(lens) + H)
+    T = sum(lens)
+    qkv = (torch.randn(T, 3, H, hd, generator=g) * 0.8).to(torch.bfloat16)
+    dout = torch.randn(T, H, hd, generator=g).to(torch.bfloat16)
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32)
+    slopes = K.alibi_slopes(H)
+    ref_in = qkv.float().requires_grad_(True)
+    ref = K.attention_alibi_varlen_ref(ref_in[:, 0], ref_in[:, 1], ref_in[:, 2], cu, slopes)
+    (ref * dout.float()).sum().backward()
+    x = qkv.cuda().requires_grad_(True)
+    out = ops.attn_varlen(x, cu.cuda(), max(lens), slopes.cuda())
+    (out.float() * dout.cuda().float()).sum().backward()
+    close(out.float(), ref, rtol=1e-2, atol_scale=1e-2, name='out')
+    close(x.grad.float(), ref_in.grad, rtol=2e-2, atol_scale=2e-2, name='dqkv')
+
+
+def test_attn_layout_with_integer_data(ops):
+    """Exact small-integer operands (products and sums exact in bf16/fp32) catch any fragment-layout transposition."""
+    H, hd, L = 2, 32, 70
+    g = torch.Generator().manual_seed(0)
+    q = torch.zeros(L, H, hd)
+    k = torch.zeros(L, H, hd)
+    v = torch.randint(-3, 4, (L, H, hd), generator=g).float()           # asymmetric V
+    qkv = torch.stack((q, k, v), dim=1).to(torch.bfloat16)
+    cu = torch.tensor([0, L], dtype=torch.int32)
+    out = ops.attn_varlen(qkv.cuda(), cu.cuda(), L, None).float().cpu()   # zero scores, no alibi: out[i] = mean_{j<=i} v[j]
+    ref = torch.cumsum(v, dim=0) / torch.arange(1, L + 1).view(L, 1, 1)
+    assert (out - ref).abs().max() < 0.02

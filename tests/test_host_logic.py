@@ -99,7 +99,7 @@ def test_layer_id_grammar_and_sizes():
                 assert c[k] == e[k], (lid, k)
     with pytest.raises(AssertionError):
         RNNBase(16, 32, [], ['linear'], ['smamba'])             # smamba needs in == out
-    for lid in ('cgpt_h8_l6', 'mamba_s16', 'lstm', 'conv1d_4'):
+    for lid in ('gpt_h8_l6', 'mamba_s16', 'lstm', 'conv1d_4'):
         with pytest.raises(NotImplementedError):
             RNNBase(32, 32, [], ['linear'], [lid])
 
@@ -118,6 +118,37 @@ def test_state_dict_layout_equals_reference(name, oracle_ops):
         for mod in ref:
             assert {k: tuple(v.shape) for k, v in sd[mod].items()} == {k: tuple(v.shape) for k, v in ref[mod].items()}, (prefix, mod)
         model.load_state_dict(ref)                              # and it loads
+
+
+def test_cgpt_layer_id_and_module_equals_oracle_restatement(oracle_ops):
+    """cgpt: layer-id grammar, parameter layout, and the block structure against the oracle restatement (attention core =
+    oracle on both sides here; the HIP attention kernels are checked on the GPU box).  flash_attn is absent from the reference
+    checkout, so there is no golden vector: parity unpinned."""
+    from offpolicy_rnn.models.rnn_base import RNNBase, parse_cgpt_id
+    from offpolicy_rnn.models.flash_attention.TransformerFlashAttention import PackedSeqs
+    from oracle import network as NW
+    assert parse_cgpt_id('cgpt_h8_l6_p0.1_ml1024_rms') == dict(nhead=8, nlayer=6, pdrop=0.1, maxlength=1024, ln=False)
+    assert parse_cgpt_id('cgpt') == dict(nhead=8, nlayer=4, pdrop=0.1, maxlength=1024, ln=True)
+    D = 64
+    for lid, ln in (('cgpt_h2_l2_p0.0_ml64', True), ('cgpt_h4_l1_p0.0_rms', False)):
+        torch.manual_seed(1)
+        net = RNNBase(D, D, [], ['linear'], [lid])
+        cfg = parse_cgpt_id(lid)
+        per_layer = 3 * D * D + 3 * D + D * D + D + 4 * D * D + 4 * D + 4 * D * D + D + 2 * (2 * D if ln else D)
+        assert sum(p.numel() for p in net.parameters()) == cfg['nlayer'] * per_layer + (2 * D if ln else D) + D * D + D
+        assert net.rnn_hidden_state_input_size == [cfg['maxlength']]
+        x = torch.randn(2, 11, D)
+        table = np.array([[1, 6, 3], [4, 7, 0]])
+        hid = net.make_init_state(2, torch.device('cpu'))
+        hid.set_attention_concat_mask(PackedSeqs(table, 11, torch.device('cpu')))
+        net.eval()
+        y, _, _ = net.meta_forward(x, hid)
+        sd = {k: v.detach() for k, v in net.state_dict().items()}
+        padded = np.zeros((2, 11), dtype=np.int64)                   # the reference pads the table to the row length (:360-361)
+        padded[:, :3] = table
+        ref = NW.rnn_base_forward(sd, dict(layer_type=[lid], activation=['linear']), x, NW.Flags(seqlens=torch.from_numpy(padded)))
+        np.testing.assert_allclose(y.detach(), ref, rtol=2e-2, atol=2e-2)           # bf16 casts on both sides
+        assert torch.all(y[0, 10] == 0)                                              # padding slot outside every sequence
 
 
 # ------------------------------------------------------------------------------------------------ batch layout

@@ -77,3 +77,64 @@ def test_full_size_step_runs_and_is_finite():
         v = v[0] if isinstance(v, tuple) else v
         assert np.isfinite(v), k
     assert not torch.equal(before, alg.policy.store.flat)
+
+
+def test_cgpt_layer_gpu_vs_oracle():
+    """cgpt decoder (bf16 MFMA attention + bf16 projections) against the oracle restatement; north_star: 1e-2 for bf16.  Parity unpinned."""
+    from offpolicy_rnn.models.rnn_base import RNNBase
+    from offpolicy_rnn.models.flash_attention.TransformerFlashAttention import PackedSeqs
+    from oracle import network as NW
+    D, lid = 128, 'cgpt_h4_l2_p0.0_ml256_rms'
+    torch.manual_seed(3)
+    net = RNNBase(D, D, [], ['linear'], [lid])
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    x = torch.randn(3, 90, D)
+    table = np.zeros((3, 90), dtype=np.int64)
+    table[0, :3], table[1, :2], table[2, :1] = (1, 50, 30), (40, 45), (90,)
+    w = torch.randn(3, 90, D)
+    xr = x.clone().requires_grad_(True)
+    pr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = NW.rnn_base_forward(pr, dict(layer_type=[lid], activation=['linear']), xr, NW.Flags(seqlens=torch.from_numpy(table)))
+    (ref * w).sum().backward()
+    net.to('cuda')
+    net.eval()
+    xg = x.clone().cuda().requires_grad_(True)
+    hid = net.make_init_state(3, torch.device('cuda'))
+    hid.set_attention_concat_mask(PackedSeqs(table, 90, torch.device('cuda')))
+    y, _, _ = net.meta_forward(xg, hid)
+    (y * w.cuda()).sum().backward()
+    scale = ref.abs().max().item()
+    assert (y.detach().cpu() - ref.detach()).abs().max().item() < 2e-2 * scale
+    gs = xr.grad.abs().max().item()
+    assert (xg.grad.cpu() - xr.grad).abs().max().item() < 4e-2 * gs
+    for k, p in net.named_parameters():
+        g_ref = pr[k].grad
+        assert (p.grad.cpu() - g_ref).abs().max().item() < 4e-2 * max(g_ref.abs().max().item(), 1e-3), k
+
+
+def test_cgpt_td3_update_gpu_vs_oracle():
+    """BASELINE config-3 family (cgpt TD3) end to end at reduced width: one update on cuda:0 vs the oracle trainer (bf16 tolerances)."""
+    from offpolicy_rnn import alg_init
+    from oracle.trainer import OracleTrainer, default_parameter
+    from test_oracle_golden import _push as opush
+    lid, lens = 'cgpt_h2_l2_p0.0_ml64', [12, 5, 7, 12, 4, 9, 6]
+    torch.manual_seed(5)
+    alg = alg_init(make_parameter(lid, D=64, algo='td3', sac_batch_size=33))
+    par = default_parameter(rnn=lid, D=64, algo='td3', sac_batch_size=33, policy_embedding_dim=16, value_embedding_dim=16,
+                            policy_uni_model_input_mapping_dim=16, value_uni_model_input_mapping_dim=16, max_buffer_transition_num=5000)
+    cpu_sd = lambda m: {k: {n: t.detach().cpu() for n, t in d.items()} for k, d in m.state_dict().items()}
+    tr = OracleTrainer(par, 5, 3, 12, policy_state=cpu_sd(alg.policy), value_state=cpu_sd(alg.values[0]))
+    rs = np.random.RandomState(9)
+    for n in lens:
+        o, a, r = _synth(rs, n, 5, 3)
+        _push(alg.replay_buffer, o, a, r, early_done=(n != 12))
+        opush(tr.buffer, o, a, r, early_done=(n != 12))
+    logs = []
+    for runner in (alg, tr):
+        torch.manual_seed(200)
+        np.random.seed(200)
+        logs.append(runner.train_one_batch())
+    for k, v in logs[1].items():
+        got = logs[0][k][0] if isinstance(logs[0][k], tuple) else logs[0][k]
+        want = v[0] if isinstance(v, tuple) else v
+        assert got == pytest.approx(want, rel=5e-2, abs=5e-2), (k, got, want)
