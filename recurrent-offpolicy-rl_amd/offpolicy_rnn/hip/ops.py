@@ -145,6 +145,90 @@ def selective_scan_fn(u, delta, A, B, C, start, D=None, z=None, delta_bias=None,
     return res.transpose(1, 2)
 
 
+# ---------------------------------------------------------------------------------------------- fused Mamba mixer
+class MambaInnerFn(torch.autograd.Function):
+    """in_proj -> masked causal conv + SiLU -> x_proj -> dt_proj -> selective scan (gate, skip, resets) -> out_proj as ONE
+    autograd node (interface counterpart of the reference's `MambaInnerFn`, selective_scan_interface_new.py:169-335, which
+    only exists for d_conv <= 4).  Everything is token-major; the backward writes every gradient straight into its slot of
+    two buffers - dxz [M, 2Di] (conv backward fills the x half, scan backward the z half) and dx_dbl [M, R+2N] (scan
+    backward fills the B / C columns) - through the kernels' token strides, so autograd's slice-backward zero-fill + copy +
+    add passes (8 x 273 MB per update at config 2) disappear.  GEMMs are library calls (torch.mm)."""
+
+    @staticmethod
+    def forward(ctx, x, in_w, conv_w, conv_b, xproj_w, dt_w, dt_b, A_log, D, out_w, mask, start):
+        _need_cuda('mamba_inner', x, in_w, conv_w, xproj_w, dt_w, A_log, out_w)
+        Bsz, L, Dm = x.shape
+        Di, N = A_log.shape
+        R = dt_w.shape[1]
+        K = conv_w.shape[-1]
+        M = Bsz * L
+        x2 = x.reshape(M, Dm)
+        maskf, startf = _flags(mask, Bsz, L), _flags(start, Bsz, L)
+        xz = torch.mm(x2, in_w.t())                                        # [M, 2Di] = (x | z)
+        cw = conv_w.reshape(Di, K).contiguous()
+        xc = torch.empty(M, Di, dtype=torch.float32, device=x.device)
+        check(lib().resel_causal_conv1d_fwd(_p(xz), 2 * Di, _p(cw), _p(conv_b), _p(maskf), _p(xc), Di, Bsz, L, Di, K, 1, _stream()),
+              'causal_conv1d_fwd')
+        x_dbl = torch.mm(xc, xproj_w.t())                                  # [M, R + 2N] = (delta_r | B | C)
+        dt = torch.mm(x_dbl[:, :R], dt_w.t())                              # [M, Di]; bias enters the scan as delta_bias
+        A = -torch.exp(A_log.float())
+        need_grad = any(ctx.needs_input_grad)
+        ck = _ws(lib().resel_selective_scan_ckpt_bytes(Bsz, L, Di, N), x.device) if need_grad else None
+        y = torch.empty(M, Di, dtype=torch.float32, device=x.device)
+        zptr = ctypes.c_void_p(xz.data_ptr() + 4 * Di)
+        bptr, cptr = ctypes.c_void_p(x_dbl.data_ptr() + 4 * R), ctypes.c_void_p(x_dbl.data_ptr() + 4 * (R + N))
+        check(lib().resel_selective_scan_fwd(_p(xc), Di, _p(dt), Di, zptr, 2 * Di, _p(A), bptr, R + 2 * N, cptr, R + 2 * N,
+                                             _p(D), _p(dt_b), _p(startf), _p(y), Di, _p(ck), None, Bsz, L, Di, N, 1, _stream()),
+              'selective_scan_fwd')
+        out = torch.mm(y, out_w.t())
+        ctx.save_for_backward(x2, in_w, cw, conv_b, xproj_w, dt_w, dt_b, A, D, out_w, maskf, startf, xz, xc, x_dbl, dt, y, ck)
+        ctx.dims = (Bsz, L, Dm, Di, N, R, K, conv_w.shape)
+        return out.view(Bsz, L, -1)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x2, in_w, cw, conv_b, xproj_w, dt_w, dt_b, A, D, out_w, maskf, startf, xz, xc, x_dbl, dt, y, ck) = ctx.saved_tensors
+        Bsz, L, Dm, Di, N, R, K, cw_shape = ctx.dims
+        M = Bsz * L
+        dev = x2.device
+        do2 = dout.reshape(M, -1)
+        if not do2.is_contiguous():
+            do2 = do2.contiguous()
+        d_out_w = torch.mm(do2.t(), y)
+        dy = torch.mm(do2, out_w)                                          # [M, Di]
+        dxz = torch.empty(M, 2 * Di, dtype=torch.float32, device=dev)      # fully written: conv bwd -> [:, :Di], scan bwd -> [:, Di:]
+        dx_dbl = torch.empty(M, R + 2 * N, dtype=torch.float32, device=dev)
+        dxc = torch.empty(M, Di, dtype=torch.float32, device=dev)
+        ddt = torch.empty(M, Di, dtype=torch.float32, device=dev)
+        dA = torch.empty(Di, N, dtype=torch.float32, device=dev)
+        dD = torch.empty(Di, dtype=torch.float32, device=dev)
+        ddt_b = torch.empty(Di, dtype=torch.float32, device=dev)
+        ws = _ws(lib().resel_selective_scan_bwd_workspace_bytes(Bsz, L, Di, N), dev)
+        P = lambda t, off: ctypes.c_void_p(t.data_ptr() + 4 * off)
+        check(lib().resel_selective_scan_bwd(
+            _p(xc), Di, _p(dt), Di, P(xz, Di), 2 * Di, _p(A), P(x_dbl, R), R + 2 * N, P(x_dbl, R + N), R + 2 * N,
+            _p(D), _p(dt_b), _p(startf), _p(dy), Di, _p(ck),
+            _p(dxc), Di, _p(ddt), Di, P(dxz, Di), 2 * Di, P(dx_dbl, R), R + 2 * N, P(dx_dbl, R + N), R + 2 * N,
+            _p(dA), _p(dD), _p(ddt_b), _p(ws), Bsz, L, Di, N, 1, _stream()), 'selective_scan_bwd')
+        d_dt_w = torch.mm(ddt.t(), x_dbl[:, :R])
+        dx_dbl[:, :R] = torch.mm(ddt, dt_w)
+        d_xproj_w = torch.mm(dx_dbl.t(), xc)
+        dxc.addmm_(dx_dbl, xproj_w)                                        # conv output receives scan (du) + x_proj gradients
+        dcw = torch.empty(Di, K, dtype=torch.float32, device=dev)
+        dcb = torch.empty(Di, dtype=torch.float32, device=dev) if conv_b is not None else None
+        ws2 = _ws(lib().resel_causal_conv1d_bwd_workspace_bytes(Bsz, L, Di, K), dev)
+        check(lib().resel_causal_conv1d_bwd(_p(xz), 2 * Di, _p(cw), _p(conv_b), _p(maskf), _p(dxc), Di, _p(dxz), 2 * Di, _p(dcw), _p(dcb),
+                                            _p(ws2), Bsz, L, Di, K, 1, _stream()), 'causal_conv1d_bwd')
+        d_in_w = torch.mm(dxz.t(), x2)
+        dx = torch.mm(dxz, in_w).view(Bsz, L, Dm) if ctx.needs_input_grad[0] else None
+        return (dx, d_in_w, dcw.reshape(cw_shape), dcb, d_xproj_w, d_dt_w, ddt_b, dA * A, dD, d_out_w, None, None)
+
+
+def mamba_inner_fn(x, in_w, conv_w, conv_b, xproj_w, dt_w, dt_b, A_log, D, out_w, mask=None, start=None):
+    """x [B, L, D] -> [B, L, D]: the whole Mamba mixer of the training path (no biases on in/out projections)."""
+    return MambaInnerFn.apply(x.float().contiguous(), in_w, conv_w, conv_b, xproj_w, dt_w, dt_b, A_log, D, out_w, mask, start)
+
+
 # ---------------------------------------------------------------------------------------------- causal conv1d
 class CausalConv1dFn(torch.autograd.Function):
     @staticmethod

@@ -76,6 +76,12 @@ class Mamba(nn.Module):
         """x [B, T, D].  T > 1: whole packed rows from a zero state (training).  T == 1: stateful rollout step."""
         if x.shape[-2] == 1:
             return self._step(x, hidden)
+        if self.in_proj.bias is None and self.out_proj.bias is None:
+            out = ops.mamba_inner_fn(x, self.in_proj.weight, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight,
+                                     self.dt_proj.weight, self.dt_proj.bias, self.A_log, self.D, self.out_proj.weight, mask, rnn_start)
+            if hidden is None:
+                hidden = torch.zeros((1, x.shape[0], self.desired_hidden_dim), device=x.device)
+            return out, hidden
         Di, N, R = self.d_inner, self.d_state, self.dt_rank
         xz = F.linear(x, self.in_proj.weight, self.in_proj.bias)                       # [B, T, 2 Di]
         xc = ops.causal_conv1d_fn(xz[..., :Di], self.conv1d.weight, self.conv1d.bias, mask, True)

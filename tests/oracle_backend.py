@@ -23,6 +23,18 @@ def causal_conv1d_fn(x, weight, bias=None, mask=None, activation=True):
     return K.causal_conv1d_silu_ref(x, weight.reshape(x.shape[-1], -1), bias, _flag(mask, *x.shape[:2]), activation)
 
 
+def mamba_inner_fn(x, in_w, conv_w, conv_b, xproj_w, dt_w, dt_b, A_log, D, out_w, mask=None, start=None):
+    import torch.nn.functional as F
+    Di, N = A_log.shape
+    R = dt_w.shape[1]
+    xz = F.linear(x, in_w)
+    xc = causal_conv1d_fn(xz[..., :Di], conv_w, conv_b, mask, True)
+    x_dbl = F.linear(xc, xproj_w)
+    dt = F.linear(x_dbl[..., :R], dt_w)
+    y = selective_scan_tm(xc, dt, -torch.exp(A_log.float()), x_dbl[..., R:R + N], x_dbl[..., R + N:], D, xz[..., Di:], dt_b, start, True)
+    return F.linear(y, out_w)
+
+
 def _norm(rms):
     def fn(x, weight, bias, residual=None, eps=1e-6, prenorm=False, residual_in_fp32=False):
         y, res = K.add_layernorm_ref(x, residual, weight, bias, eps, rms)
@@ -101,7 +113,7 @@ def sumsq(x, out=None):
 
 def install(monkeypatch):
     from offpolicy_rnn.hip import ops
-    table = dict(selective_scan_tm=selective_scan_tm, causal_conv1d_fn=causal_conv1d_fn, layer_norm_fn=_norm(False),
+    table = dict(mamba_inner_fn=mamba_inner_fn, selective_scan_tm=selective_scan_tm, causal_conv1d_fn=causal_conv1d_fn, layer_norm_fn=_norm(False),
                  rms_norm_fn=_norm(True), gilr_scan=gilr_scan, complex_scan=complex_scan, gru_seq=gru_seq, tanh_gaussian=tanh_gaussian, attn_varlen=attn_varlen,
                  sac_target=sac_target, soft_update_=soft_update_, adamw_flat_=adamw_flat_, sumsq=sumsq)
     for k, fn in table.items():

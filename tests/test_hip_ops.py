@@ -352,3 +352,36 @@ def test_attn_layout_with_integer_data(ops):
     out = ops.attn_varlen(qkv.cuda(), cu.cuda(), L, None).float().cpu()   # zero scores, no alibi: out[i] = mean_{j<=i} v[j]
     ref = torch.cumsum(v, dim=0) / torch.arange(1, L + 1).view(L, 1, 1)
     assert (out - ref).abs().max() < 0.02
+
+
+# ------------------------------------------------------------------------------------------ fused Mamba mixer node
+@pytest.mark.parametrize('B,L,Dm,N,Kw', [(2, 70, 32, 32, 16), (3, 129, 64, 16, 4)])
+def test_mamba_inner_fused_vs_oracle_chain(ops, B, L, Dm, N, Kw):
+    """One autograd node for the whole mixer (reference MambaInnerFn, selective_scan_interface_new.py:169) against the
+    chain of CPU oracle ops under torch autograd: output and every parameter / input gradient."""
+    import oracle_backend as ob
+    g = torch.Generator().manual_seed(11)
+    Di, R = 2 * Dm, max(Dm // 16, 4)
+    x = rnd(B, L, Dm, g=g)
+    ps = dict(in_w=rnd(2 * Di, Dm, g=g, scale=Dm ** -0.5), conv_w=rnd(Di, 1, Kw, g=g, scale=0.3), conv_b=rnd(Di, g=g, scale=0.1),
+              xproj_w=rnd(R + 2 * N, Di, g=g, scale=Di ** -0.5), dt_w=rnd(Di, R, g=g, scale=R ** -0.5), dt_b=rnd(Di, g=g, scale=0.5) - 2,
+              A_log=torch.log(torch.arange(1, N + 1, dtype=torch.float32)).repeat(Di, 1), D=torch.ones(Di) + rnd(Di, g=g, scale=0.1),
+              out_w=rnd(Dm, Di, g=g, scale=Di ** -0.5))
+    start = make_start(B, L, g)
+    mask = (torch.rand(B, L, 1, generator=g) > 0.1).float()
+    w = rnd(B, L, Dm, g=g)
+
+    def run(fn, dev):
+        xs = x.to(dev).detach().clone().requires_grad_(True)
+        pp = {k: v.to(dev).detach().clone().requires_grad_(True) for k, v in ps.items()}
+        out = fn(xs, pp['in_w'], pp['conv_w'], pp['conv_b'], pp['xproj_w'], pp['dt_w'], pp['dt_b'], pp['A_log'], pp['D'], pp['out_w'],
+                 mask.to(dev), start.to(dev))
+        (out * w.to(dev)).sum().backward()
+        return out, xs.grad, {k: v.grad for k, v in pp.items()}
+
+    ref_out, ref_dx, ref_g = run(ob.mamba_inner_fn, 'cpu')
+    out, dx, gr = run(ops.mamba_inner_fn, 'cuda')
+    close(out, ref_out, name='out')
+    close(dx, ref_dx, name='dx')
+    for k in ps:
+        close(gr[k], ref_g[k], rtol=2e-4, atol_scale=5e-5, name='d' + k)
