@@ -43,6 +43,9 @@ class SAC:
         self.policy_args = self._make_policy_args(parameter)
         self.value_args = self._make_value_args(parameter)
         self.device = self._pick_device()
+        if self.device.type == 'cuda':
+            from ..hip.gemm_select import enable_tuned_gemms
+            self.tuned_gemms = enable_tuned_gemms()
         self.sample_device = self.device if parameter.cuda_inference else torch.device('cpu')
         self.base_algorithm = getattr(parameter, 'base_algorithm', 'sac')
         self.policy = make_policy_model(self.policy_args, self.base_algorithm, self.discrete_env)
