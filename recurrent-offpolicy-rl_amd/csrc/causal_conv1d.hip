@@ -1,9 +1,7 @@
 // Depthwise causal conv1d + bias + SiLU on the masked input, token-major [B*L, Di] - forward and backward.
 //
-// Memory-bound (2 floats of HBM traffic per element): each block stages a [TT + K - 1][64-channel] tile of the
-// masked input in LDS with coalesced float4 loads (16 lanes x 16 B = one 256-byte row segment), every thread
-// owns 4 channels and keeps their K taps in registers (the tap count is padded to KT in {4, 8, 16, 32} with
-// zero weights), and produces float4 outputs from K ds_read_b128 + 4K FMAs each.  The zero left pad is per
+// Memory-bound (2 floats of HBM traffic per element).  The K taps of a thread's channels live in registers (the tap
+// count is padded to KT in {4, 8, 16, 32} with zero weights).  The zero left pad is per
 // row b only: packed trajectories inside a row are separated by the mask and the reset gap, exactly like the
 // reference's nn.Conv1d over the whole row (offpolicy_rnn/models/smamba/mamba.py:210-212).
 #include "resel_common.h"
@@ -58,35 +56,86 @@ __device__ __forceinline__ void stage_x(const ConvParams& p, float (*s_x)[TILE_C
     }
 }
 
-template <int KT>
-__global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
-    __shared__ __attribute__((aligned(16))) float s_x[TT + KT - 1][TILE_C];
-    const int tid = threadIdx.x;
-    const int t0 = blockIdx.x * TT, b = blockIdx.y, d0 = blockIdx.z * TILE_C;
-    const int64_t tok0 = (int64_t)b * p.L;
-    const int tc4 = (tid & 15) * 4, tr = tid >> 4;
-    const bool c_ok = (d0 + tc4) < p.Di;
-    float4 wr[KT];
-    load_taps<KT>(p, d0 + tc4, c_ok, wr);
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c_ok && p.bias) bv = ld4(p.bias + d0 + tc4);
-    stage_x<TT + KT - 1>(p, s_x, tok0, t0 - (KT - 1), TT + KT - 1, d0, tid, 256);
-    __syncthreads();
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// Forward: no LDS.  A thread owns 2 adjacent channels and walks `tt` consecutive time steps of one row with the last KT
+// inputs in a rotating register window (slot indices are compile-time: the step loop is unrolled KT-fold), so every
+// input element is fetched once (plus the KT-1 step warm-up halo at the head of a time chunk) and every global access
+// of a wave is one fully used 512-byte row segment; the two waves of a block sit side by side on the channel axis and
+// blockIdx.x (fastest) continues it, so concurrently running blocks stream whole rows.  [The first version staged
+// 64-channel x 64-step tiles in LDS: its 256-byte row pieces at a 4 KB token stride reached only 1.07 TB/s.]
+// Loads run P steps ahead of their use in a small register ring.  The step groups are straight-line code with exactly
+// one load and (after the warm-up group) one store per step: any conditional memory operation inside them would make
+// the compiler fall back to s_waitcnt vmcnt(0) per step and serialise the ring on the load latency - hence the clamped
+// (always valid) load addresses, the mask values pre-loaded for the whole chunk (one lane per step, fetched back with
+// v_readlane) and the three instances of the group body (warm-up / full / ragged tail).
+constexpr int CONV_TT = 64;          // time steps per chunk (<= 64: one mask register pair covers chunk + halo)
+
+template <int KT, int MODE>          // MODE 0: warm-up group (only its last step produces an output), 1: full, 2: guarded tail
+__device__ __forceinline__ void conv_fwd_group(const ConvParams& p, const float* xrow, float* yrow, int tg, int t_end,
+                                               int ig, float mlo, float mhi, const f2 (&wr)[KT], f2 (&win)[KT],
+                                               f2 (&pre)[KT < 8 ? KT : 8], f2 bv) {
+    constexpr int P = KT < 8 ? KT : 8;
+    const float mreg = ig < 64 ? mlo : mhi;          // KT divides 64: a group never straddles the two mask registers
 #pragma unroll
-    for (int i = 0; i < TT / 16; ++i) {
-        const int r = tr + i * 16, t = t0 + r;
-        if (t < p.L && c_ok) {
-            float4 acc = bv;
+    for (int s = 0; s < KT; ++s) {
+        const int t = tg + s;
+        const float m = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mreg), (ig & 63) + s));
+        win[s] = pre[s % P] * f2{m, m};
+        const int tl = min(max(t + P, 0), t_end - 1);                        // clamped: always a valid token of this row
+        pre[s % P] = *reinterpret_cast<const f2*>(xrow + (int64_t)tl * p.ld_x);
+        if (MODE == 1 || (MODE == 0 && s == KT - 1) || (MODE == 2 && t < t_end)) {
+            f2 acc = bv;
 #pragma unroll
-            for (int kk = 0; kk < KT; ++kk) {
-                const float4 xv = ld4(&s_x[r + kk][tc4]);
-                acc.x = __builtin_fmaf(wr[kk].x, xv.x, acc.x); acc.y = __builtin_fmaf(wr[kk].y, xv.y, acc.y);
-                acc.z = __builtin_fmaf(wr[kk].z, xv.z, acc.z); acc.w = __builtin_fmaf(wr[kk].w, xv.w, acc.w);
-            }
-            if (p.silu) { acc.x = siluf_(acc.x); acc.y = siluf_(acc.y); acc.z = siluf_(acc.z); acc.w = siluf_(acc.w); }
-            st4(p.y + (tok0 + t) * p.ld_y + d0 + tc4, acc);
+            for (int kk = 0; kk < KT; ++kk)             // tap kk pairs with x[t - (KT-1) + kk] = slot (s + 1 + kk) mod KT
+                acc = __builtin_elementwise_fma(wr[kk], win[(s + 1 + kk) % KT], acc);
+            if (p.silu) { acc.x = siluf_(acc.x); acc.y = siluf_(acc.y); }
+            *reinterpret_cast<f2*>(yrow + (int64_t)t * p.ld_y) = acc;
         }
     }
+}
+
+template <int KT>
+__global__ __launch_bounds__(128) void conv_fwd_kernel(ConvParams p) {
+    constexpr int P = KT < 8 ? KT : 8;
+    const int lane = threadIdx.x & 63;
+    if ((blockIdx.x * 128 + (threadIdx.x & 64)) * 2 >= p.Di) return;      // whole wave past the last channel (no barriers below)
+    // lanes past the last channel of a partly filled wave shadow the last pair (same loads, same stores, same values):
+    // every lane stays active, which the v_readlane mask fetches and the exact vmcnt accounting rely on
+    const int c = min((int)(blockIdx.x * 128 + threadIdx.x) * 2, p.Di - 2);
+    const int b = blockIdx.z, t0 = blockIdx.y * CONV_TT;
+    const int t_end = min(p.L, t0 + CONV_TT);
+    const int64_t tok0 = (int64_t)b * p.L;
+    const float* xrow = p.x + tok0 * p.ld_x + c;
+    float* yrow = p.y + tok0 * p.ld_y + c;
+    f2 wr[KT], win[KT];
+#pragma unroll
+    for (int kk = 0; kk < KT; ++kk) {
+        const int k = kk - (KT - p.K);
+        wr[kk] = f2{0.f, 0.f};
+        win[kk] = f2{0.f, 0.f};
+        if (k >= 0) wr[kk] = f2{p.w[(int64_t)c * p.K + k], p.w[(int64_t)(c + 1) * p.K + k]};
+    }
+    f2 bv = {0.f, 0.f};
+    if (p.bias) bv = *reinterpret_cast<const f2*>(p.bias + c);
+    const int ts = t0 - (KT - 1);                    // time of step 0 (warm-up starts in the left halo)
+    // mask of step i = ts + i in lane i of (mlo, mhi); 0 left of the row start (zero padding) and right of the chunk
+    float mlo, mhi;
+    {
+        const int ta = ts + lane, tb = ts + 64 + lane;
+        const bool oka = ta >= 0 && ta < t_end, okb = tb >= 0 && tb < t_end;
+        const float va = p.mask ? p.mask[tok0 + min(max(ta, 0), t_end - 1)] : 1.f;
+        const float vb = p.mask ? p.mask[tok0 + min(max(tb, 0), t_end - 1)] : 1.f;
+        mlo = oka ? va : 0.f;
+        mhi = okb ? vb : 0.f;
+    }
+    f2 pre[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) pre[i] = *reinterpret_cast<const f2*>(xrow + (int64_t)min(max(ts + i, 0), t_end - 1) * p.ld_x);
+    conv_fwd_group<KT, 0>(p, xrow, yrow, ts, t_end, 0, mlo, mhi, wr, win, pre, bv);
+    int ig = KT;
+    for (; ts + ig + KT <= t_end; ig += KT) conv_fwd_group<KT, 1>(p, xrow, yrow, ts + ig, t_end, ig, mlo, mhi, wr, win, pre, bv);
+    if (ts + ig < t_end) conv_fwd_group<KT, 2>(p, xrow, yrow, ts + ig, t_end, ig, mlo, mhi, wr, win, pre, bv);
 }
 
 // Backward: one block per (row b, channel tile) walks the time tiles, so dw / dbias accumulate in registers and
@@ -209,13 +258,14 @@ extern "C" int resel_causal_conv1d_fwd(const float* x, int64_t ld_x, const float
                                        resel_stream_t stream) {
     if (!conv_args_ok(x, ld_x, y, ld_y, B, L, Di, K) || !w || (bias && !aligned16(bias))) return RESEL_EINVAL;
     ConvParams p{x, w, bias, mask, nullptr, y, nullptr, nullptr, nullptr, ld_x, ld_y, 0, 0, B, L, Di, K, silu};
-    dim3 grid((L + TT - 1) / TT, B, (Di + TILE_C - 1) / TILE_C);
+    const int KT = pad_taps(K);
+    dim3 grid((Di + 255) / 256, (L + CONV_TT - 1) / CONV_TT, B);
     hipStream_t s = (hipStream_t)stream;
-    switch (pad_taps(K)) {
-        case 4: hipLaunchKernelGGL(conv_fwd_kernel<4>, grid, dim3(256), 0, s, p); break;
-        case 8: hipLaunchKernelGGL(conv_fwd_kernel<8>, grid, dim3(256), 0, s, p); break;
-        case 16: hipLaunchKernelGGL(conv_fwd_kernel<16>, grid, dim3(256), 0, s, p); break;
-        default: hipLaunchKernelGGL(conv_fwd_kernel<32>, grid, dim3(256), 0, s, p); break;
+    switch (KT) {
+        case 4: hipLaunchKernelGGL(conv_fwd_kernel<4>, grid, dim3(128), 0, s, p); break;
+        case 8: hipLaunchKernelGGL(conv_fwd_kernel<8>, grid, dim3(128), 0, s, p); break;
+        case 16: hipLaunchKernelGGL(conv_fwd_kernel<16>, grid, dim3(128), 0, s, p); break;
+        default: hipLaunchKernelGGL(conv_fwd_kernel<32>, grid, dim3(128), 0, s, p); break;
     }
     return launch_status();
 }

@@ -47,6 +47,9 @@ void launch_maybe_timed(int slot, K kernel, dim3 grid, dim3 block, hipStream_t s
     g_prof[slot].ev.emplace_back(a, b);
 }
 
+#ifndef SSCAN_FWD_TC
+#define SSCAN_FWD_TC 32
+#endif
 constexpr int TILE_C = 64;            // channels per workgroup
 constexpr int CKS = RESEL_SSCAN_CKPT; // checkpoint stride
 constexpr int SC = 16;                // backward sub-chunk = one checkpoint interval staged in LDS
@@ -324,52 +327,56 @@ struct BwdParams {
     int B, L, Di, N, nck, softplus, nd, bc_vec;
 };
 
-// value held by lane (l ^ K), DPP where the pairing stays inside a 16-lane row
-template <int K>
-__device__ __forceinline__ float lane_xor(float v) {
-    const int x = __builtin_bit_cast(int, v);
-    int r;
-    if constexpr (K == 1) {
-        r = __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true);            // quad_perm [1,0,3,2]
-    } else if constexpr (K == 2) {
-        r = __builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true);            // quad_perm [2,3,0,1]
-    } else if constexpr (K == 4) {
-        r = __builtin_amdgcn_update_dpp(0, x, 0x104, 0xF, 0x5, false);    // row_shl:4 -> banks 0,2
-        r = __builtin_amdgcn_update_dpp(r, x, 0x114, 0xF, 0xA, false);    // row_shr:4 -> banks 1,3
-    } else if constexpr (K == 8) {
-        r = __builtin_amdgcn_update_dpp(0, x, 0x108, 0xF, 0x3, false);    // row_shl:8 -> banks 0,1
-        r = __builtin_amdgcn_update_dpp(r, x, 0x118, 0xF, 0xC, false);    // row_shr:8 -> banks 2,3
-    } else {
-        r = __shfl_xor(x, K, 64);
-    }
-    return __builtin_bit_cast(float, r);
+// Cross-lane sums for the dB / dC channel reductions.
+// butterfly_sum<V>(v, lane): sums v[0..V) over the 64 lanes with a multi-value butterfly whose stages go from the widest
+// pairing down: each halving stage pairs every lane with one lane of the other half of its 64 / 32 / 16 / 8-lane group,
+// the "low" lane keeps the lower half of the values and receives the partner's lower half, the "high" lane the upper
+// half.  The two widest stages are gfx950's v_permlane32_swap / v_permlane16_swap (swap + add = 2 instructions for
+// TWO outputs, no select), the 8- and 4-lane stages a select pair plus a DPP add (row_ror:8, row_half_mirror: any
+// involution across the group boundary will do for a sum).  After the halving stages a single value is left and is
+// summed over the remaining lane bits with DPP adds.  On return every lane holds the wave total of value index
+// value_of_lane<V>(lane); the lanes with (lane & (64 / V - 1)) == 0 cover every index exactly once.  V in {4, 8, 16}.
+__device__ __forceinline__ void permlane32_swap(float& a, float& c) {   // a[32..63] <-> c[0..31]
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(c));
 }
+__device__ __forceinline__ void permlane16_swap(float& a, float& c) {   // odd 16-lane rows of a <-> even rows of c
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(c));
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+constexpr int DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E, DPP_ROW_HALF_MIRROR = 0x141, DPP_ROW_ROR8 = 0x128;
 
-// Sum v[0..V) over the 64 lanes of the wave with a multi-value butterfly: stage s (lane bit s) halves the number of
-// values a lane carries - lanes with the bit clear keep the lower half and receive the partner's lower half.  On
-// return lane l holds (in every lane) the wave total of value index value_of_lane<V>(l); lanes l < V cover every
-// index exactly once.  V in {1, 2, 4, 8, 16}.
-template <int V, int K = 1>
+template <int V, int K = 32>
 __device__ __forceinline__ float butterfly_sum(float (&v)[V > 0 ? V : 1], int lane) {
     if constexpr (V > 1) {
         constexpr int H = V / 2;
-        const bool hi = lane & K;
         float nv[H];
+        if constexpr (K == 32 || K == 16) {
 #pragma unroll
-        for (int i = 0; i < H; ++i) {
-            const float send = hi ? v[i] : v[i + H];
-            const float keep = hi ? v[i + H] : v[i];
-            nv[i] = keep + lane_xor<K>(send);
+            for (int i = 0; i < H; ++i) {
+                float a = v[i], c = v[i + H];
+                if constexpr (K == 32) permlane32_swap(a, c); else permlane16_swap(a, c);
+                nv[i] = a + c;
+            }
+        } else {
+            static_assert(K == 8 || K == 4, "halving stages: 32, 16, 8, 4");
+            const bool hi = lane & K;
+#pragma unroll
+            for (int i = 0; i < H; ++i) {
+                const float send = hi ? v[i] : v[i + H];
+                const float keep = hi ? v[i + H] : v[i];
+                nv[i] = keep + (K == 8 ? dpp_mov<DPP_ROW_ROR8>(send) : dpp_mov<DPP_ROW_HALF_MIRROR>(send));
+            }
         }
-        return butterfly_sum<H, K * 2>(nv, lane);
+        return butterfly_sum<H, K / 2>(nv, lane);
     } else {
         float r = v[0];
-        if constexpr (K <= 1) r += lane_xor<1>(r);
-        if constexpr (K <= 2) r += lane_xor<2>(r);
-        if constexpr (K <= 4) r += lane_xor<4>(r);
-        if constexpr (K <= 8) r += lane_xor<8>(r);
-        if constexpr (K <= 16) r += lane_xor<16>(r);
-        r += lane_xor<32>(r);
+        if constexpr (K >= 8) r += dpp_mov<DPP_ROW_ROR8>(r);
+        if constexpr (K >= 4) r += dpp_mov<DPP_ROW_HALF_MIRROR>(r);
+        r += dpp_mov<DPP_QUAD_XOR2>(r);
+        r += dpp_mov<DPP_QUAD_XOR1>(r);
         return r;
     }
 }
@@ -377,32 +384,46 @@ template <int V>
 __device__ __forceinline__ int value_of_lane(int lane) {
     int idx = 0, h = V / 2;
 #pragma unroll
-    for (int bit = 1; bit < V; bit <<= 1) {
+    for (int bit = 32; h >= 1; bit >>= 1) {
         if (lane & bit) idx += h;
         h >>= 1;
     }
     return idx;
 }
 
+// Asynchronous global -> LDS copies (gfx950 global_load_lds_dwordx4 / _dword): no VGPR destination.  The LDS address is
+// the wave-uniform `lds_wave_base` + lane * size, so the LDS image of a wave-instruction is lane-linear.
+__device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ void glds4(const float* g, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+}
+
 // One workgroup = (row b, 64-channel tile); NW waves x NS states; time in 16-step sub-chunks, last to first.
-// Per sub-chunk: tile stage (softplus, delta*u, gated dout, B/C/start rows -> LDS) | forward replay from the
-// checkpoint with the state AND decay history of the 16 steps in registers | reverse sweep | epilogue on the tile.
+// Per sub-chunk: the raw operand tiles (u, delta, z, dout, B, C rows and the checkpointed state) arrive in LDS by
+// LDS-DMA, issued one sub-chunk ahead into the other half of a double buffer - the kernel is bound by VALU issue and
+// needs two waves per SIMD, i.e. <= 256 registers per lane, and the 16-step (h, dA) history of a lane already takes
+// 128 of them: a register-staged prefetch (40 more) pushed it to 302 and one wave per SIMD at half the issue rate.
+// Then: transform pass on the tile (softplus, gated dout) | forward replay from the checkpoint and reverse sweep, in
+// two 8-step halves | epilogue of each half on the tile mapping.
 template <int NS, int NW>
 __global__ __launch_bounds__(NW * 64) void sscan_bwd_kernel(BwdParams p) {
     constexpr int NT = NW * 64;
     constexpr int N = NS * NW;
     constexpr int NP = (NS + 1) / 2;
-    constexpr int BC_ITEMS = SC * N / 4;
+    constexpr int BC_ITEMS = SC * N / 4;                       // float4 items of a [SC][N] coefficient tile
     constexpr int PER_BC = (BC_ITEMS + NT - 1) / NT;
-    // everything a sub-chunk needs lives in LDS, so that the 16-step (h, dA) history can own the register file
-    __shared__ __attribute__((aligned(16))) float s_dl[SC][TILE_C];     // softplus(delta + bias)
-    __shared__ __attribute__((aligned(16))) float s_u[SC][TILE_C];
-    __shared__ __attribute__((aligned(16))) float s_dy[SC][TILE_C];     // dout * silu(z)
-    __shared__ __attribute__((aligned(16))) float s_z[SC][TILE_C];
-    __shared__ __attribute__((aligned(16))) float s_do[SC][TILE_C];
-    __shared__ __attribute__((aligned(16))) float s_part[3][NW][SC][TILE_C];
-    __shared__ __attribute__((aligned(16))) float s_B[SC][N];
-    __shared__ __attribute__((aligned(16))) float s_C[SC][N];
+    constexpr int PER_BC1 = (SC * N + NT - 1) / NT;            // dword items (unaligned B / C rows)
+    // [buffer][u | delta -> softplus(delta + bias) | z -> dout * silu'(z) | dout -> dout * silu(z)] (transformed in place)
+    __shared__ __attribute__((aligned(16))) float s_raw[2][4][SC][TILE_C];
+    __shared__ __attribute__((aligned(16))) float s_acc[2][SCH][TILE_C];     // running dD / dbias sums of the tile threads
+    __shared__ __attribute__((aligned(16))) float s_B[2][SC][N];
+    __shared__ __attribute__((aligned(16))) float s_C[2][SC][N];
+    __shared__ __attribute__((aligned(16))) float s_h0[N][TILE_C];           // checkpoint in front of the staged sub-chunk
+    __shared__ __attribute__((aligned(16))) float s_part[3][NW][SCH][TILE_C];
     __shared__ float s_st[SC];
 
     int b, dt;
@@ -419,11 +440,14 @@ __global__ __launch_bounds__(NW * 64) void sscan_bwd_kernel(BwdParams p) {
     const int tr = (tid >> 4) & (SC - 1);
     const bool c_ok = tile_thr && (d0 + tc4) < p.Di;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    // per-thread element offsets inside a sub-chunk tile (32-bit; the sub-chunk base pointers are wave-uniform)
-    const int o_u = tr * (int)p.ld_u + tc4, o_dl = tr * (int)p.ld_delta + tc4, o_z = tr * (int)p.ld_z + tc4;
-    const int o_do = tr * (int)p.ld_dout + tc4;
 
-    f2 A2p[NP], Ap[NP], dh[NP], dAacc[NP];
+    // LDS-DMA never writes the slots of channels >= Di (those lanes are masked off) nor the z tile without a gate:
+    // clear them once, so that the idle lanes of the cross-channel reductions carry zeros
+    for (int i = tid; i < 2 * 4 * SC * TILE_C / 4; i += NT) st4(&s_raw[0][0][0][0] + i * 4, zero4);
+    for (int i = tid; i < N * TILE_C / 4; i += NT) st4(&s_h0[0][0] + i * 4, zero4);
+    for (int i = tid; i < 2 * SCH * TILE_C / 4; i += NT) st4(&s_acc[0][0][0] + i * 4, zero4);
+
+    f2 A2p[NP], dh[NP], dAacc[NP];
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
         float a[2];
@@ -432,94 +456,101 @@ __global__ __launch_bounds__(NW * 64) void sscan_bwd_kernel(BwdParams p) {
             const int j = 2 * k + e;
             a[e] = (d_ok && j < NS) ? p.A[(int64_t)d * N + w * NS + j] : -1.f;
         }
-        Ap[k] = f2{a[0], a[1]};
-        A2p[k] = f2{fminf(a[0] * RESEL_LOG2E, -1e-30f), fminf(a[1] * RESEL_LOG2E, -1e-30f)};
+        A2p[k] = f2{fminf(a[0] * RESEL_LOG2E, -1e-30f), fminf(a[1] * RESEL_LOG2E, -1e-30f)};   // A * log2(e)
         dh[k] = f2{0.f, 0.f};
         dAacc[k] = f2{0.f, 0.f};
     }
-    float4 dDacc = zero4, dbacc = zero4;
+    float pst = 0.f;
 
     const int nsc = (p.L + SC - 1) / SC;
-    // register prefetch of the next sub-chunk's tile (issued while the current one is being processed)
-    float4 pu = zero4, pd = zero4, pz = zero4, pdo = zero4;
-    float4 pB[PER_BC], pC[PER_BC];
-    float pst = 0.f;
-    f2 ph0[NP];
-    auto prefetch = [&](int sc) {
-        pu = zero4; pd = zero4; pz = zero4; pdo = zero4;
-        const int ts = sc * SC;
+    // issue the LDS-DMA of sub-chunk sc into buffer sc & 1 (plus its start flags into a register)
+    auto stage_issue = [&](int sc) {
+        const int ts = sc * SC, buf = sc & 1;
         if (c_ok && ts + tr < p.L) {
-            const int64_t tok = tok0 + ts;
-            pu = ld4(p.u + tok * p.ld_u + d0 + o_u);
-            pd = ld4(p.delta + tok * p.ld_delta + d0 + o_dl);
-            pdo = ld4(p.dout + tok * p.ld_dout + d0 + o_do);
-            if (p.z) pz = ld4(p.z + tok * p.ld_z + d0 + o_z);
+            const int64_t tok = tok0 + ts + tr;
+            float* base = &s_raw[buf][0][0][0] + w * 256;                    // this wave's 4 rows of the [SC][64] tile
+            glds16(p.u + tok * p.ld_u + d0 + tc4, base);
+            glds16(p.delta + tok * p.ld_delta + d0 + tc4, base + SC * TILE_C);
+            if (p.z) glds16(p.z + tok * p.ld_z + d0 + tc4, base + 2 * SC * TILE_C);
+            glds16(p.dout + tok * p.ld_dout + d0 + tc4, base + 3 * SC * TILE_C);
         }
+        if (p.bc_vec) {
 #pragma unroll
-        for (int i = 0; i < PER_BC; ++i) {
-            const int it = tid + i * NT;
-            const int r = it / (N / 4), c = (it % (N / 4)) * 4;
-            pB[i] = zero4; pC[i] = zero4;
-            if (it < BC_ITEMS && ts + r < p.L) {
-                pB[i] = load_bc4(p.Bm, tok0 + ts + r, p.ld_b, c, p.bc_vec);
-                pC[i] = load_bc4(p.Cm, tok0 + ts + r, p.ld_c, c, p.bc_vec);
+            for (int i = 0; i < PER_BC; ++i) {
+                const int it = tid + i * NT;
+                const int r = it / (N / 4), c = (it % (N / 4)) * 4;
+                if (it < BC_ITEMS && ts + r < p.L) {
+                    glds16(p.Bm + (tok0 + ts + r) * p.ld_b + c, &s_B[buf][0][0] + (w * 64 + i * NT) * 4);
+                    glds16(p.Cm + (tok0 + ts + r) * p.ld_c + c, &s_C[buf][0][0] + (w * 64 + i * NT) * 4);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PER_BC1; ++i) {
+                const int it = tid + i * NT;
+                const int r = it / N, c = it % N;
+                if (it < SC * N && ts + r < p.L) {
+                    glds4(p.Bm + (tok0 + ts + r) * p.ld_b + c, &s_B[buf][0][0] + w * 64 + i * NT);
+                    glds4(p.Cm + (tok0 + ts + r) * p.ld_c + c, &s_C[buf][0][0] + w * 64 + i * NT);
+                }
             }
         }
         pst = (p.start && tid < SC && ts + tid < p.L) ? p.start[tok0 + ts + tid] : 0.f;
-        // state at the start of the sub-chunk: checkpoint sc-1 (written by the forward after step sc*SC)
+    };
+    // state at the start of sub-chunk sc: checkpoint sc-1 (written by the forward after step sc*SC).  Each wave fetches
+    // and later reads only its own NS rows of s_h0.
+    auto issue_h0 = [&](int sc) {
+        if (sc > 0 && d_ok) {
+#pragma unroll
+            for (int j = 0; j < NS; ++j)
+                glds4(p.ckpt + (((int64_t)b * p.nck + (sc - 1)) * N + w * NS + j) * p.Di + d, &s_h0[w * NS + j][0]);
+        }
+    };
+    auto read_h0 = [&](int sc, f2 (&h)[NP]) {
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             float a[2] = {0.f, 0.f};
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int j = 2 * k + e;
-                if (sc > 0 && d_ok && j < NS) a[e] = p.ckpt[(((int64_t)b * p.nck + (sc - 1)) * N + w * NS + j) * p.Di + d];
+                if (sc > 0 && j < NS) a[e] = s_h0[w * NS + j][lane];
             }
-            ph0[k] = f2{a[0], a[1]};
+            h[k] = f2{a[0], a[1]};
         }
     };
-    prefetch(nsc - 1);
+    __syncthreads();                                   // the clears above precede the first DMA
+    stage_issue(nsc - 1);
+    issue_h0(nsc - 1);
 
     for (int sc = nsc - 1; sc >= 0; --sc) {
-        const int ts = sc * SC;
+        const int ts = sc * SC, buf = sc & 1;
         const int sl = min(SC, p.L - ts);                 // steps in this sub-chunk
-        // ---------------- stage ----------------
+        float (*s_u)[TILE_C] = s_raw[buf][0];
+        float (*s_dl)[TILE_C] = s_raw[buf][1];
+        float (*s_gz)[TILE_C] = s_raw[buf][2];
+        float (*s_dy)[TILE_C] = s_raw[buf][3];
+        float (*sB)[N] = s_B[buf];
+        float (*sC)[N] = s_C[buf];
+        // ---------------- (A) DMA of this sub-chunk has landed; transform pass ----------------
         __syncthreads();
-        if (tile_thr) {
-            float4 dl4 = zero4, dy4 = zero4;
-            if (c_ok && tr < sl) {
-                float4 bv = zero4;
-                if (p.delta_bias) bv = ld4(p.delta_bias + d0 + tc4);
-                dl4 = pd;
-                dl4.x += bv.x; dl4.y += bv.y; dl4.z += bv.z; dl4.w += bv.w;
-                if (p.softplus) {
-                    dl4.x = softplusf_(dl4.x); dl4.y = softplusf_(dl4.y); dl4.z = softplusf_(dl4.z); dl4.w = softplusf_(dl4.w);
-                }
-                dy4 = pdo;
-                if (p.z) {
-                    dy4.x *= siluf_(pz.x); dy4.y *= siluf_(pz.y); dy4.z *= siluf_(pz.z); dy4.w *= siluf_(pz.w);
-                }
+        if (c_ok && tr < sl) {
+            float4 bv = zero4;
+            if (p.delta_bias) bv = ld4(p.delta_bias + d0 + tc4);
+            float4 dl4 = ld4(&s_dl[tr][tc4]);
+            dl4.x += bv.x; dl4.y += bv.y; dl4.z += bv.z; dl4.w += bv.w;
+            if (p.softplus) {
+                dl4.x = softplusf_(dl4.x); dl4.y = softplusf_(dl4.y); dl4.z = softplusf_(dl4.z); dl4.w = softplusf_(dl4.w);
             }
             st4(&s_dl[tr][tc4], dl4);
-            st4(&s_u[tr][tc4], pu);
-            st4(&s_dy[tr][tc4], dy4);
-            st4(&s_z[tr][tc4], pz);
-            st4(&s_do[tr][tc4], pdo);
-        }
-#pragma unroll
-        for (int i = 0; i < PER_BC; ++i) {
-            const int it = tid + i * NT;
-            if (it < BC_ITEMS) {
-                st4(&s_B[0][0] + it * 4, pB[i]);
-                st4(&s_C[0][0] + it * 4, pC[i]);
+            if (p.z) {
+                const float4 do4 = ld4(&s_dy[tr][tc4]), pz = ld4(&s_gz[tr][tc4]);
+                st4(&s_dy[tr][tc4], make_float4(do4.x * siluf_(pz.x), do4.y * siluf_(pz.y), do4.z * siluf_(pz.z), do4.w * siluf_(pz.w)));
+                st4(&s_gz[tr][tc4], make_float4(do4.x * dsiluf_(pz.x), do4.y * dsiluf_(pz.y), do4.z * dsiluf_(pz.z), do4.w * dsiluf_(pz.w)));
             }
         }
         if (tid < SC) s_st[tid] = pst;
-        f2 h0[NP];
-#pragma unroll
-        for (int k = 0; k < NP; ++k) h0[k] = ph0[k];
-        __syncthreads();
-        if (sc > 0) prefetch(sc - 1);
+        __syncthreads();                                   // (B)
+        if (sc > 0) stage_issue(sc - 1);                   // in flight during the whole replay / reverse phase
 
         // ---------------- replay + reverse, in two halves of SCH steps (later half first) ----------------
         // The (h, dA) history of SCH = 8 steps x NS states lives in registers.  The second half starts from the state
@@ -527,7 +558,7 @@ __global__ __launch_bounds__(NW * 64) void sscan_bwd_kernel(BwdParams p) {
         // replayed twice, which costs ~15 % of a half's work and lets a lane carry twice the states.
         auto replay_step = [&](int i, f2 (&h)[NP], f2 (&dAo)[NP]) {
             f2 Bq[NP];
-            lds_coef2<NS>(&s_B[i][w * NS], Bq);
+            lds_coef2<NS>(&sB[i][w * NS], Bq);
             const float sf = s_st[i];
             const float dl = s_dl[i][lane], du = dl * s_u[i][lane];
             const float dle = (sf != 0.f) ? __builtin_inff() : dl;
@@ -562,8 +593,8 @@ __global__ __launch_bounds__(NW * 64) void sscan_bwd_kernel(BwdParams p) {
                 if (i < n) {
                     const int r = base + i;
                     f2 Bq[NP], Cq[NP];
-                    lds_coef2<NS>(&s_B[r][w * NS], Bq);
-                    lds_coef2<NS>(&s_C[r][w * NS], Cq);
+                    lds_coef2<NS>(&sB[r][w * NS], Bq);
+                    lds_coef2<NS>(&sC[r][w * NS], Cq);
                     const float dl = s_dl[r][lane], dy = s_dy[r][lane];
                     const float du = dl * s_u[r][lane];
                     const f2 dl2 = {dl, dl}, du2 = {du, du}, dy2 = {dy, dy};
@@ -574,22 +605,22 @@ __global__ __launch_bounds__(NW * 64) void sscan_bwd_kernel(BwdParams p) {
                         const f2 hk = hist_h[i][k];
                         const f2 hp = (i == 0) ? hstart[k] : hist_h[i > 0 ? i - 1 : 0][k];
                         const f2 ak = hist_a[i][k];                                   // 0 at a reset step
-                        dh[k] = __builtin_elementwise_fma(dy2, Cq[k], dh[k]);
+                        const f2 dhk = __builtin_elementwise_fma(dy2, Cq[k], dh[k]);  // dL/dh_t
                         P3 = __builtin_elementwise_fma(Cq[k], hk, P3);
-                        const f2 tmp = dh[k] * hp * ak;                               // dL/d(dA) * dA
-                        P2 = __builtin_elementwise_fma(tmp, Ap[k], P2);
+                        dh[k] = dhk * ak;                                             // carried to step t-1
+                        const f2 tmp = dh[k] * hp;                                    // dL/d(dA) * dA
+                        P2 = __builtin_elementwise_fma(tmp, A2p[k], P2);              // in units of log2(e): rescaled in the epilogue
                         dAacc[k] = __builtin_elementwise_fma(tmp, dl2, dAacc[k]);
-                        const f2 gb = dh[k] * du2, gc = dy2 * hk;
+                        const f2 gb = dhk * du2, gc = dy2 * hk;
                         red[2 * k] = gb.x; red[2 * k + 1] = gb.y;
                         red[2 * NP + 2 * k] = gc.x; red[2 * NP + 2 * k + 1] = gc.y;
-                        P1 = __builtin_elementwise_fma(dh[k], Bq[k], P1);
-                        dh[k] = dh[k] * ak;
+                        P1 = __builtin_elementwise_fma(dhk, Bq[k], P1);
                     }
-                    s_part[0][w][r][lane] = P1.x + P1.y;
-                    s_part[1][w][r][lane] = P2.x + P2.y;
-                    s_part[2][w][r][lane] = P3.x + P3.y;
+                    s_part[0][w][i][lane] = P1.x + P1.y;
+                    s_part[1][w][i][lane] = P2.x + P2.y;
+                    s_part[2][w][i][lane] = P3.x + P3.y;
                     const float tot = butterfly_sum<4 * NP>(red, lane);
-                    if (lane < 4 * NP) {
+                    if ((lane & (64 / (4 * NP) - 1)) == 0) {
                         const int vi = value_of_lane<4 * NP>(lane);                   // < 2NP: dB state vi ; else dC state vi - 2NP
                         const int st = vi < 2 * NP ? vi : vi - 2 * NP;
                         if (st < NS) {
@@ -601,53 +632,67 @@ __global__ __launch_bounds__(NW * 64) void sscan_bwd_kernel(BwdParams p) {
                 }
             }
         };
+        // epilogue of rows [base, base + n) on the tile mapping (operands come back from LDS)
+        auto epilogue = [&](int base, int n) {
+            const int hr = tr - base;
+            if (c_ok && hr >= 0 && hr < n) {
+                float4 P1 = zero4, P2 = zero4, P3 = zero4;
+#pragma unroll
+                for (int ww = 0; ww < NW; ++ww) {
+                    const float4 a = ld4(&s_part[0][ww][hr][tc4]);
+                    const float4 bq = ld4(&s_part[1][ww][hr][tc4]);
+                    const float4 c = ld4(&s_part[2][ww][hr][tc4]);
+                    P1.x += a.x; P1.y += a.y; P1.z += a.z; P1.w += a.w;
+                    P2.x += bq.x; P2.y += bq.y; P2.z += bq.z; P2.w += bq.w;
+                    P3.x += c.x; P3.y += c.y; P3.z += c.z; P3.w += c.w;
+                }
+                const float4 dl4 = ld4(&s_dl[tr][tc4]), u4 = ld4(&s_u[tr][tc4]), dy4 = ld4(&s_dy[tr][tc4]);
+                float4 Dv = zero4;
+                if (p.D) Dv = ld4(p.D + d0 + tc4);
+                const int64_t tok = tok0 + ts + tr;
+                float4 o;                                   // du = delta' * sum_n dh B + D * dy
+                o.x = dl4.x * P1.x + Dv.x * dy4.x; o.y = dl4.y * P1.y + Dv.y * dy4.y;
+                o.z = dl4.z * P1.z + Dv.z * dy4.z; o.w = dl4.w * P1.w + Dv.w * dy4.w;
+                st4(p.du + tok * p.ld_du + d0 + tc4, o);
+                float4 g;                                   // d delta' = sum_n (dh h_prev dA) A + u * sum_n dh B
+                g.x = RESEL_LN2 * P2.x + u4.x * P1.x; g.y = RESEL_LN2 * P2.y + u4.y * P1.y;
+                g.z = RESEL_LN2 * P2.z + u4.z * P1.z; g.w = RESEL_LN2 * P2.w + u4.w * P1.w;
+                if (p.softplus) {                           // softplus'(x) = sigmoid(x) = 1 - exp(-softplus(x))
+                    g.x *= 1.f - fast_exp(-dl4.x); g.y *= 1.f - fast_exp(-dl4.y); g.z *= 1.f - fast_exp(-dl4.z); g.w *= 1.f - fast_exp(-dl4.w);
+                }
+                st4(p.ddelta + tok * p.ld_ddelta + d0 + tc4, g);
+                float4 aD = ld4(&s_acc[0][hr][tc4]), ab = ld4(&s_acc[1][hr][tc4]);        // this thread's own slots
+                ab.x += g.x; ab.y += g.y; ab.z += g.z; ab.w += g.w;
+                aD.x += dy4.x * u4.x; aD.y += dy4.y * u4.y; aD.z += dy4.z * u4.z; aD.w += dy4.w * u4.w;
+                st4(&s_acc[0][hr][tc4], aD);
+                st4(&s_acc[1][hr][tc4], ab);
+                if (p.z) {
+                    const float4 gc = ld4(&s_gz[tr][tc4]);  // dout * silu'(z)
+                    float4 gz;                              // times the pre-gate output y = sum_n C h + D u
+                    gz.x = gc.x * (P3.x + Dv.x * u4.x); gz.y = gc.y * (P3.y + Dv.y * u4.y);
+                    gz.z = gc.z * (P3.z + Dv.z * u4.z); gz.w = gc.w * (P3.w + Dv.w * u4.w);
+                    st4(p.dz + tok * p.ld_dz + d0 + tc4, gz);
+                }
+            }
+        };
         if (sl > SCH) {
             f2 hm[NP], scratch_a[NP];
-#pragma unroll
-            for (int k = 0; k < NP; ++k) hm[k] = h0[k];
+            read_h0(sc, hm);
             for (int i = 0; i < SCH; ++i) replay_step(i, hm, scratch_a);
             half(SCH, sl - SCH, hm);
+            __syncthreads();                               // (C)
+            epilogue(SCH, sl - SCH);
+            __syncthreads();                               // (D) s_part is rewritten by the first half
         }
-        half(0, min(sl, SCH), h0);
-        __syncthreads();
-        // ---------------- epilogue on the tile mapping (operands come back from LDS) ----------------
-        if (c_ok && tr < sl) {
-            float4 P1 = zero4, P2 = zero4, P3 = zero4;
-#pragma unroll
-            for (int ww = 0; ww < NW; ++ww) {
-                const float4 a = ld4(&s_part[0][ww][tr][tc4]);
-                const float4 bq = ld4(&s_part[1][ww][tr][tc4]);
-                const float4 c = ld4(&s_part[2][ww][tr][tc4]);
-                P1.x += a.x; P1.y += a.y; P1.z += a.z; P1.w += a.w;
-                P2.x += bq.x; P2.y += bq.y; P2.z += bq.z; P2.w += bq.w;
-                P3.x += c.x; P3.y += c.y; P3.z += c.z; P3.w += c.w;
-            }
-            const float4 dl4 = ld4(&s_dl[tr][tc4]), u4 = ld4(&s_u[tr][tc4]), dy4 = ld4(&s_dy[tr][tc4]);
-            float4 Dv = zero4;
-            if (p.D) Dv = ld4(p.D + d0 + tc4);
-            const int64_t tok = tok0 + ts;
-            float4 o;                                   // du = delta' * sum_n dh B + D * dy
-            o.x = dl4.x * P1.x + Dv.x * dy4.x; o.y = dl4.y * P1.y + Dv.y * dy4.y;
-            o.z = dl4.z * P1.z + Dv.z * dy4.z; o.w = dl4.w * P1.w + Dv.w * dy4.w;
-            st4(p.du + tok * p.ld_du + d0 + tr * (int)p.ld_du + tc4, o);
-            float4 g;                                   // d delta' = sum_n (dh h_prev dA) A + u * sum_n dh B
-            g.x = P2.x + u4.x * P1.x; g.y = P2.y + u4.y * P1.y; g.z = P2.z + u4.z * P1.z; g.w = P2.w + u4.w * P1.w;
-            if (p.softplus) {                           // softplus'(x) = sigmoid(x) = 1 - exp(-softplus(x))
-                g.x *= 1.f - fast_exp(-dl4.x); g.y *= 1.f - fast_exp(-dl4.y); g.z *= 1.f - fast_exp(-dl4.z); g.w *= 1.f - fast_exp(-dl4.w);
-            }
-            st4(p.ddelta + tok * p.ld_ddelta + d0 + tr * (int)p.ld_ddelta + tc4, g);
-            dbacc.x += g.x; dbacc.y += g.y; dbacc.z += g.z; dbacc.w += g.w;
-            dDacc.x += dy4.x * u4.x; dDacc.y += dy4.y * u4.y; dDacc.z += dy4.z * u4.z; dDacc.w += dy4.w * u4.w;
-            if (p.z) {
-                const float4 z4 = ld4(&s_z[tr][tc4]), do4 = ld4(&s_do[tr][tc4]);
-                float4 yy;                              // pre-gate output y = sum_n C h + D u
-                yy.x = P3.x + Dv.x * u4.x; yy.y = P3.y + Dv.y * u4.y; yy.z = P3.z + Dv.z * u4.z; yy.w = P3.w + Dv.w * u4.w;
-                float4 gz;
-                gz.x = do4.x * yy.x * dsiluf_(z4.x); gz.y = do4.y * yy.y * dsiluf_(z4.y);
-                gz.z = do4.z * yy.z * dsiluf_(z4.z); gz.w = do4.w * yy.w * dsiluf_(z4.w);
-                st4(p.dz + tok * p.ld_dz + d0 + tr * (int)p.ld_dz + tc4, gz);
-            }
+        {
+            f2 h0[NP];
+            read_h0(sc, h0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the checkpoint rows are in registers: their LDS slots may be refilled
+            if (sc > 0) issue_h0(sc - 1);
+            half(0, min(sl, SCH), h0);
         }
+        __syncthreads();                                   // (E)
+        epilogue(0, min(sl, SCH));
     }
     // ---- per-(b) partials of the parameter gradients
     if (d_ok) {
@@ -656,17 +701,11 @@ __global__ __launch_bounds__(NW * 64) void sscan_bwd_kernel(BwdParams p) {
             p.dA_part[((int64_t)b * p.Di + d) * N + w * NS + j] = (j & 1) ? dAacc[j / 2].y : dAacc[j / 2].x;
     }
     __syncthreads();
-    float* s_red = &s_part[0][0][0][0];               // [2][SC][64] scratch
-    if (tile_thr) {
-        st4(&s_red[(0 * SC + tr) * TILE_C + tc4], dDacc);
-        st4(&s_red[(1 * SC + tr) * TILE_C + tc4], dbacc);
-    }
-    __syncthreads();
     if (tid < 2 * TILE_C) {
         const int which = tid >> 6, c = tid & 63;
         float acc = 0.f;
 #pragma unroll
-        for (int r = 0; r < SC; ++r) acc += s_red[(which * SC + r) * TILE_C + c];
+        for (int r = 0; r < SCH; ++r) acc += s_acc[which][r][c];
         if (d0 + c < p.Di) (which ? p.dbias_part : p.dD_part)[(int64_t)b * p.Di + d0 + c] = acc;
     }
 }
@@ -773,7 +812,7 @@ extern "C" int resel_selective_scan_fwd(const float* u, int64_t ld_u, const floa
         case 4: return launch_fwd<1, 4, 32>(p, s);
         case 8: return launch_fwd<2, 4, 32>(p, s);
         case 16: return launch_fwd<4, 4, 32>(p, s);
-        case 32: return launch_fwd<8, 4, 32>(p, s);
+        case 32: return launch_fwd<8, 4, SSCAN_FWD_TC>(p, s);
         case 64: return launch_fwd<8, 8, 32>(p, s);
         default: return RESEL_EINVAL;
     }
