@@ -392,14 +392,36 @@ __device__ __forceinline__ int value_of_lane(int lane) {
 }
 
 // Asynchronous global -> LDS copies (gfx950 global_load_lds_dwordx4 / _dword): no VGPR destination.  The LDS address is
-// the wave-uniform `lds_wave_base` + lane * size, so the LDS image of a wave-instruction is lane-linear.
+// the wave-uniform `lds_wave_base` (in M0) + lane * size, so the LDS image of a wave-instruction is lane-linear.
+// Issued as inline assembly on purpose: for the builtin form hipcc guards EVERY later LDS read that may alias the
+// destination with s_waitcnt vmcnt(0), which in the sweep also waits for the global store of the previous step (a store
+// round trip per step).  Written this way the copies are invisible to the compiler's counters; the kernel retires
+// them itself with barrier_vm<N>() below.
+__device__ __forceinline__ unsigned lds_offset(const void* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
+}
 __device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+    const unsigned l = __builtin_amdgcn_readfirstlane(lds_offset(lds_wave_base));
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(l) : "memory");
 }
 __device__ __forceinline__ void glds4(const float* g, float* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+    const unsigned l = __builtin_amdgcn_readfirstlane(lds_offset(lds_wave_base));
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(l) : "memory");
+}
+
+// Workgroup barriers of the backward kernel.  While an LDS-DMA may be in flight hipcc turns every __syncthreads() into
+// s_waitcnt vmcnt(0) + s_barrier, which also drains the GLOBAL STORES a wave has just issued (du / ddelta / dz rows of an
+// epilogue, the dB / dC partials of a sweep) - a full store round trip per barrier, ~20 % of the kernel.  The kernel
+// therefore keeps its own books: barrier_lds() orders LDS traffic only, barrier_vm<N>() additionally waits until at most
+// N vector-memory operations are outstanding - the N stores issued AFTER the DMA being waited for (in-order counter).
+__device__ __forceinline__ void barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <int NPEND>
+__device__ __forceinline__ void barrier_vm() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NPEND) : "memory");
 }
 
 // One workgroup = (row b, 64-channel tile); NW waves x NS states; time in 16-step sub-chunks, last to first.
@@ -424,7 +446,8 @@ __global__ __launch_bounds__(NW * 64) void sscan_bwd_kernel(BwdParams p) {
     __shared__ __attribute__((aligned(16))) float s_C[2][SC][N];
     __shared__ __attribute__((aligned(16))) float s_h0[N][TILE_C];           // checkpoint in front of the staged sub-chunk
     __shared__ __attribute__((aligned(16))) float s_part[3][NW][SCH][TILE_C];
-    __shared__ float s_st[SC];
+    __shared__ float s_st[2][SC];
+    __shared__ __attribute__((aligned(16))) float s_cvec[2][TILE_C];        // delta_bias | D of this channel tile
 
     int b, dt;
     if (!decode_block(blockIdx.x, p.nd, p.B, b, dt)) return;
@@ -446,6 +469,12 @@ __global__ __launch_bounds__(NW * 64) void sscan_bwd_kernel(BwdParams p) {
     for (int i = tid; i < 2 * 4 * SC * TILE_C / 4; i += NT) st4(&s_raw[0][0][0][0] + i * 4, zero4);
     for (int i = tid; i < N * TILE_C / 4; i += NT) st4(&s_h0[0][0] + i * 4, zero4);
     for (int i = tid; i < 2 * SCH * TILE_C / 4; i += NT) st4(&s_acc[0][0][0] + i * 4, zero4);
+    if (tid < 2 * SC) (&s_st[0][0])[tid] = 0.f;
+    if (tid < 2 * TILE_C) {
+        const float* src = (tid < TILE_C) ? p.delta_bias : p.D;
+        const int c = tid & (TILE_C - 1);
+        (&s_cvec[0][0])[tid] = (src != nullptr && d0 + c < p.Di) ? src[d0 + c] : 0.f;
+    }
 
     f2 A2p[NP], dh[NP], dAacc[NP];
 #pragma unroll
@@ -460,7 +489,6 @@ __global__ __launch_bounds__(NW * 64) void sscan_bwd_kernel(BwdParams p) {
         dh[k] = f2{0.f, 0.f};
         dAacc[k] = f2{0.f, 0.f};
     }
-    float pst = 0.f;
 
     const int nsc = (p.L + SC - 1) / SC;
     // issue the LDS-DMA of sub-chunk sc into buffer sc & 1 (plus its start flags into a register)
@@ -495,7 +523,7 @@ __global__ __launch_bounds__(NW * 64) void sscan_bwd_kernel(BwdParams p) {
                 }
             }
         }
-        pst = (p.start && tid < SC && ts + tid < p.L) ? p.start[tok0 + ts + tid] : 0.f;
+        if (p.start && tid < SC && ts + tid < p.L) glds4(p.start + tok0 + ts + tid, &s_st[buf][0]);   // wave 0, lanes < SC
     };
     // state at the start of sub-chunk sc: checkpoint sc-1 (written by the forward after step sc*SC).  Each wave fetches
     // and later reads only its own NS rows of s_h0.
@@ -521,6 +549,7 @@ __global__ __launch_bounds__(NW * 64) void sscan_bwd_kernel(BwdParams p) {
     __syncthreads();                                   // the clears above precede the first DMA
     stage_issue(nsc - 1);
     issue_h0(nsc - 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // later iterations find their DMA retired by barrier_vm (C) / (E)
 
     for (int sc = nsc - 1; sc >= 0; --sc) {
         const int ts = sc * SC, buf = sc & 1;
@@ -531,11 +560,11 @@ __global__ __launch_bounds__(NW * 64) void sscan_bwd_kernel(BwdParams p) {
         float (*s_dy)[TILE_C] = s_raw[buf][3];
         float (*sB)[N] = s_B[buf];
         float (*sC)[N] = s_C[buf];
+        const float* sst = s_st[buf];
         // ---------------- (A) DMA of this sub-chunk has landed; transform pass ----------------
-        __syncthreads();
+        barrier_lds();
         if (c_ok && tr < sl) {
-            float4 bv = zero4;
-            if (p.delta_bias) bv = ld4(p.delta_bias + d0 + tc4);
+            const float4 bv = ld4(&s_cvec[0][tc4]);
             float4 dl4 = ld4(&s_dl[tr][tc4]);
             dl4.x += bv.x; dl4.y += bv.y; dl4.z += bv.z; dl4.w += bv.w;
             if (p.softplus) {
@@ -548,8 +577,7 @@ __global__ __launch_bounds__(NW * 64) void sscan_bwd_kernel(BwdParams p) {
                 st4(&s_gz[tr][tc4], make_float4(do4.x * dsiluf_(pz.x), do4.y * dsiluf_(pz.y), do4.z * dsiluf_(pz.z), do4.w * dsiluf_(pz.w)));
             }
         }
-        if (tid < SC) s_st[tid] = pst;
-        __syncthreads();                                   // (B)
+        barrier_lds();                                     // (B)
         if (sc > 0) stage_issue(sc - 1);                   // in flight during the whole replay / reverse phase
 
         // ---------------- replay + reverse, in two halves of SCH steps (later half first) ----------------
@@ -559,7 +587,7 @@ __global__ __launch_bounds__(NW * 64) void sscan_bwd_kernel(BwdParams p) {
         auto replay_step = [&](int i, f2 (&h)[NP], f2 (&dAo)[NP]) {
             f2 Bq[NP];
             lds_coef2<NS>(&sB[i][w * NS], Bq);
-            const float sf = s_st[i];
+            const float sf = sst[i];
             const float dl = s_dl[i][lane], du = dl * s_u[i][lane];
             const float dle = (sf != 0.f) ? __builtin_inff() : dl;
             const f2 dle2 = {dle, dle}, du2 = {du, du};
@@ -632,46 +660,39 @@ __global__ __launch_bounds__(NW * 64) void sscan_bwd_kernel(BwdParams p) {
                 }
             }
         };
-        // epilogue of rows [base, base + n) on the tile mapping (operands come back from LDS)
+        // epilogue of rows [base, base + n): one float2 (2 channels of one row) per thread, so that all 256 tile threads
+        // take part in each half's epilogue (operands come back from LDS)
         auto epilogue = [&](int base, int n) {
-            const int hr = tr - base;
-            if (c_ok && hr >= 0 && hr < n) {
-                float4 P1 = zero4, P2 = zero4, P3 = zero4;
+            const int hr = (tid >> 5) & (SCH - 1), c2 = (tid & 31) * 2;
+            const int row = base + hr;
+            if (tile_thr && hr < n && d0 + c2 < p.Di) {
+                f2 P1 = {0.f, 0.f}, P2 = P1, P3 = P1;
 #pragma unroll
                 for (int ww = 0; ww < NW; ++ww) {
-                    const float4 a = ld4(&s_part[0][ww][hr][tc4]);
-                    const float4 bq = ld4(&s_part[1][ww][hr][tc4]);
-                    const float4 c = ld4(&s_part[2][ww][hr][tc4]);
-                    P1.x += a.x; P1.y += a.y; P1.z += a.z; P1.w += a.w;
-                    P2.x += bq.x; P2.y += bq.y; P2.z += bq.z; P2.w += bq.w;
-                    P3.x += c.x; P3.y += c.y; P3.z += c.z; P3.w += c.w;
+                    P1 += *reinterpret_cast<const f2*>(&s_part[0][ww][hr][c2]);
+                    P2 += *reinterpret_cast<const f2*>(&s_part[1][ww][hr][c2]);
+                    P3 += *reinterpret_cast<const f2*>(&s_part[2][ww][hr][c2]);
                 }
-                const float4 dl4 = ld4(&s_dl[tr][tc4]), u4 = ld4(&s_u[tr][tc4]), dy4 = ld4(&s_dy[tr][tc4]);
-                float4 Dv = zero4;
-                if (p.D) Dv = ld4(p.D + d0 + tc4);
-                const int64_t tok = tok0 + ts + tr;
-                float4 o;                                   // du = delta' * sum_n dh B + D * dy
-                o.x = dl4.x * P1.x + Dv.x * dy4.x; o.y = dl4.y * P1.y + Dv.y * dy4.y;
-                o.z = dl4.z * P1.z + Dv.z * dy4.z; o.w = dl4.w * P1.w + Dv.w * dy4.w;
-                st4(p.du + tok * p.ld_du + d0 + tc4, o);
-                float4 g;                                   // d delta' = sum_n (dh h_prev dA) A + u * sum_n dh B
-                g.x = RESEL_LN2 * P2.x + u4.x * P1.x; g.y = RESEL_LN2 * P2.y + u4.y * P1.y;
-                g.z = RESEL_LN2 * P2.z + u4.z * P1.z; g.w = RESEL_LN2 * P2.w + u4.w * P1.w;
+                const f2 dl2 = *reinterpret_cast<const f2*>(&s_dl[row][c2]), u2 = *reinterpret_cast<const f2*>(&s_u[row][c2]);
+                const f2 dy2 = *reinterpret_cast<const f2*>(&s_dy[row][c2]);
+                const f2 Dv = *reinterpret_cast<const f2*>(&s_cvec[1][c2]);
+                const int64_t tok = tok0 + ts + row;
+                // du = delta' * sum_n dh B + D * dy
+                *reinterpret_cast<f2*>(p.du + tok * p.ld_du + d0 + c2) = dl2 * P1 + Dv * dy2;
+                // d delta' = sum_n (dh h_prev dA) A + u * sum_n dh B
+                f2 g = RESEL_LN2 * P2 + u2 * P1;
                 if (p.softplus) {                           // softplus'(x) = sigmoid(x) = 1 - exp(-softplus(x))
-                    g.x *= 1.f - fast_exp(-dl4.x); g.y *= 1.f - fast_exp(-dl4.y); g.z *= 1.f - fast_exp(-dl4.z); g.w *= 1.f - fast_exp(-dl4.w);
+                    g.x *= 1.f - fast_exp(-dl2.x);
+                    g.y *= 1.f - fast_exp(-dl2.y);
                 }
-                st4(p.ddelta + tok * p.ld_ddelta + d0 + tc4, g);
-                float4 aD = ld4(&s_acc[0][hr][tc4]), ab = ld4(&s_acc[1][hr][tc4]);        // this thread's own slots
-                ab.x += g.x; ab.y += g.y; ab.z += g.z; ab.w += g.w;
-                aD.x += dy4.x * u4.x; aD.y += dy4.y * u4.y; aD.z += dy4.z * u4.z; aD.w += dy4.w * u4.w;
-                st4(&s_acc[0][hr][tc4], aD);
-                st4(&s_acc[1][hr][tc4], ab);
-                if (p.z) {
-                    const float4 gc = ld4(&s_gz[tr][tc4]);  // dout * silu'(z)
-                    float4 gz;                              // times the pre-gate output y = sum_n C h + D u
-                    gz.x = gc.x * (P3.x + Dv.x * u4.x); gz.y = gc.y * (P3.y + Dv.y * u4.y);
-                    gz.z = gc.z * (P3.z + Dv.z * u4.z); gz.w = gc.w * (P3.w + Dv.w * u4.w);
-                    st4(p.dz + tok * p.ld_dz + d0 + tc4, gz);
+                *reinterpret_cast<f2*>(p.ddelta + tok * p.ld_ddelta + d0 + c2) = g;
+                f2* aD = reinterpret_cast<f2*>(&s_acc[0][hr][c2]);      // this thread's own slots
+                f2* ab = reinterpret_cast<f2*>(&s_acc[1][hr][c2]);
+                *aD += dy2 * u2;
+                *ab += g;
+                if (p.z) {                                  // dz = dout * silu'(z) * (pre-gate output y = sum_n C h + D u)
+                    const f2 gc = *reinterpret_cast<const f2*>(&s_gz[row][c2]);
+                    *reinterpret_cast<f2*>(p.dz + tok * p.ld_dz + d0 + c2) = gc * (P3 + Dv * u2);
                 }
             }
         };
@@ -680,9 +701,10 @@ __global__ __launch_bounds__(NW * 64) void sscan_bwd_kernel(BwdParams p) {
             read_h0(sc, hm);
             for (int i = 0; i < SCH; ++i) replay_step(i, hm, scratch_a);
             half(SCH, sl - SCH, hm);
-            __syncthreads();                               // (C)
+            // (C) the tile DMA of the next sub-chunk was issued before this half's sl - SCH partial-slab stores
+            if (sl == SC) barrier_vm<SCH>(); else barrier_vm<0>();
             epilogue(SCH, sl - SCH);
-            __syncthreads();                               // (D) s_part is rewritten by the first half
+            barrier_lds();                                 // (D) s_part is rewritten by the first half
         }
         {
             f2 h0[NP];
@@ -691,7 +713,8 @@ __global__ __launch_bounds__(NW * 64) void sscan_bwd_kernel(BwdParams p) {
             if (sc > 0) issue_h0(sc - 1);
             half(0, min(sl, SCH), h0);
         }
-        __syncthreads();                                   // (E)
+        // (E) retires the checkpoint DMA (and, on a short tail sub-chunk that skipped (C), the tile DMA)
+        if (sl >= SCH) barrier_vm<SCH>(); else barrier_vm<0>();
         epilogue(0, min(sl, SCH));
     }
     // ---- per-(b) partials of the parameter gradients
