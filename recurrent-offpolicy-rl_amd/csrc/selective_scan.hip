@@ -584,20 +584,51 @@ __global__ __launch_bounds__(NW * 64) void sscan_bwd_kernel(BwdParams p) {
         // The (h, dA) history of SCH = 8 steps x NS states lives in registers.  The second half starts from the state
         // after step SCH-1, obtained by a plain replay of the first half (no history kept): the first half is thus
         // replayed twice, which costs ~15 % of a half's work and lets a lane carry twice the states.
-        auto replay_step = [&](int i, f2 (&h)[NP], f2 (&dAo)[NP]) {
-            f2 Bq[NP];
-            lds_coef2<NS>(&sB[i][w * NS], Bq);
-            const float sf = sst[i];
-            const float dl = s_dl[i][lane], du = dl * s_u[i][lane];
-            const float dle = (sf != 0.f) ? __builtin_inff() : dl;
+        // Operand sets are fetched from LDS one step ahead of their use (the LDS round trip would otherwise sit at the
+        // head of every step of a wave that has only one partner on its SIMD): the replay keeps two sets in flight, the
+        // reverse sweep refills its single set between a step's arithmetic and its channel reduction, which no longer
+        // needs B / C / delta - so the prefetch costs no extra registers at the sweep's pressure peak.
+        struct RepOps { f2 Bq[NP]; float sf, dl, u; };
+        auto fetch_rep = [&](int i, RepOps& o) {
+            lds_coef2<NS>(&sB[i][w * NS], o.Bq);
+            o.sf = sst[i];
+            o.dl = s_dl[i][lane];
+            o.u = s_u[i][lane];
+        };
+        auto replay_step = [&](const RepOps& o, f2 (&h)[NP], f2 (&dAo)[NP]) {
+            const float du = o.dl * o.u;
+            const float dle = (o.sf != 0.f) ? __builtin_inff() : o.dl;
             const f2 dle2 = {dle, dle}, du2 = {du, du};
 #pragma unroll
             for (int k = 0; k < NP; ++k) {
                 const f2 arg = dle2 * A2p[k];
                 dAo[k].x = fast_exp2(arg.x);
                 dAo[k].y = fast_exp2(arg.y);
-                h[k] = __builtin_elementwise_fma(dAo[k], h[k], du2 * Bq[k]);
+                h[k] = __builtin_elementwise_fma(dAo[k], h[k], du2 * o.Bq[k]);
             }
+        };
+        // plain replay of steps [0, SCH) (no history)
+        auto replay_plain = [&](f2 (&h)[NP]) {
+            RepOps o0, o1;
+            f2 scratch[NP];
+            fetch_rep(0, o0);
+#pragma unroll
+            for (int i = 0; i < SCH; i += 2) {
+                fetch_rep(i + 1, o1);
+                __builtin_amdgcn_sched_barrier(0);
+                replay_step(o0, h, scratch);
+                fetch_rep(min(i + 2, SC - 1), o0);
+                __builtin_amdgcn_sched_barrier(0);
+                replay_step(o1, h, scratch);
+            }
+        };
+        struct RevOps { f2 Bq[NP], Cq[NP]; float dl, dy, u; };
+        auto fetch_rev = [&](int r, RevOps& o) {
+            lds_coef2<NS>(&sB[r][w * NS], o.Bq);
+            lds_coef2<NS>(&sC[r][w * NS], o.Cq);
+            o.dl = s_dl[r][lane];
+            o.dy = s_dy[r][lane];
+            o.u = s_u[r][lane];
         };
         auto half = [&](int base, int n, const f2 (&hstart)[NP]) {
             f2 hist_h[SCH][NP], hist_a[SCH][NP];
@@ -605,27 +636,36 @@ __global__ __launch_bounds__(NW * 64) void sscan_bwd_kernel(BwdParams p) {
                 f2 h[NP];
 #pragma unroll
                 for (int k = 0; k < NP; ++k) h[k] = hstart[k];
+                RepOps o0, o1;
+                fetch_rep(base, o0);
 #pragma unroll
-                for (int i = 0; i < SCH; ++i) {
+                for (int i = 0; i < SCH; i += 2) {
                     if (i < n) {
                         f2 dA[NP];
-                        replay_step(base + i, h, dA);
+                        fetch_rep(min(base + i + 1, SC - 1), o1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        replay_step(o0, h, dA);
 #pragma unroll
                         for (int k = 0; k < NP; ++k) { hist_h[i][k] = h[k]; hist_a[i][k] = dA[k]; }
-                        __builtin_amdgcn_sched_barrier(0);        // keep the unrolled steps in order (register pressure)
+                    }
+                    if (i + 1 < n) {
+                        f2 dA[NP];
+                        fetch_rep(min(base + i + 2, SC - 1), o0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        replay_step(o1, h, dA);
+#pragma unroll
+                        for (int k = 0; k < NP; ++k) { hist_h[i + 1][k] = h[k]; hist_a[i + 1][k] = dA[k]; }
                     }
                 }
             }
+            RevOps o;
+            fetch_rev(base + n - 1, o);
 #pragma unroll
             for (int i = SCH - 1; i >= 0; --i) {
                 if (i < n) {
                     const int r = base + i;
-                    f2 Bq[NP], Cq[NP];
-                    lds_coef2<NS>(&sB[r][w * NS], Bq);
-                    lds_coef2<NS>(&sC[r][w * NS], Cq);
-                    const float dl = s_dl[r][lane], dy = s_dy[r][lane];
-                    const float du = dl * s_u[r][lane];
-                    const f2 dl2 = {dl, dl}, du2 = {du, du}, dy2 = {dy, dy};
+                    const float du = o.dl * o.u;
+                    const f2 dl2 = {o.dl, o.dl}, du2 = {du, du}, dy2 = {o.dy, o.dy};
                     f2 P1 = {0.f, 0.f}, P2 = P1, P3 = P1;
                     float red[4 * NP];                     // [dB pairs | dC pairs] for the channel reduction
 #pragma unroll
@@ -633,8 +673,8 @@ __global__ __launch_bounds__(NW * 64) void sscan_bwd_kernel(BwdParams p) {
                         const f2 hk = hist_h[i][k];
                         const f2 hp = (i == 0) ? hstart[k] : hist_h[i > 0 ? i - 1 : 0][k];
                         const f2 ak = hist_a[i][k];                                   // 0 at a reset step
-                        const f2 dhk = __builtin_elementwise_fma(dy2, Cq[k], dh[k]);  // dL/dh_t
-                        P3 = __builtin_elementwise_fma(Cq[k], hk, P3);
+                        const f2 dhk = __builtin_elementwise_fma(dy2, o.Cq[k], dh[k]);  // dL/dh_t
+                        P3 = __builtin_elementwise_fma(o.Cq[k], hk, P3);
                         dh[k] = dhk * ak;                                             // carried to step t-1
                         const f2 tmp = dh[k] * hp;                                    // dL/d(dA) * dA
                         P2 = __builtin_elementwise_fma(tmp, A2p[k], P2);              // in units of log2(e): rescaled in the epilogue
@@ -642,8 +682,10 @@ __global__ __launch_bounds__(NW * 64) void sscan_bwd_kernel(BwdParams p) {
                         const f2 gb = dhk * du2, gc = dy2 * hk;
                         red[2 * k] = gb.x; red[2 * k + 1] = gb.y;
                         red[2 * NP + 2 * k] = gc.x; red[2 * NP + 2 * k + 1] = gc.y;
-                        P1 = __builtin_elementwise_fma(dhk, Bq[k], P1);
+                        P1 = __builtin_elementwise_fma(dhk, o.Bq[k], P1);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (i > 0) fetch_rev(base + i - 1, o);                            // lands during the reduction below
                     s_part[0][w][i][lane] = P1.x + P1.y;
                     s_part[1][w][i][lane] = P2.x + P2.y;
                     s_part[2][w][i][lane] = P3.x + P3.y;
@@ -652,8 +694,8 @@ __global__ __launch_bounds__(NW * 64) void sscan_bwd_kernel(BwdParams p) {
                         const int vi = value_of_lane<4 * NP>(lane);                   // < 2NP: dB state vi ; else dC state vi - 2NP
                         const int st = vi < 2 * NP ? vi : vi - 2 * NP;
                         if (st < NS) {
-                            const int64_t o = ((int64_t)dt * p.B * p.L + tok0 + ts + r) * N + w * NS + st;
-                            (vi < 2 * NP ? p.dB_part : p.dC_part)[o] = tot;
+                            const int64_t o2 = ((int64_t)dt * p.B * p.L + tok0 + ts + r) * N + w * NS + st;
+                            (vi < 2 * NP ? p.dB_part : p.dC_part)[o2] = tot;
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -697,9 +739,9 @@ __global__ __launch_bounds__(NW * 64) void sscan_bwd_kernel(BwdParams p) {
             }
         };
         if (sl > SCH) {
-            f2 hm[NP], scratch_a[NP];
+            f2 hm[NP];
             read_h0(sc, hm);
-            for (int i = 0; i < SCH; ++i) replay_step(i, hm, scratch_a);
+            replay_plain(hm);
             half(SCH, sl - SCH, hm);
             // (C) the tile DMA of the next sub-chunk was issued before this half's sl - SCH partial-slab stores
             if (sl == SC) barrier_vm<SCH>(); else barrier_vm<0>();
