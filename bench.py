@@ -93,6 +93,7 @@ def main():
     torch.manual_seed(1234 + rank)
     np.random.seed(1234 + rank)                         # each rank samples its own rows
     alg = build_trainer(args.rnn, args.rows, args.horizon, seed=rank, algo=args.algo)
+    alg.defer_log = True          # log scalars: one async D2H copy per update (inside the timed region), read on demand
     alg.grad_sync.__init__()                            # pick up the process group
     if world > 1:
         for net in [alg.policy] + alg.values + alg.target_values:

@@ -131,15 +131,6 @@ __global__ __launch_bounds__(WAVES * 64) void ln_bwd_kernel(const float* __restr
     }
 }
 
-__global__ void ln_reduce_kernel(const float* dw_part, const float* db_part, float* dw, float* db, int nblk, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float a = 0.f, b = 0.f;
-    for (int k = 0; k < nblk; ++k) { a += dw_part[(int64_t)k * C + c]; b += db_part[(int64_t)k * C + c]; }
-    dw[c] = a;
-    if (db) db[c] = b;
-}
-
 inline int bwd_blocks(int M) { const int need = (M + WAVES - 1) / WAVES; return need < BWD_BLOCKS ? need : BWD_BLOCKS; }
 inline bool ln_ok(int M, int C) { return M > 0 && C > 0 && C % 4 == 0 && C <= 2048; }
 
@@ -180,7 +171,7 @@ extern "C" int resel_add_layernorm_bwd(const float* dy, const float* dres_in, co
     else if (C <= 512) hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, blk, 0, s, dy, dres_in, res, w, stats, dx, dw_part, db_part, M, C, rms);
     else if (C <= 1024) hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, blk, 0, s, dy, dres_in, res, w, stats, dx, dw_part, db_part, M, C, rms);
     else hipLaunchKernelGGL(ln_bwd_kernel<8>, grid, blk, 0, s, dy, dres_in, res, w, stats, dx, dw_part, db_part, M, C, rms);
-    hipLaunchKernelGGL(ln_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, s, dw_part, db_part, dw,
-                       (has_bias && db) ? db : nullptr, nblk, C);
+    launch_colsum(dw_part, C, nblk, C, dw, s);
+    if (has_bias && db) launch_colsum(db_part, C, nblk, C, db, s);
     return launch_status();
 }

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(128) void conv_fwd_kernel(ConvParams p) {
 }
 
 // Backward: one block per (row b, channel tile) walks the time tiles, so dw / dbias accumulate in registers and
-// only per-row partials [B, Di, KT] / [B, Di] leave the block (summed by conv_reduce_kernel, no atomics).
+// only per-row partials [B, Di, KT] / [B, Di] leave the block (summed by colsum_kernel, no atomics).
 //   g[t]   = dy[t] * silu'(pre[t])                      pre = conv output before the activation (recomputed)
 //   dx[t]  = mask[t] * sum_k w[k] * g[t + (K-1) - k]
 //   dw[k]  = sum_t g[t] * xm[t - (K-1) + k]
@@ -228,23 +228,6 @@ __global__ __launch_bounds__(256) void conv_bwd_kernel(ConvParams p) {
     }
 }
 
-// dw[d, k] = sum_b dw_part[b, d, KT - K + k] ; dbias[d] = sum_b db_part[b, d]
-__global__ void conv_reduce_kernel(const float* dw_part, const float* db_part, float* dw, float* dbias,
-                                   int B, int Di, int K, int KT) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < Di * K) {
-        const int d = i / K, k = i % K;
-        float acc = 0.f;
-        for (int b = 0; b < B; ++b) acc += dw_part[((int64_t)b * Di + d) * KT + (KT - K) + k];
-        dw[i] = acc;
-    }
-    if (dbias != nullptr && i < Di) {
-        float acc = 0.f;
-        for (int b = 0; b < B; ++b) acc += db_part[(int64_t)b * Di + i];
-        dbias[i] = acc;
-    }
-}
-
 inline int pad_taps(int K) { return K <= 4 ? 4 : (K <= 8 ? 8 : (K <= 16 ? 16 : 32)); }
 inline bool conv_args_ok(const float* x, int64_t ld_x, const float* o, int64_t ld_o, int B, int L, int Di, int K) {
     return x && o && B > 0 && L > 0 && Di > 0 && Di % 4 == 0 && K >= 1 && K <= 32 && ld_x % 4 == 0 && ld_o % 4 == 0 &&
@@ -293,7 +276,7 @@ extern "C" int resel_causal_conv1d_bwd(const float* x, int64_t ld_x, const float
         case 16: hipLaunchKernelGGL(conv_bwd_kernel<16>, grid, dim3(256), 0, s, p); break;
         default: hipLaunchKernelGGL(conv_bwd_kernel<32>, grid, dim3(256), 0, s, p); break;
     }
-    const int n = Di * K;
-    hipLaunchKernelGGL(conv_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, dw_part, db_part, dw, dbias, B, Di, K, KT);
+    launch_colsum(dw_part, (int64_t)Di * KT, B, Di * KT, dw, s, KT, K);      // dw[d, k] = sum_b dw_part[b, d, KT - K + k]
+    if (dbias) launch_colsum(db_part, Di, B, Di, dbias, s);
     return launch_status();
 }

@@ -47,6 +47,34 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Column sums of row-major partial slabs in a fixed order (bitwise reproducible): out[o(c)] = sum_{k<K} part[k * ld + c],
+// c < C.  With taps == 0 the output index is c; otherwise the columns are [ch][padded taps KT] and only the last `taps`
+// of every KT go out, as out[ch * taps + tap].  256 threads = 16 columns x 16 row groups; grid = ceil(C / 16) blocks.
+static __global__ void colsum_kernel(const float* __restrict__ part, int64_t ld, int K, int C, float* __restrict__ out,
+                                     int KT, int taps) {
+    __shared__ float s_acc[16][17];
+    const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    float acc = 0.f;
+    if (c < C)
+        for (int k = rg; k < K; k += 16) acc += part[(int64_t)k * ld + c];
+    s_acc[rg][cl] = acc;
+    __syncthreads();
+    if (rg == 0 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += s_acc[r][cl];
+        if (taps == 0) out[c] = t;
+        else {
+            const int tap = c % KT - (KT - taps);
+            if (tap >= 0) out[(c / KT) * taps + tap] = t;
+        }
+    }
+}
+inline void launch_colsum(const float* part, int64_t ld, int K, int C, float* out, hipStream_t s, int KT = 1, int taps = 0) {
+    hipLaunchKernelGGL(colsum_kernel, dim3((C + 15) / 16), dim3(256), 0, s, part, ld, K, C, out, KT, taps);
+}
+
 inline int launch_status() { return hipGetLastError() == hipSuccess ? RESEL_OK : RESEL_ELAUNCH; }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

@@ -790,14 +790,6 @@ __global__ void sscan_reduce_bc_kernel(const float* __restrict__ part, int nd, i
     float* o = out + tok * ld + c;
     o[0] = acc.x; o[1] = acc.y; o[2] = acc.z; o[3] = acc.w;
 }
-__global__ void sscan_reduce_rows_kernel(const float* __restrict__ part, int B, int64_t n, float* out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float acc = 0.f;
-    for (int b = 0; b < B; ++b) acc += part[(int64_t)b * n + i];
-    out[i] = acc;
-}
-
 template <int NS, int NW, int TC>
 int launch_fwd(const FwdParams& p, hipStream_t s) {
     const int bp = (p.B + 7) / 8 * 8;
@@ -933,9 +925,8 @@ extern "C" int resel_selective_scan_bwd(const float* u, int64_t ld_u, const floa
     hipLaunchKernelGGL(sscan_reduce_bc_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s,
                        p.dC_part, p.nd, ntok, N, dCm, ld_dc);
     const int64_t na = (int64_t)Di * N;
-    hipLaunchKernelGGL(sscan_reduce_rows_kernel, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, s, p.dA_part, B, na, dA);
-    if (dD) hipLaunchKernelGGL(sscan_reduce_rows_kernel, dim3((Di + 255) / 256), dim3(256), 0, s, p.dD_part, B, (int64_t)Di, dD);
-    if (ddelta_bias)
-        hipLaunchKernelGGL(sscan_reduce_rows_kernel, dim3((Di + 255) / 256), dim3(256), 0, s, p.dbias_part, B, (int64_t)Di, ddelta_bias);
+    launch_colsum(p.dA_part, na, B, (int)na, dA, s);
+    if (dD) launch_colsum(p.dD_part, Di, B, Di, dD, s);
+    if (ddelta_bias) launch_colsum(p.dbias_part, Di, B, Di, ddelta_bias, s);
     return launch_status();
 }

@@ -32,6 +32,71 @@ from .sac import SAC
 FIELDS = ('state', 'last_state', 'action', 'last_action', 'next_state', 'done', 'mask', 'reward', 'reward_input', 'timeout', 'start')
 
 
+class DeferredLog(dict):
+    """The update's log dict.  Host-side entries are plain items; the device scalars travel in one asynchronous copy into
+    pinned memory and become floats on first access (`resolve()`), so a caller that does not read them - a training loop
+    logging every n-th update, bench.py - never stalls the launch queue on the update it has just enqueued."""
+
+    def __init__(self, keys, packed, pinned):
+        super().__init__()
+        self._keys = keys
+        if pinned:
+            self._buf = torch.empty(packed.shape, dtype=packed.dtype, pin_memory=True)
+            self._buf.copy_(packed, non_blocking=True)
+            self._event = torch.cuda.Event()
+            self._event.record()
+        else:
+            self._buf, self._event = packed.detach().cpu(), None
+
+    def set_host(self, items):
+        dict.update(self, items)
+
+    def resolve(self):
+        if self._keys is not None:
+            if self._event is not None:
+                self._event.synchronize()
+            vals = dict(zip(self._keys, self._buf.tolist()))
+            if 'actor_loss' in vals:
+                vals['actor_loss'] = (vals['actor_loss'],)      # a 1-tuple upstream (reference :430); kept
+            self._keys = None
+            pending = dict(self)                                # host entries override / follow, as in the reference order
+            dict.clear(self)
+            dict.update(self, vals)
+            dict.update(self, pending)
+        return self
+
+    def __getitem__(self, k):
+        if not dict.__contains__(self, k):
+            self.resolve()
+        return dict.__getitem__(self, k)
+
+    def get(self, k, default=None):
+        if not dict.__contains__(self, k):
+            self.resolve()
+        return dict.get(self, k, default)
+
+    def __contains__(self, k):
+        return dict.__contains__(self, k) or dict.__contains__(self.resolve(), k)
+
+    def __iter__(self):
+        return dict.__iter__(self.resolve())
+
+    def __len__(self):
+        return dict.__len__(self.resolve())
+
+    def keys(self):
+        return dict.keys(self.resolve())
+
+    def items(self):
+        return dict.items(self.resolve())
+
+    def values(self):
+        return dict.values(self.resolve())
+
+    def __repr__(self):
+        return dict.__repr__(self.resolve())
+
+
 class SACFullLengthRNNEnsembleQ(SAC):
     def __init__(self, parameter):
         super().__init__(parameter)
@@ -253,12 +318,14 @@ class SACFullLengthRNNEnsembleQ(SAC):
         self.policy.to(self.sample_device)
         scal.update(log_alpha=self.log_sac_alpha.detach()[0], target_q_max=self._stats[0], clip_min=self.Q_guard.state[0],
                     clip_max=self.Q_guard.state[1], q1_l2_norm_square=self.values[0].l2_norm_square())
+        for k in [k for k, v in host.items() if torch.is_tensor(v)]:      # clipped runs: the norm is a device scalar
+            scal[k] = host.pop(k).detach()
         keys = list(scal)
-        vals = torch.stack([scal[k].reshape(()).float() for k in keys]).cpu().tolist()      # the only device->host sync
-        log = dict(zip(keys, vals))
-        if 'actor_loss' in log:
-            log['actor_loss'] = (log['actor_loss'],)            # a 1-tuple upstream (reference :430); kept
-        log.update({k: float(v) for k, v in host.items()})
-        log.update(real_batch_size=batch_size, real_batch_traj_num=rows, average_traj_len=self.replay_buffer.size / len(self.replay_buffer),
-                   amp_scalar_pi=0, amp_scalar_q=0)
+        packed = torch.stack([scal[k].reshape(()).float() for k in keys])
+        log = DeferredLog(keys, packed, pinned=self.device.type == 'cuda')     # ONE device->host copy of all scalars
+        log.set_host({k: float(v) for k, v in host.items()})
+        log.set_host(dict(real_batch_size=batch_size, real_batch_traj_num=rows,
+                          average_traj_len=self.replay_buffer.size / len(self.replay_buffer), amp_scalar_pi=0, amp_scalar_q=0))
+        if not getattr(self, 'defer_log', False):
+            log.resolve()                                        # reference behaviour: floats in hand when the call returns
         return log
