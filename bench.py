@@ -140,16 +140,30 @@ def main():
                    'global_rows': Bsz * world, 'parallelism': f'dp{world}'},
     }
     if 'sscan_fwd_kernel' in kern and args.rnn.startswith('smamba'):
+        # Roofline of the hand-written kernels timed above (HIP event pair bound to each dispatch, on the launch stream).
+        # Algorithmic bytes per launch = SURVEY.md 8(d)'s per-element figures x the B*T'*Di elements of one launch;
+        # `roofline` is the one with the larger total time in the timed region, `roofline_other` the second.
         Di, N = 512, int(args.rnn.split('_s')[1].split('_')[0])
-        fwd_bytes = 4 * Bsz * Di * Tp * 4 + 4 * Bsz * N * Tp * 2 + Bsz * Tp      # u, delta, z, out + B, C + start(u8)
-        bwd_bytes = 4 * Bsz * Di * Tp * 7 + 4 * Bsz * N * Tp * 4
-        a = fwd_bytes / (kern['sscan_fwd_kernel']['avg_us'] * 1e-6) / 1e9
-        out['roofline'] = {'kernel': 'sscan_fwd_kernel', 'bound': 'hbm', 'achieved': a, 'peak': 8000.0, 'unit': 'GB/s', 'frac': a / 8000.0,
-                           'traffic': None, 'avg_us': kern['sscan_fwd_kernel']['avg_us'], 'algorithmic_bytes': fwd_bytes}
-        if 'sscan_bwd_kernel' in kern:
-            ab = bwd_bytes / (kern['sscan_bwd_kernel']['avg_us'] * 1e-6) / 1e9
-            out['roofline_bwd'] = {'kernel': 'sscan_bwd_kernel', 'bound': 'hbm', 'achieved': ab, 'peak': 8000.0, 'unit': 'GB/s',
-                                   'frac': ab / 8000.0, 'avg_us': kern['sscan_bwd_kernel']['avg_us'], 'algorithmic_bytes': bwd_bytes}
+        alg_bytes = {'sscan_fwd_kernel': 4 * Bsz * Di * Tp * 4 + 4 * Bsz * N * Tp * 2 + Bsz * Tp,      # u, delta, z, out + B, C + start
+                     'sscan_bwd_kernel': 4 * Bsz * Di * Tp * 7 + 4 * Bsz * N * Tp * 4}               # + dout, du, ddelta, dz + dB, dC
+        traffic = {}
+        tpath = os.path.join(ROOT, 'profiles', 'traffic.json')       # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get('per_launch_bytes', {})
+        lines = []
+        for name in ('sscan_fwd_kernel', 'sscan_bwd_kernel'):
+            if name in kern and kern[name]['launches'] > 0:
+                ach = alg_bytes[name] / (kern[name]['avg_us'] * 1e-6) / 1e9
+                lines.append((kern[name]['avg_us'] * kern[name]['launches'],
+                              {'kernel': name, 'bound': 'hbm', 'achieved': ach, 'peak': 8000.0, 'unit': 'GB/s', 'frac': ach / 8000.0,
+                               'traffic': traffic.get(name), 'avg_us': kern[name]['avg_us'], 'launches': kern[name]['launches'],
+                               'algorithmic_bytes': alg_bytes[name],
+                               'note': 'fp32 recurrence with N=32 states per channel: VALU-issue bound below the HBM roof (DESIGN.md 4)'}))
+        lines.sort(key=lambda t: -t[0])
+        if lines:
+            out['roofline'] = lines[0][1]
+        if len(lines) > 1:
+            out['roofline_other'] = lines[1][1]
     out['kernels'] = kern
     if world == 1 and not args.no_cpu_baseline:
         from oracle.trainer import time_cpu_baseline

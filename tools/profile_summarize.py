@@ -1,0 +1,49 @@
+"""Turn gpurun_out/prof_<tag>/ (tools/profile_bench.sh) into the tracked artefacts under profiles/:
+   <tag>_kernel_stats.csv (rocprofv3 --stats summary, verbatim), <tag>_bench.json, <tag>_summary.md and traffic.json
+   (HBM bytes per launch of the hand-written scan kernels: FETCH_SIZE [KB] x 1024 x 2 - the gfx950 correction for wide
+   coalesced reads, MI355X_MICROARCH.md 'HBM' - and WRITE_SIZE [KB] x 1024; separate --pmc passes)."""
+import collections, csv, json, os, shutil, sys
+tag = sys.argv[1]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src, dst = os.path.join(ROOT, 'gpurun_out', f'prof_{tag}'), os.path.join(ROOT, 'profiles')
+os.makedirs(dst, exist_ok=True)
+shutil.copy(os.path.join(src, f'{tag}_kernel_stats.csv'), os.path.join(dst, f'{tag}_kernel_stats.csv'))
+shutil.copy(os.path.join(src, f'{tag}_bench.json'), os.path.join(dst, f'{tag}_bench.json'))
+bench = json.loads(open(os.path.join(src, f'{tag}_bench.json')).read())
+n_upd = bench['steps'] + bench['warmup']
+
+
+def pmc(name):
+    agg = collections.defaultdict(list)
+    f = os.path.join(src, f'{tag}_{name}_counter_collection.csv')
+    if not os.path.exists(f):
+        return {}
+    for r in csv.DictReader(open(f)):
+        k = r['Kernel_Name']
+        for short in ('sscan_fwd_kernel', 'sscan_bwd_kernel', 'conv_fwd_kernel', 'conv_bwd_kernel', 'ln_fwd_kernel', 'ln_bwd_kernel'):
+            if short in k:
+                agg[short].append(float(r['Counter_Value']))
+    return {k: sum(v) / len(v) for k, v in agg.items()}
+
+
+fetch, write = pmc('fetch'), pmc('write')
+traffic = {}
+for k in sorted(set(fetch) | set(write)):
+    rd, wr = fetch.get(k, 0.0) * 1024 * 2, write.get(k, 0.0) * 1024
+    traffic[k] = {'read_bytes': rd, 'write_bytes': wr, 'total': rd + wr}
+json.dump({'source': f'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over `python3 bench.py` ({tag}); FETCH_SIZE KB x 1024 x 2 (gfx950), WRITE_SIZE KB x 1024',
+           'per_launch_bytes': {k: v['total'] for k, v in traffic.items()}, 'detail': traffic},
+          open(os.path.join(dst, 'traffic.json'), 'w'), indent=1)
+rows = list(csv.DictReader(open(os.path.join(src, f'{tag}_kernel_stats.csv'))))
+tot = sum(float(r['TotalDurationNs']) for r in rows)
+gemm = sum(float(r['TotalDurationNs']) for r in rows if r['Name'].startswith('Cijk'))
+with open(os.path.join(dst, f'{tag}_summary.md'), 'w') as fh:
+    fh.write(f'# {tag}: rocprofv3 --kernel-trace --stats over `python3 bench.py` ({n_upd} updates incl. warm-up)\n\n')
+    fh.write(f'bench line: {bench["value"]:.0f} {bench["unit"]}, {bench["ms_per_step"]:.2f} ms/update; GPU kernel time {tot / n_upd / 1e6:.2f} ms/update, '
+             f'of which library GEMMs (rocBLAS/hipBLASLt fp32) {gemm / n_upd / 1e6:.2f} ms\n\n| kernel | calls | ms/update | avg us |\n|---|---|---|---|\n')
+    for r in rows[:30]:
+        fh.write(f"| `{r['Name'][:90]}` | {r['Calls']} | {float(r['TotalDurationNs']) / n_upd / 1e6:.3f} | {float(r['AverageNs']) / 1e3:.1f} |\n")
+    fh.write('\n## HBM traffic per launch (PMC)\n\n| kernel | read MB | write MB |\n|---|---|---|\n')
+    for k, v in traffic.items():
+        fh.write(f"| {k} | {v['read_bytes'] / 1e6:.1f} | {v['write_bytes'] / 1e6:.1f} |\n")
+print(open(os.path.join(dst, f'{tag}_summary.md')).read())
