@@ -211,6 +211,29 @@ int resel_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, co
 size_t resel_sumsq_workspace_bytes(int64_t n);
 int resel_sumsq(const float* x, int64_t n, float* out, void* workspace, resel_stream_t stream);
 
+/* ---- bias + activation tail of fc / efc-E layers, fused around the library GEMM -------------------------------
+ * Replaces `activation(linear(x))` of reference models/rnn_base.py:462-474 (nn.Linear / EnsembleLinear followed by the
+ * per-layer activation module) for act = ELU, and the bias add of EnsembleLinear (ensemble_linear_model.py:60-67).
+ * y [rows, C] contiguous, rows grouped in rows / rows_per_seg segments with one bias row [C] each (bias [nseg, C]).
+ * fwd (in place): y <- act(y + bias);  act: 0 = identity, 1 = ELU(alpha = 1).
+ * bwd (from the forward OUTPUT a): gy = g * act'(.), dbias[nseg, C] = per-segment column sums of gy (dbias may be NULL;
+ *      gy may alias g when act == 0).  workspace: resel_bias_act_bwd_workspace_bytes. */
+int resel_bias_act_fwd(float* y, const float* bias, int64_t rows, int C, int64_t rows_per_seg, int act, resel_stream_t stream);
+size_t resel_bias_act_bwd_workspace_bytes(int64_t rows, int C, int64_t rows_per_seg);
+int resel_bias_act_bwd(const float* g, const float* a, float* gy, float* dbias, void* workspace, int64_t rows, int C,
+                       int64_t rows_per_seg, int act, resel_stream_t stream);
+
+/* ---- ensemble head: last hidden layer's tail + the width-1 output layer of an efc-E MLP ----------------------------
+ * The critic head of the reference is `efc-E(H) ELU -> efc-E(1)` (policy_value_models/contextual_sac_value.py via
+ * models/rnn_base.py:462-474; EnsembleLinear weight [E, H, 1], bias [E, 1, 1]).  y [E*M, H] is the hidden layer's GEMM output.
+ * fwd: a = elu(y + b2[e]) in place, q[e*M + m] = sum_c a[c] * w3[e, c] + b3[e]          (b2, w3: [E, H]; b3: [E] or NULL)
+ * bwd: gy = gq[r] * w3[e] * elu'(a), db2[E, H] = sum_m gy, dw3[E, H] = sum_m a * gq     (db3 = sum_m gq is left to the host) */
+int resel_ensemble_head_fwd(float* y, const float* b2, const float* w3, const float* b3, float* q, int64_t rows, int H,
+                            int64_t rows_per_seg, resel_stream_t stream);
+size_t resel_ensemble_head_bwd_workspace_bytes(int64_t rows, int H, int64_t rows_per_seg);
+int resel_ensemble_head_bwd(const float* gq, const float* a, const float* w3, float* gy, float* db2, float* dw3, void* workspace,
+                            int64_t rows, int H, int64_t rows_per_seg, resel_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,11 +50,14 @@ __device__ __forceinline__ float wave_sum(float v) {
 // Column sums of row-major partial slabs in a fixed order (bitwise reproducible): out[o(c)] = sum_{k<K} part[k * ld + c],
 // c < C.  With taps == 0 the output index is c; otherwise the columns are [ch][padded taps KT] and only the last `taps`
 // of every KT go out, as out[ch * taps + tap].  256 threads = 16 columns x 16 row groups; grid = ceil(C / 16) blocks.
+// blockIdx.y = batch: slab b starts at part + b * K * ld, its sums go to out + b * C (batched form: taps == 0 only).
 static __global__ void colsum_kernel(const float* __restrict__ part, int64_t ld, int K, int C, float* __restrict__ out,
                                      int KT, int taps) {
     __shared__ float s_acc[16][17];
     const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
+    part += (int64_t)blockIdx.y * K * ld;
+    out += (int64_t)blockIdx.y * C;
     float acc = 0.f;
     if (c < C)
         for (int k = rg; k < K; k += 16) acc += part[(int64_t)k * ld + c];
@@ -71,8 +74,9 @@ static __global__ void colsum_kernel(const float* __restrict__ part, int64_t ld,
         }
     }
 }
-inline void launch_colsum(const float* part, int64_t ld, int K, int C, float* out, hipStream_t s, int KT = 1, int taps = 0) {
-    hipLaunchKernelGGL(colsum_kernel, dim3((C + 15) / 16), dim3(256), 0, s, part, ld, K, C, out, KT, taps);
+inline void launch_colsum(const float* part, int64_t ld, int K, int C, float* out, hipStream_t s, int KT = 1, int taps = 0,
+                          int batch = 1) {
+    hipLaunchKernelGGL(colsum_kernel, dim3((C + 15) / 16, batch), dim3(256), 0, s, part, ld, K, C, out, KT, taps);
 }
 
 inline int launch_status() { return hipGetLastError() == hipSuccess ? RESEL_OK : RESEL_ELAUNCH; }

@@ -521,6 +521,88 @@ def sac_target(q, subset, next_logp, log_alpha, reward, done, mask, gamma, guard
     return target.reshape(reward.shape)
 
 
+# ---------------------------------------------------------------------------------------------- bias + activation tail
+ACT_IDS = {None: 0, 'linear': 0, 'elu': 1}
+
+
+@torch.no_grad()
+def bias_act_(y2, bias2, rows_per_seg, act):
+    """In place on the GEMM output y2 [rows, C] (contiguous): y2 <- act(y2 + bias2[row // rows_per_seg]); bias2 [nseg, C] or None."""
+    _need_cuda('bias_act', y2, bias2)
+    assert y2.is_contiguous() and y2.dtype == torch.float32 and (bias2 is None or bias2.is_contiguous())
+    check(lib().resel_bias_act_fwd(_p(y2), _p(bias2), y2.shape[0], y2.shape[1], int(rows_per_seg), ACT_IDS[act], _stream()), 'bias_act_fwd')
+    return y2
+
+
+@torch.no_grad()
+def bias_act_bwd(g2, a2, rows_per_seg, act, need_dbias):
+    """gy = g2 * act'(.) computed from the forward OUTPUT a2, dbias [nseg, C] = per-segment column sums of gy (or None)."""
+    _need_cuda('bias_act_bwd', g2, a2)
+    g2 = g2 if g2.is_contiguous() else g2.contiguous()
+    rows, C = g2.shape
+    aid = ACT_IDS[act]
+    if aid == 0 and not need_dbias:
+        return g2, None
+    gy = torch.empty_like(g2) if aid else g2
+    nseg = rows // int(rows_per_seg)
+    db = torch.empty(nseg, C, dtype=torch.float32, device=g2.device) if need_dbias else None
+    ws = _ws(lib().resel_bias_act_bwd_workspace_bytes(rows, C, int(rows_per_seg)), g2.device) if need_dbias else None
+    check(lib().resel_bias_act_bwd(_p(g2), _p(a2) if aid else None, _p(gy), _p(db), _p(ws), rows, C, int(rows_per_seg), aid, _stream()),
+          'bias_act_bwd')
+    return gy, db
+
+
+@torch.no_grad()
+def ensemble_head_fwd_(y3, b2, w3, b3):
+    """y3 [E, M, H] (GEMM output, overwritten with a = elu(y + b2)), b2 / w3 [E, H], b3 [E] -> q [E, M]."""
+    _need_cuda('ensemble_head', y3, b2, w3, b3)
+    E, M, H = y3.shape
+    q = torch.empty(E, M, dtype=torch.float32, device=y3.device)
+    check(lib().resel_ensemble_head_fwd(_p(y3), _p(b2), _p(w3), _p(b3), _p(q), E * M, H, M, _stream()), 'ensemble_head_fwd')
+    return q
+
+
+@torch.no_grad()
+def ensemble_head_bwd(gq, a3, w3):
+    """gq [E, M], a3 [E, M, H], w3 [E, H] -> gy [E, M, H], db2 [E, H], dw3 [E, H]."""
+    _need_cuda('ensemble_head_bwd', gq, a3, w3)
+    E, M, H = a3.shape
+    gq = gq if gq.is_contiguous() else gq.contiguous()
+    gy = torch.empty_like(a3)
+    db2 = torch.empty(E, H, dtype=torch.float32, device=a3.device)
+    dw3 = torch.empty(E, H, dtype=torch.float32, device=a3.device)
+    ws = _ws(lib().resel_ensemble_head_bwd_workspace_bytes(E * M, H, M), a3.device)
+    check(lib().resel_ensemble_head_bwd(_p(gq), _p(a3), _p(w3), _p(gy), _p(db2), _p(dw3), _p(ws), E * M, H, M, _stream()), 'ensemble_head_bwd')
+    return gy, db2, dw3
+
+
+class LinearAct(torch.autograd.Function):
+    """act(x W^T + b) for nn.Linear weights (reference rnn_base.py:462-474: `fc` layer followed by its activation module):
+    library GEMM + one in-place bias/activation pass; the backward needs the layer OUTPUT only."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        x2 = x.reshape(-1, x.shape[-1])
+        y2 = torch.mm(x2, weight.t())
+        bias_act_(y2, None if bias is None else bias.reshape(1, -1).contiguous(), y2.shape[0], act)
+        ctx.save_for_backward(x2, weight, y2)
+        ctx.act, ctx.has_bias, ctx.xshape = act, bias is not None, x.shape
+        return y2.view(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, weight, y2 = ctx.saved_tensors
+        g2 = g.reshape(y2.shape)
+        gy, db = bias_act_bwd(g2, y2, y2.shape[0], ctx.act, ctx.has_bias and ctx.needs_input_grad[2])
+        dx = torch.mm(gy, weight).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        dw = torch.mm(gy.t(), x2) if ctx.needs_input_grad[1] else None
+        return dx, dw, None if db is None else db.reshape(-1), None
+
+
+def linear_act(x, weight, bias, act):
+    return LinearAct.apply(x, weight, bias, act)
+
+
 @torch.no_grad()
 def soft_update_(target_flat, online_flat, tau):
     _need_cuda('soft_update', target_flat, online_flat)

@@ -12,46 +12,126 @@ torch's generic einsum/bmm autograd materialised a transposed [E, in, M] copy of
 import torch
 import torch.nn as nn
 
+from ..hip import ops
+
 
 class _SharedInput(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x2, weight, bias):
+    def forward(ctx, x2, weight, bias, act):
         E, n_in, n_out = weight.shape
         w_cat = weight.permute(1, 0, 2).reshape(n_in, E * n_out)                 # [in, E*out] (weights only: tiny copy)
-        if bias is not None:
-            y2 = torch.addmm(bias.reshape(E * n_out), x2, w_cat)
-        else:
+        if act is None:
+            y2 = torch.addmm(bias.reshape(E * n_out), x2, w_cat) if bias is not None else torch.mm(x2, w_cat)
+        else:                               # GEMM, then bias + activation in one in-place pass
             y2 = torch.mm(x2, w_cat)
-        ctx.save_for_backward(x2, w_cat)
-        ctx.dims = (E, n_in, n_out, bias is not None)
+            ops.bias_act_(y2, None if bias is None else bias.reshape(1, E * n_out), y2.shape[0], act)
+        ctx.save_for_backward(x2, w_cat, y2 if act is not None else None)
+        ctx.dims = (E, n_in, n_out, bias is not None, act)
         return y2.view(-1, E, n_out).transpose(0, 1)                              # [E, M, out] view
 
     @staticmethod
     def backward(ctx, g):
-        x2, w_cat = ctx.saved_tensors
-        E, n_in, n_out, has_bias = ctx.dims
+        x2, w_cat, y2 = ctx.saved_tensors
+        E, n_in, n_out, has_bias, act = ctx.dims
         g2 = g.transpose(0, 1).reshape(-1, E * n_out)                             # a view when g kept y's strides
+        need_db = has_bias and ctx.needs_input_grad[2]
+        if act is not None:
+            g2, db = ops.bias_act_bwd(g2, y2, g2.shape[0], act, need_db)
+        else:
+            db = g2.sum(dim=0, keepdim=True) if need_db else None
         dx = torch.mm(g2, w_cat.t()) if ctx.needs_input_grad[0] else None        # sums over the ensemble
         dw = torch.mm(x2.t(), g2).view(n_in, E, n_out).permute(1, 0, 2) if ctx.needs_input_grad[1] else None
-        db = g2.sum(dim=0).view(E, 1, n_out) if has_bias and ctx.needs_input_grad[2] else None
-        return dx, dw, db
+        return dx, dw, None if db is None else db.view(E, 1, n_out), None
 
 
 class _PerMember(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x3, weight, bias):
-        y = torch.baddbmm(bias, x3, weight) if bias is not None else torch.bmm(x3, weight)
-        ctx.save_for_backward(x3, weight)
-        ctx.has_bias = bias is not None
+    def forward(ctx, x3, weight, bias, act):
+        E, M, _ = x3.shape
+        if act is None and (bias is None or weight.shape[2] < 4):
+            y = torch.baddbmm(bias, x3, weight) if bias is not None else torch.bmm(x3, weight)
+        else:                               # baddbmm would first materialise the broadcast bias as a full [E, M, out] copy
+            y = torch.bmm(x3, weight)
+            ops.bias_act_(y.view(E * M, -1), None if bias is None else bias.reshape(E, -1), M, act)
+        ctx.save_for_backward(x3, weight, y if act is not None else None)
+        ctx.cfg = (bias is not None, act)
         return y
 
     @staticmethod
     def backward(ctx, g):
-        x3, weight = ctx.saved_tensors
-        dx = torch.bmm(g, weight.transpose(1, 2)) if ctx.needs_input_grad[0] else None
-        dw = torch.bmm(x3.transpose(1, 2), g) if ctx.needs_input_grad[1] else None
-        db = g.sum(dim=1, keepdim=True) if ctx.has_bias and ctx.needs_input_grad[2] else None
-        return dx, dw, db
+        x3, weight, y = ctx.saved_tensors
+        has_bias, act = ctx.cfg
+        E, M, n_out = g.shape
+        need_db = has_bias and ctx.needs_input_grad[2]
+        if act is not None or (need_db and n_out % 4 == 0):
+            gy, db = ops.bias_act_bwd(g.reshape(E * M, n_out), None if y is None else y.view(E * M, n_out), M, act, need_db)
+            gy = gy.view(E, M, n_out)
+            db = None if db is None else db.view(E, 1, n_out)
+        else:
+            gy, db = g, (g.sum(dim=1, keepdim=True) if need_db else None)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if x3.stride(0) < x3.stride(1):
+                # the input was the [E, M, in] VIEW of a shared-input layer's [M, E*in] output: write dx in that same memory
+                # layout, so that the producer's backward reads it as the [M, E*in] matrix it needs - no transposing copy
+                dx = torch.empty(M, E, weight.shape[1], dtype=g.dtype, device=g.device).transpose(0, 1)
+                torch.bmm(gy, weight.transpose(1, 2), out=dx)
+            else:
+                dx = torch.bmm(gy, weight.transpose(1, 2))
+        dw = torch.bmm(x3.transpose(1, 2), gy) if ctx.needs_input_grad[1] else None
+        return dx, dw, db, None
+
+
+class _Head(torch.autograd.Function):
+    """Per-member hidden layer + ELU + width-1 output layer as one node: q = elu(x W2 + b2) W3 + b3.  The hidden
+    activation is produced in place on the GEMM output together with q; the backward reads it once to form the hidden
+    layer's gradient, its bias gradient and the output layer's weight gradient (no [E, M, H] outer-product tensor, no
+    k = M GEMV through the GEMM library - rocBLAS' best solution for that shape runs at 1.1 TB/s)."""
+
+    @staticmethod
+    def forward(ctx, x3, w2, b2, w3, b3):
+        E, M, _ = x3.shape
+        H = w2.shape[2]
+        a = torch.bmm(x3, w2)
+        w3v = w3.reshape(E, H)
+        q = ops.ensemble_head_fwd_(a, b2.reshape(E, H), w3v, None if b3 is None else b3.reshape(E))
+        ctx.save_for_backward(x3, w2, w3v, a)
+        ctx.has_b3 = b3 is not None
+        return q.view(E, M, 1)
+
+    @staticmethod
+    def backward(ctx, gq):
+        x3, w2, w3v, a = ctx.saved_tensors
+        E, M, H = a.shape
+        gq2 = gq.reshape(E, M)
+        gy, db2, dw3 = ops.ensemble_head_bwd(gq2, a, w3v)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if x3.stride(0) < x3.stride(1):          # same layout rule as _PerMember.backward
+                dx = torch.empty(M, E, w2.shape[1], dtype=gy.dtype, device=gy.device).transpose(0, 1)
+                torch.bmm(gy, w2.transpose(1, 2), out=dx)
+            else:
+                dx = torch.bmm(gy, w2.transpose(1, 2))
+        dw2 = torch.bmm(x3.transpose(1, 2), gy)
+        db3 = gq2.sum(dim=1).view(E, 1, 1) if ctx.has_b3 else None
+        return dx, dw2, db2.view(E, 1, H), dw3.view(E, H, 1), db3
+
+
+def ensemble_head(hidden: 'EnsembleLinear', out: 'EnsembleLinear', x: torch.Tensor) -> torch.Tensor:
+    """`out(elu(hidden(x)))` for per-member x [E, ..., in] and out.weight [E, H, 1] (RNNBase.forward routes the last two
+    layers of an efc-E critic head here)."""
+    E, n_in, H = hidden.weight.shape
+    lead = tuple(x.shape[1:-1])
+    q = _Head.apply(x.reshape(E, -1, n_in), hidden.weight, hidden.bias, out.weight, out.bias if out.use_bias else None)
+    return q.reshape((E,) + lead + (1,))
+
+
+def head_fusable(hidden, hidden_act, out, out_act, x) -> bool:
+    return (isinstance(hidden, EnsembleLinear) and isinstance(out, EnsembleLinear) and isinstance(hidden_act, nn.ELU)
+            and hidden_act.alpha == 1.0 and isinstance(out_act, nn.Identity) and hidden.use_bias
+            and out.weight.shape[2] == 1 and out.weight.shape[1] == hidden.weight.shape[2] and hidden.weight.shape[2] % 4 == 0
+            and x.dim() >= 3 and x.shape[0] == hidden.num_ensemble and x.dtype == torch.float32
+            and (hidden.desire_ndim is None or hidden.desire_ndim == x.dim()))
 
 
 class EnsembleLinear(nn.Module):
@@ -65,7 +145,8 @@ class EnsembleLinear(nn.Module):
             self.bias = nn.Parameter(torch.zeros(num_ensemble, 1, output_dim))
         nn.init.trunc_normal_(self.weight, std=1 / (2 * input_dim ** 0.5))
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, act: str = None) -> torch.Tensor:
+        """act: None, or 'elu' to fuse the layer's activation module into the bias pass (RNNBase.forward does so)."""
         W = self.weight
         E, n_in, n_out = W.shape
         nd = x.dim()
@@ -79,8 +160,8 @@ class EnsembleLinear(nn.Module):
         b = self.bias if self.use_bias else None
         if shared:
             lead = tuple(x.shape[:-1])
-            y = _SharedInput.apply(x.reshape(-1, n_in), W, b)
+            y = _SharedInput.apply(x.reshape(-1, n_in), W, b, act)
         else:
             lead = tuple(x.shape[1:-1])
-            y = _PerMember.apply(x.reshape(E, -1, n_in), W, b)
+            y = _PerMember.apply(x.reshape(E, -1, n_in), W, b, act)
         return y.reshape((E,) + lead + (n_out,))                                   # a view: only the row axis is split

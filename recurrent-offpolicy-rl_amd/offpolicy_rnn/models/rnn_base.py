@@ -12,8 +12,9 @@ from typing import List, Optional, Tuple, Union
 
 import torch
 
+from ..hip import ops
 from .RNNHidden import RNNHidden
-from .ensemble_linear_model import EnsembleLinear
+from .ensemble_linear_model import EnsembleLinear, ensemble_head, head_fusable
 from .flash_attention.TransformerFlashAttention import InferenceParams, TransformerDecoder
 from .gilr.gilr import GILRLayer
 from .gru import GRU
@@ -200,7 +201,12 @@ class RNNBase(torch.nn.Module):
         out_state = RNNHidden(self.rnn_num, self.rnn_layer_type, device=x.device, batch_first=False)
         full = RNNHidden(self.rnn_num, self.rnn_layer_type, device=x.device, batch_first=True) if require_full_hidden else None
         k = 0
+        n_layers = len(self.layer_list)
+        fused_next = False
         for ind, layer in enumerate(self.layer_list):
+            if fused_next:                          # consumed by the ensemble head below
+                fused_next = False
+                continue
             lid = self.layer_type[ind]
             if is_rnn_layer(lid):
                 if lid == 'gilr':
@@ -220,9 +226,20 @@ class RNNBase(torch.nn.Module):
                 out_state.append(h)
                 if require_full_hidden:
                     full.append(x)
+                act = self.activation_list[ind]
             else:
+                act = self.activation_list[ind]
+                # efc-E(H) ELU -> efc-E(1) at the end of the stack (the critic head): one fused node
+                if ind + 2 == n_layers and head_fusable(layer, act, self.layer_list[ind + 1], self.activation_list[ind + 1], x):
+                    x = ensemble_head(layer, self.layer_list[ind + 1], x)
+                    fused_next = True
+                    continue
+                # plain ELU behind fc / efc-E: fused into the layer's bias pass (one in-place kernel; backward from the output)
+                if isinstance(act, torch.nn.ELU) and act.alpha == 1.0 and isinstance(layer, (EnsembleLinear, torch.nn.Linear)) \
+                        and x.dtype == torch.float32:
+                    x = layer(x, act='elu') if isinstance(layer, EnsembleLinear) else ops.linear_act(x, layer.weight, layer.bias, 'elu')
+                    continue
                 x = layer(x)
-            act = self.activation_list[ind]
             if isinstance(act, torch.nn.ModuleList):
                 if self.activation_type[ind].startswith('eln'):
                     x = act[0](x.transpose(-2, 0)).transpose(-2, 0)

@@ -35,6 +35,41 @@ def mamba_inner_fn(x, in_w, conv_w, conv_b, xproj_w, dt_w, dt_b, A_log, D, out_w
     return F.linear(y, out_w)
 
 
+def bias_act_(y2, bias2, rows_per_seg, act):
+    with torch.no_grad():
+        if bias2 is not None:
+            nseg = bias2.shape[0]
+            y2.view(nseg, -1, y2.shape[1]).add_(bias2.view(nseg, 1, -1))
+        if act == 'elu':
+            y2.copy_(torch.nn.functional.elu(y2))
+    return y2
+
+
+def bias_act_bwd(g2, a2, rows_per_seg, act, need_dbias):
+    gy = g2
+    if act == 'elu':
+        gy = g2 * torch.where(a2 > 0, torch.ones_like(a2), a2 + 1)
+    db = gy.reshape(-1, int(rows_per_seg), gy.shape[1]).sum(1) if need_dbias else None
+    return gy.contiguous(), db
+
+
+def ensemble_head_fwd_(y3, b2, w3, b3):
+    with torch.no_grad():
+        y3.copy_(torch.nn.functional.elu(y3 + b2.unsqueeze(1)))
+        q = (y3 * w3.unsqueeze(1)).sum(-1)
+        return q if b3 is None else q + b3.view(-1, 1)
+
+
+def ensemble_head_bwd(gq, a3, w3):
+    gy = gq.unsqueeze(-1) * w3.unsqueeze(1) * torch.where(a3 > 0, torch.ones_like(a3), a3 + 1)
+    return gy, gy.sum(1), (a3 * gq.unsqueeze(-1)).sum(1)
+
+
+def linear_act(x, weight, bias, act):
+    y = torch.nn.functional.linear(x, weight, bias)
+    return torch.nn.functional.elu(y) if act == 'elu' else y
+
+
 def _norm(rms):
     def fn(x, weight, bias, residual=None, eps=1e-6, prenorm=False, residual_in_fp32=False):
         y, res = K.add_layernorm_ref(x, residual, weight, bias, eps, rms)
@@ -113,7 +148,7 @@ def sumsq(x, out=None):
 
 def install(monkeypatch):
     from offpolicy_rnn.hip import ops
-    table = dict(mamba_inner_fn=mamba_inner_fn, selective_scan_tm=selective_scan_tm, causal_conv1d_fn=causal_conv1d_fn, layer_norm_fn=_norm(False),
+    table = dict(ensemble_head_fwd_=ensemble_head_fwd_, ensemble_head_bwd=ensemble_head_bwd, bias_act_=bias_act_, bias_act_bwd=bias_act_bwd, linear_act=linear_act, mamba_inner_fn=mamba_inner_fn, selective_scan_tm=selective_scan_tm, causal_conv1d_fn=causal_conv1d_fn, layer_norm_fn=_norm(False),
                  rms_norm_fn=_norm(True), gilr_scan=gilr_scan, complex_scan=complex_scan, gru_seq=gru_seq, tanh_gaussian=tanh_gaussian, attn_varlen=attn_varlen,
                  sac_target=sac_target, soft_update_=soft_update_, adamw_flat_=adamw_flat_, sumsq=sumsq)
     for k, fn in table.items():

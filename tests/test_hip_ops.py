@@ -385,3 +385,83 @@ def test_mamba_inner_fused_vs_oracle_chain(ops, B, L, Dm, N, Kw):
     close(dx, ref_dx, name='dx')
     for k in ps:
         close(gr[k], ref_g[k], rtol=2e-4, atol_scale=5e-5, name='d' + k)
+
+
+# ------------------------------------------------------------------------------------------ bias + activation tail
+@pytest.mark.parametrize('rows,C,nseg', [(300, 64, 1), (8 * 129, 256, 8), (1000, 2048, 1), (6 * 37, 12, 6)])
+@pytest.mark.parametrize('act', ['elu', None])
+def test_bias_act_fwd_bwd(ops, rows, C, nseg, act):
+    """act(y + bias[segment]) in place and its backward from the output (fc / efc-E tail, reference rnn_base.py:462-474)."""
+    g = torch.Generator().manual_seed(5)
+    y, bias, go = rnd(rows, C, g=g, scale=2.0), rnd(nseg, C, g=g), rnd(rows, C, g=g)
+    yr = y.clone().requires_grad_(True)
+    br = bias.clone().requires_grad_(True)
+    pre = yr.view(nseg, -1, C) + br.view(nseg, 1, C)
+    ref = (torch.nn.functional.elu(pre) if act == 'elu' else pre).reshape(rows, C)
+    ref.backward(go)
+    a = ops.bias_act_(y.cuda(), bias.cuda(), rows // nseg, act)
+    close(a, ref, name='act(y + b)')
+    gy, db = ops.bias_act_bwd(go.cuda(), a, rows // nseg, act, True)
+    close(gy, yr.grad, name='gy')
+    close(db, br.grad, rtol=2e-4, atol_scale=5e-5, name='dbias')
+
+
+def test_ensemble_mlp_fused_tail_vs_torch(ops):
+    """shared-input layer -> per-member layer -> per-member head, ELU fused into the first two (efc-8 critic head,
+    reference contextual_sac_value.py via rnn_base.py:462-474) against plain torch autograd on the CPU."""
+    from offpolicy_rnn.models.ensemble_linear_model import EnsembleLinear
+    torch.manual_seed(3)
+    E, R, T, n_in, H = 4, 3, 50, 24, 32
+    l1, l2, l3 = EnsembleLinear(n_in, H, E), EnsembleLinear(H, H, E, desire_ndim=4), EnsembleLinear(H, 1, E, desire_ndim=4)
+    for l in (l1, l2, l3):
+        torch.nn.init.normal_(l.bias, std=0.3)
+    x = torch.randn(R, T, n_in)
+    w = torch.randn(E, R, T, 1)
+
+    def ref():
+        xs = x.clone().requires_grad_(True)
+        h = xs
+        for i, l in enumerate((l1, l2, l3)):
+            h = torch.einsum('...ti,eio->e...to', h, l.weight) if i == 0 else torch.einsum('e...ti,eio->e...to', h, l.weight)
+            h = h + l.bias.view(E, 1, 1, -1)
+            if i < 2:
+                h = torch.nn.functional.elu(h)
+        (h * w).sum().backward()
+        out = [h.detach(), xs.grad] + [p.grad.clone() for l in (l1, l2, l3) for p in (l.weight, l.bias)]
+        for l in (l1, l2, l3):
+            l.zero_grad()
+        return out
+
+    from offpolicy_rnn.models.ensemble_linear_model import ensemble_head, head_fusable
+    expect = ref()
+    for l in (l1, l2, l3):
+        l.cuda()
+    for fused_head in (False, True):                 # layer-by-layer tails, then the one-node head (hidden tail + width-1 output)
+        xs = x.cuda().requires_grad_(True)
+        h1 = l1(xs, act='elu')
+        if fused_head:
+            assert head_fusable(l2, torch.nn.ELU(), l3, torch.nn.Identity(), h1)
+            h = ensemble_head(l2, l3, h1)
+        else:
+            h = l3(l2(h1, act='elu'))
+        (h * w.cuda()).sum().backward()
+        got = [h, xs.grad] + [p.grad for l in (l1, l2, l3) for p in (l.weight, l.bias)]
+        for i, (a, b) in enumerate(zip(got, expect)):
+            close(a, b, rtol=2e-4, atol_scale=5e-5, name=f'fused_head={fused_head} tensor {i}')
+        for l in (l1, l2, l3):
+            l.zero_grad()
+
+
+def test_linear_act_vs_torch(ops):
+    g = torch.Generator().manual_seed(9)
+    x, W, b, go = rnd(5, 40, 17, g=g), rnd(128, 17, g=g, scale=0.3), rnd(128, g=g), rnd(5, 40, 128, g=g)
+    xr, Wr, br = x.clone().requires_grad_(True), W.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = torch.nn.functional.elu(torch.nn.functional.linear(xr, Wr, br))
+    ref.backward(go)
+    xc, Wc, bc = (t.cuda().requires_grad_(True) for t in (x, W, b))
+    out = ops.linear_act(xc, Wc, bc, 'elu')
+    out.backward(go.cuda())
+    close(out, ref, name='out')
+    close(xc.grad, xr.grad, name='dx')
+    close(Wc.grad, Wr.grad, rtol=2e-4, atol_scale=5e-5, name='dW')
+    close(bc.grad, br.grad, rtol=2e-4, atol_scale=5e-5, name='db')
