@@ -144,7 +144,7 @@ int resel_linrec_complex_bwd(const float* vr, const float* vi, const float* lam_
  * gi = x W_ih^T + b_ih: [B, L, 3H] dense (r, z, n blocks); w_hh: [3H, H]; b_hh: [3H]; h0: [B, H] or NULL.
  *   r = sig(gi_r + W_hr h + b_hr) ; z = sig(gi_z + W_hz h + b_hz) ; n = tanh(gi_n + r * (W_hn h + b_hn))
  *   h' = (1 - z) n + z h ;  h_all: [B, L, H].  gates (optional, training): [B, L, 4H] saves r, z, n and
- *   (W_hn h + b_hn) for the backward.  Supported: H % 16 == 0, H <= 1024.
+ *   (W_hn h + b_hn) for the backward.  Supported: H % 16 == 0 and H <= 256, or H in {320, 384, 448, 512}.
  * The recurrence is T-sequential; each step is one launch (grid = H/16 unit slices x ceil(B/16) row groups)
  * enqueued back-to-back from C.  workspace: resel_gru_workspace_bytes() (re-laid-out W_hh slices, carry).
  * Backward returns the pre-activation gradients of BOTH projections: dgi [B, L, 3H] (w.r.t. gi) and

@@ -3,42 +3,54 @@
 // The recurrence is T-sequential and each step needs every hidden unit of the previous step, so a step is a
 // grid-wide dependency.  On MI355X a dependent kernel boundary (~1.5 us) is cheaper than a software grid
 // barrier (4-7 us, MI355X_MICROARCH "barrier-xcd"), so every step is ONE small launch enqueued back-to-back
-// from C (no Python in the loop): grid = (H/16 hidden-unit slices) x (B/16 row groups).  A block keeps its
-// 16-unit slice of W_hh (pre-laid-out once per call as [slice][k/4][48][4] so that one ds_read_b128 yields 4
-// consecutive k for one gate column) and its 16 rows of h_{t-1} in LDS and forms the three gate dot products
-// with fp32 FMAs (exact fp32, no reduced-precision path: parity target is 1e-4 against ATen's CPU GRU).
-// Neither roofline is tight for this layer; the reported figure is the achieved step rate.
+// from C (no Python in the loop).  What matters is then the LATENCY of one step, so the step is spread over the whole
+// chip and keeps its operands as close as possible:
+//   grid = (H/16 hidden-unit slices) x (B/4 row groups)  [16 x 16 = 256 workgroups at H = 256, B = 64: one per CU];
+//   thread (j, kq) of a workgroup owns output unit j of the slice and the kq-th 1/16 of the reduction axis, and holds
+//   that piece of W_hh for all three gates IN REGISTERS (3H/16 <= 96 floats, fetched with fully coalesced float4 loads
+//   from a copy laid out once per call as [slice][float4 chunk][thread]); the 4 rows of h_{t-1} (forward) / of the gate
+//   gradients (backward) sit in LDS and are read as broadcast float4s; the 16 partial sums of an output meet in LDS.
+// All arithmetic is exact fp32 FMA (parity target 1e-4 against ATen's CPU GRU).  [First version: 64 workgroups with
+// the W slice and 16 rows in LDS, every thread a full-length dot product - LDS-read bound at 9 us (fwd) / 23 us (bwd)
+// per step.]  Neither roofline is tight for this layer; the reported figure is the achieved step rate.
 #include "resel_common.h"
 
 namespace {
 using namespace resel;
 
 constexpr int US = 16;    // hidden units per block
-constexpr int RG = 16;    // batch rows per block
-constexpr int HMAX = 256; // LDS budget of the backward step (s_dgh 16 x 3H + W slice 3H x 16 floats)
+constexpr int RG = 4;     // batch rows per block
+constexpr int KQMAX = 16; // reduction-axis pieces: H = KC * KQ with KQ <= 16; a block has 16 * KQ threads
+constexpr int HMAX = 512;
 
-// wf[s][k4][g*16 + j][kk] = w_hh[(g*H + s*16 + j) * H + 4*k4 + kk]
-__global__ void gru_layout_fwd_kernel(const float* __restrict__ w_hh, float* __restrict__ wf, int H) {
+// forward copy: thread (kq, j) of slice s needs W_hh[g*H + s*16 + j][kq*KC + i], g < 3, i < KC = H/16, as 3*KC/4 float4s
+//   wf[((s * NC + c) * NT + tid) * 4 + e]   with chunk c = g * (KC/4) + i/4, e = i % 4, tid = kq * 16 + j, NT = 16 KQ
+__global__ void gru_layout_fwd_kernel(const float* __restrict__ w_hh, float* __restrict__ wf, int H, int KQ) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)3 * H * H) return;
-    const int kk = i & 3;
+    const int KC = H / KQ, NC = 3 * KC / 4, NT = 16 * KQ;
+    const int e = i & 3;
     int64_t r = i >> 2;
-    const int col = r % 48; r /= 48;
-    const int k4 = r % (H / 4);
-    const int s = r / (H / 4);
-    const int g = col / 16, j = col % 16;
-    wf[i] = w_hh[((int64_t)g * H + s * 16 + j) * H + 4 * k4 + kk];
+    const int tid = r % NT; r /= NT;
+    const int c = r % NC;
+    const int s = r / NC;
+    const int g = c / (KC / 4), i4 = c % (KC / 4);
+    const int kq = tid >> 4, j = tid & 15;
+    wf[i] = w_hh[((int64_t)g * H + s * 16 + j) * H + kq * KC + i4 * 4 + e];
 }
-// wb[s][g4][j][gg] = w_hh[(4*g4 + gg) * H + s*16 + j]      (g4 over 3H/4 gate rows)
-__global__ void gru_layout_bwd_kernel(const float* __restrict__ w_hh, float* __restrict__ wb, int H) {
+// backward copy: thread (kq, j) needs W_hh[q][s*16 + j] for the kq-th 1/16 of the 3H gate rows q: RC = 3H/16 values
+//   wb[((s * NC + c) * NT + tid) * 4 + e]   with q = kq * RC + c * 4 + e
+__global__ void gru_layout_bwd_kernel(const float* __restrict__ w_hh, float* __restrict__ wb, int H, int KQ) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)3 * H * H) return;
-    const int gg = i & 3;
+    const int RC = 3 * H / KQ, NC = RC / 4, NT = 16 * KQ;
+    const int e = i & 3;
     int64_t r = i >> 2;
-    const int j = r % 16; r /= 16;
-    const int g4 = r % (3 * H / 4);
-    const int s = r / (3 * H / 4);
-    wb[i] = w_hh[((int64_t)4 * g4 + gg) * H + s * 16 + j];
+    const int tid = r % NT; r /= NT;
+    const int c = r % NC;
+    const int s = r / NC;
+    const int kq = tid >> 4, j = tid & 15;
+    wb[i] = w_hh[((int64_t)kq * RC + c * 4 + e) * H + s * 16 + j];
 }
 
 struct GruFwd {
@@ -47,17 +59,28 @@ struct GruFwd {
     int B, L, H, t;
 };
 
+template <int KC>                                    // KC = H / 16: reduction elements per thread and gate
 __global__ __launch_bounds__(256) void gru_fwd_step_kernel(GruFwd p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* s_w = smem;                              // [H/4][48][4]
-    float* s_h = smem + (size_t)p.H * 48;           // [RG][H]
-    const int tid = threadIdx.x;
+    constexpr int NC = 3 * KC / 4;
+    __shared__ __attribute__((aligned(16))) float s_h[RG][KC * KQMAX];
+    __shared__ float s_p[KQMAX][RG * 3][US + 1];
+    const int tid = threadIdx.x, NT = blockDim.x, KQ = NT >> 4, H = p.H;
     const int s = blockIdx.x, b0 = blockIdx.y * RG;
-    const int H = p.H;
-    // stage the weight slice (contiguous 48*H floats) and the 16 rows of h_{t-1}
-    const float4* wsrc = reinterpret_cast<const float4*>(p.wf + (size_t)s * 48 * H);
-    for (int i = tid; i < 12 * H; i += 256) reinterpret_cast<float4*>(s_w)[i] = wsrc[i];
-    for (int i = tid; i < RG * H / 4; i += 256) {
+    const int j = tid & 15, kq = tid >> 4;
+    // this thread's piece of W_hh (registers) and the gate inputs of its output (issued first: longest latency)
+    float4 w[NC];
+    const float4* wsrc = reinterpret_cast<const float4*>(p.wf) + (size_t)s * NC * NT + tid;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) w[c] = wsrc[(size_t)c * NT];
+    const int ro = tid >> 4, uo = s * US + j;        // output mapping of the first RG*16 threads: (row ro, unit uo)
+    const bool out_thr = tid < RG * US && b0 + ro < p.B;
+    float gir = 0.f, giz = 0.f, gin = 0.f, br = 0.f, bz = 0.f, bn = 0.f;
+    if (out_thr) {
+        const float* g = p.gi + ((int64_t)(b0 + ro) * p.L + p.t) * 3 * H;
+        gir = g[uo]; giz = g[H + uo]; gin = g[2 * H + uo];
+        br = p.b_hh[uo]; bz = p.b_hh[H + uo]; bn = p.b_hh[2 * H + uo];
+    }
+    for (int i = tid; i < RG * H / 4; i += NT) {
         const int r = i / (H / 4), c4 = (i % (H / 4)) * 4;
         const int b = b0 + r;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -65,33 +88,40 @@ __global__ __launch_bounds__(256) void gru_fwd_step_kernel(GruFwd p) {
             if (p.t > 0) v = ld4(p.h_all + ((int64_t)b * p.L + (p.t - 1)) * H + c4);
             else if (p.h0) v = ld4(p.h0 + (int64_t)b * H + c4);
         }
-        st4(&s_h[r * H + c4], v);
+        st4(&s_h[r][c4], v);
     }
     __syncthreads();
-    const int r = tid >> 4, j = tid & 15;
-    const int b = b0 + r, u = s * US + j;
-    float ar = 0.f, az = 0.f, an = 0.f;
-    for (int k4 = 0; k4 < H / 4; ++k4) {
-        const float4 hv = ld4(&s_h[r * H + 4 * k4]);
-        const float4 wr = ld4(&s_w[((size_t)k4 * 48 + j) * 4]);
-        const float4 wz = ld4(&s_w[((size_t)k4 * 48 + 16 + j) * 4]);
-        const float4 wn = ld4(&s_w[((size_t)k4 * 48 + 32 + j) * 4]);
-        ar = __builtin_fmaf(hv.x, wr.x, ar); ar = __builtin_fmaf(hv.y, wr.y, ar); ar = __builtin_fmaf(hv.z, wr.z, ar); ar = __builtin_fmaf(hv.w, wr.w, ar);
-        az = __builtin_fmaf(hv.x, wz.x, az); az = __builtin_fmaf(hv.y, wz.y, az); az = __builtin_fmaf(hv.z, wz.z, az); az = __builtin_fmaf(hv.w, wz.w, az);
-        an = __builtin_fmaf(hv.x, wn.x, an); an = __builtin_fmaf(hv.y, wn.y, an); an = __builtin_fmaf(hv.z, wn.z, an); an = __builtin_fmaf(hv.w, wn.w, an);
+#pragma unroll
+    for (int r = 0; r < RG; ++r) {
+        float a[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i4 = 0; i4 < KC / 4; ++i4) {
+            const float4 hv = ld4(&s_h[r][kq * KC + i4 * 4]);
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                const float4 wv = w[g * (KC / 4) + i4];
+                a[g] = __builtin_fmaf(hv.x, wv.x, a[g]); a[g] = __builtin_fmaf(hv.y, wv.y, a[g]);
+                a[g] = __builtin_fmaf(hv.z, wv.z, a[g]); a[g] = __builtin_fmaf(hv.w, wv.w, a[g]);
+            }
+        }
+        s_p[kq][r * 3 + 0][j] = a[0];
+        s_p[kq][r * 3 + 1][j] = a[1];
+        s_p[kq][r * 3 + 2][j] = a[2];
     }
-    if (b < p.B) {
-        const int64_t tok = (int64_t)b * p.L + p.t;
-        const float* g = p.gi + tok * 3 * H;
-        const float rg = 1.f / (1.f + expf(-(g[u] + ar + p.b_hh[u])));
-        const float zg = 1.f / (1.f + expf(-(g[H + u] + az + p.b_hh[H + u])));
-        const float hn = an + p.b_hh[2 * H + u];
-        const float ng = tanhf(g[2 * H + u] + rg * hn);
-        const float hp = s_h[r * H + u];
-        p.h_all[tok * H + u] = (1.f - zg) * ng + zg * hp;
+    __syncthreads();
+    if (out_thr) {
+        float ar = 0.f, az = 0.f, an = 0.f;
+        for (int q = 0; q < KQ; ++q) { ar += s_p[q][ro * 3][j]; az += s_p[q][ro * 3 + 1][j]; an += s_p[q][ro * 3 + 2][j]; }
+        const int64_t tok = (int64_t)(b0 + ro) * p.L + p.t;
+        const float rg = 1.f / (1.f + expf(-(gir + ar + br)));
+        const float zg = 1.f / (1.f + expf(-(giz + az + bz)));
+        const float hn = an + bn;
+        const float ng = tanhf(gin + rg * hn);
+        const float hp = s_h[ro][uo];
+        p.h_all[tok * H + uo] = (1.f - zg) * ng + zg * hp;
         if (p.gates) {
             float* o = p.gates + tok * 4 * H;
-            o[u] = rg; o[H + u] = zg; o[2 * H + u] = ng; o[3 * H + u] = hn;
+            o[uo] = rg; o[H + uo] = zg; o[2 * H + uo] = ng; o[3 * H + uo] = hn;
         }
     }
 }
@@ -102,18 +132,23 @@ struct GruBwd {
     int B, L, H, t;
 };
 
+template <int KC>
 __global__ __launch_bounds__(256) void gru_bwd_step_kernel(GruBwd p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int H = p.H;
-    float* s_w = smem;                              // [3H/4][16][4]
-    float* s_g = smem + (size_t)3 * H * 16;         // [RG][3H]
-    float* s_dz = s_g + (size_t)RG * 3 * H;         // [RG][16]  dh * z for the owned units
-    const int tid = threadIdx.x;
+    constexpr int RC = 3 * KC;                       // gate rows per thread (3H / KQ)
+    constexpr int NC = RC / 4;
+    __shared__ __attribute__((aligned(16))) float s_gbuf[RG * 3 * KC * KQMAX];   // [RG][3H]: (dr | dz | dhn) of the RG rows, all H units
+    __shared__ float s_dz[RG][US];                                    // dh * z of the owned units
+    __shared__ float s_p[KQMAX][RG][US + 1];
+    const int tid = threadIdx.x, NT = blockDim.x, KQ = NT >> 4, H = p.H;
+    auto s_g = [&](int r) { return s_gbuf + (size_t)r * 3 * H; };
     const int s = blockIdx.x, b0 = blockIdx.y * RG;
-    const float4* wsrc = reinterpret_cast<const float4*>(p.wb + (size_t)s * 48 * H);
-    for (int i = tid; i < 12 * H; i += 256) reinterpret_cast<float4*>(s_w)[i] = wsrc[i];
-    // gate gradients for the 16 rows x all H units (recomputed by every unit slice of the row group: elementwise)
-    for (int i = tid; i < RG * H; i += 256) {
+    const int j = tid & 15, kq = tid >> 4;
+    float4 w[NC];
+    const float4* wsrc = reinterpret_cast<const float4*>(p.wb) + (size_t)s * NC * NT + tid;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) w[c] = wsrc[(size_t)c * NT];
+    // gate gradients for the RG rows x all H units (recomputed by every unit slice of the row group: elementwise)
+    for (int i = tid; i < RG * H; i += NT) {
         const int r = i / H, u = i % H;
         const int b = b0 + r;
         float dr_ = 0.f, dz_ = 0.f, dn_ = 0.f, dhn = 0.f, dhz = 0.f;
@@ -136,25 +171,42 @@ __global__ __launch_bounds__(256) void gru_bwd_step_kernel(GruBwd p) {
                 o2[u] = dr_; o2[H + u] = dz_; o2[2 * H + u] = dhn;
             }
         }
-        s_g[r * 3 * H + u] = dr_;
-        s_g[r * 3 * H + H + u] = dz_;
-        s_g[r * 3 * H + 2 * H + u] = dhn;
-        if (u / US == s) s_dz[r * US + (u % US)] = dhz;
+        s_g(r)[u] = dr_;
+        s_g(r)[H + u] = dz_;
+        s_g(r)[2 * H + u] = dhn;
+        if (u / US == s) s_dz[r][u % US] = dhz;
     }
     __syncthreads();
-    const int r = tid >> 4, j = tid & 15;
-    float acc = 0.f;
-    for (int g4 = 0; g4 < 3 * H / 4; ++g4) {
-        const float4 gv = ld4(&s_g[r * 3 * H + 4 * g4]);
-        const float4 wv = ld4(&s_w[((size_t)g4 * 16 + j) * 4]);
-        acc = __builtin_fmaf(gv.x, wv.x, acc); acc = __builtin_fmaf(gv.y, wv.y, acc);
-        acc = __builtin_fmaf(gv.z, wv.z, acc); acc = __builtin_fmaf(gv.w, wv.w, acc);
+#pragma unroll
+    for (int r = 0; r < RG; ++r) {
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float4 gv = ld4(s_g(r) + kq * RC + c * 4);
+            acc = __builtin_fmaf(gv.x, w[c].x, acc); acc = __builtin_fmaf(gv.y, w[c].y, acc);
+            acc = __builtin_fmaf(gv.z, w[c].z, acc); acc = __builtin_fmaf(gv.w, w[c].w, acc);
+        }
+        s_p[kq][r][j] = acc;
     }
-    const int b = b0 + r;
-    if (b < p.B) p.carry_out[(int64_t)b * H + s * US + j] = s_dz[r * US + j] + acc;
+    __syncthreads();
+    if (tid < RG * US) {
+        const int r = tid >> 4;
+        const int b = b0 + r;
+        float acc = s_dz[r][j];
+        for (int q = 0; q < KQ; ++q) acc += s_p[q][r][j];
+        if (b < p.B) p.carry_out[(int64_t)b * H + s * US + j] = acc;
+    }
 }
 
-inline bool gru_ok(int B, int L, int H) { return B > 0 && L > 0 && H > 0 && H % 16 == 0 && H <= HMAX; }
+// H = KC * KQ with KC in {4, 8, 12, 16, 24, 32} (templated) and 4 <= KQ <= 16: every multiple of 16 up to 256, and
+// 320 / 384 / 448 / 512 above
+inline int pick_kc(int H) {
+    const int cand[6] = {4, 8, 12, 16, 24, 32};
+    for (int kc : cand)
+        if (H % kc == 0 && H / kc <= KQMAX && H / kc >= 4) return kc;
+    return 0;
+}
+inline bool gru_ok(int B, int L, int H) { return B > 0 && L > 0 && H > 0 && H % 16 == 0 && H <= HMAX && pick_kc(H) > 0; }
 inline size_t wlayout_floats(int H) { return (size_t)3 * H * H; }
 
 }  // namespace
@@ -171,18 +223,21 @@ extern "C" int resel_gru_seq_fwd(const float* gi, const float* w_hh, const float
     hipStream_t s = (hipStream_t)stream;
     float* wf = (float*)workspace;
     const int64_t nw = (int64_t)3 * H * H;
-    hipLaunchKernelGGL(gru_layout_fwd_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, w_hh, wf, H);
-    const size_t lds = ((size_t)H * 48 + (size_t)RG * H) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gru_fwd_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    const int KC = pick_kc(H), KQ = H / KC;
+    hipLaunchKernelGGL(gru_layout_fwd_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, w_hh, wf, H, KQ);
     GruFwd p{gi, wf, b_hh, h0, h_all, gates, B, L, H, 0};
     dim3 grid(H / US, (B + RG - 1) / RG);
     for (int t = 0; t < L; ++t) {
         p.t = t;
-        hipLaunchKernelGGL(gru_fwd_step_kernel, grid, dim3(256), lds, s, p);
+        switch (KC) {
+            case 4: hipLaunchKernelGGL(gru_fwd_step_kernel<4>, grid, dim3(16 * KQ), 0, s, p); break;
+            case 8: hipLaunchKernelGGL(gru_fwd_step_kernel<8>, grid, dim3(16 * KQ), 0, s, p); break;
+            case 12: hipLaunchKernelGGL(gru_fwd_step_kernel<12>, grid, dim3(16 * KQ), 0, s, p); break;
+            case 16: hipLaunchKernelGGL(gru_fwd_step_kernel<16>, grid, dim3(16 * KQ), 0, s, p); break;
+            case 24: hipLaunchKernelGGL(gru_fwd_step_kernel<24>, grid, dim3(16 * KQ), 0, s, p); break;
+            case 32: hipLaunchKernelGGL(gru_fwd_step_kernel<32>, grid, dim3(16 * KQ), 0, s, p); break;
+            default: return RESEL_EINVAL;
+        }
     }
     return launch_status();
 }
@@ -196,21 +251,24 @@ extern "C" int resel_gru_seq_bwd(const float* w_hh, const float* h0, const float
     float* wb = (float*)workspace;
     float* carry = wb + wlayout_floats(H);
     const int64_t nw = (int64_t)3 * H * H;
-    hipLaunchKernelGGL(gru_layout_bwd_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, w_hh, wb, H);
+    const int KC = pick_kc(H), KQ = H / KC;
+    hipLaunchKernelGGL(gru_layout_bwd_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, w_hh, wb, H, KQ);
     if (hipMemsetAsync(carry, 0, (size_t)2 * B * H * sizeof(float), s) != hipSuccess) return RESEL_ELAUNCH;
-    const size_t lds = ((size_t)3 * H * 16 + (size_t)RG * 3 * H + RG * US) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gru_bwd_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
     GruBwd p{wb, h0, h_all, gates, dh_all, nullptr, nullptr, dgi, dgh, B, L, H, 0};
     dim3 grid(H / US, (B + RG - 1) / RG);
     for (int t = L - 1; t >= 0; --t) {
         p.t = t;
         p.carry_in = carry + (size_t)((t + 1) & 1) * B * H;
         p.carry_out = carry + (size_t)(t & 1) * B * H;
-        hipLaunchKernelGGL(gru_bwd_step_kernel, grid, dim3(256), lds, s, p);
+        switch (KC) {
+            case 4: hipLaunchKernelGGL(gru_bwd_step_kernel<4>, grid, dim3(16 * KQ), 0, s, p); break;
+            case 8: hipLaunchKernelGGL(gru_bwd_step_kernel<8>, grid, dim3(16 * KQ), 0, s, p); break;
+            case 12: hipLaunchKernelGGL(gru_bwd_step_kernel<12>, grid, dim3(16 * KQ), 0, s, p); break;
+            case 16: hipLaunchKernelGGL(gru_bwd_step_kernel<16>, grid, dim3(16 * KQ), 0, s, p); break;
+            case 24: hipLaunchKernelGGL(gru_bwd_step_kernel<24>, grid, dim3(16 * KQ), 0, s, p); break;
+            case 32: hipLaunchKernelGGL(gru_bwd_step_kernel<32>, grid, dim3(16 * KQ), 0, s, p); break;
+            default: return RESEL_EINVAL;
+        }
     }
     return launch_status();
 }
