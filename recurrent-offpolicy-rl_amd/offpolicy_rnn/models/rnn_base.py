@@ -239,7 +239,10 @@ class RNNBase(torch.nn.Module):
                         and x.dtype == torch.float32:
                     x = layer(x, act='elu') if isinstance(layer, EnsembleLinear) else ops.linear_act(x, layer.weight, layer.bias, 'elu')
                     continue
-                x = layer(x)
+                if isinstance(layer, torch.nn.Linear) and x.dim() > 2:    # 2-D call: the bias rides in the GEMM epilogue (addmm)
+                    x = torch.nn.functional.linear(x.reshape(-1, x.shape[-1]), layer.weight, layer.bias).view(*x.shape[:-1], -1)
+                else:
+                    x = layer(x)
             if isinstance(act, torch.nn.ModuleList):
                 if self.activation_type[ind].startswith('eln'):
                     x = act[0](x.transpose(-2, 0)).transpose(-2, 0)

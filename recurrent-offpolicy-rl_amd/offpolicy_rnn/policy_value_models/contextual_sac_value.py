@@ -46,7 +46,7 @@ class ContextualSACValue(ContextualModel):
         return _inputs.embedding_input(self, state, lst_state, lst_action, reward)
 
     def state_action(self, state, action):
-        sa = torch.cat((self.state_input_encoder(state), self.action_input_encoder(action)), dim=-1)
+        sa = _inputs.encode_concat([(self.state_input_encoder, state), (self.action_input_encoder, action)])
         return self.uni_model_input_mapping_activation_func(sa) if self.separate_encoder else sa
 
     def forward(self, state, lst_state, lst_action, action, rnn_memory: Optional[RNNHidden], reward, detach_embedding=False
