@@ -138,6 +138,117 @@ __global__ __launch_bounds__(128) void conv_fwd_kernel(ConvParams p) {
     if (ts + ig < t_end) conv_fwd_group<KT, 2>(p, xrow, yrow, ts + ig, t_end, ig, mlo, mhi, wr, win, pre, bv);
 }
 
+// Backward, register-window form (K <= 16, L >= 64): the same thread ownership as the forward - 2 channels, one 64-step
+// chunk of one row - with FOUR rotating windows in registers: the last KT masked inputs, the last KT gate gradients g, the
+// taps and the tap gradients.
+//   g[t]   = dy[t] * silu'(pre[t])                      pre = conv output before the activation (recomputed)
+//   dx[s]  = mask[s] * sum_k w[k] * g[s + (KT-1) - k]   (g = 0 at and beyond the row end)
+//   dw[k]  = sum_t g[t] * xm[t - (KT-1) + k],  db = sum_t g[t]      over the steps t the chunk OWNS
+// Step i of a chunk is time t = t0 - (KT+1) + i: KT steps of input warm-up, KT steps that start the g window, then 64 / KT
+// groups in which every step also emits dx[t - (KT-1)] - the warm-up length is chosen so that the dx phase starts on a
+// group boundary, which leaves three straight-line group bodies (exact vmcnt accounting, see the forward).  The last
+// chunk of a row is shifted back to end exactly at the row end (it recomputes a few dx of its neighbour, same values) and
+// owns only its own steps.  Per-chunk dw / db partials are summed by colsum_kernel (fixed order, no atomics).
+constexpr int CB_TT = 64;
+
+template <int KT, int MODE>          // MODE 0: inputs only, 1: + g window and dw / db, 2: + dx
+__device__ __forceinline__ void conv_bwd_group(const ConvParams& p, const float* xrow, const float* dyrow, float* dxrow, int tg,
+                                               int ig, int t_own0, float mlo, float mhi, const f2 (&wr)[KT], f2 (&xwin)[KT],
+                                               f2 (&gwin)[KT], f2 (&dwr)[KT], f2& dbr, f2 (&prex)[KT < 4 ? KT : 4],
+                                               f2 (&predy)[KT < 4 ? KT : 4], f2 bv) {
+    constexpr int P = KT < 4 ? KT : 4;
+    const float mreg = ig < 64 ? mlo : mhi;
+#pragma unroll
+    for (int s = 0; s < KT; ++s) {
+        const int t = tg + s;
+        const float m = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mreg), (ig & 63) + s));
+        xwin[s] = prex[s % P] * f2{m, m};
+        const int tl = min(max(t + P, 0), p.L - 1);
+        prex[s % P] = *reinterpret_cast<const f2*>(xrow + (int64_t)tl * p.ld_x);
+        if (MODE >= 1) {
+            const f2 dyv = predy[s % P];
+            predy[s % P] = *reinterpret_cast<const f2*>(dyrow + (int64_t)tl * p.ld_dy);
+            f2 acc = bv;
+#pragma unroll
+            for (int kk = 0; kk < KT; ++kk) acc = __builtin_elementwise_fma(wr[kk], xwin[(s + 1 + kk) % KT], acc);
+            const float live = (t >= 0 && t < p.L) ? 1.f : 0.f;                 // g is zero outside the row
+            f2 g = dyv * f2{live, live};
+            if (p.silu) { g.x *= dsiluf_(acc.x); g.y *= dsiluf_(acc.y); }
+            gwin[s] = g;
+            const float own = (t >= t_own0 && t < t_own0 + CB_TT) ? 1.f : 0.f;   // halo steps serve dx only
+            const f2 go = g * f2{own, own};
+            dbr += go;
+#pragma unroll
+            for (int kk = 0; kk < KT; ++kk) dwr[kk] = __builtin_elementwise_fma(go, xwin[(s + 1 + kk) % KT], dwr[kk]);
+        }
+        if (MODE == 2) {
+            f2 acc = {0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < KT; ++kk) acc = __builtin_elementwise_fma(wr[kk], gwin[(s - kk + KT) % KT], acc);
+            const int im = ig + s - (KT - 1);                                    // step index whose time is t - (KT-1)
+            const float ma = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mlo), im & 63));
+            const float mb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mhi), im & 63));
+            const float mm = im < 64 ? ma : mb;
+            *reinterpret_cast<f2*>(dxrow + (int64_t)(t - (KT - 1)) * p.ld_dx) = acc * f2{mm, mm};
+        }
+    }
+}
+
+template <int KT>
+__global__ __launch_bounds__(128) void conv_bwd_win_kernel(ConvParams p, int nchunk) {
+    constexpr int P = KT < 4 ? KT : 4;
+    const int lane = threadIdx.x & 63;
+    if ((blockIdx.x * 128 + (threadIdx.x & 64)) * 2 >= p.Di) return;      // whole wave past the last channel (no barriers below)
+    const int c_raw = (int)(blockIdx.x * 128 + threadIdx.x) * 2;
+    const int c = min(c_raw, p.Di - 2);             // shadow lanes (see the forward kernel)
+    const int b = blockIdx.z, chunk = blockIdx.y;
+    const int t_own0 = chunk * CB_TT;               // first step this chunk accounts for in dw / db
+    const int t0 = min(t_own0, p.L - CB_TT);        // the last chunk is shifted back to end at the row end
+    const int64_t tok0 = (int64_t)b * p.L;
+    const float* xrow = p.x + tok0 * p.ld_x + c;
+    const float* dyrow = p.dy + tok0 * p.ld_dy + c;
+    float* dxrow = p.dx + tok0 * p.ld_dx + c;
+    f2 wr[KT], xwin[KT], gwin[KT], dwr[KT];
+#pragma unroll
+    for (int kk = 0; kk < KT; ++kk) {
+        const int k = kk - (KT - p.K);
+        wr[kk] = f2{0.f, 0.f};
+        xwin[kk] = gwin[kk] = dwr[kk] = f2{0.f, 0.f};
+        if (k >= 0) wr[kk] = f2{p.w[(int64_t)c * p.K + k], p.w[(int64_t)(c + 1) * p.K + k]};
+    }
+    f2 bv = {0.f, 0.f}, dbr = {0.f, 0.f};
+    if (p.bias) bv = *reinterpret_cast<const f2*>(p.bias + c);
+    const int ts = t0 - (KT + 1);                   // time of step 0
+    float mlo, mhi;                                 // mask of step i in lane i of (mlo, mhi); 0 outside the row
+    {
+        const int ta = ts + lane, tb = ts + 64 + lane;
+        const float va = p.mask ? p.mask[tok0 + min(max(ta, 0), p.L - 1)] : 1.f;
+        const float vb = p.mask ? p.mask[tok0 + min(max(tb, 0), p.L - 1)] : 1.f;
+        mlo = (ta >= 0 && ta < p.L) ? va : 0.f;
+        mhi = (tb >= 0 && tb < p.L) ? vb : 0.f;
+    }
+    f2 prex[P], predy[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        prex[i] = *reinterpret_cast<const f2*>(xrow + (int64_t)min(max(ts + i, 0), p.L - 1) * p.ld_x);
+        predy[i] = *reinterpret_cast<const f2*>(dyrow + (int64_t)min(max(ts + KT + i, 0), p.L - 1) * p.ld_dy);
+    }
+    conv_bwd_group<KT, 0>(p, xrow, dyrow, dxrow, ts, 0, t_own0, mlo, mhi, wr, xwin, gwin, dwr, dbr, prex, predy, bv);
+    conv_bwd_group<KT, 1>(p, xrow, dyrow, dxrow, ts + KT, KT, t_own0, mlo, mhi, wr, xwin, gwin, dwr, dbr, prex, predy, bv);
+    for (int ig = 2 * KT; ig < 2 * KT + CB_TT; ig += KT)
+        conv_bwd_group<KT, 2>(p, xrow, dyrow, dxrow, ts + ig, ig, t_own0, mlo, mhi, wr, xwin, gwin, dwr, dbr, prex, predy, bv);
+    if (c_raw < p.Di) {
+        const int64_t row = (int64_t)b * nchunk + chunk;
+#pragma unroll
+        for (int kk = 0; kk < KT; ++kk) {
+            p.dw_part[(row * p.Di + c) * KT + kk] = dwr[kk].x;
+            p.dw_part[(row * p.Di + c + 1) * KT + kk] = dwr[kk].y;
+        }
+        p.db_part[row * p.Di + c] = dbr.x;
+        p.db_part[row * p.Di + c + 1] = dbr.y;
+    }
+}
+
 // Backward: one block per (row b, channel tile) walks the time tiles, so dw / dbias accumulate in registers and
 // only per-row partials [B, Di, KT] / [B, Di] leave the block (summed by colsum_kernel, no atomics).
 //   g[t]   = dy[t] * silu'(pre[t])                      pre = conv output before the activation (recomputed)
@@ -253,9 +364,12 @@ extern "C" int resel_causal_conv1d_fwd(const float* x, int64_t ld_x, const float
     return launch_status();
 }
 
+inline bool bwd_windowed(int L, int KT) { return KT <= 16 && L >= CB_TT; }
+inline int bwd_rows(int B, int L, int KT) { return bwd_windowed(L, KT) ? B * ((L + CB_TT - 1) / CB_TT) : B; }
+
 extern "C" size_t resel_causal_conv1d_bwd_workspace_bytes(int B, int L, int Di, int K) {
-    (void)L;
-    return ((size_t)B * Di * pad_taps(K) + (size_t)B * Di) * sizeof(float);
+    const int KT = pad_taps(K);
+    return (size_t)bwd_rows(B, L, KT) * Di * (KT + 1) * sizeof(float);
 }
 
 extern "C" int resel_causal_conv1d_bwd(const float* x, int64_t ld_x, const float* w, const float* bias, const float* mask,
@@ -265,18 +379,29 @@ extern "C" int resel_causal_conv1d_bwd(const float* x, int64_t ld_x, const float
         (bias && !aligned16(bias)))
         return RESEL_EINVAL;
     const int KT = pad_taps(K);
+    const int rows = bwd_rows(B, L, KT);            // partial rows: one per (b, chunk) or one per b
     float* dw_part = (float*)workspace;
-    float* db_part = dw_part + (size_t)B * Di * KT;
+    float* db_part = dw_part + (size_t)rows * Di * KT;
     ConvParams p{x, w, bias, mask, dy, nullptr, dx, dw_part, db_part, ld_x, 0, ld_dy, ld_dx, B, L, Di, K, silu};
-    dim3 grid(B, (Di + TILE_C - 1) / TILE_C);
     hipStream_t s = (hipStream_t)stream;
-    switch (KT) {
-        case 4: hipLaunchKernelGGL(conv_bwd_kernel<4>, grid, dim3(256), 0, s, p); break;
-        case 8: hipLaunchKernelGGL(conv_bwd_kernel<8>, grid, dim3(256), 0, s, p); break;
-        case 16: hipLaunchKernelGGL(conv_bwd_kernel<16>, grid, dim3(256), 0, s, p); break;
-        default: hipLaunchKernelGGL(conv_bwd_kernel<32>, grid, dim3(256), 0, s, p); break;
+    if (bwd_windowed(L, KT)) {
+        const int nchunk = (L + CB_TT - 1) / CB_TT;
+        dim3 grid((Di + 255) / 256, nchunk, B);
+        switch (KT) {
+            case 4: hipLaunchKernelGGL(conv_bwd_win_kernel<4>, grid, dim3(128), 0, s, p, nchunk); break;
+            case 8: hipLaunchKernelGGL(conv_bwd_win_kernel<8>, grid, dim3(128), 0, s, p, nchunk); break;
+            default: hipLaunchKernelGGL(conv_bwd_win_kernel<16>, grid, dim3(128), 0, s, p, nchunk); break;
+        }
+    } else {
+        dim3 grid(B, (Di + TILE_C - 1) / TILE_C);
+        switch (KT) {
+            case 4: hipLaunchKernelGGL(conv_bwd_kernel<4>, grid, dim3(256), 0, s, p); break;
+            case 8: hipLaunchKernelGGL(conv_bwd_kernel<8>, grid, dim3(256), 0, s, p); break;
+            case 16: hipLaunchKernelGGL(conv_bwd_kernel<16>, grid, dim3(256), 0, s, p); break;
+            default: hipLaunchKernelGGL(conv_bwd_kernel<32>, grid, dim3(256), 0, s, p); break;
+        }
     }
-    launch_colsum(dw_part, (int64_t)Di * KT, B, Di * KT, dw, s, KT, K);      // dw[d, k] = sum_b dw_part[b, d, KT - K + k]
-    if (dbias) launch_colsum(db_part, Di, B, Di, dbias, s);
+    launch_colsum(dw_part, (int64_t)Di * KT, rows, Di * KT, dw, s, KT, K);   // dw[d, k] = sum_rows dw_part[row, d, KT - K + k]
+    if (dbias) launch_colsum(db_part, Di, rows, Di, dbias, s);
     return launch_status();
 }
