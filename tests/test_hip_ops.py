@@ -465,3 +465,69 @@ def test_linear_act_vs_torch(ops):
     close(xc.grad, xr.grad, name='dx')
     close(Wc.grad, Wr.grad, rtol=2e-4, atol_scale=5e-5, name='dW')
     close(bc.grad, br.grad, rtol=2e-4, atol_scale=5e-5, name='db')
+
+
+# ------------------------------------------------------------------------------------------ BASELINE-size properties
+def test_selective_scan_full_size_properties(ops):
+    """Config-2 shapes (B 64, T' 1043, d_inner 512, N 32: too big for the CPU oracle in a test) through size-independent
+    properties of the recurrence: (1) y is linear in u for fixed delta / B / C (no gate), forward and in the u-gradient;
+    (2) a `start` reset makes the rest of the row independent of everything before it - the suffix of a packed row
+    equals the same suffix processed alone; (3) the last row equals that row processed as a batch of one."""
+    g = torch.Generator().manual_seed(21)
+    B, L, Di, N = 64, 1043, 512, 32
+    dev = 'cuda'
+    u1, u2 = rnd(B, L, Di, g=g).to(dev), rnd(B, L, Di, g=g).to(dev)
+    delta = (rnd(B, L, Di, g=g) * 0.5).to(dev)
+    A = (-torch.exp(rnd(Di, N, g=g) * 0.3)).to(dev)
+    Bm, Cm = rnd(B, L, N, g=g).to(dev), rnd(B, L, N, g=g).to(dev)
+    D, db = rnd(Di, g=g).to(dev), (rnd(Di, g=g) * 0.1).to(dev)
+    start = torch.zeros(B, L, device=dev)
+    start[:, 0] = 1
+    cut = 517
+    start[:, cut] = 1
+
+    def run(u, st=start, sl=slice(None), rows=slice(None)):
+        return ops.selective_scan_tm(u[rows, sl].contiguous(), delta[rows, sl].contiguous(), A, Bm[rows, sl].contiguous(),
+                                     Cm[rows, sl].contiguous(), D, None, db, st[rows, sl].contiguous(), True)
+
+    y1, y2, y12 = run(u1), run(u2), run(u1 + 2 * u2)
+    scale = y12.abs().max().item()
+    assert (y12 - (y1 + 2 * y2)).abs().max().item() <= 2e-5 * scale, 'linearity in u'
+    tail = run(u1, sl=slice(cut, None))
+    assert (tail - y1[:, cut:]).abs().max().item() <= 2e-5 * scale, 'reset isolation / packing'
+    one = run(u1, rows=slice(B - 1, B))
+    assert torch.equal(one, y1[B - 1:]), 'row independence must be bit-exact'
+    # backward: d/du of sum(w * y) is linear in w
+    uu = u1.clone().requires_grad_(True)
+    w1, w2 = rnd(B, L, Di, g=g).to(dev), rnd(B, L, Di, g=g).to(dev)
+    y = run(uu)
+    g1, = torch.autograd.grad(y, uu, w1, retain_graph=True)
+    g2, = torch.autograd.grad(y, uu, w2, retain_graph=True)
+    g12, = torch.autograd.grad(y, uu, w1 - 3 * w2)
+    assert (g12 - (g1 - 3 * g2)).abs().max().item() <= 2e-5 * g12.abs().max().item(), 'backward linearity'
+    # bitwise reproducibility of the backward (no atomics anywhere)
+    g1b, = torch.autograd.grad(run(uu), uu, w1)
+    assert torch.equal(g1, g1b)
+
+
+def test_conv_full_size_properties(ops):
+    """Config-2 conv (B 64, T' 1043, d_inner 512, K 16): causality, mask packing and agreement of the strided (x | z)
+    input with a contiguous copy - bit-exact, the arithmetic order does not depend on the layout."""
+    g = torch.Generator().manual_seed(22)
+    B, L, Di, Kw = 64, 1043, 512, 16
+    dev = 'cuda'
+    xz = rnd(B, L, 2 * Di, g=g).to(dev)
+    w, bias = (rnd(Di, 1, Kw, g=g) * 0.2).to(dev), (rnd(Di, g=g) * 0.1).to(dev)
+    mask = (torch.rand(B, L, 1, generator=g) > 0.05).float().to(dev)
+    y = ops.causal_conv1d_fn(xz[..., :Di], w, bias, mask, True)
+    y2 = ops.causal_conv1d_fn(xz[..., :Di].contiguous(), w, bias, mask, True)
+    assert torch.equal(y, y2)
+    x3 = xz.clone()
+    x3[:, 700:, :Di] += 1.0                            # a change at t >= 700 must not reach outputs before 700
+    y3 = ops.causal_conv1d_fn(x3[..., :Di], w, bias, mask, True)
+    assert torch.equal(y3[:, :700], y[:, :700]) and not torch.equal(y3[:, 700:], y[:, 700:])
+    gap = mask.clone()
+    gap[:, 300:300 + Kw] = 0                           # a masked gap of K steps separates the two halves completely
+    ya = ops.causal_conv1d_fn(xz[..., :Di], w, bias, gap, True)
+    yb = ops.causal_conv1d_fn(xz[:, 300 + Kw:, :Di], w, bias, gap[:, 300 + Kw:], True)
+    assert (ya[:, 300 + Kw:] - yb).abs().max().item() <= 1e-6 * ya.abs().max().item()
