@@ -73,6 +73,17 @@ def build_trainer(rnn, B, T, seed=0, algo='sac'):
     return alg
 
 
+def baseline_config(args):
+    """Which BASELINE.json `configs` entry the command line corresponds to."""
+    if args.rnn.startswith('smamba'):
+        return 'BASELINE configs[1]; at N=8 this is configs[3], B=512 global'
+    if args.rnn.startswith('cgpt'):
+        return 'BASELINE configs[2] family (cgpt TD3, B=32)'
+    if args.rnn in ('gilr', 'lru'):
+        return 'BASELINE configs[4] family (linear-RNN scan; --horizon 2000 for the full-episode case)'
+    return 'BASELINE configs[0] family (GRU) at the configs[1] size'
+
+
 def cpu_baseline(rnn):
     """The oracle trainer (CPU restatement of the same update, `kind: port`) on a bounded sample of the workload: one update
     of the same layer stack at 8 rows x T=1024 on 8 host threads (the per-step Python loops of the CPU scan do not scale
@@ -81,7 +92,8 @@ def cpu_baseline(rnn):
     import subprocess
     code = ("import json,sys; sys.path.insert(0, %r); from oracle.trainer import time_cpu_baseline; "
             "print(json.dumps(time_cpu_baseline(%r, B=%d, T=1024, updates=1, warmup=0, threads=%d)))")
-    for name, rows, threads, limit in ((rnn, 8, 8, 240), ('gru', 64, min(32, os.cpu_count() or 1), 120)):
+    gru_sample = ('gru', 64, min(32, os.cpu_count() or 1), 120)       # ATen's CPU GRU scales to ~32 threads, not beyond
+    for name, rows, threads, limit in ((gru_sample,) if rnn == 'gru' else ((rnn, 8, 8, 240), gru_sample)):
         try:
             r = subprocess.run([sys.executable, '-c', code % (ROOT, name, rows, threads)], capture_output=True, text=True, timeout=limit)
             base = json.loads(r.stdout.strip().splitlines()[-1])
@@ -155,7 +167,7 @@ def main():
         'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': f'{args.rnn} {args.algo.upper()}-REDQ full-trajectory update, B={Bsz}/GPU, T={args.horizon} (row length {Tp}), obs={OBS}, act={ACT}, '
-                               f'D=256, efc-8 critic (BASELINE configs[1]; N=8 is configs[3])',
+                               f'D=256, efc-8 critic ({baseline_config(args)})',
                    'global_rows': Bsz * world, 'parallelism': f'dp{world}'},
     }
     if 'sscan_fwd_kernel' in kern and args.rnn.startswith('smamba'):
@@ -186,6 +198,8 @@ def main():
     out['kernels'] = kern
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(args.rnn)
+        if args.rnn != 'gru':                          # north_star's named baseline: the CPU GRU trainer at the full B=64, T=1024
+            out['cpu_baseline_gru'] = cpu_baseline('gru')
     print(json.dumps(out))
 
 
