@@ -232,26 +232,26 @@ __global__ __launch_bounds__(NW * 64) void sscan_fwd_kernel(FwdParams p) {
         __syncthreads();
         if (c0 + TC < p.L) prefetch(c0 + TC);        // in flight during the whole scan phase
 
-        // ---- scan: lane = channel, wave = state group, sequential in time; B_t / C_t / start_t broadcast from LDS,
-        //      fetched one step ahead of their use
-        const int nst = min(TC, p.L - c0);
-        // ping-pong operand sets: while step t is computed from set 0, the LDS reads of step t+1 fill set 1 (and vice
-        // versa) - issued first in each half-iteration and pinned there with sched_barrier, so that their latency
-        // hides behind the VALU work instead of stalling the loop head.
+        // ---- scan: lane = channel, wave = state group, sequential in time.
+        // The lane's own column of the chunk (delta and delta*u of its channel, TC steps each) is pulled into registers
+        // up front - 2 TC independent LDS reads behind ONE wait - and the reset flags of the chunk become a bit mask in an
+        // SGPR pair, so the step loop (fully unrolled: register indices are static) reads only the wave-uniform B_t / C_t
+        // rows from LDS, one step ahead of their use (ping-pong sets pinned with sched_barrier).
         // The per-state arithmetic is written on float2 pairs: on gfx950 a wave64 v_fma_f32 / v_mul_f32 issues every
         // 4 cycles per SIMD and v_pk_fma_f32 / v_pk_mul_f32 every ~5.6 (tools/micro/valu_rate.hip), i.e. packed math
         // is ~1.4x the scalar rate; v_exp_f32 (8 cycles) stays scalar.
+        const int nst = min(TC, p.L - c0);
+        float dlr[TC], dur[TC];
+#pragma unroll
+        for (int t = 0; t < TC; ++t) { dlr[t] = s_dl[t][lane]; dur[t] = s_du[t][lane]; }
+        const unsigned long long rmask = __ballot(lane < TC && s_st[lane < TC ? lane : 0] != 0.f);
         f2 B0[NP], C0[NP], B1[NP], C1[NP];
-        float sf0, dl0, du0, sf1, dl1, du1;
-        auto fetch = [&](int t, f2 (&Bq)[NP], f2 (&Cq)[NP], float& sf, float& dlq, float& duq) {
+        auto fetch = [&](int t, f2 (&Bq)[NP], f2 (&Cq)[NP]) {
             lds_coef2<NS>(&s_B[t][w * NS], Bq);
             lds_coef2<NS>(&s_C[t][w * NS], Cq);
-            sf = s_st[t];
-            dlq = s_dl[t][lane];
-            duq = s_du[t][lane];
         };
-        auto step = [&](int t, const f2 (&Bq)[NP], const f2 (&Cq)[NP], float sf, float dlq, float duq) {
-            const float dle = (sf != 0.f) ? __builtin_inff() : dlq;    // reset: exp2(-inf) = 0 wipes h_{t-1}
+        auto step = [&](int t, const f2 (&Bq)[NP], const f2 (&Cq)[NP], float dlq, float duq) {
+            const float dle = ((rmask >> t) & 1ull) ? __builtin_inff() : dlq;    // reset: exp2(-inf) = 0 wipes h_{t-1}
             const f2 dle2 = {dle, dle}, du2 = {duq, duq};
             f2 yacc = {0.f, 0.f};
 #pragma unroll
@@ -271,15 +271,18 @@ __global__ __launch_bounds__(NW * 64) void sscan_fwd_kernel(FwdParams p) {
                 for (int j = 0; j < NS; ++j) ck[(int64_t)j * p.Di] = (j & 1) ? hp[j / 2].y : hp[j / 2].x;
             }
         };
-        fetch(0, B0, C0, sf0, dl0, du0);
-        for (int t = 0; t < nst; t += 2) {
-            fetch(min(t + 1, TC - 1), B1, C1, sf1, dl1, du1);
-            __builtin_amdgcn_sched_barrier(0);
-            step(t, B0, C0, sf0, dl0, du0);
-            if (t + 1 < nst) {
-                fetch(min(t + 2, TC - 1), B0, C0, sf0, dl0, du0);
+        fetch(0, B0, C0);
+#pragma unroll
+        for (int t = 0; t < TC; t += 2) {
+            if (t < nst) {
+                fetch(t + 1 < TC ? t + 1 : TC - 1, B1, C1);
                 __builtin_amdgcn_sched_barrier(0);
-                step(t + 1, B1, C1, sf1, dl1, du1);
+                step(t, B0, C0, dlr[t], dur[t]);
+            }
+            if (t + 1 < nst) {
+                fetch(t + 2 < TC ? t + 2 : TC - 1, B0, C0);
+                __builtin_amdgcn_sched_barrier(0);
+                step(t + 1, B1, C1, dlr[t + 1 < TC ? t + 1 : TC - 1], dur[t + 1 < TC ? t + 1 : TC - 1]);
             }
         }
         __syncthreads();
