@@ -240,6 +240,7 @@ __global__ __launch_bounds__(NW * 64) void sscan_fwd_kernel(FwdParams p) {
         // The per-state arithmetic is written on float2 pairs: on gfx950 a wave64 v_fma_f32 / v_mul_f32 issues every
         // 4 cycles per SIMD and v_pk_fma_f32 / v_pk_mul_f32 every ~5.6 (tools/micro/valu_rate.hip), i.e. packed math
         // is ~1.4x the scalar rate; v_exp_f32 (8 cycles) stays scalar.
+        static_assert(TC <= 64 && TC % 2 == 0, "one reset bit per step in a 64-bit mask; steps are processed in pairs");
         const int nst = min(TC, p.L - c0);
         float dlr[TC], dur[TC];
 #pragma unroll
