@@ -197,6 +197,30 @@ class SACFullLengthRNNEnsembleQ(SAC):
         _, _, sample, logp, _, _ = self.policy.forward(b['next_state'], b['state'], b['action'], hidden, b['reward'])
         return sample, logp
 
+    def _subset_on_device(self, subset: np.ndarray, num_ensemble: int = 0) -> torch.Tensor:
+        """int32 device copy of a critic-subset index vector without a per-update host->device copy (a pageable copy blocks
+        the host until the launch queue has drained): all ordered subsets of that size are uploaded ONCE as a table
+        (8 critics, REDQ pairs: 56 rows) and a row view is returned; oversized tables fall back to a per-subset cache."""
+        import itertools
+        import math
+        sub = np.ascontiguousarray(subset, dtype=np.int32)
+        m, E = int(sub.size), int(max(num_ensemble, sub.max() + 1))
+        tables = self.__dict__.setdefault('_subset_tables', {})
+        if (E, m) not in tables:
+            rows = None
+            if math.perm(E, m) <= 4096:
+                perms = list(itertools.permutations(range(E), m))
+                rows = ({p: i for i, p in enumerate(perms)}, torch.tensor(perms, dtype=torch.int32).to(self.device))
+            tables[(E, m)] = rows
+        rows = tables[(E, m)]
+        if rows is not None and tuple(sub.tolist()) in rows[0]:
+            return rows[1][rows[0][tuple(sub.tolist())]]
+        cache = self.__dict__.setdefault('_subset_cache', {})
+        key = sub.tobytes()
+        if key not in cache:
+            cache[key] = torch.from_numpy(sub.copy()).to(self.device)
+        return cache[key]
+
     def _select_target_ensemble(self, num_ensemble: int) -> np.ndarray:
         return np.arange(num_ensemble)                               # plain ensemble-min (REDQ trainers override)
 
@@ -204,7 +228,7 @@ class SACFullLengthRNNEnsembleQ(SAC):
         with torch.no_grad():
             sample, logp = self._next_action(b, policy_hidden)
             q = self.target_values[0].forward(b['next_state'], b['state'], b['action'], sample, target_hiddens[0], b['reward'])[0]
-            idx = torch.from_numpy(np.ascontiguousarray(self._select_target_ensemble(q.shape[0]))).to(torch.int32).to(self.device)
+            idx = self._subset_on_device(self._select_target_ensemble(q.shape[0]), q.shape[0])
             return ops.sac_target(q, idx, logp if self.base_algorithm == 'sac' else None, self.log_sac_alpha.detach(), b['reward'],
                                   b['done'], b['mask'], self.parameter.gamma, self.Q_guard.state, stats)
 
