@@ -32,6 +32,21 @@ from .sac import SAC
 FIELDS = ('state', 'last_state', 'action', 'last_action', 'next_state', 'done', 'mask', 'reward', 'reward_input', 'timeout', 'start')
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def _frozen_parameters(model):
+    params = [p for p in model.parameters() if p.requires_grad]
+    for p in params:
+        p.requires_grad_(False)
+    try:
+        yield
+    finally:
+        for p in params:
+            p.requires_grad_(True)
+
+
 class DeferredLog(dict):
     """The update's log dict.  Host-side entries are plain items; the device scalars travel in one asynchronous copy into
     pinned memory and become floats on first access (`resolve()`), so a caller that does not read them - a training loop
@@ -315,8 +330,11 @@ class SACFullLengthRNNEnsembleQ(SAC):
                 action_mean, _, act_sample, log_prob, _, _ = self.policy.forward(b['state'], b['last_state'], b['last_action'],
                                                                                 policy_hidden, b['reward_input'])
                 act_in = act_sample if self.base_algorithm == 'sac' else action_mean
-                q_pi = value.forward(b['state'], b['last_state'], b['last_action'], act_in, value_hiddens[0], b['reward_input'],
-                                     detach_embedding=True)[0]
+                # the actor objective differentiates Q only w.r.t. the action: the critic's parameters are frozen while its graph
+                # is recorded, so that the backward does not form the critic weight gradients the reference computes and drops
+                with _frozen_parameters(value):
+                    q_pi = value.forward(b['state'], b['last_state'], b['last_action'], act_in, value_hiddens[0], b['reward_input'],
+                                         detach_embedding=True)[0]
                 actor_sum = (self._actor_objective(alpha_detach, log_prob, self._q_for_policy(q_pi)) * mask).sum()
                 self.optimizer_policy.zero_grad()
                 actor_sum.backward(inputs=self.policy.parameters())

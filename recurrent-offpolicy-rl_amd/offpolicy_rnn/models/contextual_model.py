@@ -81,7 +81,9 @@ class ContextualModel:
         if rnn_memory is None:
             rnn_memory = self.make_init_state(1 if embedding_input.dim() == 2 else embedding_input.shape[0], embedding_input.device)
         n_emb = self.embedding_network.rnn_num
-        emb, emb_mem, emb_full = self.embedding_network.meta_forward(embedding_input, rnn_memory[:n_emb], require_full_hidden=True)
+        # a detached embedding is computed without a graph: same values, but no scan checkpoints / saved activations
+        with torch.set_grad_enabled(torch.is_grad_enabled() and not detach_embedding):
+            emb, emb_mem, emb_full = self.embedding_network.meta_forward(embedding_input, rnn_memory[:n_emb], require_full_hidden=True)
         if detach_embedding:
             emb = emb.detach()
         uni_in = self.uni_input_mapping_network(uni_model_input)
