@@ -332,3 +332,40 @@ def test_product_never_touches_the_oracle_and_has_no_cpu_fallback():
         ops.gilr_scan(torch.zeros(1, 4, 8), torch.zeros(1, 4, 8))
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         ops.selective_scan_tm(torch.zeros(1, 4, 8), torch.zeros(1, 4, 8), -torch.ones(8, 4), torch.zeros(1, 4, 4), torch.zeros(1, 4, 4))
+
+
+# ------------------------------------------------------------------------------------------ host utilities added for the GPU path
+def test_deferred_log_behaves_like_the_reference_dict():
+    """train_one_batch() returns a dict (reference :430-467); DeferredLog keeps that contract while the device scalars are in
+    flight: host entries readable at once, everything else materialises on first access, actor_loss stays a 1-tuple."""
+    import torch
+    from offpolicy_rnn.algorithm.sac_full_length_rnn_ensembleQ import DeferredLog
+    log = DeferredLog(['critic_loss', 'actor_loss'], torch.tensor([1.5, -2.0]), pinned=False)
+    log.set_host({'real_batch_size': 7})
+    assert isinstance(log, dict) and log['real_batch_size'] == 7
+    assert log['critic_loss'] == 1.5 and log['actor_loss'] == (-2.0,)
+    assert set(log.keys()) == {'critic_loss', 'actor_loss', 'real_batch_size'} and len(log) == 3
+    assert dict(**log)['critic_loss'] == 1.5 and 'critic_loss' in log and log.get('missing', 3) == 3
+
+
+def test_subset_table_returns_the_requested_indices(monkeypatch):
+    import oracle_backend
+    oracle_backend.install(monkeypatch)
+    from bench import build_trainer
+    alg = build_trainer('gru', 2, 16)
+    for sub in ([3, 5], [5, 3], [0, 7], list(range(8))):
+        got = alg._subset_on_device(np.asarray(sub), 8)
+        assert got.dtype == torch.int32 and got.tolist() == sub
+    assert alg._subset_on_device(np.asarray([1, 2]), 8).data_ptr() == alg._subset_on_device(np.asarray([1, 2]), 8).data_ptr()
+
+
+def test_gemm_table_is_well_formed_and_inert_without_a_gpu():
+    """hip/gemm_tuning/gfx950.csv: validator header + one solution per (op, shape); the loader is a no-op on a CPU-only host."""
+    from offpolicy_rnn.hip import gemm_select
+    lines = [ln.strip() for ln in open(gemm_select.TABLE) if ln.strip()]
+    assert [ln.split(',')[1] for ln in lines[:5]] == ['PT_VERSION', 'HIP_VERSION', 'HIPBLASLT_VERSION', 'GCN_ARCH_NAME', 'ROCBLAS_VERSION']
+    keys = [tuple(ln.split(',')[:2]) for ln in lines[5:]]
+    assert len(keys) == len(set(keys)) > 100 and all(len(ln.split(',')) == 4 for ln in lines[5:])
+    assert any('gfx950' in ln for ln in lines[:5])
+    if not torch.cuda.is_available():
+        assert gemm_select.enable_tuned_gemms() is False
