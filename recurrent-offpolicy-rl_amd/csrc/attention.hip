@@ -25,7 +25,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr float NEG_BIG = -1e30f;
-constexpr int KT = 32;          // keys per tile
+constexpr int KT = 32;          // keys per MFMA score tile
+constexpr int KTB = 128;        // keys staged in LDS per barrier pair of the forward / dQ kernel (KTB / KT sub-tiles)
 constexpr int PADE = 8;         // bf16 elements of row padding in LDS tiles (16 bytes)
 
 __device__ __forceinline__ f32x16 zero16() {
@@ -95,14 +96,59 @@ __device__ __forceinline__ void stage_kv(const AttnParams& p, int which, int t0,
     }
 }
 
+// K / V tile staging split in two so that the global loads of tile kt+1 are in flight while tile kt is being consumed:
+// load_kv fetches this thread's 16-byte pieces into registers, store_kv writes them row-major and / or transposed to LDS.
+template <int HD>
+struct KVRegs { bf16x8 k[(KTB * HD / 8 + 255) / 256], v[(KTB * HD / 8 + 255) / 256]; };
+
+template <int HD>
+__device__ __forceinline__ void load_kv(const AttnParams& p, int t0, int len, int k0, int h, int tid, KVRegs<HD>& r) {
+    constexpr int NI = (KTB * HD / 8 + 255) / 256;
+#pragma unroll
+    for (int n = 0; n < NI; ++n) {
+        const int i = tid + n * 256;
+        const int key = i / (HD / 8), c8 = (i % (HD / 8)) * 8;
+        r.k[n] = zero8();
+        r.v[n] = zero8();
+        if (i < KTB * HD / 8 && k0 + key < len) {
+            const bf16_t* base = p.qkv + ((int64_t)(t0 + k0 + key) * 3 * p.H + h) * HD + c8;
+            r.k[n] = *reinterpret_cast<const bf16x8*>(base + (int64_t)1 * p.H * HD);
+            r.v[n] = *reinterpret_cast<const bf16x8*>(base + (int64_t)2 * p.H * HD);
+        }
+    }
+}
+template <int HD, bool KTR, bool VROW, bool VTR>     // K always row-major (+ transposed: KTR); V row-major and / or transposed
+__device__ __forceinline__ void store_kv(const KVRegs<HD>& r, int tid, bf16_t (*k_lds)[HD + PADE], bf16_t (*v_lds)[HD + PADE],
+                                         bf16_t (*tr_lds)[KTB + PADE]) {
+    constexpr int NI = (KTB * HD / 8 + 255) / 256;
+#pragma unroll
+    for (int n = 0; n < NI; ++n) {
+        const int i = tid + n * 256;
+        if (i < KTB * HD / 8) {
+            const int key = i / (HD / 8), c8 = (i % (HD / 8)) * 8;
+            *reinterpret_cast<bf16x8*>(&k_lds[key][c8]) = r.k[n];
+            if (VROW) *reinterpret_cast<bf16x8*>(&v_lds[key][c8]) = r.v[n];
+            if (KTR || VTR) {
+                const bf16x8 t = KTR ? r.k[n] : r.v[n];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) tr_lds[c8 + e][key] = t[e];
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------- forward
 // MODE 0: forward (O, lse).  MODE 1: dQ (needs dout, lse, delta).
+// The softmax work per score element is what bounds these kernels at hd = 32 (4 MFMAs per 32x32 tile), so it is kept
+// minimal: the ALiBi term is one add of a per-lane constant and a per-tile offset folded into the scale FMA, the causal /
+// length mask is evaluated only on tiles that cross the diagonal or the sequence end (wave-uniform branch), and the
+// accumulator is rescaled only when some lane's running maximum actually moved.
 template <int HD, int MODE>
 __global__ __launch_bounds__(256) void attn_q_kernel(AttnParams p) {
     constexpr int KS = HD / 16, ND = HD / 32;
-    __shared__ __attribute__((aligned(16))) bf16_t k_lds[KT][HD + PADE];
-    __shared__ __attribute__((aligned(16))) bf16_t v_lds[MODE == 1 ? KT : 1][HD + PADE];          // row-major V (dQ only)
-    __shared__ __attribute__((aligned(16))) bf16_t tr_lds[HD][KT + PADE];                          // V^T (fwd) or K^T (dQ)
+    __shared__ __attribute__((aligned(16))) bf16_t k_lds[KTB][HD + PADE];
+    __shared__ __attribute__((aligned(16))) bf16_t v_lds[MODE == 1 ? KTB : 1][HD + PADE];         // row-major V (dQ only)
+    __shared__ __attribute__((aligned(16))) bf16_t tr_lds[HD][KTB + PADE];                         // V^T (fwd) or K^T (dQ)
     const int s = blockIdx.y, h = blockIdx.z;
     const int t0 = p.cu[s], len = p.cu[s + 1] - t0;
     const int qb0 = blockIdx.x * 128;
@@ -132,68 +178,101 @@ __global__ __launch_bounds__(256) void attn_q_kernel(AttnParams p) {
     f32x16 acc[ND];
 #pragma unroll
     for (int t = 0; t < ND; ++t) acc[t] = zero16();
+    // ALiBi: -slope * (q - key) = slope * row(i) - slope * (q - k0); the first term is a per-lane constant per register
+    float crow[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) crow[i] = slope2 * (float)acc_row(i, hh);
 
     const int q_hi = min(len, qb0 + 128) - 1;                    // last query of this block
-    const int ntile = q_hi / KT + 1;                             // causal: keys <= q_hi
-    const int wq_hi = qb0 + w * 32 + 31;                         // last query of this wave
-    for (int kt = 0; kt < ntile; ++kt) {
-        const int k0 = kt * KT;
+    const int nkeys = q_hi + 1;                                  // causal: keys <= q_hi
+    const int wq_lo = qb0 + w * 32, wq_hi = wq_lo + 31;          // this wave's queries
+    KVRegs<HD> kv;
+    load_kv<HD>(p, t0, len, 0, h, tid, kv);
+    for (int kb = 0; kb < nkeys; kb += KTB) {
         __syncthreads();
-        stage_kv<HD, true, MODE == 1>(p, 1, t0, len, k0, h, k_lds, tr_lds, tid, 256);              // K (+ K^T for dQ)
-        if (MODE == 0) stage_kv<HD, false, true>(p, 2, t0, len, k0, h, nullptr, tr_lds, tid, 256); // V^T
-        else stage_kv<HD, true, false>(p, 2, t0, len, k0, h, v_lds, nullptr, tid, 256);            // V row-major
+        store_kv<HD, MODE == 1, MODE == 1, MODE == 0>(kv, tid, k_lds, v_lds, tr_lds);
         __syncthreads();
-        if (k0 > wq_hi) continue;                                // tile entirely in this wave's future (uniform per wave)
+        if (kb + KTB < nkeys) load_kv<HD>(p, t0, len, kb + KTB, h, tid, kv);   // in flight while this stage is consumed
+      for (int sub = 0; sub < KTB / KT; ++sub) {
+        const int k0 = kb + sub * KT, ko = sub * KT;
+        if (k0 > wq_hi || k0 >= nkeys) break;                    // the rest lies in this wave's future (uniform per wave)
         f32x16 st = zero16();
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
-            st = mfma(*reinterpret_cast<const bf16x8*>(&k_lds[r][16 * ks + 8 * hh]), qf[ks], st);
-        // scaled + biased + masked scores, base 2
+            st = mfma(*reinterpret_cast<const bf16x8*>(&k_lds[ko + r][16 * ks + 8 * hh]), qf[ks], st);
+        // scaled + biased (+ masked) scores, base 2
+        const bool masked = (k0 + KT - 1 > wq_lo) || (wq_hi >= len);          // tile crosses the diagonal / the sequence end
+        const float off = -slope2 * (float)(q - k0);
         float sc[16];
         float mloc = NEG_BIG;
+        if (masked) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int key = k0 + acc_row(i, hh);
-            const bool ok = q_ok && key <= q;                    // (key <= q < len)
-            sc[i] = ok ? st[i] * c1 - slope2 * (float)(q - key) : NEG_BIG;
-            mloc = fmaxf(mloc, sc[i]);
+            for (int i = 0; i < 16; ++i) {
+                const bool ok = q_ok && (k0 + acc_row(i, hh)) <= q;       // (key <= q < len)
+                sc[i] = ok ? __builtin_fmaf(st[i], c1, crow[i] + off) : NEG_BIG;
+                mloc = fmaxf(mloc, sc[i]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                sc[i] = __builtin_fmaf(st[i], c1, crow[i] + off);
+                mloc = fmaxf(mloc, sc[i]);
+            }
         }
         f32x16 pt;
         if (MODE == 0) {
             mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
             const float mnew = fmaxf(m, mloc);
-            const float alpha = fast_exp2(m - mnew);
             float psum = 0.f;
+            if (masked) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float e = sc[i] > 0.5f * NEG_BIG ? fast_exp2(sc[i] - mnew) : 0.f;
-                pt[i] = e;
-                psum += e;
+                for (int i = 0; i < 16; ++i) {
+                    const float e = sc[i] > 0.5f * NEG_BIG ? fast_exp2(sc[i] - mnew) : 0.f;
+                    pt[i] = e;
+                    psum += e;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float e = fast_exp2(sc[i] - mnew);
+                    pt[i] = e;
+                    psum += e;
+                }
             }
-            l = l * alpha + psum;
+            if (__any(mnew != m)) {                              // some lane's maximum moved: rescale the running sums
+                const float alpha = fast_exp2(m - mnew);
+                l *= alpha;
+#pragma unroll
+                for (int t = 0; t < ND; ++t)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[t][i] *= alpha;
+            }
+            l += psum;
             m = mnew;
-#pragma unroll
-            for (int t = 0; t < ND; ++t)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[t][i] *= alpha;
         } else {
             // dP^T = V dO^T ; dS^T = P^T (dP^T - delta) * scale
             f32x16 dp = zero16();
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
-                dp = mfma(*reinterpret_cast<const bf16x8*>(&v_lds[r][16 * ks + 8 * hh]), dof[ks], dp);
+                dp = mfma(*reinterpret_cast<const bf16x8*>(&v_lds[ko + r][16 * ks + 8 * hh]), dof[ks], dp);
+            if (masked) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float e = sc[i] > 0.5f * NEG_BIG ? fast_exp2(sc[i] - lse2) : 0.f;
-                pt[i] = e * (dp[i] - dlt) * p.scale;
+                for (int i = 0; i < 16; ++i) {
+                    const float e = sc[i] > 0.5f * NEG_BIG ? fast_exp2(sc[i] - lse2) : 0.f;
+                    pt[i] = e * (dp[i] - dlt) * p.scale;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) pt[i] = fast_exp2(sc[i] - lse2) * (dp[i] - dlt) * p.scale;
             }
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             const bf16x8 bfr = acc_to_frag(pt, s2);
 #pragma unroll
-            for (int t = 0; t < ND; ++t) acc[t] = mfma(tr_frag(&tr_lds[32 * t + r][0], s2, hh), bfr, acc[t]);
+            for (int t = 0; t < ND; ++t) acc[t] = mfma(tr_frag(&tr_lds[32 * t + r][ko], s2, hh), bfr, acc[t]);
         }
+      }
     }
     // epilogue: acc[t][reg] = X^T[d = 32t + row(reg)][q]
     float inv = 1.f;

@@ -1,0 +1,23 @@
+"""Standalone driver of the var-len attention kernels at config-3 shapes (32 rows: sequences of 1 and 1026 tokens, H 8, hd 32)."""
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'recurrent-offpolicy-rl_amd')]
+import torch
+from offpolicy_rnn.hip import ops
+rows, H, hd = 32, 8, 32
+lens = [1, 1026] * rows
+cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device='cuda')
+T = sum(lens)
+qkv = (torch.randn(T, 3, H, hd, device='cuda') * 0.5).to(torch.bfloat16).requires_grad_(True)
+slopes = torch.tensor([2.0 ** (-8.0 * (i + 1) / H) for i in range(H)], device='cuda')
+for _ in range(5):
+    out = ops.attn_varlen(qkv, cu, max(lens), slopes)
+    out.backward(torch.ones_like(out))
+torch.cuda.synchronize()
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+a.record()
+for _ in range(20):
+    with torch.no_grad():
+        ops.attn_varlen(qkv, cu, max(lens), slopes)
+b.record(); torch.cuda.synchronize()
+print(f'fwd {a.elapsed_time(b) / 20 * 1e3:.1f} us')
