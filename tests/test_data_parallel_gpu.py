@@ -1,0 +1,67 @@
+"""world_size-2 data parallelism with the REAL HIP kernels: two processes share cuda:0 and exchange the flat gradient buffer
+through `gloo` (it stages CUDA tensors through the host; RCCL needs one GPU per rank and is exercised by the driver's
+multi-GPU bench).  Two ranks holding the SAME rows and the same actor noise must reproduce the single-process update -
+this pins the masked-sum losses + piggy-backed valid count + flat AdamW normalisation on the device path."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+pytestmark = pytest.mark.gpu
+
+
+def _build(rnn):
+    sys.path[:0] = [HERE, os.path.dirname(HERE), os.path.join(os.path.dirname(HERE), 'recurrent-offpolicy-rl_amd')]
+    from test_host_logic import _push, _synth, make_parameter
+    from offpolicy_rnn import alg_init
+    torch.manual_seed(0)
+    np.random.seed(0)
+    alg = alg_init(make_parameter(rnn, sac_batch_size=30, cuda_inference=True))
+    rs = np.random.RandomState(3)
+    for n in (12, 5, 7, 12, 9):
+        o, a, r = _synth(rs, n, 5, 3)
+        _push(alg.replay_buffer, o, a, r, early_done=(n != 12))
+    torch.manual_seed(11)
+    torch.cuda.manual_seed_all(11)
+    np.random.seed(11)
+    return alg
+
+
+def _run(alg, steps=2):
+    for _ in range(steps):
+        log = alg.train_one_batch()
+        alg.grad_num += 1
+    torch.cuda.synchronize()
+    return dict(policy=alg.policy.store.flat[:alg.policy.store.numel].detach().cpu(),
+                value=alg.values[0].store.flat[:alg.values[0].store.numel].detach().cpu(),
+                alpha=alg.log_sac_alpha.detach().cpu(), critic_loss=log['critic_loss'])
+
+
+def _worker(rank, world, port, rnn, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    alg = _build(rnn)
+    alg.grad_sync.__init__()
+    assert alg.grad_sync.world == world and alg.device.type == 'cuda'
+    torch.save(_run(alg), os.path.join(out_dir, f'rank{rank}.pt'))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('rnn', ['smamba_s8_c4_b1_nln', 'gilr'])
+def test_two_ranks_on_one_gpu_reproduce_the_single_process_update(tmp_path, rnn):
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from test_data_parallel import _free_port
+    mp.spawn(_worker, args=(2, _free_port(), rnn, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(tmp_path, f'rank{i}.pt')) for i in range(2))
+    for k in ('policy', 'value', 'alpha'):
+        assert torch.equal(r0[k], r1[k]), f'{k} diverged across ranks'
+    ref = _run(_build(rnn))                          # single process, same rows, same noise
+    for k in ('policy', 'value', 'alpha'):
+        np.testing.assert_allclose(r0[k].numpy(), ref[k].numpy(), rtol=2e-4, atol=2e-6, err_msg=k)
