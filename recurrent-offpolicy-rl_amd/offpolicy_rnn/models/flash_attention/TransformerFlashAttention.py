@@ -74,6 +74,11 @@ class RMSNorm(nn.Module):
         return x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + self.eps) * self.weight
 
 
+def _norm(mod, x, residual, prenorm):
+    fn = ops.rms_norm_fn if isinstance(mod, RMSNorm) else ops.layer_norm_fn
+    return fn(x, mod.weight, getattr(mod, 'bias', None), residual=residual, eps=mod.eps, prenorm=prenorm)
+
+
 class MHA(nn.Module):
     """Packed-QKV multi-head attention, causal + ALiBi, computed in bf16 (parameters stay fp32)."""
 
@@ -116,10 +121,13 @@ class DecoderLayer(nn.Module):
         self.mha_norm = nn.LayerNorm(d_model) if ln else RMSNorm(d_model)
         self.ffn_norm = nn.LayerNorm(d_model) if ln else RMSNorm(d_model)
 
-    def forward(self, x, cu_seqlens, max_seqlen):
-        a = self.mha(self.mha_norm(x), cu_seqlens, max_seqlen).to(torch.float32)
-        x = self.dropout(a) + x
-        return self.dropout(self.ffn(self.ffn_norm(x))) + x
+    def forward(self, h, residual, cu_seqlens, max_seqlen):
+        """Pre-norm block on a (branch output h, running residual) pair: every `x = branch + x` of the reference block
+        (TransformerFlashAttention.py:76-95) is folded into the following norm (fused add+norm kernel, fp32 residual)."""
+        normed, residual = _norm(self.mha_norm, h, residual, prenorm=True)
+        a = self.mha(normed, cu_seqlens, max_seqlen).to(torch.float32)
+        normed, residual = _norm(self.ffn_norm, self.dropout(a), residual, prenorm=True)
+        return self.dropout(self.ffn(normed)), residual
 
 
 class TransformerDecoder(nn.Module):
@@ -142,8 +150,9 @@ class TransformerDecoder(nn.Module):
             packed = PackedSeqs(seqlens.detach().cpu().numpy(), row_len, x.device)
         flat = x.reshape(batch * row_len, dim)
         t = flat.index_select(0, packed.indices)
+        residual = None
         for layer in self.decoder_layers:
-            t = layer(t, packed.cu_seqlens, packed.max_seqlen)
-        t = self.output_fc(self.output_ln(t))
+            t, residual = layer(t, residual, packed.cu_seqlens, packed.max_seqlen)
+        t = self.output_fc(_norm(self.output_ln, t, residual, prenorm=False))
         out = torch.zeros_like(flat).index_copy(0, packed.indices, t)
         return out.view(batch, row_len, dim)

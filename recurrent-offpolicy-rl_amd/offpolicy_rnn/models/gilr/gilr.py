@@ -21,7 +21,8 @@ class PositionWiseFeedForward(nn.Module):
 
     def forward(self, x):
         y = self.dropout(self.activation(self.w_1(x)))
-        return self.layer_norm(self.dropout(self.w_2(y)) + x)
+        return ops.layer_norm_fn(self.dropout(self.w_2(y)), self.layer_norm.weight, self.layer_norm.bias, residual=x,
+                                 eps=self.layer_norm.eps)        # fused add + LayerNorm
 
 
 class GILRLayer(nn.Module):
