@@ -47,6 +47,19 @@ def _frozen_parameters(model):
             p.requires_grad_(True)
 
 
+@contextlib.contextmanager
+def _ensemble_subset(model, member_index):
+    from ..models.ensemble_linear_model import EnsembleLinear
+    layers = [l for l in model.uni_network.layer_list if isinstance(l, EnsembleLinear)]
+    for l in layers:
+        l.member_index = member_index
+    try:
+        yield
+    finally:
+        for l in layers:
+            l.member_index = None
+
+
 class DeferredLog(dict):
     """The update's log dict.  Host-side entries are plain items; the device scalars travel in one asynchronous copy into
     pinned memory and become floats on first access (`resolve()`), so a caller that does not read them - a training loop
@@ -212,7 +225,7 @@ class SACFullLengthRNNEnsembleQ(SAC):
         _, _, sample, logp, _, _ = self.policy.forward(b['next_state'], b['state'], b['action'], hidden, b['reward'])
         return sample, logp
 
-    def _subset_on_device(self, subset: np.ndarray, num_ensemble: int = 0) -> torch.Tensor:
+    def _subset_on_device(self, subset: np.ndarray, num_ensemble: int = 0, as_long: bool = False) -> torch.Tensor:
         """int32 device copy of a critic-subset index vector without a per-update host->device copy (a pageable copy blocks
         the host until the launch queue has drained): all ordered subsets of that size are uploaded ONCE as a table
         (8 critics, REDQ pairs: 56 rows) and a row view is returned; oversized tables fall back to a per-subset cache."""
@@ -225,15 +238,17 @@ class SACFullLengthRNNEnsembleQ(SAC):
             rows = None
             if math.perm(E, m) <= 4096:
                 perms = list(itertools.permutations(range(E), m))
-                rows = ({p: i for i, p in enumerate(perms)}, torch.tensor(perms, dtype=torch.int32).to(self.device))
+                t32 = torch.tensor(perms, dtype=torch.int32).to(self.device)
+                rows = ({p: i for i, p in enumerate(perms)}, t32, t32.long())
             tables[(E, m)] = rows
         rows = tables[(E, m)]
         if rows is not None and tuple(sub.tolist()) in rows[0]:
-            return rows[1][rows[0][tuple(sub.tolist())]]
+            return rows[2 if as_long else 1][rows[0][tuple(sub.tolist())]]
         cache = self.__dict__.setdefault('_subset_cache', {})
-        key = sub.tobytes()
+        key = (sub.tobytes(), as_long)
         if key not in cache:
-            cache[key] = torch.from_numpy(sub.copy()).to(self.device)
+            t = torch.from_numpy(sub.copy()).to(self.device)
+            cache[key] = t.long() if as_long else t
         return cache[key]
 
     def _select_target_ensemble(self, num_ensemble: int) -> np.ndarray:
@@ -242,8 +257,17 @@ class SACFullLengthRNNEnsembleQ(SAC):
     def get_target_Q(self, b, policy_hidden, target_hiddens, stats):
         with torch.no_grad():
             sample, logp = self._next_action(b, policy_hidden)
-            q = self.target_values[0].forward(b['next_state'], b['state'], b['action'], sample, target_hiddens[0], b['reward'])[0]
-            idx = self._subset_on_device(self._select_target_ensemble(q.shape[0]), q.shape[0])
+            tv = self.target_values[0]
+            E = tv.uni_network.layer_list[-1].num_ensemble
+            subset = np.asarray(self._select_target_ensemble(E))
+            if subset.size < E:
+                # REDQ: only the sampled target critics are evaluated (same numbers: the others were never used)
+                with _ensemble_subset(tv, self._subset_on_device(subset, E, as_long=True)):
+                    q = tv.forward(b['next_state'], b['state'], b['action'], sample, target_hiddens[0], b['reward'])[0]
+                idx = self._subset_on_device(np.arange(subset.size), subset.size)
+            else:
+                q = tv.forward(b['next_state'], b['state'], b['action'], sample, target_hiddens[0], b['reward'])[0]
+                idx = self._subset_on_device(subset, E)
             return ops.sac_target(q, idx, logp if self.base_algorithm == 'sac' else None, self.log_sac_alpha.detach(), b['reward'],
                                   b['done'], b['mask'], self.parameter.gamma, self.Q_guard.state, stats)
 

@@ -120,9 +120,11 @@ class _Head(torch.autograd.Function):
 def ensemble_head(hidden: 'EnsembleLinear', out: 'EnsembleLinear', x: torch.Tensor) -> torch.Tensor:
     """`out(elu(hidden(x)))` for per-member x [E, ..., in] and out.weight [E, H, 1] (RNNBase.forward routes the last two
     layers of an efc-E critic head here)."""
-    E, n_in, H = hidden.weight.shape
+    w2, b2 = hidden.active_params()
+    w3, b3 = out.active_params()
+    E, n_in, H = w2.shape
     lead = tuple(x.shape[1:-1])
-    q = _Head.apply(x.reshape(E, -1, n_in), hidden.weight, hidden.bias, out.weight, out.bias if out.use_bias else None)
+    q = _Head.apply(x.reshape(E, -1, n_in), w2, b2, w3, b3)
     return q.reshape((E,) + lead + (1,))
 
 
@@ -130,7 +132,7 @@ def head_fusable(hidden, hidden_act, out, out_act, x) -> bool:
     return (isinstance(hidden, EnsembleLinear) and isinstance(out, EnsembleLinear) and isinstance(hidden_act, nn.ELU)
             and hidden_act.alpha == 1.0 and isinstance(out_act, nn.Identity) and hidden.use_bias
             and out.weight.shape[2] == 1 and out.weight.shape[1] == hidden.weight.shape[2] and hidden.weight.shape[2] % 4 == 0
-            and x.dim() >= 3 and x.shape[0] == hidden.num_ensemble and x.dtype == torch.float32
+            and x.dim() >= 3 and x.shape[0] == hidden.active_members() and x.dtype == torch.float32
             and (hidden.desire_ndim is None or hidden.desire_ndim == x.dim()))
 
 
@@ -144,10 +146,22 @@ class EnsembleLinear(nn.Module):
         if bias:
             self.bias = nn.Parameter(torch.zeros(num_ensemble, 1, output_dim))
         nn.init.trunc_normal_(self.weight, std=1 / (2 * input_dim ** 0.5))
+        self.member_index = None            # optional int64 device vector: evaluate only these ensemble members
+
+    def active_members(self) -> int:
+        return self.num_ensemble if self.member_index is None else int(self.member_index.numel())
+
+    def active_params(self):
+        """(weight, bias) of the members being evaluated: all of them, or the `member_index` subset (REDQ's target only
+        needs its M sampled critics - reference sac_full_length_rnn_redq.py:16-34 evaluates all E and discards E - M)."""
+        b = self.bias if self.use_bias else None
+        if self.member_index is None:
+            return self.weight, b
+        return self.weight.index_select(0, self.member_index), None if b is None else b.index_select(0, self.member_index)
 
     def forward(self, x: torch.Tensor, act: str = None) -> torch.Tensor:
         """act: None, or 'elu' to fuse the layer's activation module into the bias pass (RNNBase.forward does so)."""
-        W = self.weight
+        W, b = self.active_params()
         E, n_in, n_out = W.shape
         nd = x.dim()
         shared = True                       # True: every member sees the same input (x has no ensemble axis)
@@ -157,7 +171,6 @@ class EnsembleLinear(nn.Module):
             shared = not ((self.desire_ndim is None or self.desire_ndim == 4) and x.shape[0] == E)
         elif nd == 5:
             shared = False
-        b = self.bias if self.use_bias else None
         if shared:
             lead = tuple(x.shape[:-1])
             y = _SharedInput.apply(x.reshape(-1, n_in), W, b, act)
