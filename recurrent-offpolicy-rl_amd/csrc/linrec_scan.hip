@@ -244,18 +244,6 @@ __global__ __launch_bounds__(NSEG * 64) void linrec_complex_bwd_kernel(const flo
     }
 }
 
-__global__ void linrec_complex_reduce_kernel(const float* part, int nrow, int C, float* dlr, float* dli, float* dgm) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float a = 0.f, b = 0.f, g = 0.f;
-    for (int r = 0; r < nrow; ++r) {
-        const float* p = part + (int64_t)r * 3 * C + c;
-        a += p[0]; b += p[C]; g += p[2 * (int64_t)C];
-    }
-    dlr[c] = a; dli[c] = b;
-    if (dgm) dgm[c] = g;
-}
-
 }  // namespace
 
 extern "C" int resel_linrec_real_fwd(const float* v, const float* f, const float* start, const float* h0, float* h,
@@ -300,7 +288,10 @@ extern "C" int resel_linrec_complex_bwd(const float* vr, const float* vi, const 
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(linrec_complex_bwd_kernel, dim3((C + TILE_C - 1) / TILE_C, B), dim3(NSEG * 64), 0, s,
                        vr, vi, lam_re, lam_im, gamma, start, h0r, h0i, hr, hi, dhr, dhi, dvr, dvi, (float*)workspace, B, L, C);
-    hipLaunchKernelGGL(linrec_complex_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)workspace, B * NSEG, C,
-                       dlam_re, dlam_im, dgamma);
+    // per-(row, segment) partials [B * NSEG][3][C] -> d lambda_re, d lambda_im, d gamma (fixed summation order)
+    const float* part = (const float*)workspace;
+    launch_colsum(part, 3 * (int64_t)C, B * NSEG, C, dlam_re, s);
+    launch_colsum(part + C, 3 * (int64_t)C, B * NSEG, C, dlam_im, s);
+    if (dgamma) launch_colsum(part + 2 * (int64_t)C, 3 * (int64_t)C, B * NSEG, C, dgamma, s);
     return launch_status();
 }

@@ -14,7 +14,7 @@ import tempfile
 
 import torch
 
-TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'gemm_tuning', 'gfx950.csv')
+TABLE = os.environ.get('RESEL_GEMM_TABLE') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'gemm_tuning', 'gfx950.csv')
 _state = {'loaded': None}
 
 
