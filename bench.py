@@ -160,7 +160,7 @@ def main():
         dt, trained = tmax.item(), tot.item()
     if rank != 0:
         return
-    Bsz, Tp = args.rows, alg.replay_buffer._last_batch_array.shape[1]
+    Bsz, Tp = args.rows, alg.replay_buffer._last_batch_shape[1]
     kern = {name: dict(launches=n, avg_us=avg) for name, (n, avg) in prof.items()}
     out = {
         'metric': 'env-steps/sec trained', 'value': trained / dt, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps,

@@ -234,6 +234,17 @@ size_t resel_ensemble_head_bwd_workspace_bytes(int64_t rows, int H, int64_t rows
 int resel_ensemble_head_bwd(const float* gq, const float* a, const float* w3, float* gy, float* db2, float* dw3, void* workspace,
                             int64_t rows, int H, int64_t rows_per_seg, resel_stream_t stream);
 
+/* ---- packed trajectory batch from a device-resident replay ring --------------------------------------------------
+ * Device counterpart of NestedMemoryArray.sample_trajs' packing loop (reference buffers/transition_buffer/
+ * nested_replay_memory.py:140-176) plus the trainer's flag surgery (algorithm/sac_full_length_rnn_ensembleQ.py:338-342).
+ * buffer [capacity, W] fp32 ring; segments [nseg][4] int32 = (batch row, first slot, length incl. `skip` leading slots,
+ * first transition index) - the host-side sampling plan; pre_pairs [npairs][2] = (dst column, src column) of the pre-step
+ * slot (next_state <- state, reward <- reward_input, state <- last_state of the trajectory's first transition).
+ * out [rows, Tp, W + 3]: the W field columns, then validity, the target pass's validity and start flags. */
+int resel_gather_trajs(const float* buffer, int W, const int* segments, int nseg, int max_len, int skip, int rows, int Tp,
+                       int c_mask, int c_start, int c_done, int c_timeout, const int* pre_pairs, int npairs,
+                       float* out, resel_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

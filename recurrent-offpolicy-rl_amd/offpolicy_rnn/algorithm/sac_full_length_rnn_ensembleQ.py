@@ -156,6 +156,7 @@ class SACFullLengthRNNEnsembleQ(SAC):
         self._stats = torch.zeros(2, dtype=torch.float32, device=self.device)
 
     step = property(lambda self: self.train_one_batch)          # north_star's "algorithm.step()" alias
+    device_replay = True        # keep a device mirror of the replay ring and assemble sampled batches on the GPU (CUDA only)
 
     def _get_skip_len(self):
         skip = 0
@@ -197,6 +198,13 @@ class SACFullLengthRNNEnsembleQ(SAC):
         d0, t0 = R['done'][0], R['timeout'][0]
         host[..., d0][arr[..., t0] > 0] = 0                          # time-limit terminations bootstrap
         dev = staged.to(self.device, non_blocking=True)
+        return self._batch_views(dev, table)
+
+    def _batch_views(self, dev, table):
+        """Field / flag views of the device batch array (rows, T', W + 3)."""
+        rows, T = dev.shape[:2]
+        W = dev.shape[2] - 3
+        R = self.replay_buffer.name2range
         out = {name: dev[..., R[name][0]:R[name][1]] for name in FIELDS}
         out['valid'], out['total_valid'], out['total_start'] = dev[..., W:W + 1], dev[..., W + 1:W + 2], dev[..., W + 2:W + 3]
         # per-row sequence-length tables (reference :358-366) are consumed by attention layers only
@@ -312,11 +320,19 @@ class SACFullLengthRNNEnsembleQ(SAC):
         host: Dict[str, float] = {}
         for utd_idx in range(par.utd):
             self.timer.register_point(tag='sample_trajs', level=2)
-            batch, batch_size, valid, table = self.replay_buffer.sample_trajs(
-                par.sac_batch_size, None, randomize_mask=par.randomize_mask, valid_number_post_randomized=par.valid_number_post_randomized,
-                equalize_data_of_each_traj=True, random_trunc_traj=par.random_trunc_traj, nest_stack_trajs=self.allow_nest_stack)
-            self.timer.register_end(level=2)
-            b = self._upload_batch(batch, valid, table)
+            if getattr(self, 'device_replay', False) and self.device.type == 'cuda' \
+                    and self.replay_buffer.device_supported(randomize_mask=par.randomize_mask):
+                # device-resident ring: the host decides WHICH trajectories go where, the batch array is built on the GPU
+                dev, batch_size, table = self.replay_buffer.sample_trajs_device(
+                    self.device, par.sac_batch_size, None, random_trunc_traj=par.random_trunc_traj, nest_stack_trajs=self.allow_nest_stack)
+                self.timer.register_end(level=2)
+                b = self._batch_views(dev, table)
+            else:
+                batch, batch_size, valid, table = self.replay_buffer.sample_trajs(
+                    par.sac_batch_size, None, randomize_mask=par.randomize_mask, valid_number_post_randomized=par.valid_number_post_randomized,
+                    equalize_data_of_each_traj=True, random_trunc_traj=par.random_trunc_traj, nest_stack_trajs=self.allow_nest_stack)
+                self.timer.register_end(level=2)
+                b = self._upload_batch(batch, valid, table)
             rows = b['state'].shape[0]
             value, target_value = self.values[0], self.target_values[0]
             # hidden states + side channels: the target pass uses the one-slot-earlier flags (reference :368-378)

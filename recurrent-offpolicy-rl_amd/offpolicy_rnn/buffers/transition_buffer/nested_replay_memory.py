@@ -133,4 +133,79 @@ class NestedMemoryArray(MemoryArray):
         if randomize_mask and not equalize_data_of_each_traj:
             self._mask_rnd_select(result.mask, valid_number_post_randomized)
         self._last_batch_array = view                           # the single array behind every field view
+        self._last_batch_shape = view.shape[:2]
         return result, total_size, valid, traj_len_array
+
+    # ------------------------------------------------------------------ device-resident variant
+    def device_supported(self, randomize_mask=False, **_):
+        """The device packer covers every sampling mode whose randomness lives in the PLAN (which trajectories, truncated
+        lengths, row packing); per-transition mask randomisation stays on the host path."""
+        return not randomize_mask
+
+    def _mirror(self, device):
+        """Device copy of the ring, refreshed for the rows written since the last call (a rollout adds one trajectory
+        between updates; the synthetic benchmark fills the ring once)."""
+        import torch
+        st = self.__dict__.setdefault('_dev_state', {'buf': None})
+        dirty = getattr(self, '_dirty', None)
+        if st['buf'] is None or st['buf'].device != device or st['buf'].shape != self.memory_buffer.shape or dirty is None \
+                or len(dirty) > 64:
+            st['buf'] = torch.from_numpy(self.memory_buffer).to(device)
+        else:
+            for s0, n in dirty:                      # through pinned memory: a pageable copy would stall the launch queue
+                rows = torch.from_numpy(self.memory_buffer[s0:s0 + n])
+                st['buf'][s0:s0 + n].copy_(rows.pin_memory() if device.type == 'cuda' else rows, non_blocking=True)
+        self._dirty = []
+        return st['buf']
+
+    def sample_trajs_device(self, device, batch_size, max_sample_size=None, get_all=False, random_trunc_traj=False,
+                            nest_stack_trajs=True):
+        """Same sampling decisions (and numpy RNG consumption) as `sample_trajs`, but the batch array is assembled on the
+        device by `ops.gather_trajs` from the device mirror of the ring: returns (batch [rows, T', W + 3] on `device`,
+        total_size, traj_len_array)."""
+        import torch
+        from ...hip import ops
+        skip = self._skip_step
+        if get_all:
+            picked = np.arange(self.available_traj_num)
+        else:
+            if random_trunc_traj:
+                batch_size *= 2
+            picked = self._traj_ind_sample(batch_size, max_sample_size)
+        if random_trunc_traj:
+            lens = [np.random.randint(0, self.trajectory_length[i]) + 1 + skip for i in picked]
+        else:
+            lens = [self.trajectory_length[i] + skip for i in picked]
+        starts = [self.trajectory_start[i] for i in picked]
+        groups = self.load_equalize(lens, self.max_traj_step) if nest_stack_trajs else [[i] for i in range(len(lens))]
+        nrow = len(groups)
+        total_size = int(sum(lens) - len(lens) * skip)
+        plan, table, longest = [], [], 0
+        for r, grp in enumerate(groups):
+            pos, seq = 0, [1]
+            for j in grp:
+                plan.append((r, pos, lens[j], starts[j]))
+                seq.append(lens[j])
+                pos += lens[j]
+            longest = max(longest, pos)
+            table.append(seq)
+        longest += 1
+        traj_len_array = np.zeros((nrow, max(len(s) for s in table)))
+        for r, seq in enumerate(table):
+            traj_len_array[r, :len(seq)] = seq
+        R = self.name2range
+        pairs = []
+        for dst, src in (('next_state', 'state'), ('reward', 'reward_input'), ('state', 'last_state')):
+            pairs += list(zip(range(*R[dst]), range(*R[src])))
+        st = self.__dict__.setdefault('_dev_plan', {})
+        if st.get('device') != device:
+            st.update(device=device, pairs=torch.tensor(pairs, dtype=torch.int32).to(device), pinned=None)
+        seg = np.asarray(plan, dtype=np.int32)
+        if st['pinned'] is None or st['pinned'].shape[0] < len(plan):
+            st['pinned'] = torch.empty((max(2 * len(plan), 256), 4), dtype=torch.int32, pin_memory=device.type == 'cuda')
+        st['pinned'][:len(plan)] = torch.from_numpy(seg)
+        seg_dev = st['pinned'][:len(plan)].to(device, non_blocking=True)
+        out = ops.gather_trajs(self._mirror(device), seg_dev, int(seg[:, 2].max()), skip, nrow, longest, R['mask'][0], R['start'][0],
+                               R['done'][0], R['timeout'][0] if R['timeout'][1] > R['timeout'][0] else -1, st['pairs'])
+        self._last_batch_shape = (nrow, longest)
+        return out, total_size, traj_len_array

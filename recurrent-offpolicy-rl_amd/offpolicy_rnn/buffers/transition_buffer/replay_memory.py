@@ -48,6 +48,7 @@ class MemoryArray:
         self.transition_count = 0
         self._last_saving_time = 0
         self._last_saving_size = 0
+        self._dirty: List[Tuple[int, int]] = []      # (first row, count) written since a device mirror last synchronised
 
     # ------------------------------------------------------------------ layout
     def _init_memory_buffer(self, transition: Transition):
@@ -108,6 +109,7 @@ class MemoryArray:
             del self.trajectory_start[:drop]
             del self.trajectory_length[:drop]
         self.trajectory_start.append(self.ptr)
+        self._dirty.append((self.ptr, n))
         for tr in memory:
             self.memory_buffer[self.ptr] = self.transition_to_array(tr)[0]
             self.ptr += 1
@@ -136,6 +138,7 @@ class MemoryArray:
             if b > a:
                 rows[:, a:b] = np.asarray(fields[name], dtype=np.float64).reshape(n, -1)
         self.trajectory_start.append(self.ptr)
+        self._dirty.append((self.ptr, n))
         self.trajectory_length.append(n)
         self.transition_count += n
         self.ptr += n

@@ -56,6 +56,7 @@ SIGNATURES = {
     'resel_ensemble_head_fwd': (c_int, [P, P, P, P, P, L, I, L, S]),
     'resel_ensemble_head_bwd_workspace_bytes': (c_size_t, [L, I, L]),
     'resel_ensemble_head_bwd': (c_int, [P, P, P, P, P, P, P, L, I, L, S]),
+    'resel_gather_trajs': (c_int, [P, I, P, I, I, I, I, I, I, I, I, I, P, I, P, S]),
 }
 
 

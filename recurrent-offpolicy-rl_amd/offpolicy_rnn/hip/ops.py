@@ -604,6 +604,20 @@ def linear_act(x, weight, bias, act):
 
 
 @torch.no_grad()
+def gather_trajs(buffer, segments, max_len, skip, rows, row_len, c_mask, c_start, c_done, c_timeout, pre_pairs):
+    """Packed batch [rows, row_len, W + 3] from the device ring `buffer` [capacity, W] and the int32 plan `segments` [nseg, 4]
+    (row, first slot, length incl. skip, first transition); see include/resel_hip.h `resel_gather_trajs`."""
+    _need_cuda('gather_trajs', buffer, segments, pre_pairs)
+    assert buffer.dtype == torch.float32 and buffer.is_contiguous() and segments.dtype == torch.int32 and segments.is_contiguous()
+    W = buffer.shape[1]
+    out = torch.empty(rows, row_len, W + 3, dtype=torch.float32, device=buffer.device)
+    check(lib().resel_gather_trajs(_p(buffer), W, _p(segments), segments.shape[0], int(max_len), int(skip), int(rows), int(row_len),
+                                   int(c_mask), int(c_start), int(c_done), int(c_timeout), _p(pre_pairs), pre_pairs.shape[0], _p(out),
+                                   _stream()), 'gather_trajs')
+    return out
+
+
+@torch.no_grad()
 def soft_update_(target_flat, online_flat, tau):
     _need_cuda('soft_update', target_flat, online_flat)
     check(lib().resel_soft_update(_p(target_flat), _p(online_flat), float(tau), target_flat.numel(), _stream()), 'soft_update')

@@ -23,4 +23,4 @@ pr = cProfile.Profile(); pr.enable()
 for _ in range(3):
     alg.train_one_batch(); alg.grad_num += 1
 pr.disable(); torch.cuda.synchronize()
-st = pstats.Stats(pr); st.sort_stats('cumulative').print_stats(18); st.print_callers("method 'to' of")
+st = pstats.Stats(pr); st.sort_stats('tottime').print_stats(28)
