@@ -18,6 +18,25 @@ TABLE = os.environ.get('RESEL_GEMM_TABLE') or os.path.join(os.path.dirname(os.pa
 _state = {'loaded': None}
 
 
+def _read_with_current_validators(tunable, path):
+    """The table is rejected when any validator string differs (e.g. a point release of the same library build).  Solution
+    names are stable across such releases, so retry once with this process' validator lines; entries the libraries no
+    longer know are ignored by TunableOp.  Only when the architecture is still gfx950."""
+    try:
+        cur = dict(tunable.get_validators())
+        old = dict(ln.strip().split(',')[1:3] for ln in open(path) if ln.startswith('Validator'))
+        if 'gfx950' not in cur.get('GCN_ARCH_NAME', '') or cur == old:
+            return False
+        tmp = os.path.join(tempfile.gettempdir(), f'resel_gemm_table_{os.getpid()}.csv')
+        with open(tmp, 'w') as fh:
+            for k, v in cur.items():
+                fh.write(f'Validator,{k},{v}\n')
+            fh.writelines(ln for ln in open(path) if not ln.startswith('Validator'))
+        return bool(tunable.read_file(tmp))
+    except Exception:
+        return False
+
+
 def enable_tuned_gemms(path=TABLE):
     """Idempotent; returns True when the table was accepted (validators - torch / rocBLAS / hipBLASLt versions and the
     gfx950 arch string - must match the running stack, otherwise the libraries' defaults stay in force)."""
@@ -36,6 +55,8 @@ def enable_tuned_gemms(path=TABLE):
         except AttributeError:
             pass
         ok = bool(tunable.read_file(path))
+        if not ok:
+            ok = _read_with_current_validators(tunable, path)
         if not ok:
             tunable.enable(False)
     _state['loaded'] = ok
