@@ -193,7 +193,11 @@ __global__ __launch_bounds__(256) void gru_fwd_persistent_kernel(GruFwd p, u64* 
             }
         }
         __syncthreads();
-        if (s_fail) { if (tid == 0) atomicExch(err, 1); return; }     // uniform: written before the barrier
+        if (s_fail) {                                // uniform: written before the barrier.  Fail LOUDLY: poison the output
+            if (tid == 0) atomicExch(err, 1);
+            if (out_thr) p.h_all[((int64_t)(b0 + ro) * p.L + t) * H + uo] = __builtin_nanf("");
+            return;
+        }
 #pragma unroll
         for (int r = 0; r < RG; ++r) {
             float a[3] = {0.f, 0.f, 0.f};
@@ -394,7 +398,11 @@ __global__ __launch_bounds__(256) void gru_bwd_persistent_kernel(GruBwd p, u64* 
             if (u / US == s) s_dz[r][u % US] = dhz;
         }
         __syncthreads();
-        if (s_fail) { if (tid == 0) atomicExch(err, 2); return; }
+        if (s_fail) {                                // fail loudly: poison this step's projection gradients
+            if (tid == 0) atomicExch(err, 2);
+            if (tid < RG * US && b0 + (tid >> 4) < p.B) p.dgi[((int64_t)(b0 + (tid >> 4)) * p.L + t) * 3 * H + s * US + j] = __builtin_nanf("");
+            return;
+        }
 #pragma unroll
         for (int r = 0; r < RG; ++r) {
             float acc = 0.f;
