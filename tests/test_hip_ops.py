@@ -215,7 +215,7 @@ def test_lru_scan_fwd_bwd(ops, B, L, C):
 
 
 # ------------------------------------------------------------------------------------------------ GRU
-@pytest.mark.parametrize('B,L,H', [(3, 20, 64), (18, 40, 256), (2, 130, 32), (5, 9, 80), (2, 6, 384)])
+@pytest.mark.parametrize('B,L,H', [(3, 20, 64), (18, 40, 256), (2, 130, 32), (5, 9, 80), (2, 6, 384), (68, 6, 256)])
 def test_gru_seq_fwd_bwd_vs_aten(ops, B, L, H):
     """Against torch.nn.GRU on CPU (the reference's GRU layer is exactly that module, rnn_base.py:59)."""
     g = torch.Generator().manual_seed(H + L)
