@@ -111,7 +111,8 @@ def test_selective_scan_reset_isolation(ops):
 
 
 # ------------------------------------------------------------------------------------------------ conv1d
-@pytest.mark.parametrize('B,L,Di,Kw', [(2, 50, 64, 4), (3, 130, 96, 16), (1, 70, 128, 3), (2, 65, 64, 8), (1, 200, 64, 20)])
+@pytest.mark.parametrize('B,L,Di,Kw', [(2, 50, 64, 4), (3, 130, 96, 16), (1, 70, 128, 3), (2, 65, 64, 8), (1, 200, 64, 20),
+                                        (2, 64, 72, 8), (1, 300, 520, 16), (3, 129, 256, 2)])
 def test_causal_conv1d_fwd_bwd(ops, B, L, Di, Kw):
     g = torch.Generator().manual_seed(L + Kw)
     xz = rnd(B, L, 2 * Di, g=g)
@@ -388,7 +389,7 @@ def test_mamba_inner_fused_vs_oracle_chain(ops, B, L, Dm, N, Kw):
 
 
 # ------------------------------------------------------------------------------------------ bias + activation tail
-@pytest.mark.parametrize('rows,C,nseg', [(300, 64, 1), (8 * 129, 256, 8), (1000, 2048, 1), (6 * 37, 12, 6)])
+@pytest.mark.parametrize('rows,C,nseg', [(300, 64, 1), (8 * 129, 256, 8), (1000, 2048, 1), (6 * 37, 12, 6), (7, 8, 1), (2 * 513, 260, 2)])
 @pytest.mark.parametrize('act', ['elu', None])
 def test_bias_act_fwd_bwd(ops, rows, C, nseg, act):
     """act(y + bias[segment]) in place and its backward from the output (fc / efc-E tail, reference rnn_base.py:462-474)."""
