@@ -32,28 +32,39 @@ __device__ __forceinline__ Seg segment(int w, int L) {
     return s;
 }
 
+// keep_t = 1 - start_t of the row (1 everywhere without a start tensor, 0 at the sentinel slot L): staged once per
+// workgroup in LDS.  Read from global inside the time loops it was a load + wait + branch per step, which serialised every
+// wave on two dependent memory round trips per step (gilr forward: 130 us, 83 % of the wave time parked in s_waitcnt).
+__device__ __forceinline__ void stage_keep(float* s_keep, const float* __restrict__ start, int b, int L) {
+    for (int t = threadIdx.x; t <= L; t += blockDim.x) s_keep[t] = t < L ? (start ? 1.f - start[(int64_t)b * L + t] : 1.f) : 0.f;
+    __syncthreads();
+}
+
 // ------------------------------------------------------------------------------------------ real (gilr)
 __device__ __forceinline__ void gilr_gate(float vraw, float fraw, float keep, int act, float& v, float& fe) {
     v = act ? tanhf_(vraw) : vraw;
     fe = (act ? sigmoidf_(fraw) : fraw) * keep;
 }
 
+template <bool ACT>
 __global__ __launch_bounds__(NSEG * 64) void linrec_real_fwd_kernel(const float* __restrict__ v, const float* __restrict__ f,
                                                                     const float* __restrict__ start, const float* __restrict__ h0,
-                                                                    float* __restrict__ h, int B, int L, int C, int act) {
+                                                                    float* __restrict__ h, int B, int L, int C) {
+    constexpr int act = ACT ? 1 : 0;
     __shared__ float s_a[NSEG][TILE_C], s_c[NSEG][TILE_C];
+    extern __shared__ float s_keep[];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int b = blockIdx.y, c = blockIdx.x * TILE_C + lane;
+    stage_keep(s_keep, start, b, L);
     const bool ok = c < C;
     const int64_t base = (int64_t)b * L * C + c;
     const Seg sg = segment(w, L);
     float a = 1.f, hl = 0.f;
     if (ok) {
-#pragma unroll 4
+#pragma unroll 8
         for (int t = sg.t0; t < sg.t1; ++t) {
-            const float keep = start ? 1.f - start[(int64_t)b * L + t] : 1.f;
             float vv, fe;
-            gilr_gate(v[base + (int64_t)t * C], f[base + (int64_t)t * C], keep, act, vv, fe);
+            gilr_gate(v[base + (int64_t)t * C], f[base + (int64_t)t * C], s_keep[t], act, vv, fe);
             hl = __builtin_fmaf(fe, hl - vv, vv);                 // f h + (1 - f) v
             a *= fe;
         }
@@ -65,11 +76,10 @@ __global__ __launch_bounds__(NSEG * 64) void linrec_real_fwd_kernel(const float*
     for (int ww = 0; ww < w; ++ww) hin = __builtin_fmaf(s_a[ww][lane], hin, s_c[ww][lane]);
     if (ok) {
         float hc = hin;
-#pragma unroll 4
+#pragma unroll 8
         for (int t = sg.t0; t < sg.t1; ++t) {
-            const float keep = start ? 1.f - start[(int64_t)b * L + t] : 1.f;
             float vv, fe;
-            gilr_gate(v[base + (int64_t)t * C], f[base + (int64_t)t * C], keep, act, vv, fe);
+            gilr_gate(v[base + (int64_t)t * C], f[base + (int64_t)t * C], s_keep[t], act, vv, fe);
             hc = __builtin_fmaf(fe, hc - vv, vv);
             h[base + (int64_t)t * C] = hc;
         }
@@ -77,26 +87,29 @@ __global__ __launch_bounds__(NSEG * 64) void linrec_real_fwd_kernel(const float*
 }
 
 // g_t = dh_t + f_{t+1} g_{t+1} ;  dv_t = g_t (1 - f_t) ;  df_t = g_t (h_{t-1} - v_t)   (then through tanh / sigmoid)
+template <bool ACT>
 __global__ __launch_bounds__(NSEG * 64) void linrec_real_bwd_kernel(const float* __restrict__ v, const float* __restrict__ f,
                                                                     const float* __restrict__ start, const float* __restrict__ h0,
                                                                     const float* __restrict__ h, const float* __restrict__ dh,
                                                                     float* __restrict__ dv, float* __restrict__ df,
-                                                                    int B, int L, int C, int act) {
+                                                                    int B, int L, int C) {
+    constexpr int act = ACT ? 1 : 0;
     __shared__ float s_a[NSEG][TILE_C], s_c[NSEG][TILE_C];
+    extern __shared__ float s_keep[];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int b = blockIdx.y, c = blockIdx.x * TILE_C + lane;
+    stage_keep(s_keep, start, b, L);
     const bool ok = c < C;
     const int64_t base = (int64_t)b * L * C + c;
     const Seg sg = segment(w, L);
-    auto gate_f = [&](int t) -> float {                          // effective gate f_t (0 beyond the row end)
-        if (t >= L) return 0.f;
-        const float keep = start ? 1.f - start[(int64_t)b * L + t] : 1.f;
-        const float fr = f[base + (int64_t)t * C];
-        return (act ? sigmoidf_(fr) : fr) * keep;
+    auto gate_f = [&](int t) -> float {                          // effective gate f_t (0 beyond the row end: keep sentinel)
+        const float fr = f[base + (int64_t)min(t, L - 1) * C];
+        return (act ? sigmoidf_(fr) : fr) * s_keep[t];
     };
     float a = 1.f, gl = 0.f;
     if (ok && sg.t1 > sg.t0) {
         float fnext = gate_f(sg.t1);
+#pragma unroll 8
         for (int t = sg.t1 - 1; t >= sg.t0; --t) {
             gl = __builtin_fmaf(fnext, gl, dh[base + (int64_t)t * C]);
             a *= fnext;
@@ -111,14 +124,17 @@ __global__ __launch_bounds__(NSEG * 64) void linrec_real_bwd_kernel(const float*
     if (ok && sg.t1 > sg.t0) {
         float g = gin;
         float fnext = gate_f(sg.t1);
+        const float hzero = h0 ? h0[(int64_t)b * C + c] : 0.f;
+#pragma unroll 8
         for (int t = sg.t1 - 1; t >= sg.t0; --t) {
             g = __builtin_fmaf(fnext, g, dh[base + (int64_t)t * C]);
-            const float keep = start ? 1.f - start[(int64_t)b * L + t] : 1.f;
+            const float keep = s_keep[t];
             const float vraw = v[base + (int64_t)t * C], fraw = f[base + (int64_t)t * C];
             const float vv = act ? tanhf_(vraw) : vraw;
             const float sg_ = act ? sigmoidf_(fraw) : fraw;
             const float fe = sg_ * keep;
-            const float hprev = t > 0 ? h[base + (int64_t)(t - 1) * C] : (h0 ? h0[(int64_t)b * C + c] : 0.f);
+            const float hload = h[base + (int64_t)max(t - 1, 0) * C];      // clamped address: no branch around the load
+            const float hprev = t > 0 ? hload : hzero;
             float gv = g * (1.f - fe);
             float gf = g * (hprev - vv) * keep;
             if (act) {
@@ -139,17 +155,19 @@ __global__ __launch_bounds__(NSEG * 64) void linrec_complex_fwd_kernel(const flo
                                                                        const float* __restrict__ h0r, const float* __restrict__ h0i,
                                                                        float* __restrict__ hr, float* __restrict__ hi, int B, int L, int C) {
     __shared__ float s_ar[NSEG][TILE_C], s_ai[NSEG][TILE_C], s_cr[NSEG][TILE_C], s_ci[NSEG][TILE_C];
+    extern __shared__ float s_keep[];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int b = blockIdx.y, c = blockIdx.x * TILE_C + lane;
+    stage_keep(s_keep, start, b, L);
     const bool ok = c < C;
     const int64_t base = (int64_t)b * L * C + c;
     const Seg sg = segment(w, L);
     const float lr = ok ? lam_re[c] : 0.f, li = ok ? lam_im[c] : 0.f, gm = (ok && gamma) ? gamma[c] : 1.f;
     float ar = 1.f, ai = 0.f, cr = 0.f, ci = 0.f;
     if (ok) {
-#pragma unroll 4
+#pragma unroll 8
         for (int t = sg.t0; t < sg.t1; ++t) {
-            const float keep = start ? 1.f - start[(int64_t)b * L + t] : 1.f;
+            const float keep = s_keep[t];
             const float fr = lr * keep, fi = li * keep;
             const float xr = gm * vr[base + (int64_t)t * C], xi = gm * vi[base + (int64_t)t * C];
             const float nr = cr * fr - ci * fi + xr, ni = cr * fi + ci * fr + xi;
@@ -168,9 +186,9 @@ __global__ __launch_bounds__(NSEG * 64) void linrec_complex_fwd_kernel(const flo
     }
     if (ok) {
         float cr2 = xr0, ci2 = xi0;
-#pragma unroll 4
+#pragma unroll 8
         for (int t = sg.t0; t < sg.t1; ++t) {
-            const float keep = start ? 1.f - start[(int64_t)b * L + t] : 1.f;
+            const float keep = s_keep[t];
             const float fr = lr * keep, fi = li * keep;
             const float xr = gm * vr[base + (int64_t)t * C], xi = gm * vi[base + (int64_t)t * C];
             const float nr = cr2 * fr - ci2 * fi + xr, ni = cr2 * fi + ci2 * fr + xi;
@@ -191,16 +209,19 @@ __global__ __launch_bounds__(NSEG * 64) void linrec_complex_bwd_kernel(const flo
                                                                        float* __restrict__ dvr, float* __restrict__ dvi,
                                                                        float* __restrict__ part, int B, int L, int C) {
     __shared__ float s_ar[NSEG][TILE_C], s_ai[NSEG][TILE_C], s_cr[NSEG][TILE_C], s_ci[NSEG][TILE_C];
+    extern __shared__ float s_keep[];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int b = blockIdx.y, c = blockIdx.x * TILE_C + lane;
+    stage_keep(s_keep, start, b, L);
     const bool ok = c < C;
     const int64_t base = (int64_t)b * L * C + c;
     const Seg sg = segment(w, L);
     const float lr = ok ? lam_re[c] : 0.f, li = ok ? lam_im[c] : 0.f, gm = (ok && gamma) ? gamma[c] : 1.f;
-    auto keep_at = [&](int t) -> float { return t >= L ? 0.f : (start ? 1.f - start[(int64_t)b * L + t] : 1.f); };
+    auto keep_at = [&](int t) -> float { return s_keep[t]; };          // sentinel slot L holds 0
     float ar = 1.f, ai = 0.f, gr = 0.f, gi = 0.f;
     if (ok && sg.t1 > sg.t0) {
         float kn = keep_at(sg.t1);
+#pragma unroll 8
         for (int t = sg.t1 - 1; t >= sg.t0; --t) {
             const float fr = lr * kn, fi = -li * kn;                 // conj(f_{t+1})
             const float nr = gr * fr - gi * fi + dhr[base + (int64_t)t * C], ni = gr * fi + gi * fr + dhi[base + (int64_t)t * C];
@@ -222,13 +243,15 @@ __global__ __launch_bounds__(NSEG * 64) void linrec_complex_bwd_kernel(const flo
     if (ok && sg.t1 > sg.t0) {
         float g_r = xr0, g_i = xi0;
         float kn = keep_at(sg.t1);
+        const float h0r_ = h0r ? h0r[(int64_t)b * C + c] : 0.f, h0i_ = h0i ? h0i[(int64_t)b * C + c] : 0.f;
+#pragma unroll 8
         for (int t = sg.t1 - 1; t >= sg.t0; --t) {
             const float fr = lr * kn, fi = -li * kn;
             const float nr = g_r * fr - g_i * fi + dhr[base + (int64_t)t * C], ni = g_r * fi + g_i * fr + dhi[base + (int64_t)t * C];
             g_r = nr; g_i = ni;
             const float kt = keep_at(t);
-            const float pr = t > 0 ? hr[base + (int64_t)(t - 1) * C] : (h0r ? h0r[(int64_t)b * C + c] : 0.f);
-            const float pi = t > 0 ? hi[base + (int64_t)(t - 1) * C] : (h0i ? h0i[(int64_t)b * C + c] : 0.f);
+            const float plr = hr[base + (int64_t)max(t - 1, 0) * C], pli = hi[base + (int64_t)max(t - 1, 0) * C];
+            const float pr = t > 0 ? plr : h0r_, pi = t > 0 ? pli : h0i_;
             dlr += kt * (g_r * pr + g_i * pi);                      // d/d lam_re : g . h_prev
             dli += kt * (g_i * pr - g_r * pi);                      // d/d lam_im
             dgm += g_r * vr[base + (int64_t)t * C] + g_i * vi[base + (int64_t)t * C];
@@ -249,8 +272,10 @@ __global__ __launch_bounds__(NSEG * 64) void linrec_complex_bwd_kernel(const flo
 extern "C" int resel_linrec_real_fwd(const float* v, const float* f, const float* start, const float* h0, float* h,
                                      int B, int L, int C, int fuse_act, resel_stream_t stream) {
     if (!v || !f || !h || B <= 0 || L <= 0 || C <= 0) return RESEL_EINVAL;
-    hipLaunchKernelGGL(linrec_real_fwd_kernel, dim3((C + TILE_C - 1) / TILE_C, B), dim3(NSEG * 64), 0, (hipStream_t)stream,
-                       v, f, start, h0, h, B, L, C, fuse_act);
+    const dim3 grid((C + TILE_C - 1) / TILE_C, B), blk(NSEG * 64);
+    const size_t lds = (size_t)(L + 1) * sizeof(float);          // keep table (dynamic LDS)
+    if (fuse_act) hipLaunchKernelGGL(linrec_real_fwd_kernel<true>, grid, blk, lds, (hipStream_t)stream, v, f, start, h0, h, B, L, C);
+    else hipLaunchKernelGGL(linrec_real_fwd_kernel<false>, grid, blk, lds, (hipStream_t)stream, v, f, start, h0, h, B, L, C);
     return launch_status();
 }
 
@@ -258,8 +283,10 @@ extern "C" int resel_linrec_real_bwd(const float* v, const float* f, const float
                                      const float* dh, float* dv, float* df, int B, int L, int C, int fuse_act,
                                      resel_stream_t stream) {
     if (!v || !f || !h || !dh || !dv || !df || B <= 0 || L <= 0 || C <= 0) return RESEL_EINVAL;
-    hipLaunchKernelGGL(linrec_real_bwd_kernel, dim3((C + TILE_C - 1) / TILE_C, B), dim3(NSEG * 64), 0, (hipStream_t)stream,
-                       v, f, start, h0, h, dh, dv, df, B, L, C, fuse_act);
+    const dim3 grid((C + TILE_C - 1) / TILE_C, B), blk(NSEG * 64);
+    const size_t lds = (size_t)(L + 1) * sizeof(float);
+    if (fuse_act) hipLaunchKernelGGL(linrec_real_bwd_kernel<true>, grid, blk, lds, (hipStream_t)stream, v, f, start, h0, h, dh, dv, df, B, L, C);
+    else hipLaunchKernelGGL(linrec_real_bwd_kernel<false>, grid, blk, lds, (hipStream_t)stream, v, f, start, h0, h, dh, dv, df, B, L, C);
     return launch_status();
 }
 
@@ -267,8 +294,8 @@ extern "C" int resel_linrec_complex_fwd(const float* vr, const float* vi, const 
                                         const float* gamma, const float* start, const float* h0r, const float* h0i,
                                         float* hr, float* hi, int B, int L, int C, resel_stream_t stream) {
     if (!vr || !vi || !lam_re || !lam_im || !hr || !hi || B <= 0 || L <= 0 || C <= 0) return RESEL_EINVAL;
-    hipLaunchKernelGGL(linrec_complex_fwd_kernel, dim3((C + TILE_C - 1) / TILE_C, B), dim3(NSEG * 64), 0, (hipStream_t)stream,
-                       vr, vi, lam_re, lam_im, gamma, start, h0r, h0i, hr, hi, B, L, C);
+    hipLaunchKernelGGL(linrec_complex_fwd_kernel, dim3((C + TILE_C - 1) / TILE_C, B), dim3(NSEG * 64), (size_t)(L + 1) * sizeof(float),
+                       (hipStream_t)stream, vr, vi, lam_re, lam_im, gamma, start, h0r, h0i, hr, hi, B, L, C);
     return launch_status();
 }
 
@@ -286,7 +313,7 @@ extern "C" int resel_linrec_complex_bwd(const float* vr, const float* vi, const 
         B <= 0 || L <= 0 || C <= 0)
         return RESEL_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(linrec_complex_bwd_kernel, dim3((C + TILE_C - 1) / TILE_C, B), dim3(NSEG * 64), 0, s,
+    hipLaunchKernelGGL(linrec_complex_bwd_kernel, dim3((C + TILE_C - 1) / TILE_C, B), dim3(NSEG * 64), (size_t)(L + 1) * sizeof(float), s,
                        vr, vi, lam_re, lam_im, gamma, start, h0r, h0i, hr, hi, dhr, dhi, dvr, dvi, (float*)workspace, B, L, C);
     // per-(row, segment) partials [B * NSEG][3][C] -> d lambda_re, d lambda_im, d gamma (fixed summation order)
     const float* part = (const float*)workspace;
