@@ -318,6 +318,7 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) bf16_t qT[4][HD][KT + PADE];       // per-wave transposed Q tile  [d][q]
     __shared__ __attribute__((aligned(16))) bf16_t doT[4][HD][KT + PADE];      // per-wave transposed dO tile [d][q]
     __shared__ float s_red[4][2 * ND][16][64];
+    __shared__ float s_lse[4][KT], s_dlt[4][KT];               // per-wave lse / delta of the query tile (one coalesced load)
     const int s = blockIdx.y, h = blockIdx.z;
     const int t0 = p.cu[s], len = p.cu[s + 1] - t0;
     const int k0 = blockIdx.x * KT;
@@ -341,6 +342,9 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnParams p) {
     f32x16 dkt[ND], dvt[ND];
 #pragma unroll
     for (int t = 0; t < ND; ++t) { dkt[t] = zero16(); dvt[t] = zero16(); }
+    float crow[16];                                              // ALiBi: -slope (q - key) = -slope row(i) - slope (q0 - key)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) crow[i] = -slope2 * (float)acc_row(i, hh);
     const int nqt = (len + KT - 1) / KT;
     const int qt_first = k0 / KT;                                // first query tile that can see these keys
     const int niter = (nqt - qt_first + 3) / 4;
@@ -359,7 +363,13 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnParams p) {
                 doa_f[ks] = *reinterpret_cast<const bf16x8*>(p.dout + ((int64_t)(t0 + qa) * p.H + h) * HD + 16 * ks + 8 * hh);
             }
         }
+        float l2q = 0.f, dlq = 0.f;
+        if (active && hh == 0 && qa < len) {
+            l2q = p.lse[(int64_t)h * p.T + t0 + qa];
+            dlq = p.delta[(int64_t)h * p.T + t0 + qa];
+        }
         __syncthreads();                                         // previous iteration's transposed tiles fully consumed
+        if (hh == 0) { s_lse[w][r] = l2q; s_dlt[w][r] = dlq; }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -376,18 +386,25 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnParams p) {
             dp = mfma(doa_f[ks], vf[ks], dp);                    // dP[q][key]
         }
         f32x16 pm, ds;
+        const bool masked = (q0 < k0 + KT - 1) || (q0 + KT > len) || (k0 + KT > len);      // diagonal tile or ragged end (wave-uniform)
+        const float off = -slope2 * (float)(q0 - key);
+        if (masked) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int qq = q0 + acc_row(i, hh);
-            const bool ok = k_ok && qq < len && key <= qq;
-            float e = 0.f, dl = 0.f;
-            if (ok) {
-                const float l2 = p.lse[(int64_t)h * p.T + t0 + qq];
-                dl = p.delta[(int64_t)h * p.T + t0 + qq];
-                e = fast_exp2(sacc[i] * c1 - slope2 * (float)(qq - key) - l2);
+            for (int i = 0; i < 16; ++i) {
+                const int row = acc_row(i, hh), qq = q0 + row;
+                const bool ok = k_ok && qq < len && key <= qq;
+                const float e = ok ? fast_exp2(__builtin_fmaf(sacc[i], c1, crow[i] + off) - s_lse[w][row]) : 0.f;
+                pm[i] = e;
+                ds[i] = e * (dp[i] - s_dlt[w][row]) * p.scale;
             }
-            pm[i] = e;
-            ds[i] = e * (dp[i] - dl) * p.scale;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = acc_row(i, hh);
+                const float e = fast_exp2(__builtin_fmaf(sacc[i], c1, crow[i] + off) - s_lse[w][row]);
+                pm[i] = e;
+                ds[i] = e * (dp[i] - s_dlt[w][row]) * p.scale;
+            }
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
