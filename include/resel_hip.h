@@ -245,6 +245,34 @@ int resel_gather_trajs(const float* buffer, int W, const int* segments, int nseg
                        int c_mask, int c_start, int c_done, int c_timeout, const int* pre_pairs, int npairs,
                        float* out, resel_stream_t stream);
 
+/* ---- one-token rollout step (T = 1): the policy forward between updates -------------------------------------------
+ * Reference: the outer loop calls policy.forward once per environment step (algorithm/sac.py:319-326), which reaches
+ * Mamba.step (models/smamba/mamba.py:257-305; its GPU branch calls causal_conv1d_update and the Triton
+ * selective_state_update, mamba_ssm/ops/triton/selective_state_update.py:21-154) and, for cgpt, flash-attn's MHA with
+ * InferenceParams (models/flash_attention/TransformerFlashAttention.py:13-27,76-81; models/rnn_base.py:437-452).
+ * All three read the old state and write a NEW state buffer (functional, like the reference's returned hidden), take
+ * row strides in elements, and read nothing from the host - so a whole policy step can be captured in a hipGraph.
+ *
+ * resel_mamba_conv_step: window[b, d, :] <- (window[b, d, 1:], x[b, d]);  xc = silu(sum_k window * w[d, k] + bias[d]).
+ *   x [B, Di] (row stride ldx), state_in / state_out [B, Di, K] (row strides ld_in / ld_out), w [Di, K], bias [Di] or NULL.
+ * resel_selective_state_update: dt = softplus(x_db[:, :R] w_dt^T + dt_bias); A = -exp(A_log);
+ *   h <- h * exp(dt A) + dt * Bm * xc;  y = sum_n h * Cm + D * xc;  y *= silu(z) if z.
+ *   x_db [B, R + 2N] = (dt low-rank | Bm | Cm) (row stride ld_xdb), w_dt [Di, R], state [B, Di, N], z [B, Di] (row stride ldz).
+ * resel_attn_decode: appends this token's k, v to kv_cache [Bmax, max_seqlen, 2, H, hd] (bf16) at position `pos` and
+ *   returns softmax_j<=pos(scale q.k_j - slope_h (pos - j)) v_j as out [B, H, hd] bf16.  qkv [B, 3, H, hd] bf16 (row stride
+ *   ld_qkv).  pos = *pos_dev when pos_dev != NULL (device step counter: graph replay), else pos_host.  hd in {32, 64}.
+ *   pos >= max_seqlen: RESEL_EINVAL for a host position; with a device counter the output row is NaN (the reference's
+ *   flash-attn asserts on a full cache). */
+int resel_mamba_conv_step(const float* x, int64_t ldx, const float* state_in, int64_t ld_in, float* state_out, int64_t ld_out,
+                          const float* w, const float* bias, float* xc, int B, int Di, int K, resel_stream_t stream);
+int resel_selective_state_update(const float* state_in, int64_t ld_in, float* state_out, int64_t ld_out, const float* xc,
+                                 const float* x_db, int64_t ld_xdb, const float* w_dt, const float* dt_bias, const float* A_log,
+                                 const float* D, const float* z, int64_t ldz, float* y, int B, int Di, int N, int R,
+                                 resel_stream_t stream);
+int resel_attn_decode(const uint16_t* qkv, int64_t ld_qkv, uint16_t* kv_cache, const int32_t* pos_dev, int pos_host,
+                      const float* slopes, uint16_t* out, float scale, int B, int H, int head_dim, int max_seqlen,
+                      resel_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

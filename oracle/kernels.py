@@ -213,6 +213,45 @@ def attention_alibi_varlen_ref(q, k, v, cu_seqlens, slopes=None, scale=None):
 
 
 # --------------------------------------------------------------------------------------------
+# one-token rollout step  (reference: offpolicy_rnn/models/smamba/mamba.py:257-305 CPU branch ==
+# mamba_ssm/ops/triton/selective_state_update.py:123-154 `selective_state_update_ref`;
+# flash_attn MHA with inference_params: append k, v to the cache, attend over positions 0..pos)
+# --------------------------------------------------------------------------------------------
+def mamba_step_ref(conv_state, ssm_state, xz, conv_w, conv_b, xproj_w, dt_w, dt_b, A_log, D):
+    """conv_state [B, Di, K], ssm_state [B, Di, N], xz [B, 2 Di] -> (y [B, Di], conv_state', ssm_state')."""
+    Di = xz.shape[-1] // 2
+    x, z = xz[:, :Di], xz[:, Di:]                                              # :261
+    conv_state = torch.roll(conv_state, shifts=-1, dims=-1)                    # :265
+    conv_state = torch.cat((conv_state[:, :, :-1], x.unsqueeze(-1)), dim=-1)   # :266
+    x = torch.sum(conv_state * conv_w, dim=-1)                                 # :268
+    if conv_b is not None:
+        x = x + conv_b
+    x = F.silu(x)                                                              # :271
+    x_db = F.linear(x, xproj_w)                                                # :281
+    R, N = dt_w.shape[1], ssm_state.shape[-1]
+    dt, Bm, Cm = x_db[:, :R], x_db[:, R:R + N], x_db[:, R + N:]
+    dt = F.softplus(F.linear(dt, dt_w) + dt_b)                                 # :284,290
+    A = -torch.exp(A_log.float())                                              # :285
+    dA = torch.exp(dt.unsqueeze(-1) * A)                                       # :291
+    dB = dt.unsqueeze(-1) * Bm.unsqueeze(1)                                    # :292
+    ssm_state = ssm_state * dA + x.unsqueeze(-1) * dB                          # :293
+    y = (ssm_state * Cm.unsqueeze(1)).sum(-1) + D * x                          # :294-295
+    return y * F.silu(z), conv_state, ssm_state                                # :296
+
+
+def attn_decode_ref(q, k_cache, v_cache, pos, slopes=None, scale=None):
+    """q [B, H, d] at position `pos`; k_cache, v_cache [B, S, H, d] already holding positions 0..pos.  -> [B, H, d]."""
+    d = q.shape[-1]
+    scale = (1.0 / math.sqrt(d)) if scale is None else scale
+    k, v = k_cache[:, :pos + 1].float(), v_cache[:, :pos + 1].float()
+    sc = torch.einsum('bhd,bjhd->bhj', q.float(), k) * scale
+    if slopes is not None:
+        j = torch.arange(pos + 1, dtype=torch.float32)
+        sc = sc - slopes.float()[None, :, None] * (pos - j)[None, None, :]
+    return torch.einsum('bhj,bjhd->bhd', torch.softmax(sc, dim=-1), v)
+
+
+# --------------------------------------------------------------------------------------------
 # ensemble (batched) linear  (reference: offpolicy_rnn/models/ensemble_linear_model.py:29-60)
 # --------------------------------------------------------------------------------------------
 def ensemble_linear_ref(x, weight, bias=None, desire_ndim=None):

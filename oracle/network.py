@@ -185,6 +185,68 @@ def smamba_layer(p, pre, x, cfg, flags=None, semantics='gpu'):
     return _ff_block(p, pre + 'head.', h, eps)
 
 
+def smamba_layer_step(p, pre, x, hidden, cfg):
+    """One rollout token through BlockList (mamba.py:492-526) with Mamba.forward's T == 1 branch (:134-157):
+    x [B, D], hidden [B, blocks * Di * (K + N)] -> (y [B, D], new hidden)."""
+    eps, rms = 1e-8, cfg['rms_norm']
+    K_, N = cfg['d_conv'], cfg['d_state']
+    residual, h, outs = None, x, []
+    chunks = torch.chunk(hidden, cfg['block_num'], dim=-1)                     # :500
+    for i in range(cfg['block_num']):
+        bp = f'{pre}layers.{i}.'
+        h, residual = K.add_layernorm_ref(h, residual, p[bp + 'norm.weight'], p.get(bp + 'norm.bias'), eps, rms)
+        mp = bp + 'mixer.'
+        xz = F.linear(h, p[mp + 'in_proj.weight'])
+        B, Di = xz.shape[0], xz.shape[1] // 2
+        conv = chunks[i][:, :Di * K_].reshape(B, Di, K_)                       # :138-141
+        ssm = chunks[i][:, Di * K_:].reshape(B, Di, N)                         # :142-143
+        y, conv, ssm = K.mamba_step_ref(conv, ssm, xz, p[mp + 'conv1d.weight'][:, 0, :], p[mp + 'conv1d.bias'],
+                                        p[mp + 'x_proj.weight'], p[mp + 'dt_proj.weight'], p[mp + 'dt_proj.bias'],
+                                        p[mp + 'A_log'], p[mp + 'D'])
+        h = F.linear(y, p[mp + 'out_proj.weight'])
+        outs.append(torch.cat((conv.reshape(B, -1), ssm.reshape(B, -1)), dim=-1))   # :153-156
+    if not cfg['use_ff']:
+        h, _ = K.add_layernorm_ref(h, residual, p[pre + 'norm_f.weight'], p.get(pre + 'norm_f.bias'), eps, rms)
+        h = F.linear(h, p[pre + 'head.weight'])
+    else:
+        h = _ff_block(p, pre + 'head.', h + residual, eps)
+    return h, torch.cat(outs, dim=-1)
+
+
+def rollout_layer(p, lid, x, h0):
+    """What T successive one-token `meta_forward` calls with a carried hidden state compute for a single-layer RNNBase
+    (rnn_base.py:437-457; the rollout of algorithm/sac.py:319-326): x [B, T, D], h0 [B, hidden] -> (y [B, T, D], hT).
+    gru / gilr / lru are pure recurrences, so the T steps are one pass from h0; smamba goes through Mamba.step."""
+    pre = 'layer_list.0.'
+    c = parse_layer_id(lid)
+    if c['kind'] == 'gru':
+        gi = F.linear(x, p[pre + 'weight_ih_l0'], p[pre + 'bias_ih_l0'])
+        y = K.gru_seq_ref(gi, p[pre + 'weight_hh_l0'], p[pre + 'bias_hh_l0'], h0)
+        return y, y[:, -1]
+    if c['kind'] == 'gilr':
+        u = K.ensemble_linear_ref(x, p[pre + 'in_proj.weight'], p[pre + 'in_proj.bias'], desire_ndim=4)
+        h, last = K.linrec_real_ref(u[0], u[1], None, h0, fuse_act=True)                     # gilr.py:48-62
+        return _ff_block(p, pre + 'ff.', F.linear(h, p[pre + 'out_proj.weight'], p[pre + 'out_proj.bias'])), last
+    if c['kind'] == 'lru':
+        u = K.ensemble_linear_ref(x, p[pre + 'in_proj.weight'], p[pre + 'in_proj.bias'], desire_ndim=4)
+        params = torch.exp(p[pre + 'params_log'])
+        nu, theta, gamma = params[0], params[1], params[2]
+        mag = torch.exp(-nu)
+        C = h0.shape[-1] // 2                                                                  # hidden = (real | imag), lru.py:122-124
+        hr, hi = K.linrec_complex_ref(u[0], u[1], mag * torch.cos(theta), mag * torch.sin(theta), None,
+                                      h0[:, :C], h0[:, C:], gamma=gamma)
+        out = K.ensemble_linear_ref(torch.stack((hr, hi), dim=0), p[pre + 'middle_proj.weight'], p[pre + 'middle_proj.bias'],
+                                    desire_ndim=4)
+        return _ff_block(p, pre + 'ff.', out[0] - out[1] + u[2]), torch.cat((hr[:, -1], hi[:, -1]), dim=-1)
+    if c['kind'] == 'smamba':
+        ys, h = [], h0
+        for t in range(x.shape[1]):
+            y, h = smamba_layer_step(p, pre, x[:, t], h, c)
+            ys.append(y)
+        return torch.stack(ys, dim=1), h
+    raise NotImplementedError(lid)
+
+
 def seqlens_to_cu(seqlens: torch.Tensor):
     """Per-row length table -> (token indices, cu_seqlens) like flash_attn.bert_padding.
     unpad_input_for_concatenated_sequences (called at TransformerFlashAttention.py:107)."""

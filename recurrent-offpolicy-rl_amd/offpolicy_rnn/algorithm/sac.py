@@ -77,6 +77,11 @@ class SAC:
         self.last_state_np = np.zeros((1, self.obs_dim))
         self.reward_np = np.zeros((1, 1))
         self.sample_hidden = None
+        # on the GPU the per-step policy forward is replayed as one hipGraph (hip/graph_step.py); RESEL_GRAPH_ROLLOUT=0: eager
+        self.graph_step = None
+        if self.sample_device.type == 'cuda' and os.environ.get('RESEL_GRAPH_ROLLOUT', '1') != '0':
+            from ..hip.graph_step import GraphedPolicyStep
+            self.graph_step = GraphedPolicyStep(self.policy, self.sample_device, batch_size=1)
         self.sample_num = 0
         self.grad_num = 0
         self.start_time = time.time()
@@ -152,6 +157,19 @@ class SAC:
         self.last_state_np = np.zeros((1, self.obs_dim))
         self.reward_np = np.zeros((1, 1))
         self.sample_hidden = self._init_sample_hidden()
+        if self.graph_step is not None:
+            self.graph_step.load_hidden(self.sample_hidden)
+
+    def sample_action(self) -> np.ndarray:
+        """One policy step on the current rollout state (reference sac.py:319-326) -> sampled action [1, act_dim]."""
+        if self.graph_step is not None:
+            return self.graph_step(self.state_np, self.last_state_np, self.last_action_np, self.reward_np)[1].reshape(1, -1)
+        with torch.no_grad():
+            _, _, act_sample, _, self.sample_hidden, _ = self.policy.forward(
+                state=n2t_2dim(self.state_np, self.sample_device), lst_state=n2t_2dim(self.last_state_np, self.sample_device),
+                lst_action=n2t_2dim(self.last_action_np, self.sample_device), rnn_memory=self.sample_hidden,
+                reward=n2t_2dim(self.reward_np, self.sample_device))
+        return t2n(act_sample).reshape(1, -1)
 
     def env_step(self, next_obs, act, reward, done):
         self.last_state_np = self.state_np.copy()
@@ -193,12 +211,7 @@ class SAC:
             self.policy.train()
             self.policy.to(self.sample_device)
             for _ in range(self.parameter.step_per_iteration):
-                with torch.no_grad():
-                    _, _, act_sample, _, self.sample_hidden, _ = self.policy.forward(
-                        state=n2t_2dim(self.state_np, self.sample_device), lst_state=n2t_2dim(self.last_state_np, self.sample_device),
-                        lst_action=n2t_2dim(self.last_action_np, self.sample_device), rnn_memory=self.sample_hidden,
-                        reward=n2t_2dim(self.reward_np, self.sample_device))
-                act_sample = t2n(act_sample).reshape(1, -1)
+                act_sample = self.sample_action()
                 next_state, reward, done, _ = self.env.step(unorm_act(act_sample[0], self.env.action_space))
                 ep_ret += reward
                 ep_len += 1
@@ -232,6 +245,8 @@ class SAC:
         path = os.path.join(self.logger.output_dir, 'model') if model_dir is None else model_dir
         if load_policy:
             self.policy.load(path, map_location=self.sample_device)
+            if self.graph_step is not None:
+                self.graph_step.invalidate()
         if load_value:
             for i in range(len(self.values)):
                 self.values[i].load(path, index=f'{i}', map_location=self.device)

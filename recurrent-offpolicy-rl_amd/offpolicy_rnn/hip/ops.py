@@ -617,6 +617,43 @@ def gather_trajs(buffer, segments, max_len, skip, rows, row_len, c_mask, c_start
     return out
 
 
+# ---- one-token rollout step (T = 1, no autograd) ----------------------------------------------------------------------
+@torch.no_grad()
+def mamba_step(hidden, xz, conv_w, conv_b, xproj_w, dt_w, dt_b, A_log, D, d_conv, d_state):
+    """smamba mixer state update for one token (reference smamba/mamba.py:257-305).
+    hidden [B, Di*K + Di*N] = (conv window | ssm state), xz [B, 2 Di] = in_proj output.  -> (y [B, Di], new hidden)."""
+    _need_cuda('mamba_step', hidden, xz)
+    B, Di, K, N, R = xz.shape[0], xz.shape[1] // 2, d_conv, d_state, dt_w.shape[1]
+    assert hidden.shape == (B, Di * (K + N)) and hidden.stride(1) == 1 and xz.stride(1) == 1
+    new_hidden = torch.empty((B, Di * (K + N)), dtype=torch.float32, device=xz.device)
+    xc = torch.empty((B, Di), dtype=torch.float32, device=xz.device)
+    s = _stream()
+    check(lib().resel_mamba_conv_step(_p(xz), xz.stride(0), _p(hidden), hidden.stride(0), _p(new_hidden), new_hidden.stride(0),
+                                      _p(conv_w), _p(conv_b), _p(xc), B, Di, K, s), 'mamba_conv_step')
+    x_db = torch.nn.functional.linear(xc, xproj_w)                                   # [B, R + 2N]
+    y = torch.empty_like(xc)
+    z = xz[:, Di:]
+    check(lib().resel_selective_state_update(_p(hidden[:, Di * K:]), hidden.stride(0), _p(new_hidden[:, Di * K:]), new_hidden.stride(0),
+                                             _p(xc), _p(x_db), x_db.stride(0), _p(dt_w), _p(dt_b), _p(A_log), _p(D),
+                                             _p(z), xz.stride(0), _p(y), B, Di, N, R, s), 'selective_state_update')
+    return y, new_hidden
+
+
+@torch.no_grad()
+def attn_decode(qkv, kv_cache, pos, slopes, scale):
+    """Append this token's k, v to kv_cache [Bmax, S, 2, H, hd] (bf16, in place) and attend over positions 0..pos.
+    qkv [B, 3, H, hd] bf16; pos: host int, or an int32 device tensor (graph replay).  -> [B, H, hd] bf16."""
+    _need_cuda('attn_decode', qkv, kv_cache)
+    B, _, H, hd = qkv.shape
+    assert qkv.dtype == torch.bfloat16 and kv_cache.dtype == torch.bfloat16 and qkv.is_contiguous() and kv_cache.is_contiguous()
+    assert kv_cache.shape[0] >= B and kv_cache.shape[2:] == (2, H, hd)
+    out = torch.empty((B, H, hd), dtype=torch.bfloat16, device=qkv.device)
+    dev = pos if torch.is_tensor(pos) else None
+    check(lib().resel_attn_decode(_p(qkv), 3 * H * hd, _p(kv_cache), _p(dev), 0 if dev is not None else int(pos), _p(slopes), _p(out),
+                                  float(scale), B, H, hd, kv_cache.shape[1], _stream()), 'attn_decode')
+    return out
+
+
 @torch.no_grad()
 def soft_update_(target_flat, online_flat, tau):
     _need_cuda('soft_update', target_flat, online_flat)

@@ -220,6 +220,8 @@ class RNNBase(torch.nn.Module):
                     x = layer(x, inference_params=None if multi else hidden_state[k],
                               seqlens=hidden_state.attention_concat_mask if multi else None)
                     h = hidden_state[k]
+                    if not multi:
+                        h.seqlen_offset += x.shape[-2]        # reference :451-452
                 else:                                   # gru: no reset / mask handling (reference :453-454)
                     x, h = layer(x, hidden_state[k])
                 k += 1

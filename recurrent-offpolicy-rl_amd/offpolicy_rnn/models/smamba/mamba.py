@@ -96,27 +96,16 @@ class Mamba(nn.Module):
         return out, hidden
 
     def _step(self, x, hidden):
-        """One-token rollout update (reference mamba.py:257-305): conv window rolled left, newest tap last."""
+        """One-token rollout update (reference mamba.py:257-305): conv window rolled left, newest tap last; the window
+        roll + conv + SiLU and the dt_proj + softplus + state update + gate are one kernel each (ops.mamba_step)."""
         B = x.shape[0]
-        Di, N, K, R = self.d_inner, self.d_state, self.d_conv, self.dt_rank
         if hidden is None:
             hidden = torch.zeros((1, B, self.desired_hidden_dim), device=x.device)
-        conv_state = hidden[0, :, :self.conv_hidden_dim].reshape(B, Di, K)
-        ssm_state = hidden[0, :, self.conv_hidden_dim:].reshape(B, Di, N)
-        xz = self.in_proj(x[:, 0])
-        xi, z = xz.chunk(2, dim=-1)
-        conv_state = torch.cat((conv_state[:, :, 1:], xi.unsqueeze(-1)), dim=-1)
-        xi = F.silu((conv_state * self.conv1d.weight[:, 0, :]).sum(-1) + self.conv1d.bias)
-        x_db = self.x_proj(xi)
-        dt = F.softplus(F.linear(x_db[:, :R], self.dt_proj.weight) + self.dt_proj.bias)
-        Bm, Cm = x_db[:, R:R + N], x_db[:, R + N:]
-        A = -torch.exp(self.A_log.float())
-        ssm_state = ssm_state * torch.exp(dt.unsqueeze(-1) * A) + (dt * xi).unsqueeze(-1) * Bm.unsqueeze(1)
-        y = (ssm_state * Cm.unsqueeze(1)).sum(-1) + self.D * xi
-        y = y * F.silu(z)
-        out = self.out_proj(y).unsqueeze(1)
-        hidden = torch.cat((conv_state.reshape(1, B, -1), ssm_state.reshape(1, B, -1)), dim=-1)
-        return out, hidden
+        xz = F.linear(x[:, 0], self.in_proj.weight, self.in_proj.bias)
+        y, new_hidden = ops.mamba_step(hidden[0], xz, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight,
+                                       self.dt_proj.weight, self.dt_proj.bias, self.A_log, self.D, self.d_conv, self.d_state)
+        out = F.linear(y, self.out_proj.weight, self.out_proj.bias).unsqueeze(1)
+        return out, new_hidden.unsqueeze(0)
 
 
 def _init_weights(module, n_layer, n_residuals_per_layer=1):

@@ -279,6 +279,37 @@ def gen_layers():
     print('layers ok')
 
 
+def gen_rollout():
+    """T = 1 rollout steps through the reference's own modules: one token per meta_forward call, hidden carried
+    (what algorithm/sac.py:319-326 does between updates).  Per-step outputs + the final hidden state."""
+    from offpolicy_rnn.models.rnn_base import RNNBase
+    out = {}
+    B, L, D = 2, 9, 32
+    g = torch.Generator().manual_seed(11)
+    x0 = torch.randn(B, L, D, generator=g)
+    for lid in ['gru', 'gilr', 'lru', 'smamba_s8_c6_b2_nln', 'smamba_s16_c4_b1', 'smamba_s8_c5_b1_ff']:
+        torch.manual_seed(4)
+        net = RNNBase(D, D, [], ['linear'], [lid])
+        with torch.no_grad():
+            for n_, p_ in net.named_parameters():
+                if 'bias' in n_ and p_.abs().sum() == 0:
+                    p_.copy_(torch.randn(p_.shape, generator=g) * 0.1)
+        hid = net.make_rnd_init_state(B, torch.device('cpu'))
+        out[f'{lid}|h0'] = t2n(hid[0])
+        ys = []
+        with torch.no_grad():
+            for t in range(L):
+                y, hid, _ = net.meta_forward(x0[:, t:t + 1], hid)
+                ys.append(y)
+        out[f'{lid}|y'] = t2n(torch.cat(ys, dim=1))
+        out[f'{lid}|hT'] = t2n(hid[0])
+        for n_, p_ in net.state_dict().items():
+            out[f'{lid}|p|{n_}'] = t2n(p_)
+    out['x'] = t2n(x0)
+    np.savez_compressed(os.path.join(OUT, 'rollout.npz'), **out)
+    print('rollout ok')
+
+
 def make_parameter(rnn, D=32, algo='sac', **over):
     from offpolicy_rnn.parameter.ParameterSAC import Parameter
     p = Parameter()
@@ -396,5 +427,6 @@ if __name__ == '__main__':
     gen_sample_trajs()
     gen_selective_scan()
     gen_layers()
+    gen_rollout()
     gen_layer_ids()
     gen_models_and_train()

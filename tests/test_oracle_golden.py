@@ -108,6 +108,16 @@ def test_smamba_layer_both_semantics(lid):
     np.testing.assert_allclose(y2.detach(), g[f'{lid}|y_step'], rtol=1e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize('lid', ['gru', 'gilr', 'lru', 'smamba_s8_c6_b2_nln', 'smamba_s16_c4_b1', 'smamba_s8_c5_b1_ff'])
+def test_rollout_steps(lid):
+    """One-token steps with a carried (random) hidden state, as recorded from the reference's own modules."""
+    g = load_golden('rollout.npz')
+    p = {k: v.detach() for k, v in _layer_params(g, lid).items()}
+    y, hT = NW.rollout_layer(p, lid, T(g['x']), T(g[f'{lid}|h0'])[0])
+    np.testing.assert_allclose(y, g[f'{lid}|y'], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(hT, g[f'{lid}|hT'][0], rtol=1e-4, atol=2e-5)
+
+
 def test_layer_id_table():
     table = json.load(open(os.path.join(GOLDEN, 'layer_ids.json')))
     for lid, e in table.items():
