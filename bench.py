@@ -104,8 +104,61 @@ def cpu_baseline(rnn):
     return {'value': None, 'unit': 'env-steps/s', 'cores': 0, 'kind': 'port', 'sample': 'cpu sample did not finish: ' + err}
 
 
+def rollout_mode(args):
+    """`--mode rollout`: the per-environment-step policy forward between updates, one environment
+    (B = 1), same architecture as the update benchmark.  A "step" is one policy step: inputs from host numpy rows, sampled
+    action back on the host.  `value` is the hipGraph replay path (what the trainer's loop uses); the eager launch
+    sequence and the CPU step (oracle restatement; the reference samples on the CPU by default) are reported beside it."""
+    torch.cuda.set_device(0)
+    torch.manual_seed(1234)
+    from offpolicy_rnn import alg_init
+    alg = alg_init(make_parameter(args.rnn, 2, 64, algo=args.algo))
+    rs = np.random.RandomState(0)
+    n = args.warmup + args.steps
+    obs, act, rew = rs.randn(n + 1, 1, OBS), np.tanh(rs.randn(n + 1, 1, ACT)), rs.randn(n + 1, 1, 1)
+
+    def run(graph):
+        keep, alg.graph_step = alg.graph_step, (alg.graph_step if graph else None)
+        alg.state_np, alg.last_state_np, alg.last_action_np, alg.reward_np = obs[1], obs[0], act[0], rew[0]
+        alg.sample_hidden = alg._init_sample_hidden()
+        if graph:
+            alg.graph_step.load_hidden(alg.sample_hidden)
+        for i in range(n):
+            if i == args.warmup:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            alg.state_np, alg.last_state_np, alg.last_action_np, alg.reward_np = obs[i + 1], obs[i], act[i], rew[i]
+            a = alg.sample_action()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        alg.graph_step = keep
+        assert np.isfinite(a).all()
+        return dt / args.steps
+
+    eager, graph = run(False), run(True)
+    out = {'metric': 'policy steps/sec (rollout, one environment)', 'value': 1.0 / graph, 'unit': 'steps/s', 'n_gpus': 1, 'steps': args.steps,
+           'warmup': args.warmup, 'ms_per_step': 1e3 * graph, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+           'dtype': 'f32', 'data': 'synthetic',
+           'config': {'workload': f'{args.rnn} {args.algo.upper()} policy, one token per step, B=1, obs={OBS}, act={ACT}, D=256; '
+                                  f'host numpy in -> sampled action on the host'},
+           'graph_us_per_step': 1e6 * graph, 'eager_us_per_step': 1e6 * eager}
+    if not args.no_cpu_baseline and not args.rnn.startswith('cgpt'):
+        import subprocess
+        code = ("import json,sys; sys.path.insert(0, %r); from oracle.trainer import time_cpu_rollout; "
+                "print(json.dumps(time_cpu_rollout(%r, steps=500, threads=1)))") % (ROOT, args.rnn)
+        try:
+            r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=240)
+            base = json.loads(r.stdout.strip().splitlines()[-1])
+            out['cpu_baseline'] = {'value': base['value'], 'unit': 'steps/s', 'cores': base['cores'], 'kind': 'port', 'sample': base['sample']}
+        except Exception as e:
+            out['cpu_baseline'] = {'value': None, 'unit': 'steps/s', 'cores': 0, 'kind': 'port', 'sample': 'failed: ' + repr(e)[:100]}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument('--mode', default='update', choices=['update', 'rollout'],
+                    help='update: train_one_batch (the headline metric); rollout: the per-env-step policy forward at B=1')
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
@@ -115,6 +168,8 @@ def main():
     ap.add_argument('--horizon', type=int, default=1024)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
+    if args.mode == 'rollout':
+        return rollout_mode(args)
 
     from offpolicy_rnn.parallel.data_parallel import init_from_env
     import torch.distributed as dist

@@ -213,11 +213,10 @@ def smamba_layer_step(p, pre, x, hidden, cfg):
     return h, torch.cat(outs, dim=-1)
 
 
-def rollout_layer(p, lid, x, h0):
+def rollout_layer(p, lid, x, h0, pre='layer_list.0.'):
     """What T successive one-token `meta_forward` calls with a carried hidden state compute for a single-layer RNNBase
     (rnn_base.py:437-457; the rollout of algorithm/sac.py:319-326): x [B, T, D], h0 [B, hidden] -> (y [B, T, D], hT).
     gru / gilr / lru are pure recurrences, so the T steps are one pass from h0; smamba goes through Mamba.step."""
-    pre = 'layer_list.0.'
     c = parse_layer_id(lid)
     if c['kind'] == 'gru':
         gi = F.linear(x, p[pre + 'weight_ih_l0'], p[pre + 'bias_ih_l0'])
@@ -383,6 +382,50 @@ def policy_forward(p, cfg, state, lst_state, lst_action, flags=None, reward=None
     noise = torch.randn_like(mu) if noise is None else noise
     mean, sample, logp = K.tanh_gaussian_ref(mu, logstd, noise)
     return mean, emb, sample, logp
+
+
+def rnn_base_step(p, spec, x, hidden):
+    """RNNBase.meta_forward on ONE token with carried state (rnn_base.py:405-478): x [B, D], hidden = list of [B, hidden_k]
+    per recurrent layer -> (y [B, D'], new hidden list)."""
+    new, k = [], 0
+    for ind, (lid, act) in enumerate(zip(spec['layer_type'], spec['activation'])):
+        pre = f'layer_list.{ind}.'
+        c = parse_layer_id(lid)
+        if c['kind'] == 'fc':
+            x = F.linear(x, p[pre + 'weight'], p[pre + 'bias'])
+        elif c['kind'] == 'efc':
+            x = K.ensemble_linear_ref(x, p[pre + 'weight'], p.get(pre + 'bias'), None)
+        else:
+            y, h = rollout_layer(p, lid, x.unsqueeze(1), hidden[k], pre)
+            x = y[:, 0]
+            new.append(h)
+            k += 1
+        assert '+' not in act
+        x = ACT[act](x)
+    return x, new
+
+
+def policy_step(p, cfg, state, lst_state, lst_action, hidden, reward=None, noise=None, algo='sac', sample_std=0.1):
+    """One rollout step of the policy (algorithm/sac.py:319-326 -> contextual_sac_policy_single_head.py:92-107 /
+    contextual_td3_policy.py:18-36 on a single token).  hidden: recurrent states of the embedding stack.
+    -> (mean, sample, logp, new hidden)."""
+    emb_in = embedding_input(p, cfg, state, lst_state, lst_action, reward)
+    emb, hidden = rnn_base_step(p['embedding_model'], _spec(cfg, 'embedding'), emb_in, hidden)
+    uni_in = state
+    if cfg['uni_model_input_mapping_dim'] > 0:
+        m = p['uni_input_mapping_network']
+        uni_in = ACT[cfg['embedding_activations'][-1]](F.linear(state, m['layer_list.0.weight'], m['layer_list.0.bias']))
+    uni_act = list(cfg['uni_model_activations'][:-1]) + ['linear']
+    out, _ = rnn_base_step(p['universal_model'], dict(layer_type=cfg['uni_model_layer_type'], activation=uni_act),
+                           torch.cat((uni_in, emb), dim=-1), [])
+    if algo == 'td3':
+        mean = torch.tanh(out)
+        noise = torch.randn_like(out) if noise is None else noise
+        return mean, torch.clamp(mean + noise * sample_std, -1, 1), torch.zeros_like(mean), hidden
+    logstd, mu = out.chunk(2, dim=-1)
+    noise = torch.randn_like(mu) if noise is None else noise
+    mean, sample, logp = K.tanh_gaussian_ref(mu, logstd, noise)
+    return mean, sample, logp, hidden
 
 
 def value_forward(p, cfg, state, lst_state, lst_action, action, flags=None, reward=None,

@@ -278,3 +278,24 @@ def time_cpu_baseline(rnn='gru', B=64, T=1024, obs=17, act=6, updates=1, warmup=
     dt = time.time() - t0
     return dict(value=n / dt, seconds_per_update=dt / updates, cores=torch.get_num_threads(),
                 sample=f'{updates} update(s) of {rnn} SAC-REDQ at B={B},T={T},D=256 after {warmup} warm-up')
+
+
+def time_cpu_rollout(rnn='gru', obs=17, act=6, steps=200, warmup=10, threads=1, seed=0):
+    """bench.py --mode rollout `cpu_baseline` leg: the policy's one-token step (the reference samples on the CPU unless
+    --cuda_inference, algorithm/sac.py:48-50) on the host cores.  Returns dict(value=policy steps/s, us_per_step, ...)."""
+    torch.set_num_threads(threads)
+    torch.manual_seed(seed)
+    par = default_parameter(rnn=rnn)
+    tr = OracleTrainer(par, obs, act, 8)
+    spec = tr.pcfg['embedding_layer_type']
+    hidden = [torch.zeros(1, NW.hidden_size_of(l, 256, 256)) for l in spec if NW.is_rnn(l)]
+    g = torch.Generator().manual_seed(seed)
+    s, ls, la, r = torch.randn(1, obs, generator=g), torch.randn(1, obs, generator=g), torch.randn(1, act, generator=g), torch.randn(1, 1, generator=g)
+    with torch.no_grad():
+        for i in range(warmup + steps):
+            if i == warmup:
+                t0 = time.time()
+            _, sample, _, hidden = NW.policy_step(tr.policy, tr.pcfg, s, ls, la, hidden, r)
+    dt = time.time() - t0
+    return dict(value=steps / dt, us_per_step=1e6 * dt / steps, cores=torch.get_num_threads(),
+                sample=f'{steps} policy steps of {rnn} (D=256, obs={obs}, act={act}) on {threads} thread(s) after {warmup} warm-up')

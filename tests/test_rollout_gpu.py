@@ -163,6 +163,40 @@ def test_graphed_policy_step_matches_eager(ops, rnn, algo):
     assert not np.allclose(before, after)
 
 
+@pytest.mark.parametrize('name', ['gru_sac', 'gru_td3', 'gilr_sac', 'lru_sac', 'smamba_sac'])
+def test_policy_step_vs_oracle(ops, name):
+    """Whole policy step (encoders -> recurrent stack -> MLP head -> squashed Gaussian) on the reference's trained-run
+    weights: graphed GPU step vs the CPU oracle's `policy_step`, same hidden carry, means and log-probs at fp32 tolerance."""
+    import json
+    import os
+    from conftest import GOLDEN, nested
+    from offpolicy_rnn import alg_init
+    from oracle import network as NW
+    from oracle.trainer import OracleTrainer, default_parameter
+    from test_host_logic import make_parameter
+    m = json.load(open(os.path.join(GOLDEN, 'train_meta.json')))[name]
+    g = load_golden(f'train_{name}.npz')
+    alg = alg_init(make_parameter(m['rnn'], algo=m['algo'], cuda_inference=True))
+    alg.policy.load_state_dict(nested(g, 'policy0|'))
+    par = default_parameter(rnn=m['rnn'], D=32, algo=m['algo'], policy_embedding_dim=16, value_embedding_dim=16,
+                            policy_uni_model_input_mapping_dim=16, value_uni_model_input_mapping_dim=16)
+    tr = OracleTrainer(par, 5, 3, 12, policy_state=nested(g, 'policy0|'), value_state=nested(g, 'value0|'))
+    rs = np.random.RandomState(5)
+    n = 10
+    obs, acts, rew = rs.randn(n + 1, 1, 5), np.tanh(rs.randn(n + 1, 1, 3)), rs.randn(n + 1, 1, 1)
+    h0 = alg.policy.make_rnd_init_state(1, alg.device)
+    alg.graph_step.load_hidden(h0)
+    hidden = [h[0].cpu().clone() for h in h0._data]
+    for t in range(n):
+        gmean, gsample, glogp = alg.graph_step(obs[t + 1], obs[t], acts[t], rew[t])
+        with torch.no_grad():
+            mean, sample, logp, hidden = NW.policy_step(tr.policy, tr.pcfg, T(obs[t + 1]), T(obs[t]), T(acts[t]), hidden, T(rew[t]),
+                                                        noise=torch.zeros(1, 3), algo=m['algo'])
+        np.testing.assert_allclose(gmean, mean, rtol=1e-4, atol=2e-5, err_msg=f'{name} step {t}')
+    for got, want in zip(alg.graph_step._hidden._data, hidden):
+        np.testing.assert_allclose(got[0].cpu(), want, rtol=1e-4, atol=2e-5)
+
+
 def test_rollout_loop_uses_the_graph(ops):
     """The trainer's environment loop (sac.py) goes through the graphed step when sampling on the GPU."""
     from offpolicy_rnn import alg_init
