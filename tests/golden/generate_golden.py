@@ -403,6 +403,24 @@ def gen_models_and_train():
         json.dump(meta, f, indent=1, sort_keys=True)
 
 
+def gen_checkpoints():
+    """Checkpoint files exactly as the reference writes them (`SAC.save`, algorithm/sac.py; `<name>-<index>-<module>.pt`,
+    models/contextual_model.py:135-143) for the initial networks of two of the trained-run fixtures: same seeds, so the
+    tensors equal the `policy0|` / `value0|` entries of train_<name>.npz."""
+    from offpolicy_rnn.algorithm.sac_full_length_rnn_redq_sep_optim import SACFullLengthRNNREDQ_SEP_OPTIM
+    T = ENV['T']
+    for name, rnn, lens in [('gru_sac', 'gru', [T] * 6), ('smamba_sac', 'smamba_s8_c3_b2_nln', [T, 5, 7, T, 4, 9, 6])]:
+        torch.manual_seed(100)
+        np.random.seed(100)
+        par = make_parameter(rnn, algo='sac', sac_batch_size=int(sum(lens) * 0.6))
+        alg = SACFullLengthRNNREDQ_SEP_OPTIM(par)
+        path = os.path.join(OUT, f'ckpt_{name}')
+        os.makedirs(path, exist_ok=True)
+        alg.save(path)
+        alg.process_pool.shutdown()
+        print('checkpoint', name, sorted(os.listdir(path)))
+
+
 def gen_layer_ids():
     """F9: layer-id string -> constructed hyper-parameters + hidden-state width."""
     from offpolicy_rnn.models.rnn_base import RNNBase
@@ -430,3 +448,4 @@ if __name__ == '__main__':
     gen_rollout()
     gen_layer_ids()
     gen_models_and_train()
+    gen_checkpoints()
