@@ -253,8 +253,11 @@ int resel_gather_trajs(const float* buffer, int W, const int* segments, int nseg
  * All three read the old state and write a NEW state buffer (functional, like the reference's returned hidden), take
  * row strides in elements, and read nothing from the host - so a whole policy step can be captured in a hipGraph.
  *
- * resel_mamba_conv_step: window[b, d, :] <- (window[b, d, 1:], x[b, d]);  xc = silu(sum_k window * w[d, k] + bias[d]).
- *   x [B, Di] (row stride ldx), state_in / state_out [B, Di, K] (row strides ld_in / ld_out), w [Di, K], bias [Di] or NULL.
+ * resel_mamba_conv_step: window[b, d, :] <- (window[b, d, 1:], x[b, d]);  xc = act(sum_k taps * w[d, k] + bias[d]) over the
+ *   newest K - 1 stored taps + x.  x [B, Di] (row stride ldx); state rows (strides ld_in / ld_out) hold W taps per channel at
+ *   [d * stride_d + j * stride_k], oldest first: W = K, strides (K, 1) for smamba's [Di, K] window; W = K - 1, strides
+ *   (1, Di) for the time-major [K - 1, Di] tail of the s6 `mamba` and `conv1d` layers (models/s6/mamba.py:166-176,
+ *   models/conv1d/conv1d.py:27-37).  w [Di, K], bias [Di] or NULL; act: 1 = SiLU, 0 = none.
  * resel_selective_state_update: dt = softplus(x_db[:, :R] w_dt^T + dt_bias); A = -exp(A_log);
  *   h <- h * exp(dt A) + dt * Bm * xc;  y = sum_n h * Cm + D * xc;  y *= silu(z) if z.
  *   x_db [B, R + 2N] = (dt low-rank | Bm | Cm) (row stride ld_xdb), w_dt [Di, R], state [B, Di, N], z [B, Di] (row stride ldz).
@@ -264,7 +267,8 @@ int resel_gather_trajs(const float* buffer, int W, const int* segments, int nseg
  *   pos >= max_seqlen: RESEL_EINVAL for a host position; with a device counter the output row is NaN (the reference's
  *   flash-attn asserts on a full cache). */
 int resel_mamba_conv_step(const float* x, int64_t ldx, const float* state_in, int64_t ld_in, float* state_out, int64_t ld_out,
-                          const float* w, const float* bias, float* xc, int B, int Di, int K, resel_stream_t stream);
+                          int64_t stride_d, int64_t stride_k, int W, const float* w, const float* bias, float* xc, int B, int Di,
+                          int K, int act, resel_stream_t stream);
 int resel_selective_state_update(const float* state_in, int64_t ld_in, float* state_out, int64_t ld_out, const float* xc,
                                  const float* x_db, int64_t ld_xdb, const float* w_dt, const float* dt_bias, const float* A_log,
                                  const float* D, const float* z, int64_t ldz, float* y, int B, int Di, int N, int R,

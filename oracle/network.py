@@ -25,8 +25,23 @@ def parse_layer_id(layer_id: str) -> dict:
         return dict(kind='fc')
     if layer_id.startswith('efc'):
         return dict(kind='efc', ensemble=int(layer_id.split('-')[-1]))
-    if layer_id in ('gru', 'gilr', 'lru'):
+    if layer_id in ('gru', 'gilr', 'lru', 'gilr_lstm'):
         return dict(kind=layer_id)
+    if layer_id.startswith('conv1d'):                               # rnn_base.py:227-234
+        return dict(kind='conv1d', d_conv=int(layer_id.split('_')[-1]) if '_' in layer_id else 4)
+    if layer_id.startswith('mamba'):                                # rnn_base.py:118-135
+        cfg = dict(kind='mamba', d_conv=4, d_state=16, use_ff=True)
+        for c in layer_id.split('_')[1:]:
+            if c.startswith('s'):
+                cfg['d_state'] = int(c[1:])
+            elif c.startswith('c'):
+                cfg['d_conv'] = int(c[1:])
+            elif c.startswith('no'):
+                if c[2:] == 'ff':
+                    cfg['use_ff'] = False
+            else:
+                raise ValueError(f'Pattern {c} has not been implemented!')
+        return cfg
     if layer_id.startswith('smamba'):                               # rnn_base.py:137-163
         cfg = dict(kind='smamba', d_conv=4, d_state=16, block_num=2, rms_norm=True, use_ff=False)
         for c in layer_id.split('_')[1:]:
@@ -70,8 +85,12 @@ def is_rnn(layer_id: str) -> bool:
 def hidden_size_of(layer_id: str, in_dim: int, out_dim: int) -> int:
     """rnn_hidden_state_input_size (rnn_base.py:107-247)."""
     c = parse_layer_id(layer_id)
-    if c['kind'] == 'lru':
+    if c['kind'] in ('lru', 'gilr_lstm'):
         return out_dim * 2
+    if c['kind'] == 'conv1d':
+        return in_dim * (c['d_conv'] - 1)                           # conv1d/conv1d.py:21
+    if c['kind'] == 'mamba':
+        return in_dim * 2 * c['d_state'] + in_dim * 2 * (c['d_conv'] - 1)     # s6/mamba.py:105
     if c['kind'] == 'smamba':
         return (in_dim * 2 * c['d_conv'] + in_dim * 2 * c['d_state']) * c['block_num']   # smamba/mamba.py:70-72,446
     if c['kind'] == 'cgpt':
@@ -140,6 +159,74 @@ def lru_layer(p, pre, x, flags=None):
     out = K.ensemble_linear_ref(out, p[pre + 'middle_proj.weight'], p[pre + 'middle_proj.bias'], desire_ndim=4)
     out = out[0] - out[1] + u[2]                                    # lru.py:167
     return _ff_block(p, pre + 'ff.', out)
+
+
+def gilr_lstm_layer(p, pre, x, flags=None, h0=None):
+    """offpolicy_rnn/models/gilr_lstm/gilr_lstm.py:39-75.  h0 [B, 2C] = (stage-1 state | stage-2 state).  -> (y, hT)."""
+    u = K.ensemble_linear_ref(x, p[pre + 'in_proj.weight'], p[pre + 'in_proj.bias'], desire_ndim=4)
+    start = None if flags is None or flags.rnn_start is None else flags.rnn_start[..., 0]
+    C = u.shape[-1]
+    c0, m0 = (None, None) if h0 is None else (h0[:, :C], h0[:, C:])
+    c, c_last = K.linrec_real_ref(u[0], u[1], start, c0, fuse_act=True)                      # :48-58
+    g = K.ensemble_linear_ref(c, p[pre + 'middle_proj.weight'], p[pre + 'middle_proj.bias'], desire_ndim=4)
+    f, i, o, z = torch.sigmoid(g[0]), torch.sigmoid(g[1]), torch.sigmoid(g[2]), torch.tanh(g[3])    # :59-62
+    m, m_last = K.linrec_real_ref(i * z, f, start, m0, fuse_act=False)                       # :63-70
+    y = F.linear(m * o, p[pre + 'out_proj.weight'], p[pre + 'out_proj.bias'])                 # :71-72
+    return y, torch.cat((c_last, m_last), dim=-1)
+
+
+def conv1d_layer(p, pre, x, flags=None, h0=None):
+    """offpolicy_rnn/models/conv1d/conv1d.py:27-50: depthwise conv over (hidden ++ masked x), no activation, then FF.
+    h0 [B, (K-1) C] time-major.  -> (y, hT)."""
+    B, L, C = x.shape
+    w = p[pre + 'conv1d.weight']                                    # [C, 1, K]
+    Kw = w.shape[-1]
+    hid = torch.zeros(B, Kw - 1, C) if h0 is None else h0.reshape(B, Kw - 1, C)
+    if flags is not None and flags.mask is not None:
+        x = x * flags.mask                                          # :30-31
+    rows = torch.cat((hid, x), dim=1)                               # :32
+    y = F.conv1d(rows.transpose(1, 2), w, p.get(pre + 'conv1d.bias'), groups=C)[:, :, :L].transpose(1, 2)   # :33-35
+    return _ff_block(p, pre + 'ff.', y), rows[:, rows.shape[1] - (Kw - 1):].reshape(B, -1)
+
+
+def s6_mamba_layer(p, pre, x, cfg, flags=None, h0=None):
+    """MambaResidualBlock.forward over MambaBlock.forward / .ssm (offpolicy_rnn/models/s6/mamba.py:41-67,142-237) with
+    the sequential scan of selective_scan/cpu_scan.py:6-62.  h0 [B, Di N + (K-1) Di] = (ssm | conv tail).  -> (y, hT)."""
+    B, L, D = x.shape
+    N, Kw = cfg['d_state'], cfg['d_conv']
+    mp = pre + 'mixer.'
+    h = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-5) * p[pre + 'norm.weight']     # RMSNorm :240-250
+    xz = F.linear(h, p[mp + 'in_proj.weight'])
+    Di = xz.shape[-1] // 2
+    xi, res = xz[..., :Di], xz[..., Di:]
+    ssm0 = torch.zeros(B, Di, N) if h0 is None else h0[:, :Di * N].reshape(B, Di, N)
+    conv0 = torch.zeros(B, Kw - 1, Di) if h0 is None else h0[:, Di * N:].reshape(B, Kw - 1, Di)
+    if flags is not None and flags.mask is not None:
+        xi = xi * flags.mask                                        # :131-132
+    rows = torch.cat((conv0, xi), dim=1)
+    xc = F.conv1d(rows.transpose(1, 2), p[mp + 'conv1d.weight'], p[mp + 'conv1d.bias'], groups=Di)[:, :, :L].transpose(1, 2)
+    conv_tail = rows[:, rows.shape[1] - (Kw - 1):]
+    xc = F.silu(xc)                                                 # :178
+    x_db = F.linear(xc, p[mp + 'x_proj.weight'])
+    R = x_db.shape[-1] - 2 * N
+    delta = F.softplus(F.linear(x_db[..., :R], p[mp + 'dt_proj.weight'], p[mp + 'dt_proj.bias']))   # :229
+    A = -torch.exp(p[mp + 'A_log'].float())
+    Bm, Cm = x_db[..., R:R + N], x_db[..., R + N:]
+    start = torch.zeros(B, L) if flags is None or flags.rnn_start is None else flags.rnn_start[..., 0]
+    state, ys = ssm0, []
+    for t in range(L):                                              # cpu_scan.py:41-57
+        dA = torch.exp(delta[:, t, :, None] * A) * (1 - start[:, t])[:, None, None]
+        state = dA * state + (delta[:, t] * xc[:, t])[:, :, None] * Bm[:, t, None, :]
+        ys.append((state * Cm[:, t, None, :]).sum(-1))
+    y = torch.stack(ys, dim=1) + xc * p[mp + 'D']
+    y = y * F.silu(res)                                             # :181
+    out = F.linear(y, p[mp + 'out_proj.weight']) + x                # :183, :62
+    if cfg['use_ff']:
+        out = _ff_block(p, pre + 'ff.', out)
+    else:
+        out = out * torch.rsqrt(out.pow(2).mean(-1, keepdim=True) + 1e-5) * p[pre + 'norm_f.weight']
+        out = F.linear(out, p[pre + 'ff.weight'])
+    return out, torch.cat((state.reshape(B, -1), conv_tail.reshape(B, -1)), dim=-1)
 
 
 def mamba_mixer(p, pre, x, cfg, start, mask):
@@ -237,6 +324,12 @@ def rollout_layer(p, lid, x, h0, pre='layer_list.0.'):
         out = K.ensemble_linear_ref(torch.stack((hr, hi), dim=0), p[pre + 'middle_proj.weight'], p[pre + 'middle_proj.bias'],
                                     desire_ndim=4)
         return _ff_block(p, pre + 'ff.', out[0] - out[1] + u[2]), torch.cat((hr[:, -1], hi[:, -1]), dim=-1)
+    if c['kind'] == 'gilr_lstm':
+        return gilr_lstm_layer(p, pre, x, None, h0)
+    if c['kind'] == 'conv1d':
+        return conv1d_layer(p, pre, x, None, h0)
+    if c['kind'] == 'mamba':
+        return s6_mamba_layer(p, pre, x, c, None, h0)
     if c['kind'] == 'smamba':
         ys, h = [], h0
         for t in range(x.shape[1]):
@@ -323,6 +416,12 @@ def rnn_base_forward(p: Dict[str, torch.Tensor], spec: dict, x, flags: Optional[
             x = lru_layer(p, pre, x, flags)
         elif c['kind'] == 'smamba':
             x = smamba_layer(p, pre, x, c, flags, smamba_semantics)
+        elif c['kind'] == 'gilr_lstm':
+            x = gilr_lstm_layer(p, pre, x, flags)[0]
+        elif c['kind'] == 'conv1d':
+            x = conv1d_layer(p, pre, x, flags)[0]
+        elif c['kind'] == 'mamba':
+            x = s6_mamba_layer(p, pre, x, c, flags)[0]
         elif c['kind'] == 'cgpt':
             x = cgpt_layer(p, pre, x, c, flags)
         if '+' in act:                                              # rnn_base.py:250-258, 461-467
@@ -542,6 +641,43 @@ def init_rnn_base(in_dim, out_dim, hidden, activation, layer_type) -> Dict[str, 
                 p[pre + 'norm_f.weight'] = torch.ones(D)
                 if not c['rms_norm']:
                     p[pre + 'norm_f.bias'] = torch.zeros(D)
+        elif k == 'gilr_lstm':                                      # gilr_lstm.py:23-31, rnn_base.py:312-320
+            p[pre + 'in_proj.weight'] = torch.stack([_xavier(item, last).t() for _ in range(2)])
+            p[pre + 'in_proj.bias'] = torch.zeros(2, 1, item)
+            p[pre + 'middle_proj.weight'] = torch.stack([_xavier(item, item).t() for _ in range(4)])
+            p[pre + 'middle_proj.bias'] = torch.zeros(4, 1, item)
+            p[pre + 'out_proj.weight'] = _xavier(item, item)
+            p[pre + 'out_proj.bias'] = torch.zeros(item)
+            p[pre + 'layer_norm.weight'] = torch.ones(item)
+            p[pre + 'layer_norm.bias'] = torch.zeros(item)
+        elif k == 'conv1d':                                         # conv1d.py:12-24 (torch default inits)
+            conv = torch.nn.Conv1d(item, item, c['d_conv'], groups=item)
+            p[pre + 'conv1d.weight'] = conv.weight.detach().clone()
+            p[pre + 'conv1d.bias'] = conv.bias.detach().clone()
+            _ff_init(p, pre + 'ff.', item)
+        elif k == 'mamba':                                          # s6/mamba.py:69-128
+            assert last == item
+            D, N, Kc = item, c['d_state'], c['d_conv']
+            Di, R = 2 * D, math.ceil(D / 16)
+            mp = pre + 'mixer.'
+            p[mp + 'in_proj.weight'] = _default_linear(2 * Di, D, False)['weight']
+            conv = torch.nn.Conv1d(Di, Di, Kc, groups=Di)
+            p[mp + 'conv1d.weight'] = conv.weight.detach().clone()
+            p[mp + 'conv1d.bias'] = conv.bias.detach().clone()
+            p[mp + 'x_proj.weight'] = _default_linear(R + 2 * N, Di, False)['weight']
+            std = R ** -0.5
+            p[mp + 'dt_proj.weight'] = torch.empty(Di, R).uniform_(-std, std)
+            dt = torch.exp(torch.rand(Di) * (math.log(0.1) - math.log(0.001)) + math.log(0.001)).clamp(min=1e-4)
+            p[mp + 'dt_proj.bias'] = dt + torch.log(-torch.expm1(-dt))
+            p[mp + 'A_log'] = torch.log(torch.arange(1, N + 1, dtype=torch.float32)).repeat(Di, 1)
+            p[mp + 'D'] = torch.ones(Di)
+            p[mp + 'out_proj.weight'] = _default_linear(D, Di, False)['weight']
+            p[pre + 'norm.weight'] = torch.ones(D)
+            if c['use_ff']:
+                _ff_init(p, pre + 'ff.', D)
+            else:
+                p[pre + 'ff.weight'] = _default_linear(D, D, False)['weight']
+                p[pre + 'norm_f.weight'] = torch.ones(D)
         elif k == 'cgpt':
             D = last
             for i in range(c['nlayer']):

@@ -81,7 +81,7 @@ def skip_len(par) -> int:
     """_get_skip_len (sac_full_length_rnn_ensembleQ.py:57-68)."""
     s = 0
     for lt in (par.value_layer_type + par.value_embedding_layer_type + par.policy_layer_type + par.policy_embedding_layer_type):
-        if 'smamba' in lt:
+        if 'mamba' in lt or 'conv1d' in lt:                       # smamba, mamba (s6) and conv1d carry a conv window
             s = max(s, NW.parse_layer_id(lt)['d_conv'])
     return s + 1
 

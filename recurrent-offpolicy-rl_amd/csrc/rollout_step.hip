@@ -15,27 +15,31 @@ namespace {
 using namespace resel;
 
 // ---- smamba: conv window ----------------------------------------------------------------------------------------
-// one thread per (row, channel); window rows are K contiguous floats
+// one thread per (row, channel).  The stored window holds W taps of channel d at st[d * sd + j * sk], oldest first:
+//   smamba (mamba.py:138-141): [Di, K] rows, W = K (the oldest tap is dropped);  s6 `mamba` (s6/mamba.py:166-176): time-major
+//   [K - 1, Di], W = K - 1.  The conv reads the newest K - 1 stored taps + x; the new window is (stored[1:], x).
 __global__ __launch_bounds__(256) void conv_step_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ st_in,
-                                                        int64_t ld_in, float* __restrict__ st_out, int64_t ld_out,
-                                                        const float* __restrict__ w, const float* __restrict__ bias,
-                                                        float* __restrict__ xc, int B, int Di, int K) {
+                                                        int64_t ld_in, float* __restrict__ st_out, int64_t ld_out, int64_t sd, int64_t sk,
+                                                        int W, const float* __restrict__ w, const float* __restrict__ bias,
+                                                        float* __restrict__ xc, int B, int Di, int K, int act) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * Di) return;
     const int b = i / Di, d = i % Di;
-    const float* si = st_in + (int64_t)b * ld_in + (int64_t)d * K;
-    float* so = st_out + (int64_t)b * ld_out + (int64_t)d * K;
+    const float* si = st_in + (int64_t)b * ld_in + (int64_t)d * sd;
+    float* so = st_out + (int64_t)b * ld_out + (int64_t)d * sd;
     const float* wd = w + (int64_t)d * K;
     const float xn = x[(int64_t)b * ldx + d];
     float acc = bias ? bias[d] : 0.f;
-    for (int k = 0; k + 1 < K; ++k) {
-        const float v = si[k + 1];
-        so[k] = v;
-        acc = __builtin_fmaf(v, wd[k], acc);
+    const int off = W - (K - 1);
+    for (int j = 1; j < W; ++j) {
+        const float v = si[(int64_t)j * sk];
+        so[(int64_t)(j - 1) * sk] = v;
+        if (j >= off) acc = __builtin_fmaf(v, wd[j - off], acc);
     }
-    so[K - 1] = xn;
+    if (off == 0 && W > 0) acc = __builtin_fmaf(si[0], wd[0], acc);
+    if (W > 0) so[(int64_t)(W - 1) * sk] = xn;
     acc = __builtin_fmaf(xn, wd[K - 1], acc);
-    xc[(int64_t)b * Di + d] = siluf_(acc);
+    xc[(int64_t)b * Di + d] = act ? siluf_(acc) : acc;
 }
 
 // ---- smamba: state update -----------------------------------------------------------------------------------------
@@ -177,12 +181,13 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const uint16_t* __rest
 extern "C" {
 
 int resel_mamba_conv_step(const float* x, int64_t ldx, const float* state_in, int64_t ld_in, float* state_out, int64_t ld_out,
-                          const float* w, const float* bias, float* xc, int B, int Di, int K, resel_stream_t stream) {
+                          int64_t stride_d, int64_t stride_k, int W, const float* w, const float* bias, float* xc, int B, int Di,
+                          int K, int act, resel_stream_t stream) {
     if (!x || !state_in || !state_out || !w || !xc) return RESEL_EINVAL;
-    if (B <= 0 || Di <= 0 || K <= 0) return RESEL_EINVAL;
+    if (B <= 0 || Di <= 0 || K <= 0 || (W != K && W != K - 1)) return RESEL_EINVAL;
     const int n = B * Di;
     hipLaunchKernelGGL(conv_step_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, ldx, state_in, ld_in, state_out,
-                       ld_out, w, bias, xc, B, Di, K);
+                       ld_out, stride_d, stride_k, W, w, bias, xc, B, Di, K, act);
     return launch_status();
 }
 

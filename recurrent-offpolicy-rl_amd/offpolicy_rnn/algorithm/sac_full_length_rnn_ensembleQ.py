@@ -164,6 +164,10 @@ class SACFullLengthRNNEnsembleQ(SAC):
             for i, lid in enumerate(net.layer_type):
                 if 'smamba' in lid:
                     skip = max(net.layer_list[i].d_conv, skip)
+                elif 'mamba' in lid:
+                    skip = max(net.layer_list[i].mixer.d_conv, skip)
+                elif 'conv1d' in lid:
+                    skip = max(net.layer_list[i].d_conv, skip)
         return skip + 1
 
     def _get_whether_require_amp(self):

@@ -57,7 +57,7 @@ SIGNATURES = {
     'resel_ensemble_head_bwd_workspace_bytes': (c_size_t, [L, I, L]),
     'resel_ensemble_head_bwd': (c_int, [P, P, P, P, P, P, P, L, I, L, S]),
     'resel_gather_trajs': (c_int, [P, I, P, I, I, I, I, I, I, I, I, I, P, I, P, S]),
-    'resel_mamba_conv_step': (c_int, [P, L, P, L, P, L, P, P, P, I, I, I, S]),
+    'resel_mamba_conv_step': (c_int, [P, L, P, L, P, L, L, L, I, P, P, P, I, I, I, I, S]),
     'resel_selective_state_update': (c_int, [P, L, P, L, P, P, L, P, P, P, P, P, L, P, I, I, I, I, S]),
     'resel_attn_decode': (c_int, [P, L, P, P, I, P, P, F, I, I, I, I, S]),
 }

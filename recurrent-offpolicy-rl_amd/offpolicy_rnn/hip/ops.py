@@ -619,24 +619,46 @@ def gather_trajs(buffer, segments, max_len, skip, rows, row_len, c_mask, c_start
 
 # ---- one-token rollout step (T = 1, no autograd) ----------------------------------------------------------------------
 @torch.no_grad()
+def conv_step(x, window, weight, bias, d_conv, layout, act):
+    """Depthwise conv on one token with a rolling window.  x [B, Di] (row-strided view), window [B, *] rows holding
+    layout 'dk': [Di, K] per row (smamba) or 'kd': time-major [K - 1, Di] (s6 mamba / conv1d).  -> (xc [B, Di], new window)."""
+    _need_cuda('conv_step', x, window)
+    B, Di, K = x.shape[0], x.shape[1], d_conv
+    W, sd, sk = (K, K, 1) if layout == 'dk' else (K - 1, 1, Di)
+    assert window.shape == (B, Di * W) and window.stride(1) == 1 and x.stride(1) == 1
+    new = torch.empty((B, Di * W), dtype=torch.float32, device=x.device)
+    xc = torch.empty((B, Di), dtype=torch.float32, device=x.device)
+    check(lib().resel_mamba_conv_step(_p(x), x.stride(0), _p(window), window.stride(0), _p(new), new.stride(0), sd, sk, W,
+                                      _p(weight), _p(bias), _p(xc), B, Di, K, int(bool(act)), _stream()), 'mamba_conv_step')
+    return xc, new
+
+
+@torch.no_grad()
+def selective_state_update(state, xc, x_db, dt_w, dt_b, A_log, D, z=None):
+    """state [B, Di*N] (row-strided view), xc [B, Di], x_db [B, R + 2N] = (dt low-rank | B | C), z [B, Di] view or None.
+    -> (y [B, Di], new state [B, Di*N])   (reference selective_state_update.py:123-154 with dt_proj folded in)."""
+    _need_cuda('selective_state_update', state, xc, x_db)
+    B, Di = xc.shape
+    R = dt_w.shape[1]
+    N = (x_db.shape[1] - R) // 2
+    assert state.shape == (B, Di * N) and state.stride(1) == 1 and x_db.stride(1) == 1 and xc.is_contiguous()
+    new = torch.empty((B, Di * N), dtype=torch.float32, device=xc.device)
+    y = torch.empty_like(xc)
+    check(lib().resel_selective_state_update(_p(state), state.stride(0), _p(new), new.stride(0), _p(xc), _p(x_db), x_db.stride(0),
+                                             _p(dt_w), _p(dt_b), _p(A_log), _p(D), _p(z), 0 if z is None else z.stride(0), _p(y),
+                                             B, Di, N, R, _stream()), 'selective_state_update')
+    return y, new
+
+
+@torch.no_grad()
 def mamba_step(hidden, xz, conv_w, conv_b, xproj_w, dt_w, dt_b, A_log, D, d_conv, d_state):
     """smamba mixer state update for one token (reference smamba/mamba.py:257-305).
     hidden [B, Di*K + Di*N] = (conv window | ssm state), xz [B, 2 Di] = in_proj output.  -> (y [B, Di], new hidden)."""
-    _need_cuda('mamba_step', hidden, xz)
-    B, Di, K, N, R = xz.shape[0], xz.shape[1] // 2, d_conv, d_state, dt_w.shape[1]
-    assert hidden.shape == (B, Di * (K + N)) and hidden.stride(1) == 1 and xz.stride(1) == 1
-    new_hidden = torch.empty((B, Di * (K + N)), dtype=torch.float32, device=xz.device)
-    xc = torch.empty((B, Di), dtype=torch.float32, device=xz.device)
-    s = _stream()
-    check(lib().resel_mamba_conv_step(_p(xz), xz.stride(0), _p(hidden), hidden.stride(0), _p(new_hidden), new_hidden.stride(0),
-                                      _p(conv_w), _p(conv_b), _p(xc), B, Di, K, s), 'mamba_conv_step')
+    Di, K = xz.shape[1] // 2, d_conv
+    xc, window = conv_step(xz[:, :Di], hidden[:, :Di * K], conv_w, conv_b, K, 'dk', True)
     x_db = torch.nn.functional.linear(xc, xproj_w)                                   # [B, R + 2N]
-    y = torch.empty_like(xc)
-    z = xz[:, Di:]
-    check(lib().resel_selective_state_update(_p(hidden[:, Di * K:]), hidden.stride(0), _p(new_hidden[:, Di * K:]), new_hidden.stride(0),
-                                             _p(xc), _p(x_db), x_db.stride(0), _p(dt_w), _p(dt_b), _p(A_log), _p(D),
-                                             _p(z), xz.stride(0), _p(y), B, Di, N, R, s), 'selective_state_update')
-    return y, new_hidden
+    y, state = selective_state_update(hidden[:, Di * K:], xc, x_db, dt_w, dt_b, A_log, D, xz[:, Di:])
+    return y, torch.cat((window, state), dim=-1)
 
 
 @torch.no_grad()

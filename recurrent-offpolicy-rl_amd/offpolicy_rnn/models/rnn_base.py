@@ -1,10 +1,10 @@
 """RNNBase: a stack of layers selected by layer-id strings, with a per-layer (norm, activation) tail
 (reference offpolicy_rnn/models/rnn_base.py:31-532).
 
-Layer-id grammar kept from the reference (:101-247): `fc`, `efc-<E>`, `gru`, `gilr`, `lru`,
-`smamba[_s<N>][_c<K>][_b<blocks>][_n<ln|...>][_ff]`, `cgpt[_h<H>][_l<L>][_p<drop>][_ml<M>][_rms]`.  Ids of reference layers
-that are outside the MI355X hot path (`lstm`, `mamba*`, `gilr_lstm`, `conv1d*`, `e<rnn>-<E>`, `gpt*`, `transformer*`) are recognised and rejected
-with an explicit message.  Module / parameter naming (`layer_list.<i>.…`, `activation_list.<i>.0.…`) matches the
+Layer-id grammar kept from the reference (:101-247): `fc`, `efc-<E>`, `gru`, `gilr`, `lru`, `gilr_lstm`,
+`smamba[_s<N>][_c<K>][_b<blocks>][_n<ln|...>][_ff]`, `mamba[_s<N>][_c<K>][_noff]`, `conv1d[_<K>]`,
+`cgpt[_h<H>][_l<L>][_p<drop>][_ml<M>][_rms]`.  Ids of reference layers that are outside this build (`lstm`, `e<rnn>-<E>`,
+`econv1d*`, `gpt*`, `transformer*`, `cgru`) are recognised and rejected with an explicit message.  Module / parameter naming (`layer_list.<i>.…`, `activation_list.<i>.0.…`) matches the
 reference so that its per-module checkpoints load."""
 import copy
 import os
@@ -16,14 +16,17 @@ from ..hip import ops
 from .RNNHidden import RNNHidden
 from .ensemble_linear_model import EnsembleLinear, ensemble_head, head_fusable
 from .flash_attention.TransformerFlashAttention import InferenceParams, TransformerDecoder
+from .conv1d.conv1d import Conv1d
 from .gilr.gilr import GILRLayer
+from .gilr_lstm.gilr_lstm import GILRLSTMLayer
 from .gru import GRU
+from .s6.mamba import MambaResidualBlock
 from .lru.lru import LRULayer
 from .smamba.mamba import BlockList as MambaBlockList
 
 ACTIVATIONS = {'tanh': torch.nn.Tanh, 'relu': torch.nn.ReLU, 'sigmoid': torch.nn.Sigmoid, 'leaky_relu': torch.nn.LeakyReLU,
                'linear': torch.nn.Identity, 'elu': torch.nn.ELU, 'gelu': torch.nn.GELU}
-_UNSUPPORTED_PREFIXES = ('lstm', 'mamba', 'gilr_lstm', 'conv1d', 'econv1d', 'gpt', 'transformer', 'cgru', 'elru', 'egilr')
+_UNSUPPORTED_PREFIXES = ('lstm', 'econv1d', 'gpt', 'transformer', 'cgru', 'elru', 'egilr')
 
 
 def parse_smamba_id(layer_id: str) -> dict:
@@ -39,6 +42,22 @@ def parse_smamba_id(layer_id: str) -> dict:
             cfg['rms_norm'] = tok[1:] != 'ln'
         elif tok.startswith('f'):
             cfg['use_ff'] = cfg['use_ff'] or tok[1:] == 'f'
+        else:
+            raise ValueError(f'Pattern {tok} has not been implemented!')
+    return cfg
+
+
+def parse_mamba_id(layer_id: str) -> dict:
+    """`mamba[_s<N>][_c<K>][_noff]` (reference rnn_base.py:118-135)."""
+    cfg = dict(d_conv=4, d_state=16, use_ff=True)
+    for tok in layer_id.split('_')[1:]:
+        if tok.startswith('s'):
+            cfg['d_state'] = int(tok[1:])
+        elif tok.startswith('c'):
+            cfg['d_conv'] = int(tok[1:])
+        elif tok.startswith('no'):
+            if tok[2:] == 'ff':
+                cfg['use_ff'] = False
         else:
             raise ValueError(f'Pattern {tok} has not been implemented!')
     return cfg
@@ -106,6 +125,15 @@ class RNNBase(torch.nn.Module):
             return GILRLayer(n_in, n_out, batch_first=True), n_out
         if lid == 'lru':
             return LRULayer(n_in, n_out, batch_first=True), n_out * 2
+        if lid == 'gilr_lstm':
+            return GILRLSTMLayer(n_in, n_out, batch_first=True), n_out * 2
+        if lid.startswith('mamba'):
+            cfg = parse_mamba_id(lid)
+            layer = MambaResidualBlock(n_in, n_out, d_conv=cfg['d_conv'], d_state=cfg['d_state'], use_ff=cfg['use_ff'])
+            return layer, layer.mixer.desired_hidden_dim
+        if lid.startswith('conv1d'):
+            layer = Conv1d(n_in, n_out, d_conv=int(lid.split('_')[-1]) if '_' in lid else 4)
+            return layer, layer.desired_hidden_dim
         if lid.startswith('smamba'):
             cfg = parse_smamba_id(lid)
             assert n_in == n_out, f'mamba_simple require input_dim == output_dim, while got {n_in} and {n_out}'
@@ -117,7 +145,7 @@ class RNNBase(torch.nn.Module):
             return TransformerDecoder(n_in, cfg['nhead'], 4 * n_in, cfg['nlayer'], cfg['pdrop'], cfg['ln']), cfg['maxlength']
         if lid.startswith(_UNSUPPORTED_PREFIXES):
             raise NotImplementedError(f'layer id {lid!r} exists in the reference but is outside the MI355X hot path of this build '
-                                      f'(supported: fc, efc-<E>, gru, gilr, lru, smamba_*, cgpt_*)')
+                                      f'(supported: fc, efc-<E>, gru, gilr, lru, gilr_lstm, smamba_*, mamba_*, conv1d_*, cgpt_*)')
         raise NotImplementedError(f'unknown layer id {lid!r}')
 
     @staticmethod
@@ -155,7 +183,12 @@ class RNNBase(torch.nn.Module):
                 torch.nn.init.xavier_uniform_(m.out_proj.weight)
                 torch.nn.init.constant_(m.out_proj.bias, 0)
                 xavier_ensemble(m.in_proj)
-            elif isinstance(m, (MambaBlockList, TransformerDecoder)):
+            elif isinstance(m, GILRLSTMLayer):
+                torch.nn.init.xavier_uniform_(m.out_proj.weight)
+                torch.nn.init.constant_(m.out_proj.bias, 0)
+                xavier_ensemble(m.in_proj)
+                xavier_ensemble(m.middle_proj)
+            elif isinstance(m, (MambaBlockList, TransformerDecoder, MambaResidualBlock, Conv1d)):
                 pass
             else:
                 for name, param in m.named_parameters():
@@ -209,12 +242,16 @@ class RNNBase(torch.nn.Module):
                 continue
             lid = self.layer_type[ind]
             if is_rnn_layer(lid):
-                if lid == 'gilr':
+                if lid in ('gilr', 'gilr_lstm'):
                     x, h = layer(x, hidden_state[k], hidden_state.rnn_start)
                 elif lid == 'lru':
                     x, h = layer(x, hidden_state[k], hidden_state.rnn_start, hidden_state.grad_detach)
                 elif lid.startswith('smamba'):
                     x, h = layer(x, hidden_state[k], hidden_state.rnn_start, hidden_state.mask)
+                elif lid.startswith('mamba'):
+                    x, h = layer(x, hidden_state[k], hidden_state.rnn_start, hidden_state.mask, hidden_state.grad_detach)
+                elif lid.startswith('conv1d'):
+                    x, h = layer(x, hidden_state[k], hidden_state.mask)
                 elif lid.startswith('cgpt'):
                     multi = x.dim() == 3 and x.shape[-2] > 1          # whole packed rows (training) vs one rollout step
                     x = layer(x, inference_params=None if multi else hidden_state[k],

@@ -233,7 +233,8 @@ def gen_layers():
     mask[1, 15:] = 0
     mask[0, 8] = 0
     w = torch.randn(B, L, D, generator=g)
-    for lid in ['gru', 'gilr', 'lru', 'smamba_s8_c6_b2_nln', 'smamba_s16_c4_b1', 'smamba_s8_c5_b1_ff']:
+    for lid in ['gru', 'gilr', 'lru', 'smamba_s8_c6_b2_nln', 'smamba_s16_c4_b1', 'smamba_s8_c5_b1_ff',
+                'gilr_lstm', 'conv1d_5', 'mamba_s8_c3', 'mamba_s4_c5_noff']:          # appended: earlier entries keep their draws
         torch.manual_seed(3)
         net = RNNBase(D, D, [], ['linear'], [lid])
         with torch.no_grad():          # the zero-initialised biases would hide bias-handling bugs
@@ -287,7 +288,8 @@ def gen_rollout():
     B, L, D = 2, 9, 32
     g = torch.Generator().manual_seed(11)
     x0 = torch.randn(B, L, D, generator=g)
-    for lid in ['gru', 'gilr', 'lru', 'smamba_s8_c6_b2_nln', 'smamba_s16_c4_b1', 'smamba_s8_c5_b1_ff']:
+    for lid in ['gru', 'gilr', 'lru', 'smamba_s8_c6_b2_nln', 'smamba_s16_c4_b1', 'smamba_s8_c5_b1_ff',
+                'gilr_lstm', 'conv1d_5', 'mamba_s8_c3', 'mamba_s4_c5_noff']:
         torch.manual_seed(4)
         net = RNNBase(D, D, [], ['linear'], [lid])
         with torch.no_grad():
@@ -425,7 +427,8 @@ def gen_layer_ids():
     """F9: layer-id string -> constructed hyper-parameters + hidden-state width."""
     from offpolicy_rnn.models.rnn_base import RNNBase
     table = {}
-    for lid in ['gru', 'gilr', 'lru', 'smamba', 'smamba_s32_c16_b2_nln', 'smamba_b1_c8_s64_ff', 'smamba_s8_c3_b3']:
+    for lid in ['gru', 'gilr', 'lru', 'smamba', 'smamba_s32_c16_b2_nln', 'smamba_b1_c8_s64_ff', 'smamba_s8_c3_b3',
+                'gilr_lstm', 'conv1d', 'conv1d_7', 'mamba', 'mamba_s8_c6_noff']:
         net = RNNBase(32, 32, [], ['linear'], [lid])
         lay = net.layer_list[0]
         e = dict(hidden=int(net.rnn_hidden_state_input_size[0]), nparam=int(sum(p.numel() for p in net.parameters())))

@@ -73,7 +73,7 @@ def _layer_params(g, tag):
     return {k[len(pre):]: T(np.array(v)).requires_grad_(True) for k, v in g.items() if k.startswith(pre)}
 
 
-@pytest.mark.parametrize('lid', ['gru', 'gilr', 'lru'])
+@pytest.mark.parametrize('lid', ['gru', 'gilr', 'lru', 'gilr_lstm', 'conv1d_5', 'mamba_s8_c3', 'mamba_s4_c5_noff'])
 def test_layer_fwd_bwd(lid):
     g = load_golden('layers.npz')
     p = _layer_params(g, lid)
@@ -108,14 +108,16 @@ def test_smamba_layer_both_semantics(lid):
     np.testing.assert_allclose(y2.detach(), g[f'{lid}|y_step'], rtol=1e-4, atol=2e-5)
 
 
-@pytest.mark.parametrize('lid', ['gru', 'gilr', 'lru', 'smamba_s8_c6_b2_nln', 'smamba_s16_c4_b1', 'smamba_s8_c5_b1_ff'])
+@pytest.mark.parametrize('lid', ['gru', 'gilr', 'lru', 'smamba_s8_c6_b2_nln', 'smamba_s16_c4_b1', 'smamba_s8_c5_b1_ff', 'gilr_lstm',
+                                 'conv1d_5', 'mamba_s8_c3', 'mamba_s4_c5_noff'])
 def test_rollout_steps(lid):
     """One-token steps with a carried (random) hidden state, as recorded from the reference's own modules."""
     g = load_golden('rollout.npz')
     p = {k: v.detach() for k, v in _layer_params(g, lid).items()}
     y, hT = NW.rollout_layer(p, lid, T(g['x']), T(g[f'{lid}|h0'])[0])
     np.testing.assert_allclose(y, g[f'{lid}|y'], rtol=1e-4, atol=2e-5)
-    np.testing.assert_allclose(hT, g[f'{lid}|hT'][0], rtol=1e-4, atol=2e-5)
+    # (conv1d / mamba return the state as (B, 1, X) - conv1d.py:45, s6/mamba.py:185-188 - same memory order as (1, B, X))
+    np.testing.assert_allclose(hT, g[f'{lid}|hT'].reshape(hT.shape), rtol=1e-4, atol=2e-5)
 
 
 def test_layer_id_table():

@@ -9,7 +9,8 @@ from conftest import load_golden
 from oracle import kernels as K
 
 pytestmark = pytest.mark.gpu
-ROLLOUT_IDS = ['gru', 'gilr', 'lru', 'smamba_s8_c6_b2_nln', 'smamba_s16_c4_b1', 'smamba_s8_c5_b1_ff']
+ROLLOUT_IDS = ['gru', 'gilr', 'lru', 'smamba_s8_c6_b2_nln', 'smamba_s16_c4_b1', 'smamba_s8_c5_b1_ff', 'gilr_lstm', 'conv1d_5',
+               'mamba_s8_c3', 'mamba_s4_c5_noff']
 
 
 @pytest.fixture(scope='module')
@@ -95,7 +96,7 @@ def test_layer_steps_match_reference_recording(ops, lid):
             y, hid, _ = net.meta_forward(x[:, t:t + 1], hid)
             ys.append(y)
     np.testing.assert_allclose(torch.cat(ys, dim=1).cpu(), g[f'{lid}|y'], rtol=1e-4, atol=2e-5)
-    np.testing.assert_allclose(hid[0].cpu(), g[f'{lid}|hT'], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(hid[0].cpu().reshape(-1), g[f'{lid}|hT'].reshape(-1), rtol=1e-4, atol=2e-5)
 
 
 @pytest.mark.parametrize('lid,steps', [('cgpt_h8_l2_p0', 70), ('cgpt_h4_l1_p0_ml64_rms', 64)])
@@ -123,6 +124,7 @@ def test_cgpt_steps_match_packed_forward(ops, lid, steps):
 
 # ------------------------------------------------------------------------------------------------ hipGraph replay of the policy step
 @pytest.mark.parametrize('rnn,algo', [('gru', 'sac'), ('smamba_s8_c4_b2_nln', 'sac'), ('gilr', 'td3'), ('lru', 'sac'),
+                                      ('gilr_lstm', 'sac'), ('conv1d_3', 'sac'), ('mamba_s8_c3', 'td3'),
                                        ('cgpt_h1_l2_p0_ml32', 'td3')])
 def test_graphed_policy_step_matches_eager(ops, rnn, algo):
     from offpolicy_rnn import alg_init
