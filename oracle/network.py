@@ -459,6 +459,17 @@ def _spec(cfg, which):
     return dict(layer_type=cfg[f'{which}_layer_type'], activation=cfg[f'{which}_activations'])
 
 
+def categorical_head(out):
+    """ContextualSACDiscretePolicy.process_model_out (contextual_sac_discrete_policy.py:111-125): softmax with a 0.01
+    floor, through torch.distributions.Categorical (which renormalises).  -> (mode, sample, log-probs of all actions)."""
+    probs = (out - torch.max(out, dim=-1, keepdim=True).values).exp()
+    probs = probs / probs.sum(dim=-1, keepdim=True)
+    probs = probs + 0.01
+    probs = probs / probs.sum(dim=-1, keepdim=True)
+    dist = torch.distributions.Categorical(probs=probs)
+    return dist.mode.unsqueeze(-1), dist.sample().unsqueeze(-1), torch.log(dist.probs)
+
+
 def policy_forward(p, cfg, state, lst_state, lst_action, flags=None, reward=None, noise=None,
                    algo='sac', sample_std=0.1, **kw):
     """ContextualSACPolicySingleHead.forward (contextual_sac_policy_single_head.py:92-107) and
@@ -472,6 +483,9 @@ def policy_forward(p, cfg, state, lst_state, lst_action, flags=None, reward=None
     uni_act = list(cfg['uni_model_activations'][:-1]) + ['linear']  # contextual_sac_policy_single_head.py:20-21
     out = rnn_base_forward(p['universal_model'], dict(layer_type=cfg['uni_model_layer_type'], activation=uni_act),
                            torch.cat((uni_in, emb), dim=-1), flags, **kw)
+    if cfg.get('discrete'):                                         # contextual_sac_discrete_policy.py:104-125
+        mean, sample, logp = categorical_head(out)
+        return mean, emb, sample, logp
     if algo == 'td3':
         mean = torch.tanh(out)
         noise = torch.randn_like(out) if noise is None else noise
@@ -534,7 +548,13 @@ def value_forward(p, cfg, state, lst_state, lst_action, action, flags=None, rewa
     emb = rnn_base_forward(p['embedding_model'], _spec(cfg, 'embedding'), emb_in, flags, **kw)
     if detach_embedding:
         emb = emb.detach()                                          # contextual_model.py:70-71
-    if cfg['separate_encoder'] and cfg['uni_model_input_mapping_dim'] > 0:
+    if cfg.get('discrete'):                                         # contextual_sac_discrete_value.py:99-110: phi_s(state) only
+        if cfg['separate_encoder'] and cfg['uni_model_input_mapping_dim'] > 0:
+            sa = ACT[cfg['embedding_activations'][-1]](F.linear(state, p['state_input_encoder_q']['weight'],
+                                                                p['state_input_encoder_q']['bias']))
+        else:
+            sa = state
+    elif cfg['separate_encoder'] and cfg['uni_model_input_mapping_dim'] > 0:
         sa = torch.cat((F.linear(state, p['state_input_encoder_q']['weight'], p['state_input_encoder_q']['bias']),
                         F.linear(action, p['action_input_encoder_q']['weight'], p['action_input_encoder_q']['bias'])), -1)
         sa = ACT[cfg['embedding_activations'][-1]](sa)              # contextual_sac_value.py:106-107
@@ -718,16 +738,16 @@ def init_model(cfg, kind: str) -> Dict[str, Dict[str, torch.Tensor]]:
     mapping = cfg['uni_model_input_mapping_dim']
     if kind == 'policy':
         uni_in = sd if mapping == 0 else mapping
-        out = ad * 2 if cfg.get('algo', 'sac') == 'sac' else ad
+        out = ad * 2 if cfg.get('algo', 'sac') == 'sac' and not cfg.get('discrete') else ad
         p['universal_model'] = init_rnn_base(cfg['embedding_size'] + uni_in, out, cfg['uni_model_hidden'],
                                              cfg['uni_model_activations'], cfg['uni_model_layer_type'])
         if mapping > 0:
             p['uni_input_mapping_network'] = init_rnn_base(sd, mapping, [], [cfg['embedding_activations'][-1]], ['fc'])
     else:
-        uni_in = sd + ad
+        uni_in = sd if cfg.get('discrete') else sd + ad
         if mapping > 0 and cfg['separate_encoder']:
-            uni_in = mapping * 2
-        p['universal_model'] = init_rnn_base(cfg['embedding_size'] + uni_in, 1, cfg['uni_model_hidden'],
+            uni_in = mapping if cfg.get('discrete') else mapping * 2
+        p['universal_model'] = init_rnn_base(cfg['embedding_size'] + uni_in, ad if cfg.get('discrete') else 1, cfg['uni_model_hidden'],
                                              cfg['uni_model_activations'], cfg['uni_model_layer_type'])
     if cfg['separate_encoder']:
         p['state_encoder'] = _default_linear(basic, sd)
@@ -739,7 +759,8 @@ def init_model(cfg, kind: str) -> Dict[str, Dict[str, torch.Tensor]]:
             p['reward_encoder'] = _default_linear(basic, 1)
         if kind == 'value' and mapping > 0:
             p['state_input_encoder_q'] = _default_linear(mapping, sd)
-            p['action_input_encoder_q'] = _default_linear(mapping, ad)
+            if not cfg.get('discrete'):
+                p['action_input_encoder_q'] = _default_linear(mapping, ad)
     return p
 
 

@@ -16,6 +16,7 @@ from typing import Dict
 
 import numpy as np
 import torch
+import torch.nn.functional as F
 
 from . import network as NW
 from .buffer import OracleBuffer, Transition
@@ -96,12 +97,15 @@ def allow_nest_stack(par) -> bool:
 
 class OracleTrainer:
     def __init__(self, par, obs_dim, act_dim, max_traj_len, smamba_semantics='gpu', gru_impl='ref',
-                 policy_state=None, value_state=None):
+                 policy_state=None, value_state=None, discrete=False):
         self.par, self.obs_dim, self.act_dim = par, obs_dim, act_dim
         self.algo = par.base_algorithm
+        self.discrete = discrete                                   # act_dim discrete actions (sac.py:49,72-79)
+        if discrete:
+            par.no_alpha_auto_tune = True                          # sac.py:74
         self.fw = dict(smamba_semantics=smamba_semantics, gru_impl=gru_impl)
-        self.pcfg = model_cfg(par, obs_dim, act_dim, 'policy')
-        self.vcfg = model_cfg(par, obs_dim, act_dim, 'value')
+        self.pcfg = dict(model_cfg(par, obs_dim, act_dim, 'policy'), discrete=discrete)
+        self.vcfg = dict(model_cfg(par, obs_dim, act_dim, 'value'), discrete=discrete)
         clone = lambda sd: {m: {k: v.clone().float() for k, v in d.items()} for m, d in sd.items()}
         self.policy = clone(policy_state) if policy_state is not None else NW.init_model(self.pcfg, 'policy')
         self.value = clone(value_state) if value_state is not None else NW.init_model(self.vcfg, 'value')
@@ -115,14 +119,14 @@ class OracleTrainer:
             # td3_full_length_rnn_ensembleQ.py:21-22 flips the flag only AFTER SAC.__init__ built log_alpha,
             # so a TD3 trainer starts (and stays) at log_alpha = 0 unless the user passed --no_alpha_auto_tune
             par.no_alpha_auto_tune = True
-        self.target_entropy = -float(act_dim) * par.target_entropy_ratio  # sac.py:79
+        self.target_entropy = par.target_entropy_ratio if discrete else -float(act_dim) * par.target_entropy_ratio  # sac.py:79
         self.opt_policy = torch.optim.AdamW(self._groups(self.policy, par.rnn_policy_lr, par.policy_l2_norm),
                                             lr=par.policy_lr, weight_decay=par.policy_l2_norm)
         self.opt_value = torch.optim.AdamW(self._groups(self.value, par.rnn_value_lr, par.value_l2_norm),
                                            lr=par.value_lr, weight_decay=par.value_l2_norm)
         self.opt_alpha = torch.optim.AdamW([self.log_alpha], lr=par.alpha_lr)   # sac.py:90 (default weight_decay!)
         self.buffer = OracleBuffer(par.max_buffer_transition_num, max_traj_len, additional_history_len=skip_len(par))
-        self.guard = QValueGuard()
+        self.guard = QValueGuard(1.0 if discrete else 1 - 1e-3)  # sac_full_length_rnn_ensembleQ.py:43-46
         self.nest = allow_nest_stack(par)
         self.grad_num = 0
 
@@ -187,6 +191,8 @@ class OracleTrainer:
             # critic step (:392 -> :261-295)
             q, _ = NW.value_forward(self.value, self.vcfg, state, last_state, last_action, action, f_online,
                                     reward_input, **self.fw)
+            if self.discrete:                                       # select_with_action (:158)
+                q = q.gather(-1, action.long().unsqueeze(0).expand(q.shape[0], -1, -1, -1))
             Q_loss = ((q - target_Q.unsqueeze(0)).pow(2).sum(dim=0) * mask).sum() / valid_num
             self.opt_value.zero_grad()
             Q_loss.backward()
@@ -209,7 +215,10 @@ class OracleTrainer:
                 qpi, _ = NW.value_forward(self.value, self.vcfg, state, last_state, last_action, act_in, f_online,
                                           reward_input, detach_embedding=True, **self.fw)
                 qbar = qpi.mean(dim=0)                              # sac_full_length_rnn_redq.py:46
-                if self.algo == 'sac':
+                if self.discrete:                                   # sac_full_length_rnn_redq.py:84-86
+                    actor_loss = (((((alpha * logp) - qbar) * logp.exp()).sum(dim=-1, keepdim=True)) * mask).sum() / valid_num
+                    logp = (logp * logp.exp()).sum(dim=-1, keepdim=True)        # logged form (:425)
+                elif self.algo == 'sac':
                     actor_loss = (((alpha * logp) - qbar) * mask).sum() / valid_num
                 else:
                     actor_loss = ((-qbar) * mask).sum() / valid_num
@@ -243,6 +252,14 @@ class OracleTrainer:
 
     def _target_Q(self, state, action, next_state, done, reward, flags, alpha):
         par = self.par
+        if self.discrete:                                           # sac_full_length_rnn_redq.py:52-72
+            with torch.no_grad():
+                onehot = F.one_hot(action.squeeze(-1).long(), num_classes=self.act_dim).float()
+                _, _, sample, logp = NW.policy_forward(self.policy, self.pcfg, next_state, state, onehot, flags, reward, **self.fw)
+                nq, _ = NW.value_forward(self.target_value, self.vcfg, next_state, state, onehot, sample, flags, reward, **self.fw)
+                idx = np.random.permutation(nq.shape[0])[:par.redq_m]
+                v = ((nq[idx, :].min(dim=0).values - alpha * logp) * logp.exp()).sum(dim=-1, keepdim=True)
+                return reward + (1 - done) * par.gamma * self.guard.clamp(v)
         with torch.no_grad():
             mean, _, sample, logp = NW.policy_forward(self.policy, self.pcfg, next_state, state, action, flags, reward,
                                                       algo=self.algo, sample_std=par.sample_std, **self.fw)

@@ -55,12 +55,15 @@ class SAC:
             v.to(self.device)
         self.policy.to(self.sample_device)
         self._value_update(tau=0.0)
+        if self.discrete_env:
+            parameter.no_alpha_auto_tune = True                  # reference sac.py:72-74: fixed temperature for discrete actions
         if getattr(parameter, 'no_alpha_auto_tune', False):
             alpha0 = math.log(parameter.sac_alpha)
         else:
             alpha0 = 0.0
         self.log_sac_alpha = torch.tensor([alpha0], dtype=torch.float32, device=self.device).requires_grad_(True)
-        self.target_entropy = -float(np.prod(self.env.action_space.shape)) * parameter.target_entropy_ratio
+        self.target_entropy = parameter.target_entropy_ratio if self.discrete_env else \
+            -float(np.prod(self.env.action_space.shape)) * parameter.target_entropy_ratio
         # optimizers: one flat AdamW per network (a single learning rate here; the *_sep_optim trainers regroup)
         self.optimizer_policy = FlatAdamW(self.policy.store, lambda m: parameter.policy_lr, lambda m: parameter.policy_l2_norm)
         self.optimizers_value = [FlatAdamW(v.store, lambda m: parameter.value_lr, lambda m: parameter.value_l2_norm) for v in self.values]
@@ -79,7 +82,7 @@ class SAC:
         self.sample_hidden = None
         # on the GPU the per-step policy forward is replayed as one hipGraph (hip/graph_step.py); RESEL_GRAPH_ROLLOUT=0: eager
         self.graph_step = None
-        if self.sample_device.type == 'cuda' and os.environ.get('RESEL_GRAPH_ROLLOUT', '1') != '0':
+        if self.sample_device.type == 'cuda' and os.environ.get('RESEL_GRAPH_ROLLOUT', '1') != '0' and not self.discrete_env:
             from ..hip.graph_step import GraphedPolicyStep
             self.graph_step = GraphedPolicyStep(self.policy, self.sample_device, batch_size=1)
         self.sample_num = 0
@@ -174,7 +177,11 @@ class SAC:
     def env_step(self, next_obs, act, reward, done):
         self.last_state_np = self.state_np.copy()
         self.state_np = np.asarray(next_obs).copy().reshape((1, -1))
-        self.last_action_np = np.asarray(act).copy().reshape((1, -1))
+        if self.discrete_env:                                     # one-hot of the action index (reference :167-169)
+            self.last_action_np = np.zeros((1, self.act_dim))
+            self.last_action_np[..., int(np.asarray(act).reshape(-1)[0])] = 1
+        else:
+            self.last_action_np = np.asarray(act).copy().reshape((1, -1))
         self.reward_np = np.array([[reward]])
         if done:
             self.env_reset()
@@ -212,7 +219,8 @@ class SAC:
             self.policy.to(self.sample_device)
             for _ in range(self.parameter.step_per_iteration):
                 act_sample = self.sample_action()
-                next_state, reward, done, _ = self.env.step(unorm_act(act_sample[0], self.env.action_space))
+                act_env = unorm_act(act_sample[0], self.env.action_space)
+                next_state, reward, done, _ = self.env.step(int(act_env) if self.discrete_env else act_env)
                 ep_ret += reward
                 ep_len += 1
                 self._push(act_sample, next_state, reward, done, ep_len)

@@ -266,7 +266,29 @@ class SACFullLengthRNNEnsembleQ(SAC):
     def _select_target_ensemble(self, num_ensemble: int) -> np.ndarray:
         return np.arange(num_ensemble)                               # plain ensemble-min (REDQ trainers override)
 
+    def _target_Q_discrete(self, b, policy_hidden, target_hiddens, stats):
+        """Discrete-action target (reference sac_full_length_rnn_redq.py:52-72): V(s') = sum_a pi(a|s') (min_subset Q'(s', a) -
+        alpha log pi(a|s')); the last action enters the networks as a one-hot vector.  Guard clamp / update, done masking
+        and the batch statistics go through the same fused kernel as the continuous target (one pseudo-critic, no log-prob)."""
+        with torch.no_grad():
+            onehot = self.policy.action2onehot(b['action'])
+            _, _, sample, logp, _, _ = self.policy.forward(b['next_state'], b['state'], onehot, policy_hidden, b['reward'])
+            tv = self.target_values[0]
+            E = tv.uni_network.layer_list[-1].num_ensemble
+            subset = np.asarray(self._select_target_ensemble(E))
+            if subset.size < E:
+                with _ensemble_subset(tv, self._subset_on_device(subset, E, as_long=True)):
+                    q = tv.forward(b['next_state'], b['state'], onehot, sample, target_hiddens[0], b['reward'])[0]
+            else:
+                q = tv.forward(b['next_state'], b['state'], onehot, sample, target_hiddens[0], b['reward'])[0][self._subset_on_device(subset, E, as_long=True)]
+            alpha = self.log_sac_alpha.detach().exp()
+            v = ((q.min(dim=0).values - alpha * logp) * logp.exp()).sum(dim=-1, keepdim=True)
+            return ops.sac_target(v.unsqueeze(0).contiguous(), self._subset_on_device(np.arange(1), 1), None, self.log_sac_alpha.detach(),
+                                  b['reward'], b['done'], b['mask'], self.parameter.gamma, self.Q_guard.state, stats)
+
     def get_target_Q(self, b, policy_hidden, target_hiddens, stats):
+        if self.discrete_env:
+            return self._target_Q_discrete(b, policy_hidden, target_hiddens, stats)
         with torch.no_grad():
             sample, logp = self._next_action(b, policy_hidden)
             tv = self.target_values[0]
@@ -355,6 +377,8 @@ class SACFullLengthRNNEnsembleQ(SAC):
             # 2. critic step
             value.train()
             q = value.forward(b['state'], b['last_state'], b['last_action'], b['action'], value_hiddens[0], b['reward_input'])[0]
+            if self.discrete_env:                                   # Q of the action taken (reference :158)
+                q = q.gather(-1, b['action'].long().unsqueeze(0).expand(q.shape[0], -1, -1, -1))
             q_loss_sum = ((q - target_Q.unsqueeze(0)).pow(2).sum(dim=0) * mask).sum()
             self.optimizer_value.zero_grad()
             q_loss_sum.backward()
@@ -379,7 +403,12 @@ class SACFullLengthRNNEnsembleQ(SAC):
                 with _frozen_parameters(value):
                     q_pi = value.forward(b['state'], b['last_state'], b['last_action'], act_in, value_hiddens[0], b['reward_input'],
                                          detach_embedding=True)[0]
-                actor_sum = (self._actor_objective(alpha_detach, log_prob, self._q_for_policy(q_pi)) * mask).sum()
+                if self.discrete_env:                               # expectation over the action distribution (reference redq :85-86)
+                    objective = (self._actor_objective(alpha_detach, log_prob, self._q_for_policy(q_pi)) * log_prob.exp()).sum(dim=-1, keepdim=True)
+                    log_prob = (log_prob * log_prob.exp()).sum(dim=-1, keepdim=True)          # logged as -entropy (:425)
+                else:
+                    objective = self._actor_objective(alpha_detach, log_prob, self._q_for_policy(q_pi))
+                actor_sum = (objective * mask).sum()
                 self.optimizer_policy.zero_grad()
                 actor_sum.backward(inputs=self.policy.parameters())
                 pstore = self.policy.store

@@ -81,18 +81,28 @@ def install_stubs(obs_dim=5, act_dim=3, T=12):
         def sample(self):
             return np.random.uniform(-1, 1, self.shape)
 
+    class Discrete(Space):
+        def __init__(self, n):
+            self.n, self.shape = n, ()
+
+        def seed(self, s):
+            pass
+
+        def sample(self):
+            return int(np.random.randint(self.n))
+
     class Env:
         pass
 
     gym.Space, gym.Env = Space, Env
-    gym.spaces = types.SimpleNamespace(Box=Box)
+    gym.spaces = types.SimpleNamespace(Box=Box, Discrete=Discrete)
     sys.modules['gym'] = gym
     sys.modules['gym.spaces'] = gym.spaces
 
     class FakeEnv(Env):
         def __init__(self):
             self.observation_space = Box(-np.inf, np.inf, (ENV['obs'],))
-            self.action_space = Box(-1, 1, (ENV['act'],))
+            self.action_space = Discrete(ENV['act']) if ENV.get('discrete') else Box(-1, 1, (ENV['act'],))
             self.t = 0
 
         def seed(self, s):
@@ -112,7 +122,7 @@ def install_stubs(obs_dim=5, act_dim=3, T=12):
 
     def make_env(name, seed):
         return dict(train_env=FakeEnv(), eval_env=FakeEnv(), train_tasks=[], eval_tasks=[None], max_rollouts_per_task=1,
-                    max_trajectory_len=ENV['T'], obs_dim=ENV['obs'], act_dim=ENV['act'], act_continuous=True,
+                    max_trajectory_len=ENV['T'], obs_dim=ENV['obs'], act_dim=ENV['act'], act_continuous=not ENV.get('discrete'),
                     seed=seed, multiagent=False)
 
     me.make_env = make_env
@@ -405,6 +415,72 @@ def gen_models_and_train():
         json.dump(meta, f, indent=1, sort_keys=True)
 
 
+def gen_discrete_train():
+    """Discrete-action SAC-REDQ (categorical actor, all-action critic; reference contextual_sac_discrete_*.py and
+    sac_full_length_rnn_redq.py:52-89): initial weights, one forward of actor / critic, three consecutive updates."""
+    from offpolicy_rnn.algorithm.sac_full_length_rnn_redq_sep_optim import SACFullLengthRNNREDQ_SEP_OPTIM
+    from offpolicy_rnn.buffers.transition_buffer.replay_memory import Transition
+    obs, act, T = ENV['obs'], 4, ENV['T']
+    ENV['discrete'], keep_act = True, ENV['act']
+    ENV['act'] = act
+    meta = {}
+    for name, rnn, lens in [('gru_sac_discrete', 'gru', [T] * 6), ('gilr_sac_discrete', 'gilr', [T, 5, 7, T, 4, 9, 6])]:
+        torch.manual_seed(100)
+        np.random.seed(100)
+        par = make_parameter(rnn, algo='sac', sac_batch_size=int(sum(lens) * 0.6), sac_alpha=0.2)
+        alg = SACFullLengthRNNREDQ_SEP_OPTIM(par)
+        assert alg.discrete_env
+        out = {}
+        out.update(flat_sd(alg.policy.state_dict(), 'policy0|'))
+        out.update(flat_sd(alg.values[0].state_dict(), 'value0|'))
+        rs = np.random.RandomState(9)
+        for L in lens:
+            o, r = rs.randn(L + 1, obs), rs.randn(L)
+            a = rs.randint(act, size=(L, 1)).astype(np.float64)
+            oh = np.eye(act)[a[:, 0].astype(int)]
+            for t in range(L):
+                alg.replay_buffer.mem_push(Transition(
+                    state=o[t:t + 1], last_state=o[t - 1:t] if t > 0 else np.zeros((1, obs)),
+                    last_action=oh[t - 1:t] if t > 0 else np.zeros((1, act)), action=a[t:t + 1], next_state=o[t + 1:t + 2],
+                    reward=float(r[t]), logp=None, mask=1, start=(t == 0), done=(t == L - 1),
+                    reward_input=np.array([[r[t - 1] if t > 0 else 0.0]]), timeout=(t == L - 1) and L == T))
+        np.random.seed(5)
+        batch, _, valid, table = alg.replay_buffer.sample_trajs(par.sac_batch_size, None, equalize_data_of_each_traj=True,
+                                                                nest_stack_trajs=alg.allow_nest_stack)
+        f32 = lambda a_: torch.from_numpy(np.array(a_, copy=True)).float()
+        st, ls, la, ac, rs_, ri = map(f32, (batch.state, batch.last_state, batch.last_action, batch.action, batch.start,
+                                            batch.reward_input))
+        hp = alg.policy.make_init_state(st.shape[0], torch.device('cpu'))
+        hp.set_rnn_start(rs_)
+        hp.set_mask(f32(valid))
+        mean, emb, samp, logp, _, _ = alg.policy.forward(st, ls, la, hp, ri)
+        hv = alg.values[0].make_init_state(st.shape[0], torch.device('cpu'))
+        hv.set_rnn_start(rs_)
+        hv.set_mask(f32(valid))
+        q, qemb, _, _ = alg.values[0].forward(st, ls, la, ac, hv, ri)
+        for k, v in dict(fw_state=st, fw_last_state=ls, fw_last_action=la, fw_action=ac, fw_start=rs_, fw_valid=f32(valid),
+                         fw_mean=mean.float(), fw_emb=emb, fw_logp=logp, fw_q=q, fw_qemb=qemb).items():
+            out[k] = t2n(v)
+        torch.manual_seed(200)
+        np.random.seed(200)
+        logs = []
+        for _ in range(3):
+            log = alg.train_one_batch()
+            alg.grad_num += 1
+            logs.append({k: (float(v[0]) if isinstance(v, tuple) else float(v)) for k, v in log.items()})
+        out.update(flat_sd(alg.policy.state_dict(), 'policy3|'))
+        out.update(flat_sd(alg.values[0].state_dict(), 'value3|'))
+        out.update(flat_sd(alg.target_values[0].state_dict(), 'target3|'))
+        np.savez_compressed(os.path.join(OUT, f'train_{name}.npz'), **out)
+        meta[name] = dict(rnn=rnn, algo='sac', lens=lens, sac_batch_size=par.sac_batch_size, logs=logs, n_actions=act,
+                          sac_alpha=0.2, skip_len=alg._get_skip_len(), nest=bool(alg.allow_nest_stack))
+        alg.process_pool.shutdown()
+        print('train', name, logs[-1]['critic_loss'])
+    ENV['discrete'], ENV['act'] = False, keep_act
+    with open(os.path.join(OUT, 'train_discrete_meta.json'), 'w') as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+
+
 def gen_checkpoints():
     """Checkpoint files exactly as the reference writes them (`SAC.save`, algorithm/sac.py; `<name>-<index>-<module>.pt`,
     models/contextual_model.py:135-143) for the initial networks of two of the trained-run fixtures: same seeds, so the
@@ -452,3 +528,4 @@ if __name__ == '__main__':
     gen_layer_ids()
     gen_models_and_train()
     gen_checkpoints()
+    gen_discrete_train()

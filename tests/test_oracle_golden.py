@@ -183,3 +183,63 @@ def test_train_one_batch_three_updates(name):
             for k, v in d.items():
                 np.testing.assert_allclose(net[mname][k].detach(), v, rtol=2e-3, atol=2e-5, err_msg=f'{pre}{mname}.{k}')
     np.testing.assert_allclose(tr.log_alpha.detach(), g['log_alpha3'], rtol=1e-5, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------- discrete actions
+DMETA = json.load(open(os.path.join(GOLDEN, 'train_discrete_meta.json')))
+
+
+def push_discrete(buffer, Transition, rs, L, obs, act, T):
+    """Same draws as generate_golden.gen_discrete_train: integer actions, one-hot last actions."""
+    o, r = rs.randn(L + 1, obs), rs.randn(L)
+    a = rs.randint(act, size=(L, 1)).astype(np.float64)
+    oh = np.eye(act)[a[:, 0].astype(int)]
+    for t in range(L):
+        buffer.mem_push(Transition(
+            state=o[t:t + 1], last_state=o[t - 1:t] if t > 0 else np.zeros((1, obs)),
+            last_action=oh[t - 1:t] if t > 0 else np.zeros((1, act)), action=a[t:t + 1], next_state=o[t + 1:t + 2],
+            reward=float(r[t]), logp=None, mask=1, start=(t == 0), done=(t == L - 1),
+            reward_input=np.array([[r[t - 1] if t > 0 else 0.0]]), timeout=(t == L - 1) and L == T))
+
+
+def discrete_trainer(name):
+    from oracle.buffer import Transition
+    m = DMETA[name]
+    g = load_golden(f'train_{name}.npz')
+    par = default_parameter(rnn=m['rnn'], D=32, algo='sac', sac_batch_size=m['sac_batch_size'], sac_alpha=m['sac_alpha'],
+                            policy_embedding_dim=16, value_embedding_dim=16, policy_uni_model_input_mapping_dim=16,
+                            value_uni_model_input_mapping_dim=16, max_buffer_transition_num=5000)
+    tr = OracleTrainer(par, 5, m['n_actions'], 12, policy_state=nested(g, 'policy0|'), value_state=nested(g, 'value0|'), discrete=True)
+    rs = np.random.RandomState(9)
+    for n in m['lens']:
+        push_discrete(tr.buffer, Transition, rs, n, 5, m['n_actions'], 12)
+    return tr, g, m
+
+
+@pytest.mark.parametrize('name', list(DMETA))
+def test_discrete_policy_value_forward(name):
+    tr, g, m = discrete_trainer(name)
+    f = lambda k: T(g[k])
+    flags = NW.Flags(f('fw_start'), f('fw_valid'))
+    mean, emb, samp, logp = NW.policy_forward(tr.policy, tr.pcfg, f('fw_state'), f('fw_last_state'), f('fw_last_action'), flags, None, **tr.fw)
+    q, qemb = NW.value_forward(tr.value, tr.vcfg, f('fw_state'), f('fw_last_state'), f('fw_last_action'), f('fw_action'), flags, None, **tr.fw)
+    assert q.shape[-1] == m['n_actions'] and logp.shape[-1] == m['n_actions']
+    for k, v in dict(fw_mean=mean.float(), fw_emb=emb, fw_logp=logp, fw_q=q, fw_qemb=qemb).items():
+        np.testing.assert_allclose(v.detach(), g[k], rtol=1e-4, atol=2e-5, err_msg=k)
+
+
+@pytest.mark.parametrize('name', list(DMETA))
+def test_discrete_three_updates(name):
+    tr, g, m = discrete_trainer(name)
+    torch.manual_seed(200)
+    np.random.seed(200)
+    for it in range(3):
+        log = tr.train_one_batch()
+        tr.grad_num += 1
+        for k, v in m['logs'][it].items():
+            got = log[k][0] if isinstance(log[k], tuple) else log[k]
+            assert got == pytest.approx(v, rel=2e-3, abs=2e-4), (it, k, got, v)
+    for pre, net in (('policy3|', tr.policy), ('value3|', tr.value), ('target3|', tr.target_value)):
+        for mname, d in nested(g, pre).items():
+            for k, v in d.items():
+                np.testing.assert_allclose(net[mname][k].detach(), v, rtol=2e-3, atol=2e-5, err_msg=f'{pre}{mname}.{k}')

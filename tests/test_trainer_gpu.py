@@ -104,6 +104,27 @@ def test_train_one_batch_gpu_vs_oracle_more_layer_ids(rnn):
                 np.testing.assert_allclose(sd[mod][k].detach().cpu(), v.detach(), rtol=1e-3, atol=2e-5, err_msg=f'{mod}.{k}')
 
 
+@pytest.mark.parametrize('name', ['gru_sac_discrete', 'gilr_sac_discrete'])
+def test_discrete_train_one_batch_gpu_vs_reference_logs(name):
+    """Discrete-action SAC-REDQ on cuda:0 against the dicts / parameters the reference itself logged (three updates)."""
+    from test_host_logic import discrete_alg
+    alg, g, m = discrete_alg(name)
+    assert alg.device.type == 'cuda'
+    torch.manual_seed(200)
+    np.random.seed(200)
+    for it in range(3):
+        log = alg.train_one_batch()
+        alg.grad_num += 1
+        for k, v in m['logs'][it].items():
+            got = log[k][0] if isinstance(log[k], tuple) else log[k]
+            assert got == pytest.approx(v, rel=2e-3, abs=5e-4), (it, k, got, v)
+    for pre, net in (('policy3|', alg.policy), ('value3|', alg.values[0]), ('target3|', alg.target_values[0])):
+        sd = net.state_dict()
+        for mod, d in nested(g, pre).items():
+            for k, v in d.items():
+                np.testing.assert_allclose(sd[mod][k].detach().cpu(), v, rtol=2e-3, atol=2e-5, err_msg=f'{pre}{mod}.{k}')
+
+
 def test_full_size_step_runs_and_is_finite():
     """BASELINE config-2 shapes (smamba_s32_c16_b2_nln, D=256, T=1024) at a reduced row count: finite, non-trivial update."""
     from offpolicy_rnn import alg_init
