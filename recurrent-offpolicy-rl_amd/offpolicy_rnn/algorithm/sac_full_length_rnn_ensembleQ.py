@@ -18,6 +18,8 @@ What is organised differently for the MI355X:
 """
 from typing import Dict, List
 
+import os
+
 import numpy as np
 import torch
 
@@ -154,6 +156,8 @@ class SACFullLengthRNNEnsembleQ(SAC):
                                                                        self.policy.uni_network, self.policy.embedding_network)
                                     for lid in net.layer_type)
         self._stats = torch.zeros(2, dtype=torch.float32, device=self.device)
+        self._shared_policy_out = None
+        self.share_policy_pass = self._policy_pass_shareable()
 
     step = property(lambda self: self.train_one_batch)          # north_star's "algorithm.step()" alias
     device_replay = True        # keep a device mirror of the replay ring and assemble sampled batches on the GPU (CUDA only)
@@ -172,6 +176,27 @@ class SACFullLengthRNNEnsembleQ(SAC):
 
     def _get_whether_require_amp(self):
         return False
+
+    _SHIFT_INVARIANT_IDS = ('smamba', 'mamba', 'gilr', 'lru', 'conv1d')      # state cleared / masked at the first token of a trajectory
+
+    def _policy_pass_shareable(self) -> bool:
+        """The target pass evaluates the policy on (s', s, a): the SAME token sequence as the actor pass on (s, s_prev,
+        a_prev), one slot earlier (that is what the pre-step slot and the `total_*` flags of the reference build,
+        sac_full_length_rnn_ensembleQ.py:338-378), with the SAME parameters (the actor is updated after both).  When every
+        layer's output at a token depends only on the tokens of its own trajectory - pointwise layers and recurrent layers
+        that reset / mask at the trajectory start - the actor pass is the target pass shifted by one slot, so ONE policy
+        forward (with a graph) serves both and the second is skipped.  Not for `gru` (no reset: the leading padding slots
+        differ between the two passes), `cgpt` (dropout), TD3 / discrete heads (kept on the plain path),
+        RESEL_SHARE_POLICY_PASS=0."""
+        if os.environ.get('RESEL_SHARE_POLICY_PASS', '1') == '0' or self.base_algorithm != 'sac' or self.discrete_env:
+            return False
+        if type(self)._next_action is not SACFullLengthRNNEnsembleQ._next_action:
+            return False
+        for net in (self.policy.embedding_network, self.policy.uni_network):
+            for lid in net.layer_type:
+                if not (lid == 'fc' or lid.startswith('efc') or lid.startswith(self._SHIFT_INVARIANT_IDS)):
+                    return False
+        return not any(isinstance(m, torch.nn.Dropout) and m.p > 0 for mod in self.policy.contextual_modules.values() for m in mod.modules())
 
     def _mask_mean(self, data: torch.Tensor, mask: torch.Tensor, valid_num) -> torch.Tensor:
         return (data * mask).sum() / valid_num
@@ -289,8 +314,16 @@ class SACFullLengthRNNEnsembleQ(SAC):
     def get_target_Q(self, b, policy_hidden, target_hiddens, stats):
         if self.discrete_env:
             return self._target_Q_discrete(b, policy_hidden, target_hiddens, stats)
+        self._shared_policy_out = None
+        if self._share_this_update:
+            with torch.enable_grad():           # one policy forward with a graph: the actor step reuses it one slot later
+                emb_in = self.policy.get_embedding_input(b['next_state'], b['state'], b['action'], b['reward'])
+                self._shared_policy_out = self.policy.meta_forward(emb_in, b['next_state'], policy_hidden, False)[0]
         with torch.no_grad():
-            sample, logp = self._next_action(b, policy_hidden)
+            if self._shared_policy_out is not None:
+                _, sample, logp = self.policy.process_model_out(self._shared_policy_out.detach())
+            else:
+                sample, logp = self._next_action(b, policy_hidden)
             tv = self.target_values[0]
             E = tv.uni_network.layer_list[-1].num_ensemble
             subset = np.asarray(self._select_target_ensemble(E))
@@ -370,6 +403,8 @@ class SACFullLengthRNNEnsembleQ(SAC):
             mask = b['mask']
 
             # 1. target (no grad); guard clamp/update + max|target| + sum(mask) happen inside the fused kernel
+            actor_due = self.grad_num % par.policy_update_per == 0 and (utd_idx + 1) / par.utd * par.policy_utd > policy_update_cnt
+            self._share_this_update = self.share_policy_pass and actor_due
             self.policy.eval()
             target_Q = self.get_target_Q(b, target_policy_hidden, target_hiddens, self._stats)
             valid_num = self._stats[1]
@@ -395,8 +430,13 @@ class SACFullLengthRNNEnsembleQ(SAC):
 
             # 4. actor (+ alpha) step
             if self.grad_num % par.policy_update_per == 0 and (utd_idx + 1) / par.utd * par.policy_utd > policy_update_cnt:
-                action_mean, _, act_sample, log_prob, _, _ = self.policy.forward(b['state'], b['last_state'], b['last_action'],
-                                                                                policy_hidden, b['reward_input'])
+                if self._shared_policy_out is not None:            # the target pass's head outputs, one slot later
+                    out2 = torch.nn.functional.pad(self._shared_policy_out[:, :-1], (0, 0, 1, 0))
+                    self._shared_policy_out = None
+                    action_mean, act_sample, log_prob = self.policy.process_model_out(out2)
+                else:
+                    action_mean, _, act_sample, log_prob, _, _ = self.policy.forward(b['state'], b['last_state'], b['last_action'],
+                                                                                    policy_hidden, b['reward_input'])
                 act_in = act_sample if self.base_algorithm == 'sac' else action_mean
                 # the actor objective differentiates Q only w.r.t. the action: the critic's parameters are frozen while its graph
                 # is recorded, so that the backward does not form the critic weight gradients the reference computes and drops
