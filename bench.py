@@ -244,7 +244,7 @@ def main():
                               {'kernel': name, 'bound': 'hbm', 'achieved': ach, 'peak': 8000.0, 'unit': 'GB/s', 'frac': ach / 8000.0,
                                'traffic': traffic.get(name), 'avg_us': kern[name]['avg_us'], 'launches': kern[name]['launches'],
                                'algorithmic_bytes': alg_bytes[name],
-                               'note': 'fp32 recurrence with N=32 states per channel: VALU-issue bound below the HBM roof (DESIGN.md 4)'}))
+                               'note': f'fp32 recurrence with N={N} states per channel: VALU-issue bound below the HBM roof (DESIGN.md 4)'}))
         lines.sort(key=lambda t: -t[0])
         if lines:
             out['roofline'] = lines[0][1]
