@@ -277,6 +277,16 @@ int resel_attn_decode(const uint16_t* qkv, int64_t ld_qkv, uint16_t* kv_cache, c
                       const float* slopes, uint16_t* out, float scale, int B, int H, int head_dim, int max_seqlen,
                       resel_stream_t stream);
 
+/* ---- C = W^T N over a very long reduction dimension (weight gradients of the narrow Mamba projections) ----------------
+ * Replaces autograd's `grad.t() @ input` of the x_proj / dt_proj F.linear calls (reference
+ * models/smamba/mamba_ssm/ops/selective_scan_interface_new.py:261-335; models/smamba/mamba.py:231-233).
+ * wide [K, Wd] (row stride ldw, Wd % 4 == 0, 16-byte aligned rows), narrow [K, Nd <= 96] (row stride ldn);
+ * out = wide^T narrow as [Wd, Nd], or its transpose [Nd, Wd] when transposed != 0.  fp32 MFMA, the reduction is split over
+ * the grid and summed in a fixed order (deterministic).  workspace: resel_atb_workspace_bytes(K, Wd, Nd). */
+size_t resel_atb_workspace_bytes(int64_t K, int Wd, int Nd);
+int resel_atb(const float* wide, int64_t ldw, int Wd, const float* narrow, int64_t ldn, int Nd, float* out, int transposed,
+              void* workspace, int64_t K, resel_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

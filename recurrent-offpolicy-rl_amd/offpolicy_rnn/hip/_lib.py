@@ -59,6 +59,8 @@ SIGNATURES = {
     'resel_gather_trajs': (c_int, [P, I, P, I, I, I, I, I, I, I, I, I, P, I, P, S]),
     'resel_mamba_conv_step': (c_int, [P, L, P, L, P, L, L, L, I, P, P, P, I, I, I, I, S]),
     'resel_selective_state_update': (c_int, [P, L, P, L, P, P, L, P, P, P, P, P, L, P, I, I, I, I, S]),
+    'resel_atb_workspace_bytes': (c_size_t, [L, I, I]),
+    'resel_atb': (c_int, [P, L, I, P, L, I, P, I, P, L, S]),
     'resel_attn_decode': (c_int, [P, L, P, P, I, P, P, F, I, I, I, I, S]),
 }
 

@@ -210,7 +210,9 @@ class MambaInnerFn(torch.autograd.Function):
             _p(D), _p(dt_b), _p(startf), _p(dy), Di, _p(ck),
             _p(dxc), Di, _p(ddt), Di, P(dxz, Di), 2 * Di, P(dx_dbl, R), R + 2 * N, P(dx_dbl, R + N), R + 2 * N,
             _p(dA), _p(dD), _p(ddt_b), _p(ws), Bsz, L, Di, N, 1, _stream()), 'selective_scan_bwd')
-        d_dt_w = torch.mm(ddt.t(), x_dbl[:, :R])
+        # [Di, R] with a 66 752-long reduction: hand-written MFMA kernel (the library reaches 7 TFLOP/s on this shape)
+        d_dt_w = atb(ddt, x_dbl[:, :R]) if R <= 32 and Di % 4 == 0 and ddt.stride(1) == 1 and ddt.stride(0) % 4 == 0 \
+            else torch.mm(ddt.t(), x_dbl[:, :R])
         dx_dbl[:, :R] = torch.mm(ddt, dt_w)
         d_xproj_w = torch.mm(dx_dbl.t(), xc)
         dxc.addmm_(dx_dbl, xproj_w)                                        # conv output receives scan (du) + x_proj gradients
@@ -614,6 +616,21 @@ def gather_trajs(buffer, segments, max_len, skip, rows, row_len, c_mask, c_start
     check(lib().resel_gather_trajs(_p(buffer), W, _p(segments), segments.shape[0], int(max_len), int(skip), int(rows), int(row_len),
                                    int(c_mask), int(c_start), int(c_done), int(c_timeout), _p(pre_pairs), pre_pairs.shape[0], _p(out),
                                    _stream()), 'gather_trajs')
+    return out
+
+
+@torch.no_grad()
+def atb(wide, narrow, transposed=False):
+    """wide [K, Wd] (column stride 1, Wd % 4 == 0), narrow [K, Nd <= 96] -> wide^T narrow [Wd, Nd] (or [Nd, Wd] if transposed):
+    the long-reduction weight-gradient GEMMs of the narrow Mamba projections on a hand-written fp32 MFMA kernel."""
+    _need_cuda('atb', wide, narrow)
+    K, Wd = wide.shape
+    Nd = narrow.shape[1]
+    assert narrow.shape[0] == K and wide.stride(1) == 1 and narrow.stride(1) == 1
+    out = torch.empty((Nd, Wd) if transposed else (Wd, Nd), dtype=torch.float32, device=wide.device)
+    ws = _ws(lib().resel_atb_workspace_bytes(K, Wd, Nd), wide.device)
+    check(lib().resel_atb(_p(wide), wide.stride(0), Wd, _p(narrow), narrow.stride(0), Nd, _p(out), int(bool(transposed)), _p(ws), K,
+                          _stream()), 'atb')
     return out
 
 

@@ -532,3 +532,17 @@ def test_conv_full_size_properties(ops):
     ya = ops.causal_conv1d_fn(xz[..., :Di], w, bias, gap, True)
     yb = ops.causal_conv1d_fn(xz[:, 300 + Kw:, :Di], w, bias, gap[:, 300 + Kw:], True)
     assert (ya[:, 300 + Kw:] - yb).abs().max().item() <= 1e-6 * ya.abs().max().item()
+
+
+@pytest.mark.parametrize('K,Wd,Nd,ldn,tr', [(66752, 512, 16, 80, False), (66752, 512, 80, 80, True), (1001, 132, 33, 40, False),
+                                            (7, 4, 1, 1, True), (4100, 1024, 96, 96, False)])
+def test_atb_long_reduction_gemm(ops, K, Wd, Nd, ldn, tr):
+    g = torch.Generator().manual_seed(K + Wd)
+    wide = rnd(K, Wd, g=g).cuda()
+    narrow_full = rnd(K, ldn, g=g).cuda()
+    narrow = narrow_full[:, :Nd]
+    got = ops.atb(wide, narrow, tr)
+    ref = (wide.double().t() @ narrow.double())
+    ref = ref.t() if tr else ref
+    close(got.cpu(), ref.float().cpu(), rtol=1e-4, atol_scale=2e-5, name='atb')
+    assert torch.equal(got, ops.atb(wide, narrow, tr))           # fixed summation order
