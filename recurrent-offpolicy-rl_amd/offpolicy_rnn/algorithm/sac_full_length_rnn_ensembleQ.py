@@ -190,6 +190,8 @@ class SACFullLengthRNNEnsembleQ(SAC):
         RESEL_SHARE_POLICY_PASS=0."""
         if os.environ.get('RESEL_SHARE_POLICY_PASS', '1') == '0' or self.base_algorithm != 'sac' or self.discrete_env:
             return False
+        if self.parameter.randomize_first_hidden:        # the two passes would start from two different random states
+            return False
         if type(self)._next_action is not SACFullLengthRNNEnsembleQ._next_action:
             return False
         for net in (self.policy.embedding_network, self.policy.uni_network):
