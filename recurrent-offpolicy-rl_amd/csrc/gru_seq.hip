@@ -181,8 +181,20 @@ __global__ __launch_bounds__(256) void gru_fwd_persistent_kernel(GruFwd p, u64* 
         } else {
             const u64* src = xg + (size_t)((t - 1) & 1) * RG * H;
             const unsigned epoch = (unsigned)t;      // h_{t-1} was published with tag t
-            for (int i = tid; i < RG * H; i += NT) {
-                u64 x = __hip_atomic_load(src + i, RESEL_RLX_AGENT);
+            // all granules of this thread are requested before the first tag is looked at: one L2 round trip in the common
+            // case instead of one per granule (the polls were the longest part of a step)
+            constexpr int NPOLL = (RG * KC + 15) / 16;           // = RG * H / NT  (H = KC * KQ, NT = 16 * KQ)
+            u64 xv[NPOLL];
+#pragma unroll
+            for (int q = 0; q < NPOLL; ++q) {
+                const int i = tid + q * NT;
+                xv[q] = i < RG * H ? __hip_atomic_load(src + i, RESEL_RLX_AGENT) : 0;
+            }
+#pragma unroll
+            for (int q = 0; q < NPOLL; ++q) {
+                const int i = tid + q * NT;
+                if (i >= RG * H) continue;
+                u64 x = xv[q];
                 unsigned spins = 0;
                 while ((unsigned)(x >> 32) != epoch) {
                     if (++spins > SPIN_LIMIT) { s_fail = 1; break; }
@@ -358,6 +370,12 @@ __global__ __launch_bounds__(256) void gru_bwd_persistent_kernel(GruBwd p, u64* 
             }
         }
         const u64* src = xg + (size_t)((k - 1) & 1) * RG * H;
+        u64 xv[PER];                                             // every carry granule requested before the first tag check
+#pragma unroll
+        for (int n = 0; n < PER; ++n) {
+            const int i = tid + n * NT;
+            xv[n] = (k > 0 && i < RG * H) ? __hip_atomic_load(src + i, RESEL_RLX_AGENT) : 0;
+        }
 #pragma unroll
         for (int n = 0; n < PER; ++n) {
             const int i = tid + n * NT;
@@ -365,7 +383,7 @@ __global__ __launch_bounds__(256) void gru_bwd_persistent_kernel(GruBwd p, u64* 
             const int r = i / H, u = i % H;
             float carry = 0.f;
             if (k > 0) {
-                u64 x = __hip_atomic_load(src + i, RESEL_RLX_AGENT);
+                u64 x = xv[n];
                 unsigned spins = 0;
                 while ((unsigned)(x >> 32) != (unsigned)k) {
                     if (++spins > SPIN_LIMIT) { s_fail = 1; break; }
