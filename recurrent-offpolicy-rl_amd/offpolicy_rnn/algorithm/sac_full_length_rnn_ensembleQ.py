@@ -177,7 +177,9 @@ class SACFullLengthRNNEnsembleQ(SAC):
     def _get_whether_require_amp(self):
         return False
 
-    _SHIFT_INVARIANT_IDS = ('smamba', 'mamba', 'gilr', 'lru', 'conv1d')      # state cleared / masked at the first token of a trajectory
+    # state cleared / masked at the first token of a trajectory; cgpt attends inside per-trajectory segments whose table
+    # is shifted with the tokens (`target_attention_mask`, reference :358-366)
+    _SHIFT_INVARIANT_IDS = ('smamba', 'mamba', 'gilr', 'lru', 'conv1d', 'cgpt')
 
     def _policy_pass_shareable(self) -> bool:
         """The target pass evaluates the policy on (s', s, a): the SAME token sequence as the actor pass on (s, s_prev,
@@ -186,7 +188,7 @@ class SACFullLengthRNNEnsembleQ(SAC):
         layer's output at a token depends only on the tokens of its own trajectory - pointwise layers and recurrent layers
         that reset / mask at the trajectory start - the actor pass is the target pass shifted by one slot, so ONE policy
         forward (with a graph) serves both and the second is skipped.  Not for `gru` (no reset: the leading padding slots
-        differ between the two passes), `cgpt` (dropout), TD3 / discrete heads (kept on the plain path),
+        differ between the two passes), layers with active dropout (`cgpt_*_p0.1`), TD3 / discrete heads (kept on the plain path),
         RESEL_SHARE_POLICY_PASS=0."""
         if os.environ.get('RESEL_SHARE_POLICY_PASS', '1') == '0' or self.base_algorithm != 'sac' or self.discrete_env:
             return False

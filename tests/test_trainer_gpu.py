@@ -125,6 +125,36 @@ def test_discrete_train_one_batch_gpu_vs_reference_logs(name):
                 np.testing.assert_allclose(sd[mod][k].detach().cpu(), v, rtol=2e-3, atol=2e-5, err_msg=f'{pre}{mod}.{k}')
 
 
+@pytest.mark.parametrize('rnn,tol', [('smamba_s8_c4_b2_nln', 1e-4), ('gilr', 1e-4), ('cgpt_h1_l2_p0.0_ml64', 3e-2)])
+def test_shared_policy_pass_equals_two_passes_gpu(rnn, tol, monkeypatch):
+    """One policy forward for the target and the actor pass vs the reference's two passes, real kernels, ragged
+    nested trajectories, same seeds: logged scalars and the updated policy agree (cgpt: to its bf16 attention tolerance)."""
+    from offpolicy_rnn import alg_init
+    runs = []
+    for flag in ('1', '0'):
+        monkeypatch.setenv('RESEL_SHARE_POLICY_PASS', flag)
+        torch.manual_seed(5)
+        np.random.seed(5)
+        alg = alg_init(make_parameter(rnn, sac_batch_size=40))
+        assert alg.share_policy_pass == (flag == '1')
+        rs = np.random.RandomState(9)
+        for n in [12, 5, 7, 12, 4, 9, 6]:
+            o, a, r = _synth(rs, n, 5, 3)
+            _push(alg.replay_buffer, o, a, r, early_done=(n != 12))
+        torch.manual_seed(200)
+        np.random.seed(200)
+        logs = []
+        for _ in range(2):
+            logs.append(dict(alg.train_one_batch()))
+            alg.grad_num += 1
+        runs.append((logs, alg.policy.store.flat.detach().clone()))
+    for a, b in zip(runs[0][0], runs[1][0]):
+        for k in b:
+            va, vb = (a[k][0] if isinstance(a[k], tuple) else a[k]), (b[k][0] if isinstance(b[k], tuple) else b[k])
+            assert va == pytest.approx(vb, rel=tol, abs=tol), k
+    np.testing.assert_allclose(runs[0][1].cpu(), runs[1][1].cpu(), rtol=tol, atol=tol * 1e-1)
+
+
 def test_full_size_step_runs_and_is_finite():
     """BASELINE config-2 shapes (smamba_s32_c16_b2_nln, D=256, T=1024) at a reduced row count: finite, non-trivial update."""
     from offpolicy_rnn import alg_init
