@@ -244,6 +244,11 @@ def main():
                               {'kernel': name, 'bound': 'hbm', 'achieved': ach, 'peak': 8000.0, 'unit': 'GB/s', 'frac': ach / 8000.0,
                                'traffic': traffic.get(name), 'avg_us': kern[name]['avg_us'], 'launches': kern[name]['launches'],
                                'algorithmic_bytes': alg_bytes[name],
+                               # VALU-issue view of the same launch: lane-cycles spent per (row, step, channel, state) at 256 CUs x
+                               # 64 fp32 lanes x 2.4 GHz, against the instruction-count floor of the recurrence (forward: delta*A,
+                               # exp2 at quarter rate, 2 fma = 7; backward: + replay and 10 gradient ops + butterfly sums ~ 24)
+                               'valu_cycles_per_state': kern[name]['avg_us'] * 1e-6 * 256 * 64 * 2.4e9 / (Bsz * Tp * Di * N),
+                               'valu_floor_cycles_per_state': 7 if name == 'sscan_fwd_kernel' else 24,
                                'note': f'fp32 recurrence with N={N} states per channel: VALU-issue bound below the HBM roof (DESIGN.md 4)'}))
         lines.sort(key=lambda t: -t[0])
         if lines:
