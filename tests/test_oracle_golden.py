@@ -5,6 +5,7 @@ import os
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from conftest import GOLDEN, load_golden, nested
 from oracle import kernels as K
@@ -243,3 +244,34 @@ def test_discrete_three_updates(name):
         for mname, d in nested(g, pre).items():
             for k, v in d.items():
                 np.testing.assert_allclose(net[mname][k].detach(), v, rtol=2e-3, atol=2e-5, err_msg=f'{pre}{mname}.{k}')
+
+
+# ---------------------------------------------------------------------------------------------- cgpt attention (unpinned)
+def test_alibi_slopes_are_the_published_geometric_sequences():
+    """flash_attn is un-vendored (parity unpinned): anchor the restatement on the published ALiBi definition
+    (slopes 2^(-8 i / H) for power-of-two head counts; interleaved sequence otherwise)."""
+    np.testing.assert_allclose(K.alibi_slopes(8), [2.0 ** -(i + 1) for i in range(8)], rtol=0, atol=0)
+    np.testing.assert_allclose(K.alibi_slopes(4), [2.0 ** -(2 * (i + 1)) for i in range(4)], rtol=1e-7)
+    s12 = K.alibi_slopes(12)
+    assert len(s12) == 12 and np.allclose(s12[:8], [2.0 ** -(i + 1) for i in range(8)]) and np.allclose(s12[8:], [2.0 ** -(i + 0.5) for i in range(4)])
+
+
+@pytest.mark.parametrize('H,d,lens', [(8, 32, [7, 1, 19]), (4, 16, [33])])
+def test_attention_restatement_equals_torch_sdpa_with_alibi_bias(H, d, lens):
+    """Independent implementation check of the oracle's packed causal + ALiBi attention: torch's own
+    scaled_dot_product_attention with an explicit additive bias -slope_h (i - j) and a causal mask, per sequence."""
+    g = torch.Generator().manual_seed(3)
+    Tn = sum(lens)
+    q, k, v = (torch.randn(Tn, H, d, generator=g) for _ in range(3))
+    cu = torch.tensor(np.concatenate(([0], np.cumsum(lens))), dtype=torch.int32)
+    slopes = K.alibi_slopes(H)
+    got = K.attention_alibi_varlen_ref(q, k, v, cu, slopes)
+    for s in range(len(lens)):
+        a, b = int(cu[s]), int(cu[s + 1])
+        n = b - a
+        i, j = torch.arange(n)[:, None], torch.arange(n)[None, :]
+        bias = -slopes[:, None, None] * (i - j).float()[None]
+        bias = bias.masked_fill((j > i)[None], float('-inf'))
+        ref = F.scaled_dot_product_attention(q[a:b].transpose(0, 1)[None], k[a:b].transpose(0, 1)[None], v[a:b].transpose(0, 1)[None],
+                                             attn_mask=bias[None])[0].transpose(0, 1)
+        np.testing.assert_allclose(got[a:b], ref, rtol=1e-5, atol=1e-6)
