@@ -369,6 +369,7 @@ class SACFullLengthRNNEnsembleQ(SAC):
 
     def _finish_step(self, optimizer, store, local_count):
         """Exchange (sum) the flat gradient + the local valid count, then AdamW with grad / global count."""
+        store.collect_grads()
         store.grad[store.numel] = local_count
         self.grad_sync.all_reduce_(store.grad)
         return 1.0 / store.grad[store.numel:store.numel + 1]

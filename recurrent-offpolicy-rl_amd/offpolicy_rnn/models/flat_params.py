@@ -54,10 +54,28 @@ class FlatParameterStore:
         return self
 
     def zero_grad(self):
+        """Zero the flat gradient buffer and detach the per-parameter `.grad`s: with `.grad = None` autograd's AccumulateGrad
+        keeps the incoming gradient tensor as is (no kernel) instead of launching one tiny add per parameter into the view;
+        `collect_grads()` then moves all of them into the flat buffer with a multi-tensor copy (2-3 launches per network
+        instead of ~40)."""
         self.grad.zero_()
-        for p, o, n in self.slices:          # autograd accumulates in place as long as .grad stays a view
-            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
-                p.grad = self.grad[o:o + n].view(p.shape)
+        for p, _, _ in self.slices:
+            p.grad = None
+
+    def collect_grads(self):
+        """After backward(): gather the gradients autograd left on the parameters into the flat buffer and re-point
+        `.grad` at the views (so that everything downstream - clipping, all-reduce, AdamW, user code - sees one buffer)."""
+        dst, src = [], []
+        base = self.grad.data_ptr()
+        for p, o, n in self.slices:
+            g = p.grad
+            view = self.grad[o:o + n].view(p.shape)
+            if g is not None and g.data_ptr() != base + 4 * o:
+                dst.append(view)
+                src.append(g.detach())
+            p.grad = view
+        if dst:
+            torch._foreach_copy_(dst, src)
 
     def segments(self, lr_of_module, wd_of_module):
         """-> (seg_end int64[n], seg_lr[n], seg_wd[n]) tensors on the buffer's device, one segment per module."""
