@@ -1,0 +1,17 @@
+"""Soak run: N consecutive updates of the bench configuration; prints the log scalars every 20 updates and checks they stay finite."""
+import sys, os, math
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'recurrent-offpolicy-rl_amd')]
+import torch
+from bench import build_trainer
+rnn = sys.argv[1] if len(sys.argv) > 1 else 'smamba_s32_c16_b2_nln'
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 120
+alg = build_trainer(rnn, 64, 1024)
+for i in range(n):
+    log = dict(alg.train_one_batch())
+    alg.grad_num += 1
+    vals = {k: (v[0] if isinstance(v, tuple) else v) for k, v in log.items()}
+    assert all(math.isfinite(float(v)) for v in vals.values()), (i, vals)
+    if i % 20 == 0 or i == n - 1:
+        print(i, {k: round(float(vals[k]), 4) for k in ('critic_loss', 'actor_loss', 'log_prob', 'log_alpha', 'target_q_max', 'clip_min', 'clip_max') if k in vals})
+print('soak ok')
