@@ -157,6 +157,7 @@ class SACFullLengthRNNEnsembleQ(SAC):
                                     for lid in net.layer_type)
         self._stats = torch.zeros(2, dtype=torch.float32, device=self.device)
         self._shared_policy_out = None
+        self._share_this_update = False
         self.share_policy_pass = self._policy_pass_shareable()
 
     step = property(lambda self: self.train_one_batch)          # north_star's "algorithm.step()" alias
