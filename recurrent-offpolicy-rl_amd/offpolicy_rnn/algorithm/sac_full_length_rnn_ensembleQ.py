@@ -156,6 +156,10 @@ class SACFullLengthRNNEnsembleQ(SAC):
                                                                        self.policy.uni_network, self.policy.embedding_network)
                                     for lid in net.layer_type)
         self._stats = torch.zeros(2, dtype=torch.float32, device=self.device)
+        # latency-bound value embeddings (gru) of the two graph-free critic passes run on a side stream next to the policy pass
+        self.overlap_value_embedding = (self.device.type == 'cuda' and os.environ.get('RESEL_OVERLAP_EMBEDDING', '1') != '0'
+                                        and not self.discrete_env and any(lid == 'gru' for lid in self.values[0].embedding_network.layer_type))
+        self._side_stream = self._target_stream = None
         self._shared_policy_out = None
         self._share_this_update = False
         self.share_policy_pass = self._policy_pass_shareable()
@@ -262,6 +266,13 @@ class SACFullLengthRNNEnsembleQ(SAC):
         return h
 
     # ------------------------------------------------------------------------------------------ target
+    def _prefetch_value_embedding(self, model, args, hidden):
+        if not self.overlap_value_embedding:
+            return
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=self.device)
+        model.prefetch_embedding(args, hidden, self._side_stream)
+
     def _next_action(self, b, hidden):
         """(a', log pi(a'|s')) on the shifted inputs (s', s, a); TD3 trainers override."""
         _, _, sample, logp, _, _ = self.policy.forward(b['next_state'], b['state'], b['action'], hidden, b['reward'])
@@ -324,6 +335,7 @@ class SACFullLengthRNNEnsembleQ(SAC):
             with torch.enable_grad():           # one policy forward with a graph: the actor step reuses it one slot later
                 emb_in = self.policy.get_embedding_input(b['next_state'], b['state'], b['action'], b['reward'])
                 self._shared_policy_out = self.policy.meta_forward(emb_in, b['next_state'], policy_hidden, False)[0]
+        self._prefetch_value_embedding(self.target_values[0], (b['next_state'], b['state'], b['action'], b['reward']), target_hiddens[0])
         with torch.no_grad():
             if self._shared_policy_out is not None:
                 _, sample, logp = self.policy.process_model_out(self._shared_policy_out.detach())
@@ -412,12 +424,28 @@ class SACFullLengthRNNEnsembleQ(SAC):
             actor_due = self.grad_num % par.policy_update_per == 0 and (utd_idx + 1) / par.utd * par.policy_utd > policy_update_cnt
             self._share_this_update = self.share_policy_pass and actor_due
             self.policy.eval()
-            target_Q = self.get_target_Q(b, target_policy_hidden, target_hiddens, self._stats)
+            target_done = None
+            if self.overlap_value_embedding:
+                # latency-bound layers: the whole (graph-free) target computation goes to a second stream, so that the critic's
+                # forward below (main stream) runs beside the target policy pass and the target critic's embedding pass
+                main = torch.cuda.current_stream(self.device)
+                if self._target_stream is None:
+                    self._target_stream = torch.cuda.Stream(device=self.device)
+                self._target_stream.wait_stream(main)
+                with torch.cuda.stream(self._target_stream):
+                    target_Q = self.get_target_Q(b, target_policy_hidden, target_hiddens, self._stats)
+                    target_done = torch.cuda.Event()
+                    target_done.record(self._target_stream)
+            else:
+                target_Q = self.get_target_Q(b, target_policy_hidden, target_hiddens, self._stats)
             valid_num = self._stats[1]
 
             # 2. critic step
             value.train()
             q = value.forward(b['state'], b['last_state'], b['last_action'], b['action'], value_hiddens[0], b['reward_input'])[0]
+            if target_done is not None:
+                main.wait_event(target_done)
+                target_Q.record_stream(main)
             if self.discrete_env:                                   # Q of the action taken (reference :158)
                 q = q.gather(-1, b['action'].long().unsqueeze(0).expand(q.shape[0], -1, -1, -1))
             q_loss_sum = ((q - target_Q.unsqueeze(0)).pow(2).sum(dim=0) * mask).sum()
@@ -436,6 +464,7 @@ class SACFullLengthRNNEnsembleQ(SAC):
 
             # 4. actor (+ alpha) step
             if self.grad_num % par.policy_update_per == 0 and (utd_idx + 1) / par.utd * par.policy_utd > policy_update_cnt:
+                self._prefetch_value_embedding(value, (b['state'], b['last_state'], b['last_action'], b['reward_input']), value_hiddens[0])
                 if self._shared_policy_out is not None:            # the target pass's head outputs, one slot later
                     out2 = torch.nn.functional.pad(self._shared_policy_out[:, :-1], (0, 0, 1, 0))
                     self._shared_policy_out = None

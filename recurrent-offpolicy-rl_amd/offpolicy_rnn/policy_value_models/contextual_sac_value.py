@@ -51,7 +51,7 @@ class ContextualSACValue(ContextualModel):
 
     def forward(self, state, lst_state, lst_action, action, rnn_memory: Optional[RNNHidden], reward, detach_embedding=False
                 ) -> Tuple[torch.Tensor, torch.Tensor, RNNHidden, Optional[RNNHidden]]:
-        emb_in = self.get_embedding_input(state, lst_state, lst_action, reward)
+        emb_in = None if getattr(self, '_prefetched', None) is not None else self.get_embedding_input(state, lst_state, lst_action, reward)
         value, rnn_memory, emb, full = self.meta_forward(emb_in, self.state_action(state, action), rnn_memory, detach_embedding)
         return value, emb, rnn_memory, full
 
