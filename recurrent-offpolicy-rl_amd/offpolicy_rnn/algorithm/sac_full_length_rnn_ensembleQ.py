@@ -163,6 +163,8 @@ class SACFullLengthRNNEnsembleQ(SAC):
         self._shared_policy_out = None
         self._share_this_update = False
         self.share_policy_pass = self._policy_pass_shareable()
+        if self.share_policy_pass:              # the shared pass records an autograd graph inside the target computation: keep that on one stream
+            self.overlap_value_embedding = False
 
     step = property(lambda self: self.train_one_batch)          # north_star's "algorithm.step()" alias
     device_replay = True        # keep a device mirror of the replay ring and assemble sampled batches on the GPU (CUDA only)
