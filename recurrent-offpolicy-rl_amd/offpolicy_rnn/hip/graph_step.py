@@ -55,9 +55,9 @@ class GraphedPolicyStep:
     # ------------------------------------------------------------------------------------------ capture
     def _forward(self):
         o, a = self._layout['obs'], self._layout['act']
-        x = self._in_dev
-        state, lst_state = x[:, :o], x[:, o:2 * o]
-        lst_action, reward = x[:, 2 * o:2 * o + a], x[:, 2 * o + a:2 * o + a + 1]
+        x = self._in_dev.unsqueeze(1)           # [B, 1, .]: B environments, one token each (a 2-D input would be ONE sequence of length B)
+        state, lst_state = x[..., :o], x[..., o:2 * o]
+        lst_action, reward = x[..., 2 * o:2 * o + a], x[..., 2 * o + a:2 * o + a + 1]
         mean, _, sample, logp, new_hidden, _ = self.policy.forward(state=state, lst_state=lst_state, lst_action=lst_action,
                                                                    rnn_memory=self._hidden, reward=reward)
         self._out_dev[:, :a].copy_(mean.reshape(self.B, a))

@@ -208,3 +208,27 @@ def test_rollout_loop_uses_the_graph(ops):
     acts = [alg.sample_action() for _ in range(3)]
     assert alg.graph_step._graph is not None
     assert all(a.shape == (1, alg.act_dim) and np.isfinite(a).all() for a in acts)
+
+
+@pytest.mark.parametrize('rnn,algo', [('smamba_s8_c4_b1_nln', 'sac'), ('cgpt_h1_l1_p0_ml32', 'td3'), ('gru', 'sac')])
+def test_graphed_policy_step_with_several_environments(ops, rnn, algo):
+    """The step kernels take B rows: one graph replay advances B independent environments (rows must not mix)."""
+    from offpolicy_rnn import alg_init
+    from offpolicy_rnn.hip.graph_step import GraphedPolicyStep
+    from test_host_logic import make_parameter
+    alg = alg_init(make_parameter(rnn, algo=algo, cuda_inference=True))
+    B, n = 3, 6
+    rs = np.random.RandomState(1)
+    o, a = alg.obs_dim, alg.act_dim
+    obs, acts, rew = rs.randn(n + 1, B, o), np.tanh(rs.randn(n + 1, B, a)), rs.randn(n + 1, B, 1)
+    batched = GraphedPolicyStep(alg.policy, alg.device, batch_size=B)
+    batched.load_hidden(None)
+    singles = [GraphedPolicyStep(alg.policy, alg.device, batch_size=1) for _ in range(B)]
+    for s1 in singles:
+        s1.load_hidden(None)
+    tol = 3e-2 if rnn.startswith('cgpt') else 1e-5
+    for t in range(n):
+        mean_b = batched(obs[t + 1], obs[t], acts[t], rew[t])[0]
+        for r, s1 in enumerate(singles):
+            mean_1 = s1(obs[t + 1, r:r + 1], obs[t, r:r + 1], acts[t, r:r + 1], rew[t, r:r + 1])[0]
+            np.testing.assert_allclose(mean_b[r:r + 1], mean_1, rtol=tol, atol=tol, err_msg=f'{rnn} step {t} row {r}')
