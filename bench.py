@@ -136,12 +136,29 @@ def rollout_mode(args):
         return dt / args.steps
 
     eager, graph = run(False), run(True)
+    batched = None
+    if args.envs > 1:                                  # B independent environments advanced by ONE graph replay
+        from offpolicy_rnn.hip.graph_step import GraphedPolicyStep
+        E = args.envs
+        step = GraphedPolicyStep(alg.policy, alg.device, batch_size=E)
+        step.load_hidden(None)
+        ob, ac, rw = rs.randn(2, E, OBS), np.tanh(rs.randn(E, ACT)), rs.randn(E, 1)
+        for i in range(n):
+            if i == args.warmup:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            if i % 900 == 899:
+                step.load_hidden(None)                 # stay inside a cgpt KV cache
+            step(ob[i & 1], ob[1 - (i & 1)], ac, rw)
+        batched = (time.perf_counter() - t0) / args.steps
     out = {'metric': 'policy steps/sec (rollout, one environment)', 'value': 1.0 / graph, 'unit': 'steps/s', 'n_gpus': 1, 'steps': args.steps,
            'warmup': args.warmup, 'ms_per_step': 1e3 * graph, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
            'dtype': 'f32', 'data': 'synthetic',
            'config': {'workload': f'{args.rnn} {args.algo.upper()} policy, one token per step, B=1, obs={OBS}, act={ACT}, D=256; '
                                   f'host numpy in -> sampled action on the host'},
            'graph_us_per_step': 1e6 * graph, 'eager_us_per_step': 1e6 * eager}
+    if batched is not None:
+        out['batched'] = {'envs': args.envs, 'us_per_replay': 1e6 * batched, 'env_steps_per_s': args.envs / batched}
     if not args.no_cpu_baseline and not args.rnn.startswith('cgpt'):
         import subprocess
         code = ("import json,sys; sys.path.insert(0, %r); from oracle.trainer import time_cpu_rollout; "
@@ -167,6 +184,7 @@ def main():
     ap.add_argument('--rows', type=int, default=64, help='trajectories per GPU per update')
     ap.add_argument('--horizon', type=int, default=1024)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--envs', type=int, default=1, help='rollout mode: also time one graph replay over this many environments')
     args = ap.parse_args()
     if args.mode == 'rollout':
         return rollout_mode(args)
