@@ -155,6 +155,36 @@ def test_shared_policy_pass_equals_two_passes_gpu(rnn, tol, monkeypatch):
     np.testing.assert_allclose(runs[0][1].cpu(), runs[1][1].cpu(), rtol=tol, atol=tol * 1e-1)
 
 
+def test_gru_stream_overlap_equals_serial_order(monkeypatch):
+    """gru: the graph-free passes run on side streams next to the critic forward / the policy forward.  Streams change the
+    schedule, not the arithmetic: same seeds -> the same logs and parameters as the single-stream order, bit for bit."""
+    from offpolicy_rnn import alg_init
+    runs = []
+    for flag in ('1', '0'):
+        monkeypatch.setenv('RESEL_OVERLAP_EMBEDDING', flag)
+        torch.manual_seed(5)
+        np.random.seed(5)
+        alg = alg_init(make_parameter('gru', sac_batch_size=60))
+        assert alg.overlap_value_embedding == (flag == '1') and not alg.share_policy_pass
+        rs = np.random.RandomState(9)
+        for n in [12] * 8:
+            o, a, r = _synth(rs, n, 5, 3)
+            _push(alg.replay_buffer, o, a, r, early_done=False)
+        torch.manual_seed(200)
+        np.random.seed(200)
+        logs = []
+        for _ in range(4):
+            logs.append(dict(alg.train_one_batch()))
+            alg.grad_num += 1
+        torch.cuda.synchronize()
+        runs.append((logs, alg.policy.store.flat.detach().clone(), alg.values[0].store.flat.detach().clone()))
+    for a, b in zip(runs[0][0], runs[1][0]):
+        for k in b:
+            va, vb = (a[k][0] if isinstance(a[k], tuple) else a[k]), (b[k][0] if isinstance(b[k], tuple) else b[k])
+            assert va == vb, (k, va, vb)
+    assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
+
+
 def test_full_size_step_runs_and_is_finite():
     """BASELINE config-2 shapes (smamba_s32_c16_b2_nln, D=256, T=1024) at a reduced row count: finite, non-trivial update."""
     from offpolicy_rnn import alg_init
