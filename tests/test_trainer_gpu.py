@@ -12,6 +12,8 @@ from conftest import GOLDEN, load_golden, nested
 from test_host_logic import _push, _synth, make_parameter
 
 pytestmark = pytest.mark.gpu
+from offpolicy_rnn.utility import rng as _rng_mod           # noqa: E402  (conftest put the package on sys.path)
+_DEVICE_RANDN = _rng_mod.randn                               # the product's device-side draw, before the fixture below swaps it
 META = json.load(open(os.path.join(GOLDEN, 'train_meta.json')))
 
 
@@ -183,6 +185,22 @@ def test_gru_stream_overlap_equals_serial_order(monkeypatch):
             va, vb = (a[k][0] if isinstance(a[k], tuple) else a[k]), (b[k][0] if isinstance(b[k], tuple) else b[k])
             assert va == vb, (k, va, vb)
     assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
+
+
+@pytest.mark.parametrize('rnn', ['smamba_s8_c4_b1_nln', 'gru', 'cgpt_h1_l1_p0_ml32'])
+def test_train_loop_end_to_end_gpu(rnn, tmp_path, monkeypatch):
+    """`alg.train()` on cuda:0 with GPU sampling: graphed rollouts feed the device-mirrored replay ring, updates interleave
+    every `update_interval` environment steps, the iteration-0 checkpoint is written."""
+    from offpolicy_rnn import alg_init
+    from test_host_logic import _short_run_parameter
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(_rng_mod, 'randn', _DEVICE_RANDN)    # graph capture needs the device generator (no host copies)
+    alg = alg_init(_short_run_parameter(rnn, cuda_inference=True))
+    assert alg.graph_step is not None
+    alg.train()
+    assert alg.graph_step._graph is not None and alg.sample_num >= 70 and alg.grad_num >= 8
+    assert os.path.exists(os.path.join(alg.logger.output_dir, 'model', 'log_sac_alpha.pt'))
+    assert all(torch.isfinite(p).all() for p in alg.policy.parameters()) and all(torch.isfinite(p).all() for p in alg.values[0].parameters())
 
 
 def test_full_size_step_runs_and_is_finite():
