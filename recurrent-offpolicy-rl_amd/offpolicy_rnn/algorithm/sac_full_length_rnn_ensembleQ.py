@@ -195,13 +195,15 @@ class SACFullLengthRNNEnsembleQ(SAC):
         layer's output at a token depends only on the tokens of its own trajectory - pointwise layers and recurrent layers
         that reset / mask at the trajectory start - the actor pass is the target pass shifted by one slot, so ONE policy
         forward (with a graph) serves both and the second is skipped.  Not for `gru` (no reset: the leading padding slots
-        differ between the two passes), layers with active dropout (`cgpt_*_p0.1`), TD3 / discrete heads (kept on the plain path),
+        differ between the two passes), layers with active dropout (`cgpt_*_p0.1`), the TD3 trainer that smooths a frozen target policy, discrete heads,
         RESEL_SHARE_POLICY_PASS=0."""
-        if os.environ.get('RESEL_SHARE_POLICY_PASS', '1') == '0' or self.base_algorithm != 'sac' or self.discrete_env:
+        if os.environ.get('RESEL_SHARE_POLICY_PASS', '1') == '0' or self.discrete_env or not self.target_from_live_policy:
             return False
         if self.parameter.randomize_first_hidden:        # the two passes would start from two different random states
             return False
         if type(self)._next_action is not SACFullLengthRNNEnsembleQ._next_action:
+            return False
+        if self.base_algorithm not in ('sac', 'td3'):
             return False
         for net in (self.policy.embedding_network, self.policy.uni_network):
             for lid in net.layer_type:
@@ -275,9 +277,16 @@ class SACFullLengthRNNEnsembleQ(SAC):
             self._side_stream = torch.cuda.Stream(device=self.device)
         model.prefetch_embedding(args, hidden, self._side_stream)
 
+    target_from_live_policy = True        # (the non-REDQ TD3 trainer evaluates its frozen target policy instead)
+
     def _next_action(self, b, hidden):
-        """(a', log pi(a'|s')) on the shifted inputs (s', s, a); TD3 trainers override."""
-        _, _, sample, logp, _, _ = self.policy.forward(b['next_state'], b['state'], b['action'], hidden, b['reward'])
+        """(a', log pi(a'|s')) on the shifted inputs (s', s, a)."""
+        net = self.policy if self.target_from_live_policy else self.target_policy
+        mean, _, sample, logp, _, _ = net.forward(b['next_state'], b['state'], b['action'], hidden, b['reward'])
+        return self._target_action(mean, sample, logp)
+
+    def _target_action(self, mean, sample, logp):
+        """What the target uses from the policy head's (mean, sample, log-prob); TD3 trainers smooth the mean instead."""
         return sample, logp
 
     def _subset_on_device(self, subset: np.ndarray, num_ensemble: int = 0, as_long: bool = False) -> torch.Tensor:
@@ -339,8 +348,8 @@ class SACFullLengthRNNEnsembleQ(SAC):
                 self._shared_policy_out = self.policy.meta_forward(emb_in, b['next_state'], policy_hidden, False)[0]
         self._prefetch_value_embedding(self.target_values[0], (b['next_state'], b['state'], b['action'], b['reward']), target_hiddens[0])
         with torch.no_grad():
-            if self._shared_policy_out is not None:
-                _, sample, logp = self.policy.process_model_out(self._shared_policy_out.detach())
+            if self._shared_policy_out is not None:     # same head, same random draws as policy.forward would make
+                sample, logp = self._target_action(*self.policy.process_model_out(self._shared_policy_out.detach()))
             else:
                 sample, logp = self._next_action(b, policy_hidden)
             tv = self.target_values[0]

@@ -13,9 +13,7 @@ class TD3FullLengthRNNEnsembleQ(SACFullLengthRNNEnsembleQ):
         super().__init__(parameter)
         self.parameter.no_alpha_auto_tune = True      # set after SAC.__init__ built log_alpha = 0, exactly as upstream
 
-    def _next_action(self, b, hidden):
-        net = self.policy if self.target_from_live_policy else self.target_policy
-        mean = net.forward(b['next_state'], b['state'], b['action'], hidden, b['reward'])[0]
+    def _target_action(self, mean, sample, logp):
         par = self.parameter
         noise = torch.clamp(rng.randn_like(mean) * par.target_action_noise_std, -par.target_action_noise_clip, par.target_action_noise_clip)
         return torch.clamp(mean + noise, -1, 1), None

@@ -18,6 +18,11 @@ class ContextualTD3Policy(ContextualSACPolicy):
     def forward(self, state, lst_state, lst_action, rnn_memory, reward=None, detach_embedding=False):
         emb_in = self.get_embedding_input(state, lst_state, lst_action, reward)
         out, rnn_memory, emb, full = self.meta_forward(emb_in, state, rnn_memory, detach_embedding)
+        action_mean, action_sample, log_prob = self.process_model_out(out)
+        return action_mean, emb, action_sample, log_prob, rnn_memory, full
+
+    def process_model_out(self, out):
+        """Head of the deterministic actor (reference :30-35): tanh mean, exploration sample with one N(0, I) draw."""
         action_mean = torch.tanh(out)
         action_sample = torch.clamp(action_mean + rng.randn_like(out) * self.sample_std, -1, 1)
-        return action_mean, emb, action_sample, torch.zeros_like(action_sample), rnn_memory, full
+        return action_mean, action_sample, torch.zeros_like(action_sample)
