@@ -76,8 +76,10 @@ class ContextualModel:
             raise NotImplementedError('the MI355X build keeps parameters in fp32')
 
     # ------------------------------------------------------------------------------------------ forward
-    def meta_forward(self, embedding_input: torch.Tensor, uni_model_input: torch.Tensor, rnn_memory=None, detach_embedding=False
-                     ) -> Tuple[torch.Tensor, RNNHidden, torch.Tensor, RNNHidden]:
+    def meta_forward(self, embedding_input: torch.Tensor, uni_model_input: torch.Tensor, rnn_memory=None, detach_embedding=False,
+                     uni_grad_part=None) -> Tuple[torch.Tensor, RNNHidden, torch.Tensor, RNNHidden]:
+        """uni_grad_part = (x_part, col0): the head input is differentiated only through that column block of
+        `uni_model_input` (which must carry no graph of its own, like the detached embedding beside it)."""
         if rnn_memory is None:
             rnn_memory = self.make_init_state(1 if embedding_input.dim() == 2 else embedding_input.shape[0], embedding_input.device)
         n_emb = self.embedding_network.rnn_num
@@ -100,7 +102,7 @@ class ContextualModel:
         if emb.dim() - uni_in.dim() == 1:
             uni_in = uni_in.unsqueeze(0).repeat_interleave(repeats=emb.shape[0], dim=0)
         out, uni_mem, uni_full = self.uni_network.meta_forward(torch.cat((uni_in, emb), dim=-1), rnn_memory[n_emb:],
-                                                               require_full_hidden=True)
+                                                               require_full_hidden=True, first_grad_part=uni_grad_part)
         return out, emb_mem + uni_mem, emb, emb_full + uni_full
 
     def prefetch_embedding(self, embedding_args, rnn_memory, stream) -> None:

@@ -16,8 +16,12 @@ from ..hip import ops
 
 
 class _SharedInput(torch.autograd.Function):
+    """x_part / col0: optional differentiable column block of x2 (x2[:, col0:col0 + k] holds the values of x_part): the
+    backward then forms ONLY that block of dX - the actor step differentiates the critic's first layer with respect to the
+    action encoding alone (128 of 384 input columns at config 2: a third of the dX GEMM)."""
+
     @staticmethod
-    def forward(ctx, x2, weight, bias, act):
+    def forward(ctx, x2, weight, bias, act, x_part=None, col0=0):
         E, n_in, n_out = weight.shape
         w_cat = weight.permute(1, 0, 2).reshape(n_in, E * n_out)                 # [in, E*out] (weights only: tiny copy)
         if act is None:
@@ -27,6 +31,7 @@ class _SharedInput(torch.autograd.Function):
             ops.bias_act_(y2, None if bias is None else bias.reshape(1, E * n_out), y2.shape[0], act)
         ctx.save_for_backward(x2, w_cat, y2 if act is not None else None)
         ctx.dims = (E, n_in, n_out, bias is not None, act)
+        ctx.part = None if x_part is None else (col0, x_part.shape[-1], tuple(x_part.shape))
         return y2.view(-1, E, n_out).transpose(0, 1)                              # [E, M, out] view
 
     @staticmethod
@@ -41,7 +46,11 @@ class _SharedInput(torch.autograd.Function):
             db = g2.sum(dim=0, keepdim=True) if need_db else None
         dx = torch.mm(g2, w_cat.t()) if ctx.needs_input_grad[0] else None        # sums over the ensemble
         dw = torch.mm(x2.t(), g2).view(n_in, E, n_out).permute(1, 0, 2) if ctx.needs_input_grad[1] else None
-        return dx, dw, None if db is None else db.view(E, 1, n_out), None
+        dpart = None
+        if ctx.part is not None and ctx.needs_input_grad[4]:
+            col0, k, shape = ctx.part
+            dpart = torch.mm(g2, w_cat[col0:col0 + k].t()).view(shape)
+        return dx, dw, None if db is None else db.view(E, 1, n_out), None, dpart, None
 
 
 class _PerMember(torch.autograd.Function):
@@ -159,8 +168,9 @@ class EnsembleLinear(nn.Module):
             return self.weight, b
         return self.weight.index_select(0, self.member_index), None if b is None else b.index_select(0, self.member_index)
 
-    def forward(self, x: torch.Tensor, act: str = None) -> torch.Tensor:
-        """act: None, or 'elu' to fuse the layer's activation module into the bias pass (RNNBase.forward does so)."""
+    def forward(self, x: torch.Tensor, act: str = None, grad_part=None) -> torch.Tensor:
+        """act: None, or 'elu' to fuse the layer's activation module into the bias pass (RNNBase.forward does so).
+        grad_part = (x_part, col0): x carries no graph of its own; only its column block x_part is differentiated."""
         W, b = self.active_params()
         E, n_in, n_out = W.shape
         nd = x.dim()
@@ -173,8 +183,12 @@ class EnsembleLinear(nn.Module):
             shared = False
         if shared:
             lead = tuple(x.shape[:-1])
-            y = _SharedInput.apply(x.reshape(-1, n_in), W, b, act)
+            if grad_part is not None:
+                y = _SharedInput.apply(x.detach().reshape(-1, n_in), W, b, act, grad_part[0], grad_part[1])
+            else:
+                y = _SharedInput.apply(x.reshape(-1, n_in), W, b, act)
         else:
+            assert grad_part is None, 'grad_part is a shared-input feature'
             lead = tuple(x.shape[1:-1])
             y = _PerMember.apply(x.reshape(E, -1, n_in), W, b, act)
         return y.reshape((E,) + lead + (n_out,))                                   # a view: only the row axis is split

@@ -222,8 +222,10 @@ class RNNBase(torch.nn.Module):
         return self._make_state(batch_size, device, True)
 
     # ------------------------------------------------------------------------------------------ forward
-    def meta_forward(self, x: torch.Tensor, hidden_state: Optional[RNNHidden] = None, require_full_hidden: bool = False
-                     ) -> Tuple[torch.Tensor, RNNHidden, Optional[RNNHidden]]:
+    def meta_forward(self, x: torch.Tensor, hidden_state: Optional[RNNHidden] = None, require_full_hidden: bool = False,
+                     first_grad_part=None) -> Tuple[torch.Tensor, RNNHidden, Optional[RNNHidden]]:
+        """first_grad_part = (x_part, col0): the first layer (a shared-input efc layer) differentiates x only through that
+        column block (EnsembleLinear.forward); anything else keeps the ordinary path."""
         assert x.shape[-1] == self.input_size, f'inputting size does not match!!!! input is {x.shape[-1]}, expected: {self.input_size}'
         if hidden_state is None:
             hidden_state = self.make_init_state(x.shape[0], x.device)
@@ -276,8 +278,14 @@ class RNNBase(torch.nn.Module):
                 # plain ELU behind fc / efc-E: fused into the layer's bias pass (one in-place kernel; backward from the output)
                 if isinstance(act, torch.nn.ELU) and act.alpha == 1.0 and isinstance(layer, (EnsembleLinear, torch.nn.Linear)) \
                         and x.dtype == torch.float32:
-                    x = layer(x, act='elu') if isinstance(layer, EnsembleLinear) else ops.linear_act(x, layer.weight, layer.bias, 'elu')
+                    if isinstance(layer, EnsembleLinear):
+                        x = layer(x, act='elu', grad_part=first_grad_part if ind == 0 else None)
+                    else:
+                        assert not (ind == 0 and first_grad_part is not None)
+                        x = ops.linear_act(x, layer.weight, layer.bias, 'elu')
                     continue
+                assert not (ind == 0 and first_grad_part is not None), 'first_grad_part needs an efc first layer with ELU'
+
                 if isinstance(layer, torch.nn.Linear) and x.dim() > 2:    # 2-D call: the bias rides in the GEMM epilogue (addmm)
                     x = torch.nn.functional.linear(x.reshape(-1, x.shape[-1]), layer.weight, layer.bias).view(*x.shape[:-1], -1)
                 else:

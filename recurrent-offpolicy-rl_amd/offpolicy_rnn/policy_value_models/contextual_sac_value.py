@@ -52,8 +52,28 @@ class ContextualSACValue(ContextualModel):
     def forward(self, state, lst_state, lst_action, action, rnn_memory: Optional[RNNHidden], reward, detach_embedding=False
                 ) -> Tuple[torch.Tensor, torch.Tensor, RNNHidden, Optional[RNNHidden]]:
         emb_in = None if getattr(self, '_prefetched', None) is not None else self.get_embedding_input(state, lst_state, lst_action, reward)
-        value, rnn_memory, emb, full = self.meta_forward(emb_in, self.state_action(state, action), rnn_memory, detach_embedding)
+        part = None
+        if detach_embedding and torch.is_grad_enabled() and action.requires_grad and self._action_only_graph():
+            # actor step: frozen critic, detached embedding - the ONLY differentiable input of the head is the action encoding.
+            # Encode state and action separately so that the first layer's backward forms just that column block of dX.
+            act_fn = self.uni_model_input_mapping_activation_func
+            with torch.no_grad():
+                sa_s = act_fn(self.state_input_encoder(state))
+            sa_a = act_fn(self.action_input_encoder(action))
+            sa = torch.cat((sa_s, sa_a.detach()), dim=-1)
+            part = (sa_a, sa_s.shape[-1])
+        else:
+            sa = self.state_action(state, action)
+        value, rnn_memory, emb, full = self.meta_forward(emb_in, sa, rnn_memory, detach_embedding, uni_grad_part=part)
         return value, emb, rnn_memory, full
+
+    def _action_only_graph(self) -> bool:
+        first = self.uni_network.layer_list[0]
+        from ..models.ensemble_linear_model import EnsembleLinear
+        return (self.separate_encoder and isinstance(self.state_input_encoder, torch.nn.Linear)
+                and not self.state_input_encoder.weight.requires_grad and not self.action_input_encoder.weight.requires_grad
+                and isinstance(first, EnsembleLinear) and not first.weight.requires_grad
+                and isinstance(self.uni_network.activation_list[0], torch.nn.ELU) and len(self.uni_network.layer_list) > 1)
 
     def forward_embedding(self, state, lst_state, lst_action, rnn_memory, reward):
         return self.get_embedding(self.get_embedding_input(state, lst_state, lst_action, reward), rnn_memory)
