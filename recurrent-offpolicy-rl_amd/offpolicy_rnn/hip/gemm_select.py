@@ -8,6 +8,12 @@ gradient).  `gemm_tuning/gfx950.csv` holds the per-shape winners found on an MI3
 (`tools/tune_gemms.py` regenerates it); this module loads them with tuning switched OFF, so a run never spends time
 searching and unseen shapes fall back to the library default.  All candidates are fp32-in / fp32-accumulate solutions
 of the same two libraries - no precision change.  RESEL_GEMM_SELECT=0 disables the table.
+
+The table is keyed by exact GEMM shapes, i.e. by rows x row length of the training batch.  A run with another horizon or
+batch size misses it (measured: the untuned `smamba_b1_c8_s64_ff` configuration ran 20 % slower than after tuning).
+RESEL_GEMM_AUTOTUNE=1 keeps the table AND lets TunableOp search every shape it has not seen, once, on first use (seconds per
+shape during the first updates); the winners are written to RESEL_GEMM_AUTOTUNE_FILE (default ./resel_gemm_tuned.csv) at
+exit and can be passed back as RESEL_GEMM_TABLE or merged with `tools/tune_gemms.py merge`.
 """
 import os
 import tempfile
@@ -57,6 +63,15 @@ def enable_tuned_gemms(path=TABLE):
         ok = bool(tunable.read_file(path))
         if not ok:
             ok = _read_with_current_validators(tunable, path)
+        if os.environ.get('RESEL_GEMM_AUTOTUNE', '0') == '1':       # search unseen shapes on first use, keep the winners
+            tunable.enable(True)
+            tunable.tuning_enable(True)
+            tunable.set_filename(os.environ.get('RESEL_GEMM_AUTOTUNE_FILE', os.path.join(os.getcwd(), 'resel_gemm_tuned.csv')))
+            try:
+                torch._C._cuda_tunableop_write_file_on_exit(True)
+            except AttributeError:
+                pass
+            ok = True
         if not ok:
             tunable.enable(False)
     _state['loaded'] = ok
