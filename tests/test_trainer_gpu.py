@@ -204,6 +204,47 @@ def test_train_loop_end_to_end_gpu(rnn, tmp_path, monkeypatch):
     assert all(torch.isfinite(p).all() for p in alg.policy.parameters()) and all(torch.isfinite(p).all() for p in alg.values[0].parameters())
 
 
+@pytest.mark.parametrize('rnn', ['gilr', 'gru'])
+def test_update_schedule_variants_gpu_vs_oracle(rnn):
+    """utd = 2 critic updates per call with the actor updated on every second call (`policy_update_per` = 2): the shared
+    policy pass / stream overlap must follow the schedule (no actor step -> plain target pass).  Four calls vs the oracle."""
+    from offpolicy_rnn import alg_init
+    from oracle.trainer import OracleTrainer, default_parameter
+    from test_oracle_golden import _push as opush
+    torch.manual_seed(11)
+    over = dict(sac_batch_size=40, utd=2, policy_utd=1, policy_update_per=2)
+    alg = alg_init(make_parameter(rnn, **over))
+    cpu = lambda sd: {m: {k: v.detach().cpu().clone() for k, v in d.items()} for m, d in sd.items()}
+    par = default_parameter(rnn=rnn, D=32, policy_embedding_dim=16, value_embedding_dim=16, policy_uni_model_input_mapping_dim=16,
+                            value_uni_model_input_mapping_dim=16, max_buffer_transition_num=5000, **over)
+    tr = OracleTrainer(par, 5, 3, 12, policy_state=cpu(alg.policy.state_dict()), value_state=cpu(alg.values[0].state_dict()))
+    rs = np.random.RandomState(9)
+    for n in [12, 5, 7, 12, 4, 9, 6, 12]:
+        o, a, r = _synth(rs, n, 5, 3)
+        _push(alg.replay_buffer, o, a, r, early_done=(n != 12))
+        opush(tr.buffer, o, a, r, early_done=(n != 12))
+    logs = []
+    for runner in (alg, tr):
+        torch.manual_seed(200)
+        np.random.seed(200)
+        out = []
+        for _ in range(4):
+            out.append(dict(runner.train_one_batch()))
+            runner.grad_num += 1
+        logs.append(out)
+    for it, (a, b) in enumerate(zip(*logs)):
+        assert ('actor_loss' in b) == ('actor_loss' in a), it
+        for k, v in b.items():
+            got = a[k][0] if isinstance(a[k], tuple) else a[k]
+            want = v[0] if isinstance(v, tuple) else v
+            assert got == pytest.approx(want, rel=2e-3, abs=5e-4), (it, k, got, want)
+    for net, ref in ((alg.policy, tr.policy), (alg.values[0], tr.value), (alg.target_values[0], tr.target_value)):
+        sd = net.state_dict()
+        for mod, d in ref.items():
+            for k, v in d.items():
+                np.testing.assert_allclose(sd[mod][k].detach().cpu(), v.detach(), rtol=1e-3, atol=2e-5, err_msg=f'{mod}.{k}')
+
+
 def test_full_size_step_runs_and_is_finite():
     """BASELINE config-2 shapes (smamba_s32_c16_b2_nln, D=256, T=1024) at a reduced row count: finite, non-trivial update."""
     from offpolicy_rnn import alg_init
