@@ -129,19 +129,21 @@ def test_discrete_train_one_batch_gpu_vs_reference_logs(name):
 
 @pytest.mark.parametrize('rnn,algo,tol', [('smamba_s8_c4_b2_nln', 'sac', 1e-4), ('gilr', 'sac', 1e-4), ('cgpt_h1_l2_p0.0_ml64', 'sac', 3e-2),
                                           ('lru', 'td3', 1e-4), ('smamba_s8_c4_b1', 'td3', 1e-4), ('smamba_s8_c4_b1_nln+trunc', 'sac', 1e-4),
-                                          ('gilr+trunc', 'sac', 1e-4)])
+                                          ('gilr+trunc', 'sac', 1e-4), ('lru+rmask', 'sac', 1e-4)])
 def test_shared_policy_pass_equals_two_passes_gpu(rnn, algo, tol, monkeypatch):
     """One policy forward for the target and the actor pass vs the reference's two passes, real kernels, ragged
     nested trajectories, same seeds: logged scalars and the updated policy agree (cgpt: to its bf16 attention tolerance)."""
     from offpolicy_rnn import alg_init
     runs = []
     trunc = rnn.endswith('+trunc')           # randomly truncated trajectories: segments that start in the middle of an episode
+    rmask = rnn.endswith('+rmask')           # randomised loss mask: batches are built on the host path
     rnn = rnn.split('+')[0]
     for flag in ('1', '0'):
         monkeypatch.setenv('RESEL_SHARE_POLICY_PASS', flag)
         torch.manual_seed(5)
         np.random.seed(5)
-        alg = alg_init(make_parameter(rnn, algo=algo, sac_batch_size=40, random_trunc_traj=trunc))
+        alg = alg_init(make_parameter(rnn, algo=algo, sac_batch_size=40, random_trunc_traj=trunc, randomize_mask=rmask,
+                                      valid_number_post_randomized=16))
         assert alg.share_policy_pass == (flag == '1')
         rs = np.random.RandomState(9)
         for n in [12, 5, 7, 12, 4, 9, 6]:
