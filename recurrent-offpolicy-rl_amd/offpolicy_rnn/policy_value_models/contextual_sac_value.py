@@ -68,6 +68,9 @@ class ContextualSACValue(ContextualModel):
         return value, emb, rnn_memory, full
 
     def _action_only_graph(self) -> bool:
+        import os
+        if os.environ.get('RESEL_ACTION_ONLY_DX', '1') == '0':
+            return False
         first = self.uni_network.layer_list[0]
         from ..models.ensemble_linear_model import EnsembleLinear
         return (self.separate_encoder and isinstance(self.state_input_encoder, torch.nn.Linear)

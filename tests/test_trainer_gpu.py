@@ -250,6 +250,35 @@ def test_update_schedule_variants_gpu_vs_oracle(rnn):
                 np.testing.assert_allclose(sd[mod][k].detach().cpu(), v.detach(), rtol=1e-3, atol=2e-5, err_msg=f'{mod}.{k}')
 
 
+@pytest.mark.parametrize('rnn', ['gilr', 'gru'])
+def test_action_only_dx_equals_full_dx(rnn, monkeypatch):
+    """Actor step: the critic's first layer forms only the action-encoding block of dX (frozen critic, detached embedding).
+    Same seeds -> same logs and parameters as with the full dX GEMM (the state / embedding blocks were never consumed)."""
+    from offpolicy_rnn import alg_init
+    runs = []
+    for flag in ('1', '0'):
+        monkeypatch.setenv('RESEL_ACTION_ONLY_DX', flag)
+        torch.manual_seed(5)
+        np.random.seed(5)
+        alg = alg_init(make_parameter(rnn, sac_batch_size=40))
+        rs = np.random.RandomState(9)
+        for n in [12, 5, 7, 12, 4, 9, 6]:
+            o, a, r = _synth(rs, n, 5, 3)
+            _push(alg.replay_buffer, o, a, r, early_done=(n != 12))
+        torch.manual_seed(200)
+        np.random.seed(200)
+        logs = []
+        for _ in range(3):
+            logs.append(dict(alg.train_one_batch()))
+            alg.grad_num += 1
+        runs.append((logs, alg.policy.store.flat.detach().clone()))
+    for a, b in zip(runs[0][0], runs[1][0]):
+        for k in b:
+            va, vb = (a[k][0] if isinstance(a[k], tuple) else a[k]), (b[k][0] if isinstance(b[k], tuple) else b[k])
+            assert va == pytest.approx(vb, rel=1e-5, abs=1e-6), k
+    np.testing.assert_allclose(runs[0][1].cpu(), runs[1][1].cpu(), rtol=1e-5, atol=1e-7)
+
+
 def test_full_size_step_runs_and_is_finite():
     """BASELINE config-2 shapes (smamba_s32_c16_b2_nln, D=256, T=1024) at a reduced row count: finite, non-trivial update."""
     from offpolicy_rnn import alg_init
