@@ -2,6 +2,8 @@
 
 On the GPU box:   python tools/tune_gemms.py run --rnn smamba_s32_c16_b2_nln --rows 64 --horizon 1024 [--algo sac]
                   (three updates with TunableOp searching; winners -> gpurun_out/tuned_<tag>.csv)
+                  (--fresh searches every shape again.  Do NOT combine with PYTORCH_TUNABLEOP_ROTATING_BUFFER_SIZE: the one
+                  attempt with a 2 GB rotating buffer took the GPU box down.)
 Anywhere:         python tools/tune_gemms.py merge      (folds gpurun_out/tuned_*.csv into the tracked table; for a shape
                   seen twice the faster entry wins; validator lines must agree)
 """
@@ -15,7 +17,7 @@ TABLE = os.path.join(ROOT, 'recurrent-offpolicy-rl_amd', 'offpolicy_rnn', 'hip',
 
 
 def run(a):
-    tag = f'{a.rnn}_{a.algo}_b{a.rows}_t{a.horizon}'
+    tag = f'{a.rnn}_{a.algo}_b{a.rows}_t{a.horizon}' + ('_fresh' if a.fresh else '')
     out = os.path.join(ROOT, 'gpurun_out', f'tuned_{tag}.csv')
     os.makedirs(os.path.dirname(out), exist_ok=True)
     os.environ.update(PYTORCH_TUNABLEOP_ENABLED='1', PYTORCH_TUNABLEOP_TUNING='1', RESEL_GEMM_SELECT='0')
@@ -26,7 +28,7 @@ def run(a):
     tunable.enable(True)
     tunable.tuning_enable(True)
     tunable.set_filename(out)
-    if os.path.exists(TABLE):
+    if os.path.exists(TABLE) and not a.fresh:
         tunable.read_file(TABLE)                     # shapes already in the table are not searched again
     alg = build_trainer(a.rnn, a.rows, a.horizon, algo=a.algo)
     for _ in range(3):
@@ -67,6 +69,7 @@ if __name__ == '__main__':
     r.add_argument('--algo', default='sac')
     r.add_argument('--rows', type=int, default=64)
     r.add_argument('--horizon', type=int, default=1024)
+    r.add_argument('--fresh', action='store_true', help='search every shape again (do not preload the tracked table)')
     sub.add_parser('merge')
     a = ap.parse_args()
     {'run': run, 'merge': merge}[a.cmd](a)
