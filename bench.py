@@ -8,6 +8,10 @@ alpha step) on synthetic Gaussian trajectories.  Workload at N = 1 = BASELINE.js
 smamba_s32_c16_b2_nln SAC, B=64, T=1024, obs=17, act=6, published RESeL architecture (D=256, efc-8 critic).
 N > 1 keeps B=64 rows per GPU (weak scaling; N = 8 is configs[3]'s global B=512) with ONE RCCL all-reduce of the flat
 gradient buffer per optimizer step.  Rank 0 prints one JSON line.
+
+    python bench.py --rnn <layer id> --algo sac|td3 --rows B --horizon T      other layer families / sizes (same JSON line)
+    python bench.py --mode rollout [--envs E]                                  the per-environment-step policy forward:
+                                                                               hipGraph replay vs eager vs CPU step, optionally E environments per replay
 """
 import argparse
 import json
