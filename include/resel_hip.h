@@ -167,14 +167,26 @@ int resel_gru_seq_bwd(const float* w_hh, const float* h0, const float* h_all, co
  * qkv: [T, 3, H, hd] bf16 packed tokens (q | k | v); cu_seqlens: int32 [S + 1] device; slopes: [H] fp32 or NULL;
  * out: [T, H, hd] bf16; lse: [H, T] fp32 (base-2 log-sum-exp, saved for the backward).  hd in {32, 64}; max_seqlen bounds
  * the grid.  Backward: dqkv [T, 3, H, hd] bf16 (fully overwritten); workspace resel_attn_varlen_bwd_workspace_bytes().
- * No attention-probability dropout (the reference's published cgpt runs use p = 0.0).
+ * Attention-probability dropout (MHA(dropout=p), TransformerFlashAttention.py:67-70, active in .train() passes): p_drop in
+ * [0, 1); the keep mask is a counter function of (seed, offset, head, packed query token, key position) - no state, the
+ * backward regenerates it from the same (seed, offset).  8-bit keep threshold floor((1 - p) * 255) + 1 and the 1 / (1 - p)
+ * rescale as in flash-attn; the counter function itself is this library's (oracle/kernels.py `attn_dropout_keep`).
+ * p_drop == 0 runs the dropout-free kernels.
  */
 int resel_attn_varlen_fwd(const uint16_t* qkv, const int32_t* cu_seqlens, const float* slopes, uint16_t* out, float* lse,
-                          int T, int S, int H, int hd, int max_seqlen, float scale, resel_stream_t stream);
+                          int T, int S, int H, int hd, int max_seqlen, float scale,
+                          float p_drop, uint64_t seed, uint64_t offset, resel_stream_t stream);
 size_t resel_attn_varlen_bwd_workspace_bytes(int T, int H, int hd);
 int resel_attn_varlen_bwd(const uint16_t* qkv, const int32_t* cu_seqlens, const float* slopes, const uint16_t* out,
                           const float* lse, const uint16_t* dout, uint16_t* dqkv, void* workspace,
-                          int T, int S, int H, int hd, int max_seqlen, float scale, resel_stream_t stream);
+                          int T, int S, int H, int hd, int max_seqlen, float scale,
+                          float p_drop, uint64_t seed, uint64_t offset, resel_stream_t stream);
+
+/* Element-wise dropout y = keep(i) ? x / (1 - p) : 0 with the keep mask a counter function of (seed, offset, element index)
+ * (16-bit threshold round((1 - p) * 65536); oracle/kernels.py `dropout_keep`).  Replaces the `nn.Dropout`s of the cgpt
+ * decoder block (TransformerFlashAttention.py:48,52,72,84-85) in training-mode passes; the backward is the same call on dy
+ * with the same (seed, offset).  In place (y == x) allowed. */
+int resel_dropout(const float* x, float* y, int64_t n, float p_drop, uint64_t seed, uint64_t offset, resel_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * SAC / TD3 head, target and loss arithmetic + optimizer tail (the "fusions" of SURVEY.md section 8 row a16-a18).
@@ -240,8 +252,9 @@ int resel_ensemble_head_bwd(const float* gq, const float* a, const float* w3, fl
  * buffer [capacity, W] fp32 ring; segments [nseg][4] int32 = (batch row, first slot, length incl. `skip` leading slots,
  * first transition index) - the host-side sampling plan; pre_pairs [npairs][2] = (dst column, src column) of the pre-step
  * slot (next_state <- state, reward <- reward_input, state <- last_state of the trajectory's first transition).
- * out [rows, Tp, W + 3]: the W field columns, then validity, the target pass's validity and start flags. */
-int resel_gather_trajs(const float* buffer, int W, const int* segments, int nseg, int max_len, int skip, int rows, int Tp,
+ * out [rows, Tp, W + 3]: the W field columns, then validity, the target pass's validity and start flags.
+ * A plan entry that does not fit (row >= rows, slot range beyond Tp, transitions beyond `capacity`) is dropped. */
+int resel_gather_trajs(const float* buffer, int W, int64_t capacity, const int* segments, int nseg, int max_len, int skip, int rows, int Tp,
                        int c_mask, int c_start, int c_done, int c_timeout, const int* pre_pairs, int npairs,
                        float* out, resel_stream_t stream);
 

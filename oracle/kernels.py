@@ -189,8 +189,74 @@ def alibi_slopes(nheads: int) -> torch.Tensor:
     return torch.tensor(s, dtype=torch.float32)
 
 
-def attention_alibi_varlen_ref(q, k, v, cu_seqlens, slopes=None, scale=None):
-    """q, k, v: [T, H, d] packed tokens; cu_seqlens: int [S+1].  Returns out [T, H, d] (fp32 math)."""
+# counter-keyed dropout masks.  The reference takes its masks from flash-attn's Philox stream (attention probabilities,
+# MHA(dropout=p), TransformerFlashAttention.py:67-70) and from ATen's (nn.Dropout, :48,72) - neither stream is
+# reproducible outside those libraries, so the product defines its own counter function (include/resel_hip.h,
+# csrc/attention.hip, csrc/dropout.hip) and this is its restatement; what IS the reference's: keep probability 1 - p,
+# kept values scaled by 1 / (1 - p), softmax statistics taken before the mask, flash-attn's 8-bit keep threshold.
+_M32 = 0xFFFFFFFF
+DROP_CQ, DROP_CK, DROP_CH = 0x9E3779B1, 0x85EBCA77, 0xC2B2AE3D
+
+
+def _mix32(x):
+    """`lowbias32` on uint64 numpy arrays holding 32-bit values (or python ints)."""
+    x = x ^ (x >> 16); x = (x * 0x7FEB352D) & _M32
+    x = x ^ (x >> 15); x = (x * 0x846CA68B) & _M32
+    return x ^ (x >> 16)
+
+
+def _stream_key(seed: int, offset: int, head_term: int) -> int:
+    x = _mix32((head_term ^ (offset >> 32)) & _M32)
+    x = _mix32(x ^ (offset & _M32))
+    x = _mix32(x ^ ((seed >> 32) & _M32))
+    return _mix32(x ^ (seed & _M32))
+
+
+def attn_dropout_keep(seed: int, offset: int, H: int, q_tok0: int, n: int, p_drop: float):
+    """bool [H, n, n] keep mask of one packed sequence whose first token has packed index q_tok0:
+    keep(h, i, j) = byte (j & 3) of mix32((q_tok0 + i) * CQ ^ (j >> 2) * CK ^ head_key(h)) < floor((1 - p) * 255) + 1."""
+    import numpy as np
+    thr = int(math.floor((1.0 - p_drop) * 255.0)) + 1
+    i = (np.arange(n, dtype=np.uint64) + np.uint64(q_tok0))[:, None]
+    j = np.arange(n, dtype=np.uint64)[None, :]
+    base = ((i * np.uint64(DROP_CQ)) & np.uint64(_M32)) ^ (((j >> np.uint64(2)) * np.uint64(DROP_CK)) & np.uint64(_M32))
+    keep = np.empty((H, n, n), dtype=bool)
+    for h in range(H):
+        w = _mix32(base ^ np.uint64(_stream_key(seed, offset, (h * DROP_CH) & _M32)))
+        keep[h] = ((w >> ((j & np.uint64(3)) * np.uint64(8))) & np.uint64(0xFF)) < np.uint64(thr)
+    return torch.from_numpy(keep)
+
+
+def dropout_keep(seed: int, offset: int, n: int, p_drop: float):
+    """bool [n] keep mask of `resel_dropout`: 16-bit half (i & 1) of mix32((i >> 1) * CQ ^ key) < round((1 - p) * 65536)."""
+    import numpy as np
+    thr = int(round((1.0 - p_drop) * 65536.0))
+    i = np.arange(n, dtype=np.uint64)
+    w = _mix32((((i >> np.uint64(1)) * np.uint64(DROP_CQ)) & np.uint64(_M32)) ^ np.uint64(_stream_key(seed, offset, DROP_CH)))
+    return torch.from_numpy(((w >> ((i & np.uint64(1)) * np.uint64(16))) & np.uint64(0xFFFF)) < np.uint64(thr))
+
+
+def dropout_ref(x, p_drop: float, seed: int, offset: int):
+    if p_drop <= 0.0:
+        return x
+    keep = dropout_keep(seed, offset, x.numel(), p_drop).view(x.shape)
+    return torch.where(keep, x / (1.0 - p_drop), torch.zeros_like(x))
+
+
+class DropCounter:
+    """Mirror of the product's `ops.dropout_counter`: every draw returns (seed, offset) and advances the offset by 4."""
+    def __init__(self, seed: int, offset: int = 0):
+        self.seed, self.offset = int(seed), int(offset)
+
+    def next(self):
+        out = (self.seed, self.offset)
+        self.offset += 4
+        return out
+
+
+def attention_alibi_varlen_ref(q, k, v, cu_seqlens, slopes=None, scale=None, p_drop=0.0, seed=0, offset=0):
+    """q, k, v: [T, H, d] packed tokens; cu_seqlens: int [S+1].  Returns out [T, H, d] (fp32 math).
+    p_drop > 0: the probabilities entering P V are masked by `attn_dropout_keep` and scaled by 1 / (1 - p)."""
     T, H, d = q.shape
     scale = (1.0 / math.sqrt(d)) if scale is None else scale
     out = torch.zeros(T, H, d, dtype=torch.float32)
@@ -208,6 +274,8 @@ def attention_alibi_varlen_ref(q, k, v, cu_seqlens, slopes=None, scale=None):
             sc = sc - slopes.float()[:, None, None] * (i - j).abs().float()[None]
         sc = sc.masked_fill((j > i)[None], float('-inf'))
         p = torch.softmax(sc, dim=-1)
+        if p_drop > 0.0:
+            p = torch.where(attn_dropout_keep(seed, offset, H, a, n, p_drop), p / (1.0 - p_drop), torch.zeros_like(p))
         out[a:b] = torch.einsum('hij,jhd->ihd', p, vs)
     return out
 

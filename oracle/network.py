@@ -104,10 +104,11 @@ ACT = {'tanh': torch.tanh, 'relu': F.relu, 'sigmoid': torch.sigmoid, 'leaky_relu
 
 class Flags:
     """Side-channel of RNNHidden (offpolicy_rnn/models/RNNHidden.py:36-62)."""
-    def __init__(self, rnn_start=None, mask=None, seqlens=None):
+    def __init__(self, rnn_start=None, mask=None, seqlens=None, dropout=None):
         self.rnn_start = rnn_start      # [B, L, 1]
         self.mask = mask                # [B, L, 1]
         self.seqlens = seqlens          # int [B, L] per-row sequence-length table (cgpt)
+        self.dropout = dropout          # K.DropCounter in a training-mode pass of a p > 0 cgpt layer, else None
 
 
 # ------------------------------------------------------------------------------------------------
@@ -363,7 +364,9 @@ def _norm(p, pre, x, ln):
 
 
 def cgpt_layer(p, pre, x, cfg, flags=None, bf16=True):
-    """TransformerDecoder.forward in eval mode / p=0 (TransformerFlashAttention.py:104-121, DecoderLayer :76-85).
+    """TransformerDecoder.forward (TransformerFlashAttention.py:104-121, DecoderLayer :76-85).  Eval mode / p = 0 unless
+    `flags.dropout` carries a K.DropCounter: then the four dropout sites of every block (attention probabilities :67-70,
+    post-attention :83, FFN hidden :52, post-FFN :84) draw counter-keyed masks in that order (oracle/kernels.py).
     MHA core: attention_alibi_varlen_ref (PARITY UNPINNED)."""
     B, L, D = x.shape
     H = cfg['nhead']
@@ -375,19 +378,23 @@ def cgpt_layer(p, pre, x, cfg, flags=None, bf16=True):
         cu = torch.arange(0, (B + 1) * L, L, dtype=torch.int32)
     t = x.reshape(B * L, D)[idx]
     slopes = K.alibi_slopes(H)
+    dc = flags.dropout if (flags is not None and cfg.get('pdrop', 0.0) > 0.0) else None
+    pd = cfg.get('pdrop', 0.0) if dc is not None else 0.0
+    drop = (lambda a: K.dropout_ref(a, pd, *dc.next())) if dc is not None else (lambda a: a)
     for i in range(cfg['nlayer']):
         lp = f'{pre}decoder_layers.{i}.'
         h = _norm(p, lp + 'mha_norm.', t, cfg['ln'])
         cast = (lambda a: a.to(torch.bfloat16).float()) if bf16 else (lambda a: a)
         qkv = cast(F.linear(cast(h), cast(p[lp + 'mha.Wqkv.weight']), cast(p[lp + 'mha.Wqkv.bias'])))
         qkv = qkv.view(-1, 3, H, hd)
-        a = cast(K.attention_alibi_varlen_ref(qkv[:, 0], qkv[:, 1], qkv[:, 2], cu, slopes))
+        sd, of = dc.next() if dc is not None else (0, 0)
+        a = cast(K.attention_alibi_varlen_ref(qkv[:, 0], qkv[:, 1], qkv[:, 2], cu, slopes, None, pd, sd, of))
         a = cast(F.linear(a.reshape(-1, D), cast(p[lp + 'mha.out_proj.weight']), cast(p[lp + 'mha.out_proj.bias'])))
-        t = a + t                                                   # :83
+        t = drop(a) + t                                             # :83
         h = _norm(p, lp + 'ffn_norm.', t, cfg['ln'])
-        h = F.linear(F.gelu(F.linear(h, p[lp + 'ffn.fc1.weight'], p[lp + 'ffn.fc1.bias'])),
+        h = F.linear(drop(F.gelu(F.linear(h, p[lp + 'ffn.fc1.weight'], p[lp + 'ffn.fc1.bias']))),
                      p[lp + 'ffn.fc2.weight'], p[lp + 'ffn.fc2.bias'])
-        t = h + t                                                   # :84
+        t = drop(h) + t                                             # :84
     t = _norm(p, pre + 'output_ln.', t, cfg['ln'])
     t = F.linear(t, p[pre + 'output_fc.weight'], p[pre + 'output_fc.bias'])
     out = torch.zeros(B * L, D, dtype=t.dtype)

@@ -11,6 +11,15 @@
 // Arithmetic intensity is low for hd = 32 (4 MFMAs per 32x32 tile against ~16 exp2 per lane), so these kernels are
 // VALU/exp-bound rather than MFMA-bound; the whole attention share of a cgpt update is ~1 TFLOP.
 // Semantics restated from flash-attn's MHA(causal, alibi) - see oracle/kernels.py attention_alibi_varlen_ref: PARITY UNPINNED.
+//
+// Attention-probability dropout (MHA(dropout=p), reference TransformerFlashAttention.py:67-70): the keep mask is a pure
+// function of (seed, offset, head, packed query token, key position), so the forward, the dQ and the dK/dV kernel each
+// regenerate it for the elements they hold and nothing is stored:
+//     word(q_tok, key >> 2) = mix32((q_tok * 0x9E3779B1) ^ ((key >> 2) * 0x85EBCA77) ^ head_key)      (32 bits -> 4 keys)
+//     keep(q_tok, key)      = byte (key & 3) of that word < thr,   thr = floor((1 - p) * 255) + 1      (8-bit threshold and
+//     the 1 / (1 - p) rescale of the kept probabilities are flash-attn's; the counter function itself is this build's and
+//     is restated in oracle/kernels.py `attn_dropout_keep`).  Softmax statistics (running max, sum, lse, delta) are those
+//     of the un-dropped probabilities; only the P V, dV and dP products see the mask.
 #include "resel_common.h"
 
 namespace {
@@ -67,6 +76,23 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* row, int s, int hh) {
 }
 __device__ __forceinline__ int acc_row(int reg, int hh) { return (reg & 3) + 8 * (reg >> 2) + 4 * hh; }
 
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {          // 2-multiply avalanche finaliser ("lowbias32")
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+constexpr uint32_t DROP_CQ = 0x9E3779B1u, DROP_CK = 0x85EBCA77u, DROP_CH = 0xC2B2AE3Du;
+__device__ __forceinline__ uint32_t drop_head_key(uint64_t seed, uint64_t offset, int h) {
+    uint32_t x = mix32((uint32_t)h * DROP_CH ^ (uint32_t)(offset >> 32));
+    x = mix32(x ^ (uint32_t)offset);
+    x = mix32(x ^ (uint32_t)(seed >> 32));
+    return mix32(x ^ (uint32_t)seed);
+}
+// lane j's value within each quad of lanes (DPP quad_perm broadcast)
+template <int J>
+__device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, J | (J << 2) | (J << 4) | (J << 6), 0xf, 0xf, true);
+}
+
 struct AttnParams {
     const bf16_t* qkv;
     const int32_t* cu;
@@ -78,6 +104,9 @@ struct AttnParams {
     bf16_t* dqkv;
     int T, S, H;
     float scale;
+    uint32_t thr;               // dropout: keep iff random byte < thr (256 = keep all)
+    float rp;                   // 1 / (1 - p)
+    uint64_t seed, offset;
 };
 
 // stage a [KT keys][HD] tile of K or V (which = 1 / 2) row-major and / or transposed into LDS
@@ -143,7 +172,7 @@ __device__ __forceinline__ void store_kv(const KVRegs<HD>& r, int tid, bf16_t (*
 // minimal: the ALiBi term is one add of a per-lane constant and a per-tile offset folded into the scale FMA, the causal /
 // length mask is evaluated only on tiles that cross the diagonal or the sequence end (wave-uniform branch), and the
 // accumulator is rescaled only when some lane's running maximum actually moved.
-template <int HD, int MODE>
+template <int HD, int MODE, bool DROP>
 __global__ __launch_bounds__(256) void attn_q_kernel(AttnParams p) {
     constexpr int KS = HD / 16, ND = HD / 32;
     __shared__ __attribute__((aligned(16))) bf16_t k_lds[KTB][HD + PADE];
@@ -183,6 +212,13 @@ __global__ __launch_bounds__(256) void attn_q_kernel(AttnParams p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) crow[i] = slope2 * (float)acc_row(i, hh);
 
+    // dropout: per-lane query word and the four key-quad offsets of a tile (rows 8g + 4hh + {0..3} = keys of one quad)
+    uint32_t dq_word = 0, dk_off[4] = {0, 0, 0, 0};
+    if (DROP) {
+        dq_word = ((uint32_t)(t0 + q) * DROP_CQ) ^ drop_head_key(p.seed, p.offset, h);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dk_off[g] = (uint32_t)(2 * g + hh) * DROP_CK;
+    }
     const int q_hi = min(len, qb0 + 128) - 1;                    // last query of this block
     const int nkeys = q_hi + 1;                                  // causal: keys <= q_hi
     const int wq_lo = qb0 + w * 32, wq_hi = wq_lo + 31;          // this wave's queries
@@ -219,6 +255,12 @@ __global__ __launch_bounds__(256) void attn_q_kernel(AttnParams p) {
                 mloc = fmaxf(mloc, sc[i]);
             }
         }
+        uint32_t dw[4] = {0, 0, 0, 0};
+        if (DROP) {
+            const uint32_t kbase = (uint32_t)(k0 >> 2) * DROP_CK;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) dw[g] = mix32(dq_word ^ (kbase + dk_off[g]));
+        }
         f32x16 pt;
         if (MODE == 0) {
             mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
@@ -249,12 +291,20 @@ __global__ __launch_bounds__(256) void attn_q_kernel(AttnParams p) {
             }
             l += psum;
             m = mnew;
+            if (DROP) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) pt[i] = ((dw[i >> 2] >> (8 * (i & 3))) & 0xffu) < p.thr ? pt[i] : 0.f;
+            }
         } else {
             // dP^T = V dO^T ; dS^T = P^T (dP^T - delta) * scale
             f32x16 dp = zero16();
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
                 dp = mfma(*reinterpret_cast<const bf16x8*>(&v_lds[ko + r][16 * ks + 8 * hh]), dof[ks], dp);
+            if (DROP) {                                          // dP = mask / (1 - p) * (dO V^T)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) dp[i] = ((dw[i >> 2] >> (8 * (i & 3))) & 0xffu) < p.thr ? dp[i] * p.rp : 0.f;
+            }
             if (masked) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
@@ -278,7 +328,7 @@ __global__ __launch_bounds__(256) void attn_q_kernel(AttnParams p) {
     float inv = 1.f;
     if (MODE == 0) {
         const float ltot = l + __shfl_xor(l, 32, 64);
-        inv = ltot > 0.f ? 1.f / ltot : 0.f;
+        inv = ltot > 0.f ? (DROP ? p.rp : 1.f) / ltot : 0.f;
         if (q_ok && hh == 0) p.lse[(int64_t)h * p.T + t0 + q] = m + __log2f(fmaxf(ltot, 1e-37f));
     }
     if (q_ok) {
@@ -312,7 +362,7 @@ __global__ void attn_delta_kernel(const bf16_t* __restrict__ out, const bf16_t* 
 }
 
 // ------------------------------------------------------------------------------------------------- dK / dV
-template <int HD>
+template <int HD, bool DROP>
 __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnParams p) {
     constexpr int KS = HD / 16, ND = HD / 32;
     __shared__ __attribute__((aligned(16))) bf16_t qT[4][HD][KT + PADE];       // per-wave transposed Q tile  [d][q]
@@ -345,6 +395,15 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnParams p) {
     float crow[16];                                              // ALiBi: -slope (q - key) = -slope row(i) - slope (q0 - key)
 #pragma unroll
     for (int i = 0; i < 16; ++i) crow[i] = -slope2 * (float)acc_row(i, hh);
+    // dropout: the word of (query row, this lane's key quad) serves the four lanes of a quad, one byte each; a lane
+    // hashes the rows with (row & 3) == (lane & 3) and the quad exchanges them by DPP
+    uint32_t dk_word = 0, dq_off[4] = {0, 0, 0, 0};
+    const int dsh = 8 * (r & 3);
+    if (DROP) {
+        dk_word = ((uint32_t)(key >> 2) * DROP_CK) ^ drop_head_key(p.seed, p.offset, h);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dq_off[g] = (uint32_t)((r & 3) + 8 * g + 4 * hh) * DROP_CQ;
+    }
     const int nqt = (len + KT - 1) / KT;
     const int qt_first = k0 / KT;                                // first query tile that can see these keys
     const int niter = (nqt - qt_first + 3) / 4;
@@ -386,6 +445,22 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnParams p) {
             dp = mfma(doa_f[ks], vf[ks], dp);                    // dP[q][key]
         }
         f32x16 pm, ds;
+        bool keep[16];
+        if (DROP) {
+            const uint32_t qbase = (uint32_t)(t0 + q0) * DROP_CQ;
+            uint32_t mine[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) mine[g] = mix32((qbase + dq_off[g]) ^ dk_word);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                keep[4 * g + 0] = ((quad_bcast<0>(mine[g]) >> dsh) & 0xffu) < p.thr;
+                keep[4 * g + 1] = ((quad_bcast<1>(mine[g]) >> dsh) & 0xffu) < p.thr;
+                keep[4 * g + 2] = ((quad_bcast<2>(mine[g]) >> dsh) & 0xffu) < p.thr;
+                keep[4 * g + 3] = ((quad_bcast<3>(mine[g]) >> dsh) & 0xffu) < p.thr;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dp[i] = keep[i] ? dp[i] * p.rp : 0.f;
+        }
         const bool masked = (q0 < k0 + KT - 1) || (q0 + KT > len) || (k0 + KT > len);      // diagonal tile or ragged end (wave-uniform)
         const float off = -slope2 * (float)(q0 - key);
         if (masked) {
@@ -405,6 +480,10 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnParams p) {
                 pm[i] = e;
                 ds[i] = e * (dp[i] - s_dlt[w][row]) * p.scale;
             }
+        }
+        if (DROP) {                                              // dV sees the dropped, rescaled probabilities
+#pragma unroll
+            for (int i = 0; i < 16; ++i) pm[i] = keep[i] ? pm[i] * p.rp : 0.f;
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -443,18 +522,41 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnParams p) {
     }
 }
 
-inline bool attn_ok(int T, int S, int H, int hd, int max_seqlen) { return T > 0 && S > 0 && H > 0 && (hd == 32 || hd == 64) && max_seqlen > 0; }
+inline bool attn_ok(int T, int S, int H, int hd, int max_seqlen, float p_drop) {
+    return T > 0 && S > 0 && H > 0 && (hd == 32 || hd == 64) && max_seqlen > 0 && p_drop >= 0.f && p_drop < 1.f;
+}
+inline void set_dropout(AttnParams& p, float p_drop, uint64_t seed, uint64_t offset) {
+    p.thr = (uint32_t)floorf((1.f - p_drop) * 255.f) + 1u;       // flash-attn's 8-bit keep threshold
+    p.rp = 1.f / (1.f - p_drop);
+    p.seed = seed;
+    p.offset = offset;
+}
+
+template <int HD, bool DROP>
+void launch_fwd(const AttnParams& p, dim3 grid, hipStream_t s) {
+    hipLaunchKernelGGL((attn_q_kernel<HD, 0, DROP>), grid, dim3(256), 0, s, p);
+}
+template <int HD, bool DROP>
+void launch_bwd(const AttnParams& p, const bf16_t* out, dim3 gq, dim3 gk, hipStream_t s) {
+    const int n = p.T * p.H;
+    hipLaunchKernelGGL(attn_delta_kernel<HD>, dim3((n + 255) / 256), dim3(256), 0, s, out, p.dout, const_cast<float*>(p.delta), p.T, p.H);
+    hipLaunchKernelGGL((attn_q_kernel<HD, 1, DROP>), gq, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((attn_dkv_kernel<HD, DROP>), gk, dim3(256), 0, s, p);
+}
 
 }  // namespace
 
 extern "C" int resel_attn_varlen_fwd(const uint16_t* qkv, const int32_t* cu_seqlens, const float* slopes, uint16_t* out, float* lse,
-                                     int T, int S, int H, int hd, int max_seqlen, float scale, resel_stream_t stream) {
-    if (!qkv || !cu_seqlens || !out || !lse || !attn_ok(T, S, H, hd, max_seqlen) || !aligned16(qkv) || !aligned16(out)) return RESEL_EINVAL;
-    AttnParams p{(const bf16_t*)qkv, cu_seqlens, slopes, (bf16_t*)out, lse, nullptr, nullptr, nullptr, T, S, H, scale};
+                                     int T, int S, int H, int hd, int max_seqlen, float scale,
+                                     float p_drop, uint64_t seed, uint64_t offset, resel_stream_t stream) {
+    if (!qkv || !cu_seqlens || !out || !lse || !attn_ok(T, S, H, hd, max_seqlen, p_drop) || !aligned16(qkv) || !aligned16(out)) return RESEL_EINVAL;
+    AttnParams p{(const bf16_t*)qkv, cu_seqlens, slopes, (bf16_t*)out, lse, nullptr, nullptr, nullptr, T, S, H, scale, 256u, 1.f, 0, 0};
+    set_dropout(p, p_drop, seed, offset);
     dim3 grid((max_seqlen + 127) / 128, S, H);
     hipStream_t s = (hipStream_t)stream;
-    if (hd == 32) hipLaunchKernelGGL((attn_q_kernel<32, 0>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((attn_q_kernel<64, 0>), grid, dim3(256), 0, s, p);
+    const bool drop = p_drop > 0.f;
+    if (hd == 32) { if (drop) launch_fwd<32, true>(p, grid, s); else launch_fwd<32, false>(p, grid, s); }
+    else          { if (drop) launch_fwd<64, true>(p, grid, s); else launch_fwd<64, false>(p, grid, s); }
     return launch_status();
 }
 
@@ -465,22 +567,18 @@ extern "C" size_t resel_attn_varlen_bwd_workspace_bytes(int T, int H, int hd) {
 
 extern "C" int resel_attn_varlen_bwd(const uint16_t* qkv, const int32_t* cu_seqlens, const float* slopes, const uint16_t* out,
                                      const float* lse, const uint16_t* dout, uint16_t* dqkv, void* workspace,
-                                     int T, int S, int H, int hd, int max_seqlen, float scale, resel_stream_t stream) {
-    if (!qkv || !cu_seqlens || !out || !lse || !dout || !dqkv || !workspace || !attn_ok(T, S, H, hd, max_seqlen)) return RESEL_EINVAL;
+                                     int T, int S, int H, int hd, int max_seqlen, float scale,
+                                     float p_drop, uint64_t seed, uint64_t offset, resel_stream_t stream) {
+    if (!qkv || !cu_seqlens || !out || !lse || !dout || !dqkv || !workspace || !attn_ok(T, S, H, hd, max_seqlen, p_drop)) return RESEL_EINVAL;
     if (!aligned16(qkv) || !aligned16(out) || !aligned16(dout) || !aligned16(dqkv)) return RESEL_EINVAL;
     float* delta = (float*)workspace;
-    AttnParams p{(const bf16_t*)qkv, cu_seqlens, slopes, nullptr, const_cast<float*>(lse), (const bf16_t*)dout, delta, (bf16_t*)dqkv, T, S, H, scale};
+    AttnParams p{(const bf16_t*)qkv, cu_seqlens, slopes, nullptr, const_cast<float*>(lse), (const bf16_t*)dout, delta, (bf16_t*)dqkv, T, S, H, scale,
+                 256u, 1.f, 0, 0};
+    set_dropout(p, p_drop, seed, offset);
     hipStream_t s = (hipStream_t)stream;
-    const int n = T * H;
     dim3 gq((max_seqlen + 127) / 128, S, H), gk((max_seqlen + KT - 1) / KT, S, H);
-    if (hd == 32) {
-        hipLaunchKernelGGL(attn_delta_kernel<32>, dim3((n + 255) / 256), dim3(256), 0, s, (const bf16_t*)out, (const bf16_t*)dout, delta, T, H);
-        hipLaunchKernelGGL((attn_q_kernel<32, 1>), gq, dim3(256), 0, s, p);
-        hipLaunchKernelGGL(attn_dkv_kernel<32>, gk, dim3(256), 0, s, p);
-    } else {
-        hipLaunchKernelGGL(attn_delta_kernel<64>, dim3((n + 255) / 256), dim3(256), 0, s, (const bf16_t*)out, (const bf16_t*)dout, delta, T, H);
-        hipLaunchKernelGGL((attn_q_kernel<64, 1>), gq, dim3(256), 0, s, p);
-        hipLaunchKernelGGL(attn_dkv_kernel<64>, gk, dim3(256), 0, s, p);
-    }
+    const bool drop = p_drop > 0.f;
+    if (hd == 32) { if (drop) launch_bwd<32, true>(p, (const bf16_t*)out, gq, gk, s); else launch_bwd<32, false>(p, (const bf16_t*)out, gq, gk, s); }
+    else          { if (drop) launch_bwd<64, true>(p, (const bf16_t*)out, gq, gk, s); else launch_bwd<64, false>(p, (const bf16_t*)out, gq, gk, s); }
     return launch_status();
 }

@@ -23,9 +23,13 @@ __global__ void gather_init_kernel(float* __restrict__ out, int64_t ntok, int WO
 }
 
 // grid = (ceil(maxlen * W / 256), nseg)
-__global__ void gather_segments_kernel(const float* __restrict__ buffer, int W, const int* __restrict__ seg, int skip, int Tp,
-                                       int c_mask, int c_start, const int* __restrict__ pre_pairs, int npairs, float* __restrict__ out) {
+__global__ void gather_segments_kernel(const float* __restrict__ buffer, int W, int64_t capacity, const int* __restrict__ seg, int skip,
+                                       int rows, int Tp, int c_mask, int c_start, const int* __restrict__ pre_pairs, int npairs,
+                                       float* __restrict__ out) {
     const int4 sg = reinterpret_cast<const int4*>(seg)[blockIdx.y];       // row, pos, n, first transition
+    // a plan entry that does not fit the output / the ring is dropped (its slots stay padding) instead of written out of bounds
+    if (sg.x < 0 || sg.x >= rows || sg.y < 0 || sg.z < skip || (int64_t)sg.y + sg.z > Tp || sg.w < 0 ||
+        (int64_t)sg.w + (sg.z - skip) > capacity || (sg.z > skip ? false : sg.w >= capacity)) return;
     const int WO = W + 3;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= sg.z * W) return;
@@ -65,10 +69,10 @@ __global__ void gather_flags_kernel(float* __restrict__ out, int rows, int Tp, i
 
 }  // namespace
 
-extern "C" int resel_gather_trajs(const float* buffer, int W, const int* segments, int nseg, int max_len, int skip, int rows, int Tp,
+extern "C" int resel_gather_trajs(const float* buffer, int W, int64_t capacity, const int* segments, int nseg, int max_len, int skip, int rows, int Tp,
                                   int c_mask, int c_start, int c_done, int c_timeout, const int* pre_pairs, int npairs,
                                   float* out, resel_stream_t stream) {
-    if (!buffer || !segments || !out || W <= 0 || nseg <= 0 || max_len <= 0 || skip < 1 || rows <= 0 || Tp <= 0) return RESEL_EINVAL;
+    if (!buffer || !segments || !out || W <= 0 || capacity <= 0 || nseg <= 0 || max_len <= 0 || skip < 1 || rows <= 0 || Tp <= 0) return RESEL_EINVAL;
     if (c_mask < 0 || c_mask >= W || c_start < 0 || c_start >= W || c_done < 0 || c_done >= W || c_timeout >= W || (npairs > 0 && !pre_pairs))
         return RESEL_EINVAL;
     if (!aligned16(segments)) return RESEL_EINVAL;
@@ -77,7 +81,7 @@ extern "C" int resel_gather_trajs(const float* buffer, int W, const int* segment
     const int64_t ntok = (int64_t)rows * Tp;
     hipLaunchKernelGGL(gather_init_kernel, dim3((unsigned)((ntok * WO + 255) / 256)), dim3(256), 0, s, out, ntok, WO, c_start);
     hipLaunchKernelGGL(gather_segments_kernel, dim3((unsigned)(((int64_t)max_len * W + 255) / 256), nseg), dim3(256), 0, s, buffer, W,
-                       segments, skip, Tp, c_mask, c_start, pre_pairs, npairs, out);
+                       capacity, segments, skip, rows, Tp, c_mask, c_start, pre_pairs, npairs, out);
     hipLaunchKernelGGL(gather_flags_kernel, dim3((unsigned)((ntok + 255) / 256)), dim3(256), 0, s, out, rows, Tp, W, c_start, c_done,
                        c_timeout);
     return launch_status();

@@ -46,7 +46,11 @@ class SAC:
         if self.device.type == 'cuda':
             from ..hip.gemm_select import enable_tuned_gemms
             self.tuned_gemms = enable_tuned_gemms()
-        self.sample_device = self.device if parameter.cuda_inference else torch.device('cpu')
+        # The reference samples on the CPU unless --cuda_inference (sac.py:45-49).  This build has no CPU forward (every layer
+        # is a HIP kernel), so on a GPU the policy always lives - and samples - on the device: the flag is implied.
+        if self.device.type == 'cuda' and not parameter.cuda_inference:
+            self.logger('cuda_inference is implied on a GPU: the policy stays resident on the device (no CPU forward in this build)')
+        self.sample_device = self.device
         self.base_algorithm = getattr(parameter, 'base_algorithm', 'sac')
         self.policy = make_policy_model(self.policy_args, self.base_algorithm, self.discrete_env)
         self.values = [make_value_model(self.value_args, self.base_algorithm, self.discrete_env) for _ in range(parameter.value_net_num)]
@@ -259,4 +263,6 @@ class SAC:
             for i in range(len(self.values)):
                 self.values[i].load(path, index=f'{i}', map_location=self.device)
                 self.target_values[i].load(path, index=f'{i}-target', map_location=self.device)
-        self.log_sac_alpha = torch.load(os.path.join(path, 'log_sac_alpha.pt'), map_location=self.device)
+        # in place: optimizer_alpha holds this tensor (rebinding it, as the reference does, silently freezes the temperature)
+        with torch.no_grad():
+            self.log_sac_alpha.copy_(torch.load(os.path.join(path, 'log_sac_alpha.pt'), map_location=self.device))

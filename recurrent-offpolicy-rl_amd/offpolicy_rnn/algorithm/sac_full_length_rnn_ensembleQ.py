@@ -28,6 +28,7 @@ from ..hip import ops
 from ..models.flash_attention.TransformerFlashAttention import PackedSeqs
 from ..parallel.data_parallel import GradSync
 from ..policy_value_models.make_models import make_policy_model
+from ..utility.pinned import PinnedRing
 from ..utility.q_value_guard import QValueGuard
 from .sac import SAC
 
@@ -151,7 +152,7 @@ class SACFullLengthRNNEnsembleQ(SAC):
         self.target_policy.copy_weight_from(self.policy, tau=0.0)
         self.target_policy.eval()
         self.grad_sync = GradSync()
-        self._pinned = None
+        self._pinned = PinnedRing(torch.float32)       # staging blocks of the host-built batch (one event per block)
         self._needs_seq_table = any(lid.startswith('cgpt') for net in (self.values[0].uni_network, self.values[0].embedding_network,
                                                                        self.policy.uni_network, self.policy.embedding_network)
                                     for lid in net.layer_type)
@@ -221,12 +222,7 @@ class SACFullLengthRNNEnsembleQ(SAC):
         rows, T, W = arr.shape
         R = self.replay_buffer.name2range
         need = rows * T * (W + 3)
-        if self._pinned is None or self._pinned.numel() < need:
-            cap = max(need, rows * self.replay_buffer.max_traj_step * (W + 3))
-            self._pinned = torch.empty(cap, dtype=torch.float32)
-            if self.device.type == 'cuda':
-                self._pinned = self._pinned.pin_memory()
-        staged = self._pinned[:need].view(rows, T, W + 3)
+        staged = self._pinned.stage(need, self.device, rows * self.replay_buffer.max_traj_step * (W + 3)).view(rows, T, W + 3)
         host = staged.numpy()
         host[..., :W] = arr
         start = arr[..., R['start'][0]]
@@ -239,7 +235,7 @@ class SACFullLengthRNNEnsembleQ(SAC):
         host[..., W], host[..., W + 1], host[..., W + 2] = v, tv, ts
         d0, t0 = R['done'][0], R['timeout'][0]
         host[..., d0][arr[..., t0] > 0] = 0                          # time-limit terminations bootstrap
-        dev = staged.to(self.device, non_blocking=True)
+        dev = self._pinned.upload(staged, self.device)
         return self._batch_views(dev, table)
 
     def _batch_views(self, dev, table):

@@ -199,12 +199,13 @@ class NestedMemoryArray(MemoryArray):
             pairs += list(zip(range(*R[dst]), range(*R[src])))
         st = self.__dict__.setdefault('_dev_plan', {})
         if st.get('device') != device:
-            st.update(device=device, pairs=torch.tensor(pairs, dtype=torch.int32).to(device), pinned=None)
+            from ...utility.pinned import PinnedRing
+            st.update(device=device, pairs=torch.tensor(pairs, dtype=torch.int32).to(device), ring=PinnedRing(torch.int32, depth=4))
         seg = np.asarray(plan, dtype=np.int32)
-        if st['pinned'] is None or st['pinned'].shape[0] < len(plan):
-            st['pinned'] = torch.empty((max(2 * len(plan), 256), 4), dtype=torch.int32, pin_memory=device.type == 'cuda')
-        st['pinned'][:len(plan)] = torch.from_numpy(seg)
-        seg_dev = st['pinned'][:len(plan)].to(device, non_blocking=True)
+        # the plan block is rewritten on every sample while earlier copies may still be queued: one event per block
+        host = st['ring'].stage(seg.size, device, 1024).view(-1, 4)
+        host.copy_(torch.from_numpy(seg))
+        seg_dev = st['ring'].upload(host, device)
         out = ops.gather_trajs(self._mirror(device), seg_dev, int(seg[:, 2].max()), skip, nrow, longest, R['mask'][0], R['start'][0],
                                R['done'][0], R['timeout'][0] if R['timeout'][1] > R['timeout'][0] else -1, st['pairs'])
         self._last_batch_shape = (nrow, longest)

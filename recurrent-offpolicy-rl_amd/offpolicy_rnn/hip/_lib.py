@@ -5,14 +5,14 @@ RuntimeError when the shared library is missing or was built against another ABI
 """
 import ctypes
 import os
-from ctypes import c_float, c_int, c_int64, c_size_t, c_void_p
+from ctypes import c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libresel_hip.so')
-ABI_VERSION = 1
+ABI_VERSION = 2
 _lib = None
 
-P, I, L, F, S = c_void_p, c_int, c_int64, c_float, c_void_p
+P, I, L, F, S, U = c_void_p, c_int, c_int64, c_float, c_void_p, c_uint64
 
 # name -> (restype, argtypes); order and types mirror include/resel_hip.h
 SIGNATURES = {
@@ -39,9 +39,10 @@ SIGNATURES = {
     'resel_gru_workspace_bytes': (c_size_t, [I, I, I]),
     'resel_gru_seq_fwd': (c_int, [P, P, P, P, P, P, P, I, I, I, S]),
     'resel_gru_seq_bwd': (c_int, [P, P, P, P, P, P, P, P, I, I, I, S]),
-    'resel_attn_varlen_fwd': (c_int, [P, P, P, P, P, I, I, I, I, I, F, S]),
+    'resel_attn_varlen_fwd': (c_int, [P, P, P, P, P, I, I, I, I, I, F, F, U, U, S]),
     'resel_attn_varlen_bwd_workspace_bytes': (c_size_t, [I, I, I]),
-    'resel_attn_varlen_bwd': (c_int, [P, P, P, P, P, P, P, P, I, I, I, I, I, F, S]),
+    'resel_attn_varlen_bwd': (c_int, [P, P, P, P, P, P, P, P, I, I, I, I, I, F, F, U, U, S]),
+    'resel_dropout': (c_int, [P, P, L, F, U, U, S]),
     'resel_tanh_gaussian_fwd': (c_int, [P, P, P, P, P, I, I, S]),
     'resel_tanh_gaussian_bwd': (c_int, [P, P, P, P, P, I, I, S]),
     'resel_sac_target': (c_int, [P, P, I, P, P, P, P, P, F, P, P, P, P, I, I, S]),
@@ -56,7 +57,7 @@ SIGNATURES = {
     'resel_ensemble_head_fwd': (c_int, [P, P, P, P, P, L, I, L, S]),
     'resel_ensemble_head_bwd_workspace_bytes': (c_size_t, [L, I, L]),
     'resel_ensemble_head_bwd': (c_int, [P, P, P, P, P, P, P, L, I, L, S]),
-    'resel_gather_trajs': (c_int, [P, I, P, I, I, I, I, I, I, I, I, I, P, I, P, S]),
+    'resel_gather_trajs': (c_int, [P, I, L, P, I, I, I, I, I, I, I, I, I, P, I, P, S]),
     'resel_mamba_conv_step': (c_int, [P, L, P, L, P, L, L, L, I, P, P, P, I, I, I, I, S]),
     'resel_selective_state_update': (c_int, [P, L, P, L, P, P, L, P, P, P, P, P, L, P, I, I, I, I, S]),
     'resel_atb_workspace_bytes': (c_size_t, [L, I, I]),

@@ -438,7 +438,7 @@ def gru_seq(gi, w_hh, b_hh, h0=None):
 # ---------------------------------------------------------------------------------------------- attention (cgpt)
 class AttnVarlenFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, qkv, cu_seqlens, max_seqlen, slopes, scale):
+    def forward(ctx, qkv, cu_seqlens, max_seqlen, slopes, scale, p_drop, seed, offset):
         _need_cuda('attn_varlen', qkv, cu_seqlens)
         assert qkv.dtype == torch.bfloat16 and qkv.dim() == 4 and qkv.shape[1] == 3
         qkv = qkv.contiguous()
@@ -449,9 +449,9 @@ class AttnVarlenFn(torch.autograd.Function):
         out = torch.empty(T, H, hd, dtype=torch.bfloat16, device=qkv.device)
         lse = torch.empty(H, T, dtype=torch.float32, device=qkv.device)
         check(lib().resel_attn_varlen_fwd(_p(qkv), _p(cu), _p(slopes), _p(out), _p(lse), T, S, H, hd, int(max_seqlen), float(scale),
-                                          _stream()), 'attn_varlen_fwd')
+                                          float(p_drop), int(seed), int(offset), _stream()), 'attn_varlen_fwd')
         ctx.save_for_backward(qkv, cu, slopes, out, lse)
-        ctx.max_seqlen, ctx.scale = int(max_seqlen), float(scale)
+        ctx.max_seqlen, ctx.scale, ctx.drop = int(max_seqlen), float(scale), (float(p_drop), int(seed), int(offset))
         return out
 
     @staticmethod
@@ -462,14 +462,57 @@ class AttnVarlenFn(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         ws = _ws(lib().resel_attn_varlen_bwd_workspace_bytes(T, H, hd), qkv.device)
         check(lib().resel_attn_varlen_bwd(_p(qkv), _p(cu), _p(slopes), _p(out), _p(lse), _p(dout), _p(dqkv), _p(ws), T, cu.numel() - 1, H, hd,
-                                          ctx.max_seqlen, ctx.scale, _stream()), 'attn_varlen_bwd')
-        return dqkv, None, None, None, None
+                                          ctx.max_seqlen, ctx.scale, *ctx.drop, _stream()), 'attn_varlen_bwd')
+        return dqkv, None, None, None, None, None, None, None
 
 
-def attn_varlen(qkv, cu_seqlens, max_seqlen, slopes=None, scale=None):
-    """qkv [T, 3, H, hd] bf16 packed tokens -> out [T, H, hd] bf16: causal softmax(q k^T * scale - slope_h (i - j)) v per sequence."""
+_MASK64 = (1 << 64) - 1
+
+
+def dropout_counter(device):
+    """(seed, offset) for one counter-keyed dropout mask, taken from the device's default torch generator the way ATen's
+    own dropout kernels reserve Philox offsets: host-side bookkeeping only (no sync), deterministic under
+    `torch.manual_seed`, and every call gets a fresh offset."""
+    gen = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
+    off = gen.get_offset()
+    gen.set_offset(off + 4)
+    return gen.initial_seed() & _MASK64, off & _MASK64
+
+
+def attn_varlen(qkv, cu_seqlens, max_seqlen, slopes=None, scale=None, p_drop=0.0, seed=0, offset=0):
+    """qkv [T, 3, H, hd] bf16 packed tokens -> out [T, H, hd] bf16: causal softmax(q k^T * scale - slope_h (i - j)) v per sequence.
+    p_drop > 0: dropout on the attention probabilities with the keep mask keyed on (seed, offset) (see resel_hip.h)."""
     scale = qkv.shape[-1] ** -0.5 if scale is None else scale
-    return AttnVarlenFn.apply(qkv, cu_seqlens, max_seqlen, slopes, scale)
+    return AttnVarlenFn.apply(qkv, cu_seqlens, max_seqlen, slopes, scale, p_drop, seed, offset)
+
+
+class CounterDropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p_drop, seed, offset):
+        _need_cuda('dropout', x)
+        assert x.dtype == torch.float32
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        check(lib().resel_dropout(_p(x), _p(y), x.numel(), float(p_drop), int(seed), int(offset), _stream()), 'dropout')
+        ctx.drop = (float(p_drop), int(seed), int(offset))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        check(lib().resel_dropout(_p(dy), _p(dx), dy.numel(), *ctx.drop, _stream()), 'dropout')
+        return dx, None, None, None
+
+
+def counter_dropout(x, p_drop, seed=None, offset=None):
+    """Training-mode dropout of an fp32 tensor with a mask keyed on (seed, offset, flat element index); seed / offset default
+    to a fresh `dropout_counter` draw."""
+    if p_drop <= 0.0:
+        return x
+    if seed is None:
+        seed, offset = dropout_counter(x.device)
+    return CounterDropoutFn.apply(x, p_drop, seed, offset)
 
 
 # ---------------------------------------------------------------------------------------------- SAC / TD3 arithmetic
@@ -613,7 +656,7 @@ def gather_trajs(buffer, segments, max_len, skip, rows, row_len, c_mask, c_start
     assert buffer.dtype == torch.float32 and buffer.is_contiguous() and segments.dtype == torch.int32 and segments.is_contiguous()
     W = buffer.shape[1]
     out = torch.empty(rows, row_len, W + 3, dtype=torch.float32, device=buffer.device)
-    check(lib().resel_gather_trajs(_p(buffer), W, _p(segments), segments.shape[0], int(max_len), int(skip), int(rows), int(row_len),
+    check(lib().resel_gather_trajs(_p(buffer), W, buffer.shape[0], _p(segments), segments.shape[0], int(max_len), int(skip), int(rows), int(row_len),
                                    int(c_mask), int(c_start), int(c_done), int(c_timeout), _p(pre_pairs), pre_pairs.shape[0], _p(out),
                                    _stream()), 'gather_trajs')
     return out

@@ -91,9 +91,24 @@ def gru_seq(gi, w_hh, b_hh, h0=None):
     return K.gru_seq_ref(gi, w_hh, b_hh, h0)
 
 
-def attn_varlen(qkv, cu_seqlens, max_seqlen, slopes=None, scale=None):
-    out = K.attention_alibi_varlen_ref(qkv[:, 0], qkv[:, 1], qkv[:, 2], cu_seqlens, slopes, scale)
+def attn_varlen(qkv, cu_seqlens, max_seqlen, slopes=None, scale=None, p_drop=0.0, seed=0, offset=0):
+    out = K.attention_alibi_varlen_ref(qkv[:, 0], qkv[:, 1], qkv[:, 2], cu_seqlens, slopes, scale, p_drop, seed, offset)
     return out.to(torch.bfloat16)
+
+
+_host_counter = K.DropCounter(0)
+
+
+def dropout_counter(device):
+    return _host_counter.next()
+
+
+def counter_dropout(x, p_drop, seed=None, offset=None):
+    if p_drop <= 0.0:
+        return x
+    if seed is None:
+        seed, offset = dropout_counter(x.device)
+    return K.dropout_ref(x, p_drop, seed, offset)
 
 
 def tanh_gaussian(out2, noise):
@@ -149,7 +164,7 @@ def sumsq(x, out=None):
 def install(monkeypatch):
     from offpolicy_rnn.hip import ops
     table = dict(ensemble_head_fwd_=ensemble_head_fwd_, ensemble_head_bwd=ensemble_head_bwd, bias_act_=bias_act_, bias_act_bwd=bias_act_bwd, linear_act=linear_act, mamba_inner_fn=mamba_inner_fn, selective_scan_tm=selective_scan_tm, causal_conv1d_fn=causal_conv1d_fn, layer_norm_fn=_norm(False),
-                 rms_norm_fn=_norm(True), gilr_scan=gilr_scan, complex_scan=complex_scan, gru_seq=gru_seq, tanh_gaussian=tanh_gaussian, attn_varlen=attn_varlen,
+                 rms_norm_fn=_norm(True), gilr_scan=gilr_scan, complex_scan=complex_scan, gru_seq=gru_seq, tanh_gaussian=tanh_gaussian, attn_varlen=attn_varlen, dropout_counter=dropout_counter, counter_dropout=counter_dropout,
                  sac_target=sac_target, soft_update_=soft_update_, adamw_flat_=adamw_flat_, sumsq=sumsq)
     for k, fn in table.items():
         monkeypatch.setattr(ops, k, fn)
