@@ -37,6 +37,16 @@ __device__ __forceinline__ float softplusf_(float x) {
     return fmaxf(x, 0.0f) + l;
 }
 
+// branch-free form for the hot tile passes of the scan kernels (the ?: above compiles to a divergent branch around v_log):
+// both sides are computed, v_log_f32 is used raw (its argument 1 + e is in [1, 2]: no denormal pre-scaling needed)
+__device__ __forceinline__ float softplus_nb(float x) {
+    const float e = __builtin_amdgcn_exp2f(-RESEL_LOG2E * __builtin_fabsf(x));
+    const float lg = __builtin_amdgcn_logf(1.0f + e) * RESEL_LN2;
+    const float se = __builtin_fmaf(-0.5f * e, e, e);
+    return fmaxf(x, 0.0f) + (e < 1e-4f ? se : lg);
+}
+__device__ __forceinline__ float silu_nb(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-RESEL_LOG2E * x)); }
+
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 

@@ -32,6 +32,9 @@ using namespace resel;
 // (start, stop) HIP event pair bound to that dispatch, i.e. timed on the very stream they run on.
 struct ProfSlot { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; };
 bool g_prof_on = false;
+#ifdef SSCAN_STAMP
+unsigned long long* g_stamps = nullptr;
+#endif
 ProfSlot g_prof[2];                   // 0 = sscan_fwd_kernel, 1 = sscan_bwd_kernel
 
 template <typename K, typename P>
@@ -61,7 +64,18 @@ struct FwdParams {
     float *out, *ckpt, *last_state;
     int64_t ld_u, ld_delta, ld_z, ld_b, ld_c, ld_out;
     int B, L, Di, N, nck, softplus, nd, bc_vec;
+#ifdef SSCAN_STAMP
+    unsigned long long* stamps;     // diagnostic build only (tools/micro/sscan_lab.hip): per-wave phase cycle sums
+#endif
 };
+
+#ifdef SSCAN_STAMP
+#define STAMP(acc, last) do { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
+    (acc) += t_ - (last); (last) = t_; } while (0)
+#else
+#define STAMP(acc, last) do { } while (0)
+#endif
 
 template <int NS>
 __device__ __forceinline__ void load_coef(cfloat_p p, float (&dst)[NS]) {
@@ -201,6 +215,12 @@ __global__ __launch_bounds__(NW * 64) void sscan_fwd_kernel(FwdParams p) {
         pst = (p.start && tid < TC && c0 + tid < p.L) ? p.start[tok0 + c0 + tid] : 0.f;
     };
     prefetch(0);
+#ifdef SSCAN_STAMP
+    unsigned long long st_stage = 0, st_b1 = 0, st_scan = 0, st_b2 = 0, st_out = 0, st_last = 0, st_dummy = 0;
+    const unsigned long long st_r0 = __builtin_amdgcn_s_memrealtime();
+    STAMP(st_dummy, st_last);
+    const unsigned long long st_t0 = st_last;
+#endif
 
     for (int c0 = 0; c0 < p.L; c0 += TC) {
         // ---- stage: softplus(delta + bias), delta * u, B_t / C_t / start_t -> LDS; u and z stay in registers
@@ -213,6 +233,7 @@ __global__ __launch_bounds__(NW * 64) void sscan_fwd_kernel(FwdParams p) {
             if (p.softplus) {
                 dv.x = softplusf_(dv.x); dv.y = softplusf_(dv.y); dv.z = softplusf_(dv.z); dv.w = softplusf_(dv.w);
             }
+            if (c0 + r >= p.L) dv = zero4;              // past the end of the row: an identity step (exp2(0) = 1, delta * u = 0)
             u_r[i] = uv;
             z_r[i] = pz[i];
             if (r < TC) {
@@ -229,7 +250,9 @@ __global__ __launch_bounds__(NW * 64) void sscan_fwd_kernel(FwdParams p) {
             }
         }
         if (tid < TC) s_st[tid] = pst;
+        STAMP(st_stage, st_last);
         __syncthreads();
+        STAMP(st_b1, st_last);
         if (c0 + TC < p.L) prefetch(c0 + TC);        // in flight during the whole scan phase
 
         // ---- scan: lane = channel, wave = state group, sequential in time.
@@ -248,11 +271,21 @@ __global__ __launch_bounds__(NW * 64) void sscan_fwd_kernel(FwdParams p) {
         const unsigned long long rmask = __ballot(lane < TC && s_st[lane < TC ? lane : 0] != 0.f);
         f2 B0[NP], C0[NP], B1[NP], C1[NP];
         auto fetch = [&](int t, f2 (&Bq)[NP], f2 (&Cq)[NP]) {
+#ifdef SSCAN_AB_NOBC
+            if (t == 0) {
+#endif
             lds_coef2<NS>(&s_B[t][w * NS], Bq);
             lds_coef2<NS>(&s_C[t][w * NS], Cq);
+#ifdef SSCAN_AB_NOBC
+            }
+#endif
         };
         auto step = [&](int t, const f2 (&Bq)[NP], const f2 (&Cq)[NP], float dlq, float duq) {
+#ifdef SSCAN_AB_NOSEL
+            const float dle = dlq;
+#else
             const float dle = ((rmask >> t) & 1ull) ? __builtin_inff() : dlq;    // reset: exp2(-inf) = 0 wipes h_{t-1}
+#endif
             const f2 dle2 = {dle, dle}, du2 = {duq, duq};
             f2 yacc = {0.f, 0.f};
 #pragma unroll
@@ -264,14 +297,30 @@ __global__ __launch_bounds__(NW * 64) void sscan_fwd_kernel(FwdParams p) {
                 hp[k] = __builtin_elementwise_fma(dA, hp[k], du2 * Bq[k]);
                 yacc = __builtin_elementwise_fma(Cq[k], hp[k], yacc);
             }
+#ifdef SSCAN_AB_NOY
+            { float yk = yacc.x + yacc.y; asm volatile("" :: "v"(yk)); }
+#else
             s_y[w][t][lane] = yacc.x + yacc.y;
+#endif
             const int tabs = c0 + t + 1;
+#ifdef SSCAN_AB_NOCK
+            if (false) {
+#else
             if (p.ckpt != nullptr && (tabs % CKS) == 0 && tabs < p.L && d_ok) {
+#endif
                 float* ck = p.ckpt + (((int64_t)b * p.nck + (tabs / CKS - 1)) * N + w * NS) * p.Di + d;
 #pragma unroll
                 for (int j = 0; j < NS; ++j) ck[(int64_t)j * p.Di] = (j & 1) ? hp[j / 2].y : hp[j / 2].x;
             }
         };
+#ifdef SSCAN_FWD_FREE
+        // straight-line chunk: rows past the end of the sequence are staged as (delta, delta * u) = (0, 0), i.e. identity steps
+#pragma unroll
+        for (int t = 0; t < TC; ++t) {
+            fetch(t, B0, C0);
+            step(t, B0, C0, dlr[t], dur[t]);
+        }
+#else
         fetch(0, B0, C0);
 #pragma unroll
         for (int t = 0; t < TC; t += 2) {
@@ -286,7 +335,10 @@ __global__ __launch_bounds__(NW * 64) void sscan_fwd_kernel(FwdParams p) {
                 step(t + 1, B1, C1, dlr[t + 1 < TC ? t + 1 : TC - 1], dur[t + 1 < TC ? t + 1 : TC - 1]);
             }
         }
+#endif
+        STAMP(st_scan, st_last);
         __syncthreads();
+        STAMP(st_b2, st_last);
 
         // ---- output tile: sum the NW partials, skip term, gate, float4 store
 #pragma unroll
@@ -312,8 +364,282 @@ __global__ __launch_bounds__(NW * 64) void sscan_fwd_kernel(FwdParams p) {
         }
         // no barrier needed here: the next stage only writes s_dl/s_du/s_B/s_C/s_st (last read before the barrier
         // above), and s_y is rewritten only after the barrier that follows that stage.
+        STAMP(st_out, st_last);
     }
+#ifdef SSCAN_STAMP
+    if (p.stamps && lane == 0) {
+        unsigned long long* o = p.stamps + ((size_t)blockIdx.x * NW + w) * 8;
+        o[0] = st_stage; o[1] = st_b1; o[2] = st_scan; o[3] = st_b2; o[4] = st_out;
+        o[5] = st_last - st_t0; o[6] = __builtin_amdgcn_s_memrealtime() - st_r0; o[7] = st_r0;
+    }
+#endif
     if (p.last_state != nullptr && d_ok) {
+#pragma unroll
+        for (int j = 0; j < NS; ++j)
+            p.last_state[((int64_t)b * p.Di + d) * N + w * NS + j] = (j & 1) ? hp[j / 2].y : hp[j / 2].x;
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Forward, second edition.  Same ownership (workgroup = row b x 64 channels, lane = channel, wave = NS-state group, time in
+// TC-step chunks staged through LDS) with the per-step overheads the stamps of tools/micro/sscan_lab.hip showed removed:
+//   * resets are applied when the chunk is STAGED (delta := +inf at a start step, so exp2(delta * A) = 0): no select, no
+//     mask arithmetic in the step;
+//   * the step loop is straight-line over the whole chunk (rows past the end of the sequence are staged as identity steps:
+//     delta = 0, delta * u = 0), so the compiler software-pipelines across steps and pairs the y stores;
+//   * checkpoints leave through buffer stores (wave-uniform base in the descriptor, the per-event offset in an SGPR, the
+//     per-state offsets in registers set up once): no 64-bit address arithmetic in the loop;
+//   * the prefetched tiles of the next chunk are waited for BEFORE this chunk's output stores are issued - hipcc otherwise
+//     guards their first use with s_waitcnt vmcnt(0) and every chunk eats a full store round trip.
+// ROWS = 2: one workgroup of 2 NW waves carries TWO batch rows (rows 2k, 2k + 1 of the same channel tile), one per wave
+// quartet.  At one 256-thread workgroup per row two workgroups share a CU, the older one wins every VALU arbitration,
+// finishes ~30 % early and leaves the younger to run the rest of its row alone at one wave per SIMD (measured: 185 vs
+// 265 us); inside one workgroup the chunk barriers keep the two rows abreast.  Measured at B = 64: 276.7 us against 280.9 us
+// with one row per workgroup - the kernel is bound by total VALU work, not by the tail - so ROWS = 1 is what ships and
+// ROWS = 2 stays a build switch (SSCAN_FWD_ROWS2).
+template <int NS, int NW, int TC, int ROWS>
+__global__ __launch_bounds__(NW * 64 * ROWS) void sscan_fwd2_kernel(FwdParams p) {
+    constexpr int NT = NW * 64;
+    constexpr int N = NS * NW;
+    constexpr int NP = (NS + 1) / 2;
+    constexpr int PER_T = (TC * 16 + NT - 1) / NT;
+    constexpr int BC_ITEMS = TC * N / 4;
+    constexpr int PER_BC = (BC_ITEMS + NT - 1) / NT;
+    static_assert(TC % 2 == 0 && (TC * 16) % NT == 0, "whole tile rows per thread pass");
+    __shared__ __attribute__((aligned(16))) float sm_dl[ROWS][TC][TILE_C];      // exp argument: softplus(delta + bias), +inf at a reset
+    __shared__ __attribute__((aligned(16))) float sm_du[ROWS][TC][TILE_C];      // softplus(delta + bias) * u
+    __shared__ __attribute__((aligned(16))) float sm_y[ROWS][NW][TC][TILE_C];
+    __shared__ __attribute__((aligned(16))) float sm_B[ROWS][TC][N];
+    __shared__ __attribute__((aligned(16))) float sm_C[ROWS][TC][N];
+    __shared__ __attribute__((aligned(16))) float sm_ck[ROWS][TC / CKS][N][TILE_C];   // the chunk's checkpoints, stored with the output tile
+
+    int bpair, dt;
+    if (!decode_block(blockIdx.x, p.nd, (p.B + ROWS - 1) / ROWS, bpair, dt)) return;
+    const int row = __builtin_amdgcn_readfirstlane((int)threadIdx.x / (NW * 64));
+    const int b_raw = bpair * ROWS + row;
+    const bool row_ok = b_raw < p.B;                 // odd batch: the second row of the last pair idles (it still joins the barriers)
+    const int b = row_ok ? b_raw : p.B - 1;
+    float (*s_dl)[TILE_C] = sm_dl[row];
+    float (*s_du)[TILE_C] = sm_du[row];
+    float (*s_y)[TC][TILE_C] = sm_y[row];
+    float (*s_B)[N] = sm_B[row];
+    float (*s_C)[N] = sm_C[row];
+    float (*s_ck)[N][TILE_C] = sm_ck[row];
+    const int tid = threadIdx.x % (NW * 64);
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int d0 = dt * TILE_C;
+    const int d = d0 + lane;
+    const bool d_ok = d < p.Di;
+    const int64_t tok0 = (int64_t)b * p.L;
+
+    f2 A2p[NP], hp[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        float a[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int j = 2 * k + e;
+            a[e] = (d_ok && j < NS) ? fminf(p.A[(int64_t)d * N + w * NS + j] * RESEL_LOG2E, -1e-30f) : -1.f;
+        }
+        A2p[k] = f2{a[0], a[1]};
+        hp[k] = f2{0.f, 0.f};
+    }
+    const int tc4 = (tid & 15) * 4;
+    const int tr0 = tid >> 4;
+    const bool c_ok = (d0 + tc4) < p.Di;
+    float4 Dv = make_float4(0.f, 0.f, 0.f, 0.f), bv = Dv;
+    if (c_ok) {
+        if (p.D) Dv = ld4(p.D + d0 + tc4);
+        if (p.delta_bias) bv = ld4(p.delta_bias + d0 + tc4);
+    }
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 pu[PER_T], pd[PER_T], pz[PER_T];
+    float4 pB[PER_BC], pC[PER_BC];
+    float pst[PER_T];
+    float4 u_r[PER_T], z_r[PER_T];
+
+    auto prefetch = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < PER_T; ++i) {
+            const int t = c0 + tr0 + i * (NT / 16);
+            pu[i] = zero4; pd[i] = zero4; pz[i] = zero4; pst[i] = 0.f;
+            if (t < p.L) {
+                const int64_t tok = tok0 + t;
+                if (c_ok) {
+                    pu[i] = ld4(p.u + tok * p.ld_u + d0 + tc4);
+                    pd[i] = ld4(p.delta + tok * p.ld_delta + d0 + tc4);
+                    if (p.z) pz[i] = ld4(p.z + tok * p.ld_z + d0 + tc4);
+                }
+                if (p.start) pst[i] = p.start[tok];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < PER_BC; ++i) {
+            const int it = tid + i * NT;
+            const int t = c0 + it / (N / 4), c = (it % (N / 4)) * 4;
+            pB[i] = zero4; pC[i] = zero4;
+            if (it < BC_ITEMS && t < p.L) {
+                pB[i] = load_bc4(p.Bm, tok0 + t, p.ld_b, c, p.bc_vec);
+                pC[i] = load_bc4(p.Cm, tok0 + t, p.ld_c, c, p.bc_vec);
+            }
+        }
+    };
+    prefetch(0);
+    auto retire_prefetch = [&]() {                 // make hipcc wait for the prefetched tiles HERE (see the header comment)
+#pragma unroll
+        for (int i = 0; i < PER_T; ++i) asm volatile("" :: "v"(pu[i].x), "v"(pd[i].x), "v"(pz[i].x), "v"(pst[i]));
+#pragma unroll
+        for (int i = 0; i < PER_BC; ++i) asm volatile("" :: "v"(pB[i].x), "v"(pC[i].x));
+    };
+    retire_prefetch();
+    // Data registers of the output-phase stores stay LIVE until the end of the next scan phase: hipcc guards the first
+    // overwrite of a store's data register with s_waitcnt vmcnt - placed there, the stores have long completed.
+    constexpr int PER_CK = (TC / CKS) * ((N * 16 + NT - 1) / NT);
+    float4 y_keep[PER_T], ck_keep[PER_CK];
+#pragma unroll
+    for (int i = 0; i < PER_T; ++i) y_keep[i] = zero4;
+#pragma unroll
+    for (int i = 0; i < PER_CK; ++i) ck_keep[i] = zero4;
+    auto release_store_data = [&]() {
+#pragma unroll
+        for (int i = 0; i < PER_T; ++i) asm volatile("" :: "v"(y_keep[i].x), "v"(y_keep[i].y), "v"(y_keep[i].z), "v"(y_keep[i].w));
+#pragma unroll
+        for (int i = 0; i < PER_CK; ++i) asm volatile("" :: "v"(ck_keep[i].x), "v"(ck_keep[i].y), "v"(ck_keep[i].z), "v"(ck_keep[i].w));
+    };
+#ifdef SSCAN_STAMP
+    unsigned long long st_stage = 0, st_b1 = 0, st_scan = 0, st_b2 = 0, st_out = 0, st_last = 0, st_dummy = 0;
+    const unsigned long long st_r0 = __builtin_amdgcn_s_memrealtime();
+    STAMP(st_dummy, st_last);
+    const unsigned long long st_t0 = st_last;
+#endif
+
+    for (int c0 = 0; c0 < p.L; c0 += TC) {
+        // ---- stage
+#pragma unroll
+        for (int i = 0; i < PER_T; ++i) {
+            const int r = tr0 + i * (NT / 16);
+            float4 dv = pd[i];
+            const float4 uv = pu[i];
+            dv.x += bv.x; dv.y += bv.y; dv.z += bv.z; dv.w += bv.w;
+            if (p.softplus) {
+                dv.x = softplus_nb(dv.x); dv.y = softplus_nb(dv.y); dv.z = softplus_nb(dv.z); dv.w = softplus_nb(dv.w);
+            }
+            float4 du4 = make_float4(dv.x * uv.x, dv.y * uv.y, dv.z * uv.z, dv.w * uv.w);
+            if (c0 + TC > p.L) {                                              // last chunk only (uniform branch)
+                if (c0 + r >= p.L) { dv = zero4; du4 = zero4; }              // identity step past the end of the row
+            }
+            {                                                                 // reset: exp2(-inf * |A|) = 0 wipes the carried state
+                const bool rs = pst[i] != 0.f;
+                const float inf = __builtin_inff();
+                dv.x = rs ? inf : dv.x; dv.y = rs ? inf : dv.y; dv.z = rs ? inf : dv.z; dv.w = rs ? inf : dv.w;
+            }
+            u_r[i] = uv;
+            z_r[i] = pz[i];
+            st4(&s_dl[r][tc4], dv);
+            st4(&s_du[r][tc4], du4);
+        }
+#pragma unroll
+        for (int i = 0; i < PER_BC; ++i) {
+            const int it = tid + i * NT;
+            if (it < BC_ITEMS) {
+                st4(&s_B[0][0] + it * 4, pB[i]);
+                st4(&s_C[0][0] + it * 4, pC[i]);
+            }
+        }
+        STAMP(st_stage, st_last);
+        __syncthreads();
+        STAMP(st_b1, st_last);
+        prefetch(c0 + TC);                           // in flight during the whole scan phase (past the end: every load is guarded off)
+
+        // ---- scan
+        float dlr[TC], dur[TC];
+#pragma unroll
+        for (int t = 0; t < TC; ++t) { dlr[t] = s_dl[t][lane]; dur[t] = s_du[t][lane]; }
+        const bool ck_on = p.ckpt != nullptr;
+        f2 Bq[2][NP], Cq[2][NP];                      // operand rows one step ahead of their use (two register sets)
+        lds_coef2<NS>(&s_B[0][w * NS], Bq[0]);
+        lds_coef2<NS>(&s_C[0][w * NS], Cq[0]);
+#pragma unroll
+        for (int t = 0; t < TC; ++t) {
+            if (t + 1 < TC) {
+                lds_coef2<NS>(&s_B[t + 1][w * NS], Bq[(t + 1) & 1]);
+                lds_coef2<NS>(&s_C[t + 1][w * NS], Cq[(t + 1) & 1]);
+            }
+            const f2 dl2 = {dlr[t], dlr[t]}, du2 = {dur[t], dur[t]};
+            f2 yacc = {0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const f2 arg = dl2 * A2p[k];
+                f2 dA;
+                dA.x = fast_exp2(arg.x);
+                dA.y = fast_exp2(arg.y);
+                hp[k] = __builtin_elementwise_fma(dA, hp[k], du2 * Bq[t & 1][k]);
+                yacc = __builtin_elementwise_fma(Cq[t & 1][k], hp[k], yacc);
+            }
+            s_y[w][t][lane] = yacc.x + yacc.y;
+            if ((t + 1) % CKS == 0 && ck_on) {                               // c0 is a multiple of TC, TC of CKS
+#pragma unroll
+                for (int j = 0; j < NS; ++j) s_ck[t / CKS][w * NS + j][lane] = (j & 1) ? hp[j / 2].y : hp[j / 2].x;
+            }
+        }
+        // the next chunk's tiles have been in flight for the whole scan: retire them here, ahead of the output stores
+        retire_prefetch();
+        release_store_data();
+        STAMP(st_scan, st_last);
+        __syncthreads();
+        STAMP(st_b2, st_last);
+
+        // ---- output tile
+#pragma unroll
+        for (int i = 0; i < PER_T; ++i) {
+            const int r = tr0 + i * (NT / 16);
+            const int t = c0 + r;
+            if (t < p.L && c_ok && row_ok) {
+                float4 y = ld4(&s_y[0][r][tc4]);
+#pragma unroll
+                for (int ww = 1; ww < NW; ++ww) {
+                    const float4 q = ld4(&s_y[ww][r][tc4]);
+                    y.x += q.x; y.y += q.y; y.z += q.z; y.w += q.w;
+                }
+                const float4 uv = u_r[i];
+                y.x = __builtin_fmaf(Dv.x, uv.x, y.x); y.y = __builtin_fmaf(Dv.y, uv.y, y.y);
+                y.z = __builtin_fmaf(Dv.z, uv.z, y.z); y.w = __builtin_fmaf(Dv.w, uv.w, y.w);
+                if (p.z) {
+                    const float4 zv = z_r[i];
+                    y.x *= silu_nb(zv.x); y.y *= silu_nb(zv.y); y.z *= silu_nb(zv.z); y.w *= silu_nb(zv.w);
+                }
+                y_keep[i] = y;
+                st4(p.out + (tok0 + t) * p.ld_out + d0 + tc4, y_keep[i]);
+            }
+        }
+        if (ck_on) {                                 // checkpoints of this chunk: [N][64] rows of 256 B each, float4 per thread
+#pragma unroll
+            for (int e = 0; e < TC / CKS; ++e) {
+                const int tabs = c0 + (e + 1) * CKS;
+                float* dst = p.ckpt + ((int64_t)b * p.nck + (tabs / CKS - 1)) * N * p.Di + d0;
+#pragma unroll
+                for (int q = 0; q < (N * 16 + NT - 1) / NT; ++q) {
+                    const int it = tid + q * NT;
+                    const int n = it >> 4, c4 = (it & 15) * 4;
+                    if (tabs < p.L && it < N * 16 && d0 + c4 < p.Di && row_ok) {
+                        ck_keep[e * ((N * 16 + NT - 1) / NT) + q] = ld4(&s_ck[e][n][c4]);
+                        st4(dst + (int64_t)n * p.Di + c4, ck_keep[e * ((N * 16 + NT - 1) / NT) + q]);
+                    }
+                }
+            }
+        }
+        STAMP(st_out, st_last);
+    }
+#ifdef SSCAN_STAMP
+    if (p.stamps && lane == 0) {
+        unsigned long long* o = p.stamps + ((size_t)blockIdx.x * NW + w) * 8;
+        o[0] = st_stage; o[1] = st_b1; o[2] = st_scan; o[3] = st_b2; o[4] = st_out;
+        o[5] = st_last - st_t0; o[6] = __builtin_amdgcn_s_memrealtime() - st_r0; o[7] = st_r0;
+    }
+#endif
+    if (p.last_state != nullptr && d_ok && row_ok) {
 #pragma unroll
         for (int j = 0; j < NS; ++j)
             p.last_state[((int64_t)b * p.Di + d) * N + w * NS + j] = (j & 1) ? hp[j / 2].y : hp[j / 2].x;
@@ -797,7 +1123,18 @@ __global__ void sscan_reduce_bc_kernel(const float* __restrict__ part, int nd, i
 template <int NS, int NW, int TC>
 int launch_fwd(const FwdParams& p, hipStream_t s) {
     const int bp = (p.B + 7) / 8 * 8;
+#ifdef SSCAN_FWD1
     launch_maybe_timed(0, sscan_fwd_kernel<NS, NW, TC>, dim3(bp * p.nd), dim3(NW * 64), s, p);
+#else
+    if constexpr (NS * NW == 32) {                   // two rows per workgroup (144 KB of LDS, one workgroup per CU): -DSSCAN_FWD_ROWS2
+#ifdef SSCAN_FWD_ROWS2
+        const int bp2 = ((p.B + 1) / 2 + 7) / 8 * 8;
+        launch_maybe_timed(0, sscan_fwd2_kernel<NS, NW, TC, 2>, dim3(bp2 * p.nd), dim3(NW * 64 * 2), s, p);
+        return launch_status();
+#endif
+    }
+    launch_maybe_timed(0, sscan_fwd2_kernel<NS, NW, TC, 1>, dim3(bp * p.nd), dim3(NW * 64), s, p);
+#endif
     return launch_status();
 }
 template <int NS, int NW>
@@ -868,6 +1205,9 @@ extern "C" int resel_selective_scan_fwd(const float* u, int64_t ld_u, const floa
                 ld_u, ld_delta, ld_z, ld_b, ld_c, ld_out, B, L, Di, N, n_ckpt(L), delta_softplus,
                 (Di + TILE_C - 1) / TILE_C,
                 (ld_b % 4 == 0 && ld_c % 4 == 0 && aligned16(Bm) && aligned16(Cm)) ? 1 : 0};
+#ifdef SSCAN_STAMP
+    p.stamps = g_stamps;
+#endif
     hipStream_t s = (hipStream_t)stream;
     switch (N) {
         case 4: return launch_fwd<1, 4, 32>(p, s);
