@@ -7,7 +7,8 @@ A "step" is one `train_one_batch()` (sample B trajectories -> H2D -> target -> c
 alpha step) on synthetic Gaussian trajectories.  Workload at N = 1 = BASELINE.json configs[1]:
 smamba_s32_c16_b2_nln SAC, B=64, T=1024, obs=17, act=6, published RESeL architecture (D=256, efc-8 critic).
 N > 1 keeps B=64 rows per GPU (weak scaling; N = 8 is configs[3]'s global B=512) with ONE RCCL all-reduce of the flat
-gradient buffer per optimizer step.  Rank 0 prints one JSON line.
+gradient buffer per optimizer step; `--global-rows G` instead splits a FIXED global batch of G trajectories over the ranks
+(strong scaling, e.g. configs[3]: --global-rows 512 at N = 1, 2, 4, 8).  Rank 0 prints one JSON line.
 
     python bench.py --rnn <layer id> --algo sac|td3 --rows B --horizon T      other layer families / sizes (same JSON line)
     python bench.py --mode rollout [--envs E]                                  the per-environment-step policy forward:
@@ -88,24 +89,95 @@ def baseline_config(args):
     return 'BASELINE configs[0] family (GRU) at the configs[1] size'
 
 
-def cpu_baseline(rnn):
-    """The oracle trainer (CPU restatement of the same update, `kind: port`) on a bounded sample of the workload: one update
-    of the same layer stack at 8 rows x T=1024 on 8 host threads (the per-step Python loops of the CPU scan do not scale
-    past that: 32 threads measured 2x slower), run in a child process with a hard time limit so that the bench line can
-    never hang on the host part.  Falls back to the GRU stack (ATen's CPU GRU) when the sample does not finish."""
+def cpu_baseline(rnn, algo='sac'):
+    """CPU leg (`kind: port`: the oracle trainer, a CPU restatement of the same update; the reference itself cannot travel to
+    the GPU box).  The baseline of record is north_star's: the GRU trainer at the full B=64, T=1024 on the host cores, one
+    warm-up update then three timed ones (ATen's CPU GRU scales to ~32 threads, not beyond) - about 30 s.  Run in a child
+    process with a hard time limit so that the bench line can never hang on the host part."""
     import subprocess
     code = ("import json,sys; sys.path.insert(0, %r); from oracle.trainer import time_cpu_baseline; "
-            "print(json.dumps(time_cpu_baseline(%r, B=%d, T=1024, updates=1, warmup=0, threads=%d)))")
-    gru_sample = ('gru', 64, min(32, os.cpu_count() or 1), 120)       # ATen's CPU GRU scales to ~32 threads, not beyond
-    for name, rows, threads, limit in ((gru_sample,) if rnn == 'gru' else ((rnn, 8, 8, 240), gru_sample)):
-        try:
-            r = subprocess.run([sys.executable, '-c', code % (ROOT, name, rows, threads)], capture_output=True, text=True, timeout=limit)
-            base = json.loads(r.stdout.strip().splitlines()[-1])
-            return {'value': base['value'], 'unit': 'env-steps/s', 'cores': base['cores'], 'kind': 'port',
-                    'sample': base['sample'] + f'; {base["seconds_per_update"]:.2f} s/update'}
-        except Exception as e:                       # timeout / failure of the sample: try the cheaper one, then report null
-            err = repr(e)[:120]
-    return {'value': None, 'unit': 'env-steps/s', 'cores': 0, 'kind': 'port', 'sample': 'cpu sample did not finish: ' + err}
+            "print(json.dumps(time_cpu_baseline(%r, B=%d, T=1024, updates=%d, warmup=1, threads=%d, algo=%r)))")
+    if rnn == 'gru':
+        rows, threads, updates, limit = 64, min(32, os.cpu_count() or 1), 3, 240
+    else:                                             # same layer stack as the GPU run, bounded: 4 rows (per-step Python loops on the CPU)
+        rows, threads, updates, limit = 4, 8, 2, 240
+    try:
+        r = subprocess.run([sys.executable, '-c', code % (ROOT, rnn, rows, updates, threads, algo)], capture_output=True, text=True, timeout=limit)
+        base = json.loads(r.stdout.strip().splitlines()[-1])
+        return {'value': base['value'], 'unit': 'env-steps/s', 'cores': base['cores'], 'kind': 'port',
+                'sample': base['sample'] + f'; {base["seconds_per_update"]:.2f} s/update'}
+    except Exception as e:                           # timeout / failure of the sample
+        return {'value': None, 'unit': 'env-steps/s', 'cores': 0, 'kind': 'port', 'sample': 'cpu sample did not finish: ' + repr(e)[:120]}
+
+
+def kernel_source_stamp():
+    """sha256 over the HIP sources: ties profiles/traffic.json (PMC passes) to the kernels that were profiled."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, 'recurrent-offpolicy-rl_amd', 'csrc', '*.hip')) +
+                    glob.glob(os.path.join(ROOT, 'recurrent-offpolicy-rl_amd', 'csrc', '*.h'))):
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def roofline_lines(args, kern, Bsz, Tp):
+    """One roofline object per hand-written sequence kernel timed in the run (HIP event pair bound to each dispatch, on the
+    launch stream).  Algorithmic bytes / flops per launch = SURVEY.md 8(d)'s per-unit figures x the units of one launch
+    (DESIGN.md section 4 states both)."""
+    D, fam = 256, args.rnn.split('_')[0]
+    alg = {}
+    if fam == 'smamba':
+        Di, N = 2 * D, int(args.rnn.split('_s')[1].split('_')[0])
+        alg['sscan_fwd_kernel'] = ('hbm', 4 * Bsz * Di * Tp * 4 + 4 * Bsz * N * Tp * 2 + Bsz * Tp)       # u, delta, z, out + B, C + start
+        alg['sscan_bwd_kernel'] = ('hbm', 4 * Bsz * Di * Tp * 7 + 4 * Bsz * N * Tp * 4)                # + dout, du, ddelta, dz + dB, dC
+        alg['conv_fwd_kernel'] = ('hbm', 4 * Bsz * Di * Tp * 2)
+        alg['conv_bwd_kernel'] = ('hbm', 4 * Bsz * Di * Tp * 4)
+    elif fam == 'cgpt':
+        H = int(args.rnn.split('_h')[1].split('_')[0]) if '_h' in args.rnn else 8
+        hd = D // H
+        nsq = Bsz * (1 + (Tp - 1) ** 2)                 # every row packs a 1-token and a (T' - 1)-token sequence
+        for name, prods in (('attn_fwd_kernel', 2), ('attn_dq_kernel', 3), ('attn_dkv_kernel', 4)):   # causal half counted
+            alg[name] = ('mfma', prods * nsq * hd * H)
+    elif fam in ('gilr', 'lru'):
+        alg['linrec_real_fwd_kernel'] = ('hbm', 4 * Bsz * Tp * D * 3)
+        alg['linrec_real_bwd_kernel'] = ('hbm', 4 * Bsz * Tp * D * 5)
+        alg['linrec_complex_fwd_kernel'] = ('hbm', 4 * Bsz * Tp * D * 4 + Bsz * Tp)
+        alg['linrec_complex_bwd_kernel'] = ('hbm', 4 * Bsz * Tp * D * 6)
+    elif fam == 'gru':
+        alg['gru_fwd_kernel'] = ('hbm', 4 * Bsz * Tp * D * 4)      # gi (3H) in, h out: the recurrence itself is latency-bound (see us_per_step)
+        alg['gru_bwd_kernel'] = ('hbm', 4 * Bsz * Tp * D * 8)
+    traffic, tstamp = {}, None
+    tpath = os.path.join(ROOT, 'profiles', 'traffic.json')           # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile_bench.sh)
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        tstamp = tj.get('kernel_source_stamp')
+        if tstamp == kernel_source_stamp() and tj.get('rnn', 'smamba_s32_c16_b2_nln') == args.rnn and tj.get('rows', 64) == Bsz:
+            traffic = tj.get('per_launch_bytes', {})               # only when the PMC passes profiled THESE kernels on THIS workload
+    lines = []
+    for name, (bound, units) in alg.items():
+        if name not in kern or kern[name]['launches'] <= 0:
+            continue
+        avg = kern[name]['avg_us']
+        if bound == 'hbm':
+            ach, peak, unit = units / (avg * 1e-6) / 1e9, 8000.0, 'GB/s'
+        else:
+            ach, peak, unit = units / (avg * 1e-6) / 1e12, 2500.0, 'TFLOP/s'
+        o = {'kernel': name, 'bound': bound, 'achieved': ach, 'peak': peak, 'unit': unit, 'frac': ach / peak, 'traffic': traffic.get(name),
+             'avg_us': avg, 'launches': kern[name]['launches'], 'algorithmic_' + ('bytes' if bound == 'hbm' else 'flops'): units}
+        if name.startswith('sscan'):
+            # VALU-issue view: measured issue costs on gfx950 (tools/micro/valu_rate2.hip) are 4.5 cycles per packed-f32
+            # instruction (2 results) and 8.2 per v_exp_f32 per wave64; per (state, step) the recurrence needs 1 exp + 4 plain
+            # ops forward (17.2 cycles per wave) and 1.5 exp + ~13.5 plain ops + the channel reduction backward (~54)
+            N = int(args.rnn.split('_s')[1].split('_')[0])
+            o['valu_cycles_per_state_step'] = avg * 1e-6 * 1024 * 2.4e9 / (Bsz * Tp * 2 * D * N / 64)
+            o['valu_floor_cycles_per_state_step'] = 17.2 if name == 'sscan_fwd_kernel' else 54.0
+            o['note'] = 'fp32 recurrence, N states per channel: bound by VALU issue below the HBM roof (DESIGN.md 4, profiles/r02_pmc_sscan.md)'
+        if name.startswith('gru'):
+            o['us_per_step'] = avg / Tp if kern[name]['launches'] and avg > 50 else avg
+        lines.append((avg * kern[name]['launches'], o))
+    lines.sort(key=lambda t: -t[0])
+    return [o for _, o in lines]
 
 
 def rollout_mode(args):
@@ -185,7 +257,10 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--rnn', default='smamba_s32_c16_b2_nln')
     ap.add_argument('--algo', default='sac', choices=['sac', 'td3'])
-    ap.add_argument('--rows', type=int, default=64, help='trajectories per GPU per update')
+    ap.add_argument('--rows', type=int, default=64, help='trajectories per GPU per update (weak scaling: fixed per GPU)')
+    ap.add_argument('--global-rows', type=int, default=0,
+                    help='strong scaling: a FIXED global batch of this many trajectories per update, split evenly over the --gpus ranks '
+                         '(BASELINE configs[3]: 512)')
     ap.add_argument('--horizon', type=int, default=1024)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--envs', type=int, default=1, help='rollout mode: also time one graph replay over this many environments')
@@ -197,6 +272,9 @@ def main():
     import torch.distributed as dist
     rank, world, local = init_from_env()
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    if args.global_rows:
+        assert args.global_rows % world == 0, f'--global-rows {args.global_rows} does not split over {world} ranks'
+        args.rows = args.global_rows // world
     torch.cuda.set_device(local)
     torch.manual_seed(1234 + rank)
     np.random.seed(1234 + rank)                         # each rank samples its own rows
@@ -241,47 +319,22 @@ def main():
     kern = {name: dict(launches=n, avg_us=avg) for name, (n, avg) in prof.items()}
     out = {
         'metric': 'env-steps/sec trained', 'value': trained / dt, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps,
-        'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'strong' if args.global_rows else 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': f'{args.rnn} {args.algo.upper()}-REDQ full-trajectory update, B={Bsz}/GPU, T={args.horizon} (row length {Tp}), obs={OBS}, act={ACT}, '
                                f'D=256, efc-8 critic ({baseline_config(args)})',
                    'global_rows': Bsz * world, 'parallelism': f'dp{world}'},
     }
-    if 'sscan_fwd_kernel' in kern and args.rnn.startswith('smamba'):
-        # Roofline of the hand-written kernels timed above (HIP event pair bound to each dispatch, on the launch stream).
-        # Algorithmic bytes per launch = SURVEY.md 8(d)'s per-element figures x the B*T'*Di elements of one launch;
-        # `roofline` is the one with the larger total time in the timed region, `roofline_other` the second.
-        Di, N = 512, int(args.rnn.split('_s')[1].split('_')[0])
-        alg_bytes = {'sscan_fwd_kernel': 4 * Bsz * Di * Tp * 4 + 4 * Bsz * N * Tp * 2 + Bsz * Tp,      # u, delta, z, out + B, C + start
-                     'sscan_bwd_kernel': 4 * Bsz * Di * Tp * 7 + 4 * Bsz * N * Tp * 4}               # + dout, du, ddelta, dz + dB, dC
-        traffic = {}
-        tpath = os.path.join(ROOT, 'profiles', 'traffic.json')       # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get('per_launch_bytes', {})
-        lines = []
-        for name in ('sscan_fwd_kernel', 'sscan_bwd_kernel'):
-            if name in kern and kern[name]['launches'] > 0:
-                ach = alg_bytes[name] / (kern[name]['avg_us'] * 1e-6) / 1e9
-                lines.append((kern[name]['avg_us'] * kern[name]['launches'],
-                              {'kernel': name, 'bound': 'hbm', 'achieved': ach, 'peak': 8000.0, 'unit': 'GB/s', 'frac': ach / 8000.0,
-                               'traffic': traffic.get(name), 'avg_us': kern[name]['avg_us'], 'launches': kern[name]['launches'],
-                               'algorithmic_bytes': alg_bytes[name],
-                               # VALU-issue view of the same launch: lane-cycles spent per (row, step, channel, state) at 256 CUs x
-                               # 64 fp32 lanes x 2.4 GHz, against the instruction-count floor of the recurrence (forward: delta*A,
-                               # exp2 at quarter rate, 2 fma = 7; backward: + replay and 10 gradient ops + butterfly sums ~ 24)
-                               'valu_cycles_per_state': kern[name]['avg_us'] * 1e-6 * 256 * 64 * 2.4e9 / (Bsz * Tp * Di * N),
-                               'valu_floor_cycles_per_state': 7 if name == 'sscan_fwd_kernel' else 24,
-                               'note': f'fp32 recurrence with N={N} states per channel: VALU-issue bound below the HBM roof (DESIGN.md 4)'}))
-        lines.sort(key=lambda t: -t[0])
-        if lines:
-            out['roofline'] = lines[0][1]
-        if len(lines) > 1:
-            out['roofline_other'] = lines[1][1]
+    lines = roofline_lines(args, kern, Bsz, Tp)          # dominant hand-written kernel first
+    if lines:
+        out['roofline'] = lines[0]
+    if len(lines) > 1:
+        out['roofline_other'] = lines[1:]
     out['kernels'] = kern
     if world == 1 and not args.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline(args.rnn)
-        if args.rnn != 'gru':                          # north_star's named baseline: the CPU GRU trainer at the full B=64, T=1024
-            out['cpu_baseline_gru'] = cpu_baseline('gru')
+        out['cpu_baseline'] = cpu_baseline('gru')      # of record: north_star's CPU GRU trainer at the full B=64, T=1024
+        if args.rnn != 'gru':
+            out['cpu_baseline_same_stack'] = cpu_baseline(args.rnn, args.algo)
     print(json.dumps(out))
 
 

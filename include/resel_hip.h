@@ -37,10 +37,16 @@ typedef void* resel_stream_t; /* hipStream_t */
 int resel_abi_version(void);            /* bumps when a signature changes */
 const char* resel_build_info(void);     /* "gfx950 <date> ..." */
 
-/* Diagnostics for bench.py (off by default; the only global state of the library).  While enabled, the selective-scan
+/* Diagnostics for bench.py (off by default; the only global state of the library).  While enabled, the sequence-layer
  * kernels are dispatched with a (start, stop) HIP event pair bound to each dispatch on its own stream;
  * resel_profile_collect() synchronises those events, returns their summed duration and count and clears them.
- * kernel_id: 0 = sscan_fwd_kernel, 1 = sscan_bwd_kernel. */
+ * kernel_id: one of RESEL_PROF_* (attn_q_kernel is counted as ATTN_FWD or ATTN_DQ by its mode; the gru slots cover the
+ * persistent kernels or, on the per-step path, every step launch). */
+enum {
+    RESEL_PROF_SSCAN_FWD = 0, RESEL_PROF_SSCAN_BWD = 1, RESEL_PROF_ATTN_FWD = 2, RESEL_PROF_ATTN_DQ = 3, RESEL_PROF_ATTN_DKV = 4,
+    RESEL_PROF_LINREC_REAL_FWD = 5, RESEL_PROF_LINREC_REAL_BWD = 6, RESEL_PROF_LINREC_COMPLEX_FWD = 7, RESEL_PROF_LINREC_COMPLEX_BWD = 8,
+    RESEL_PROF_GRU_FWD = 9, RESEL_PROF_GRU_BWD = 10, RESEL_PROF_CONV_FWD = 11, RESEL_PROF_CONV_BWD = 12, RESEL_PROF_NSLOTS = 13
+};
 int resel_profile_enable(int on);
 int resel_profile_collect(int kernel_id, double* total_us, int* launches);
 

@@ -275,14 +275,14 @@ class OracleTrainer:
             return reward + (1 - done) * par.gamma * self.guard.clamp(mn)
 
 
-def time_cpu_baseline(rnn='gru', B=64, T=1024, obs=17, act=6, updates=1, warmup=0, threads=None, seed=0):
+def time_cpu_baseline(rnn='gru', B=64, T=1024, obs=17, act=6, updates=3, warmup=1, threads=None, seed=0, algo='sac'):
     """bench.py `cpu_baseline` leg: the GRU SAC trainer restatement on the host cores.
     Returns dict(value=env-steps/s trained, seconds_per_update, cores, sample)."""
     if threads:
         torch.set_num_threads(threads)
     torch.manual_seed(seed)
     np.random.seed(seed)
-    par = default_parameter(rnn=rnn, sac_batch_size=B * T - 1)
+    par = default_parameter(rnn=rnn, sac_batch_size=B * T - 1, algo=algo)
     tr = OracleTrainer(par, obs, act, T, gru_impl='aten')
     tr.fill_synthetic(2 * B, T, seed)
     for _ in range(warmup):
@@ -294,7 +294,7 @@ def time_cpu_baseline(rnn='gru', B=64, T=1024, obs=17, act=6, updates=1, warmup=
         tr.grad_num += 1
     dt = time.time() - t0
     return dict(value=n / dt, seconds_per_update=dt / updates, cores=torch.get_num_threads(),
-                sample=f'{updates} update(s) of {rnn} SAC-REDQ at B={B},T={T},D=256 after {warmup} warm-up')
+                sample=f'{updates} update(s) of {rnn} {algo.upper()}-REDQ at B={B},T={T},D=256 after {warmup} warm-up update(s)')
 
 
 def time_cpu_rollout(rnn='gru', obs=17, act=6, steps=200, warmup=10, threads=1, seed=0):

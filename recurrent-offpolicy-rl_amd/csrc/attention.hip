@@ -534,14 +534,14 @@ inline void set_dropout(AttnParams& p, float p_drop, uint64_t seed, uint64_t off
 
 template <int HD, bool DROP>
 void launch_fwd(const AttnParams& p, dim3 grid, hipStream_t s) {
-    hipLaunchKernelGGL((attn_q_kernel<HD, 0, DROP>), grid, dim3(256), 0, s, p);
+    launch_timed(RESEL_PROF_ATTN_FWD, attn_q_kernel<HD, 0, DROP>, grid, dim3(256), 0, s, p);
 }
 template <int HD, bool DROP>
 void launch_bwd(const AttnParams& p, const bf16_t* out, dim3 gq, dim3 gk, hipStream_t s) {
     const int n = p.T * p.H;
     hipLaunchKernelGGL(attn_delta_kernel<HD>, dim3((n + 255) / 256), dim3(256), 0, s, out, p.dout, const_cast<float*>(p.delta), p.T, p.H);
-    hipLaunchKernelGGL((attn_q_kernel<HD, 1, DROP>), gq, dim3(256), 0, s, p);
-    hipLaunchKernelGGL((attn_dkv_kernel<HD, DROP>), gk, dim3(256), 0, s, p);
+    launch_timed(RESEL_PROF_ATTN_DQ, attn_q_kernel<HD, 1, DROP>, gq, dim3(256), 0, s, p);
+    launch_timed(RESEL_PROF_ATTN_DKV, attn_dkv_kernel<HD, DROP>, gk, dim3(256), 0, s, p);
 }
 
 }  // namespace

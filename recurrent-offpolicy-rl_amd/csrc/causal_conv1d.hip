@@ -356,10 +356,10 @@ extern "C" int resel_causal_conv1d_fwd(const float* x, int64_t ld_x, const float
     dim3 grid((Di + 255) / 256, (L + CONV_TT - 1) / CONV_TT, B);
     hipStream_t s = (hipStream_t)stream;
     switch (KT) {
-        case 4: hipLaunchKernelGGL(conv_fwd_kernel<4>, grid, dim3(128), 0, s, p); break;
-        case 8: hipLaunchKernelGGL(conv_fwd_kernel<8>, grid, dim3(128), 0, s, p); break;
-        case 16: hipLaunchKernelGGL(conv_fwd_kernel<16>, grid, dim3(128), 0, s, p); break;
-        default: hipLaunchKernelGGL(conv_fwd_kernel<32>, grid, dim3(128), 0, s, p); break;
+        case 4: launch_timed(RESEL_PROF_CONV_FWD, conv_fwd_kernel<4>, grid, dim3(128), 0, s, p); break;
+        case 8: launch_timed(RESEL_PROF_CONV_FWD, conv_fwd_kernel<8>, grid, dim3(128), 0, s, p); break;
+        case 16: launch_timed(RESEL_PROF_CONV_FWD, conv_fwd_kernel<16>, grid, dim3(128), 0, s, p); break;
+        default: launch_timed(RESEL_PROF_CONV_FWD, conv_fwd_kernel<32>, grid, dim3(128), 0, s, p); break;
     }
     return launch_status();
 }
@@ -388,17 +388,17 @@ extern "C" int resel_causal_conv1d_bwd(const float* x, int64_t ld_x, const float
         const int nchunk = (L + CB_TT - 1) / CB_TT;
         dim3 grid((Di + 255) / 256, nchunk, B);
         switch (KT) {
-            case 4: hipLaunchKernelGGL(conv_bwd_win_kernel<4>, grid, dim3(128), 0, s, p, nchunk); break;
-            case 8: hipLaunchKernelGGL(conv_bwd_win_kernel<8>, grid, dim3(128), 0, s, p, nchunk); break;
-            default: hipLaunchKernelGGL(conv_bwd_win_kernel<16>, grid, dim3(128), 0, s, p, nchunk); break;
+            case 4: launch_timed(RESEL_PROF_CONV_BWD, conv_bwd_win_kernel<4>, grid, dim3(128), 0, s, p, nchunk); break;
+            case 8: launch_timed(RESEL_PROF_CONV_BWD, conv_bwd_win_kernel<8>, grid, dim3(128), 0, s, p, nchunk); break;
+            default: launch_timed(RESEL_PROF_CONV_BWD, conv_bwd_win_kernel<16>, grid, dim3(128), 0, s, p, nchunk); break;
         }
     } else {
         dim3 grid(B, (Di + TILE_C - 1) / TILE_C);
         switch (KT) {
-            case 4: hipLaunchKernelGGL(conv_bwd_kernel<4>, grid, dim3(256), 0, s, p); break;
-            case 8: hipLaunchKernelGGL(conv_bwd_kernel<8>, grid, dim3(256), 0, s, p); break;
-            case 16: hipLaunchKernelGGL(conv_bwd_kernel<16>, grid, dim3(256), 0, s, p); break;
-            default: hipLaunchKernelGGL(conv_bwd_kernel<32>, grid, dim3(256), 0, s, p); break;
+            case 4: launch_timed(RESEL_PROF_CONV_BWD, conv_bwd_kernel<4>, grid, dim3(256), 0, s, p); break;
+            case 8: launch_timed(RESEL_PROF_CONV_BWD, conv_bwd_kernel<8>, grid, dim3(256), 0, s, p); break;
+            case 16: launch_timed(RESEL_PROF_CONV_BWD, conv_bwd_kernel<16>, grid, dim3(256), 0, s, p); break;
+            default: launch_timed(RESEL_PROF_CONV_BWD, conv_bwd_kernel<32>, grid, dim3(256), 0, s, p); break;
         }
     }
     launch_colsum(dw_part, (int64_t)Di * KT, rows, Di * KT, dw, s, KT, K);   // dw[d, k] = sum_rows dw_part[row, d, KT - K + k]

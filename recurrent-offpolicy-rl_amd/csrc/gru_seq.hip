@@ -493,12 +493,12 @@ extern "C" int resel_gru_seq_fwd(const float* gi, const float* w_hh, const float
         if (hipMemsetAsync(base, 0, xchg_granules(B, H) * sizeof(u64) + 64, s) != hipSuccess) return RESEL_ELAUNCH;
         const dim3 pgrid((H / US) * ((B + RG - 1) / RG));
         switch (KC) {
-            case 4: hipLaunchKernelGGL(gru_fwd_persistent_kernel<4>, pgrid, dim3(16 * KQ), 0, s, p, xchg, err); break;
-            case 8: hipLaunchKernelGGL(gru_fwd_persistent_kernel<8>, pgrid, dim3(16 * KQ), 0, s, p, xchg, err); break;
-            case 12: hipLaunchKernelGGL(gru_fwd_persistent_kernel<12>, pgrid, dim3(16 * KQ), 0, s, p, xchg, err); break;
-            case 16: hipLaunchKernelGGL(gru_fwd_persistent_kernel<16>, pgrid, dim3(16 * KQ), 0, s, p, xchg, err); break;
-            case 24: hipLaunchKernelGGL(gru_fwd_persistent_kernel<24>, pgrid, dim3(16 * KQ), 0, s, p, xchg, err); break;
-            case 32: hipLaunchKernelGGL(gru_fwd_persistent_kernel<32>, pgrid, dim3(16 * KQ), 0, s, p, xchg, err); break;
+            case 4: launch_timed(RESEL_PROF_GRU_FWD, gru_fwd_persistent_kernel<4>, pgrid, dim3(16 * KQ), 0, s, p, xchg, err); break;
+            case 8: launch_timed(RESEL_PROF_GRU_FWD, gru_fwd_persistent_kernel<8>, pgrid, dim3(16 * KQ), 0, s, p, xchg, err); break;
+            case 12: launch_timed(RESEL_PROF_GRU_FWD, gru_fwd_persistent_kernel<12>, pgrid, dim3(16 * KQ), 0, s, p, xchg, err); break;
+            case 16: launch_timed(RESEL_PROF_GRU_FWD, gru_fwd_persistent_kernel<16>, pgrid, dim3(16 * KQ), 0, s, p, xchg, err); break;
+            case 24: launch_timed(RESEL_PROF_GRU_FWD, gru_fwd_persistent_kernel<24>, pgrid, dim3(16 * KQ), 0, s, p, xchg, err); break;
+            case 32: launch_timed(RESEL_PROF_GRU_FWD, gru_fwd_persistent_kernel<32>, pgrid, dim3(16 * KQ), 0, s, p, xchg, err); break;
             default: return RESEL_EINVAL;
         }
         return launch_status();
@@ -507,12 +507,12 @@ extern "C" int resel_gru_seq_fwd(const float* gi, const float* w_hh, const float
     for (int t = 0; t < L; ++t) {
         p.t = t;
         switch (KC) {
-            case 4: hipLaunchKernelGGL(gru_fwd_step_kernel<4>, grid, dim3(16 * KQ), 0, s, p); break;
-            case 8: hipLaunchKernelGGL(gru_fwd_step_kernel<8>, grid, dim3(16 * KQ), 0, s, p); break;
-            case 12: hipLaunchKernelGGL(gru_fwd_step_kernel<12>, grid, dim3(16 * KQ), 0, s, p); break;
-            case 16: hipLaunchKernelGGL(gru_fwd_step_kernel<16>, grid, dim3(16 * KQ), 0, s, p); break;
-            case 24: hipLaunchKernelGGL(gru_fwd_step_kernel<24>, grid, dim3(16 * KQ), 0, s, p); break;
-            case 32: hipLaunchKernelGGL(gru_fwd_step_kernel<32>, grid, dim3(16 * KQ), 0, s, p); break;
+            case 4: launch_timed(RESEL_PROF_GRU_FWD, gru_fwd_step_kernel<4>, grid, dim3(16 * KQ), 0, s, p); break;
+            case 8: launch_timed(RESEL_PROF_GRU_FWD, gru_fwd_step_kernel<8>, grid, dim3(16 * KQ), 0, s, p); break;
+            case 12: launch_timed(RESEL_PROF_GRU_FWD, gru_fwd_step_kernel<12>, grid, dim3(16 * KQ), 0, s, p); break;
+            case 16: launch_timed(RESEL_PROF_GRU_FWD, gru_fwd_step_kernel<16>, grid, dim3(16 * KQ), 0, s, p); break;
+            case 24: launch_timed(RESEL_PROF_GRU_FWD, gru_fwd_step_kernel<24>, grid, dim3(16 * KQ), 0, s, p); break;
+            case 32: launch_timed(RESEL_PROF_GRU_FWD, gru_fwd_step_kernel<32>, grid, dim3(16 * KQ), 0, s, p); break;
             default: return RESEL_EINVAL;
         }
     }
@@ -540,12 +540,12 @@ extern "C" int resel_gru_seq_bwd(const float* w_hh, const float* h0, const float
         p.carry_out = carry;
         const dim3 pgrid((H / US) * ((B + RG - 1) / RG));
         switch (KC) {
-            case 4: hipLaunchKernelGGL(gru_bwd_persistent_kernel<4>, pgrid, dim3(16 * KQ), 0, s, p, xchg, err); break;
-            case 8: hipLaunchKernelGGL(gru_bwd_persistent_kernel<8>, pgrid, dim3(16 * KQ), 0, s, p, xchg, err); break;
-            case 12: hipLaunchKernelGGL(gru_bwd_persistent_kernel<12>, pgrid, dim3(16 * KQ), 0, s, p, xchg, err); break;
-            case 16: hipLaunchKernelGGL(gru_bwd_persistent_kernel<16>, pgrid, dim3(16 * KQ), 0, s, p, xchg, err); break;
-            case 24: hipLaunchKernelGGL(gru_bwd_persistent_kernel<24>, pgrid, dim3(16 * KQ), 0, s, p, xchg, err); break;
-            case 32: hipLaunchKernelGGL(gru_bwd_persistent_kernel<32>, pgrid, dim3(16 * KQ), 0, s, p, xchg, err); break;
+            case 4: launch_timed(RESEL_PROF_GRU_BWD, gru_bwd_persistent_kernel<4>, pgrid, dim3(16 * KQ), 0, s, p, xchg, err); break;
+            case 8: launch_timed(RESEL_PROF_GRU_BWD, gru_bwd_persistent_kernel<8>, pgrid, dim3(16 * KQ), 0, s, p, xchg, err); break;
+            case 12: launch_timed(RESEL_PROF_GRU_BWD, gru_bwd_persistent_kernel<12>, pgrid, dim3(16 * KQ), 0, s, p, xchg, err); break;
+            case 16: launch_timed(RESEL_PROF_GRU_BWD, gru_bwd_persistent_kernel<16>, pgrid, dim3(16 * KQ), 0, s, p, xchg, err); break;
+            case 24: launch_timed(RESEL_PROF_GRU_BWD, gru_bwd_persistent_kernel<24>, pgrid, dim3(16 * KQ), 0, s, p, xchg, err); break;
+            case 32: launch_timed(RESEL_PROF_GRU_BWD, gru_bwd_persistent_kernel<32>, pgrid, dim3(16 * KQ), 0, s, p, xchg, err); break;
             default: return RESEL_EINVAL;
         }
         return launch_status();
@@ -556,12 +556,12 @@ extern "C" int resel_gru_seq_bwd(const float* w_hh, const float* h0, const float
         p.carry_in = carry + (size_t)((t + 1) & 1) * B * H;
         p.carry_out = carry + (size_t)(t & 1) * B * H;
         switch (KC) {
-            case 4: hipLaunchKernelGGL(gru_bwd_step_kernel<4>, grid, dim3(16 * KQ), 0, s, p); break;
-            case 8: hipLaunchKernelGGL(gru_bwd_step_kernel<8>, grid, dim3(16 * KQ), 0, s, p); break;
-            case 12: hipLaunchKernelGGL(gru_bwd_step_kernel<12>, grid, dim3(16 * KQ), 0, s, p); break;
-            case 16: hipLaunchKernelGGL(gru_bwd_step_kernel<16>, grid, dim3(16 * KQ), 0, s, p); break;
-            case 24: hipLaunchKernelGGL(gru_bwd_step_kernel<24>, grid, dim3(16 * KQ), 0, s, p); break;
-            case 32: hipLaunchKernelGGL(gru_bwd_step_kernel<32>, grid, dim3(16 * KQ), 0, s, p); break;
+            case 4: launch_timed(RESEL_PROF_GRU_BWD, gru_bwd_step_kernel<4>, grid, dim3(16 * KQ), 0, s, p); break;
+            case 8: launch_timed(RESEL_PROF_GRU_BWD, gru_bwd_step_kernel<8>, grid, dim3(16 * KQ), 0, s, p); break;
+            case 12: launch_timed(RESEL_PROF_GRU_BWD, gru_bwd_step_kernel<12>, grid, dim3(16 * KQ), 0, s, p); break;
+            case 16: launch_timed(RESEL_PROF_GRU_BWD, gru_bwd_step_kernel<16>, grid, dim3(16 * KQ), 0, s, p); break;
+            case 24: launch_timed(RESEL_PROF_GRU_BWD, gru_bwd_step_kernel<24>, grid, dim3(16 * KQ), 0, s, p); break;
+            case 32: launch_timed(RESEL_PROF_GRU_BWD, gru_bwd_step_kernel<32>, grid, dim3(16 * KQ), 0, s, p); break;
             default: return RESEL_EINVAL;
         }
     }

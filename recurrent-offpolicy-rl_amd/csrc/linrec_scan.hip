@@ -274,8 +274,8 @@ extern "C" int resel_linrec_real_fwd(const float* v, const float* f, const float
     if (!v || !f || !h || B <= 0 || L <= 0 || C <= 0) return RESEL_EINVAL;
     const dim3 grid((C + TILE_C - 1) / TILE_C, B), blk(NSEG * 64);
     const size_t lds = (size_t)(L + 1) * sizeof(float);          // keep table (dynamic LDS)
-    if (fuse_act) hipLaunchKernelGGL(linrec_real_fwd_kernel<true>, grid, blk, lds, (hipStream_t)stream, v, f, start, h0, h, B, L, C);
-    else hipLaunchKernelGGL(linrec_real_fwd_kernel<false>, grid, blk, lds, (hipStream_t)stream, v, f, start, h0, h, B, L, C);
+    if (fuse_act) launch_timed(RESEL_PROF_LINREC_REAL_FWD, linrec_real_fwd_kernel<true>, grid, blk, lds, (hipStream_t)stream, v, f, start, h0, h, B, L, C);
+    else launch_timed(RESEL_PROF_LINREC_REAL_FWD, linrec_real_fwd_kernel<false>, grid, blk, lds, (hipStream_t)stream, v, f, start, h0, h, B, L, C);
     return launch_status();
 }
 
@@ -285,8 +285,8 @@ extern "C" int resel_linrec_real_bwd(const float* v, const float* f, const float
     if (!v || !f || !h || !dh || !dv || !df || B <= 0 || L <= 0 || C <= 0) return RESEL_EINVAL;
     const dim3 grid((C + TILE_C - 1) / TILE_C, B), blk(NSEG * 64);
     const size_t lds = (size_t)(L + 1) * sizeof(float);
-    if (fuse_act) hipLaunchKernelGGL(linrec_real_bwd_kernel<true>, grid, blk, lds, (hipStream_t)stream, v, f, start, h0, h, dh, dv, df, B, L, C);
-    else hipLaunchKernelGGL(linrec_real_bwd_kernel<false>, grid, blk, lds, (hipStream_t)stream, v, f, start, h0, h, dh, dv, df, B, L, C);
+    if (fuse_act) launch_timed(RESEL_PROF_LINREC_REAL_BWD, linrec_real_bwd_kernel<true>, grid, blk, lds, (hipStream_t)stream, v, f, start, h0, h, dh, dv, df, B, L, C);
+    else launch_timed(RESEL_PROF_LINREC_REAL_BWD, linrec_real_bwd_kernel<false>, grid, blk, lds, (hipStream_t)stream, v, f, start, h0, h, dh, dv, df, B, L, C);
     return launch_status();
 }
 
@@ -294,7 +294,7 @@ extern "C" int resel_linrec_complex_fwd(const float* vr, const float* vi, const 
                                         const float* gamma, const float* start, const float* h0r, const float* h0i,
                                         float* hr, float* hi, int B, int L, int C, resel_stream_t stream) {
     if (!vr || !vi || !lam_re || !lam_im || !hr || !hi || B <= 0 || L <= 0 || C <= 0) return RESEL_EINVAL;
-    hipLaunchKernelGGL(linrec_complex_fwd_kernel, dim3((C + TILE_C - 1) / TILE_C, B), dim3(NSEG * 64), (size_t)(L + 1) * sizeof(float),
+    launch_timed(RESEL_PROF_LINREC_COMPLEX_FWD, linrec_complex_fwd_kernel, dim3((C + TILE_C - 1) / TILE_C, B), dim3(NSEG * 64), (size_t)(L + 1) * sizeof(float),
                        (hipStream_t)stream, vr, vi, lam_re, lam_im, gamma, start, h0r, h0i, hr, hi, B, L, C);
     return launch_status();
 }
@@ -313,7 +313,7 @@ extern "C" int resel_linrec_complex_bwd(const float* vr, const float* vi, const 
         B <= 0 || L <= 0 || C <= 0)
         return RESEL_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(linrec_complex_bwd_kernel, dim3((C + TILE_C - 1) / TILE_C, B), dim3(NSEG * 64), (size_t)(L + 1) * sizeof(float), s,
+    launch_timed(RESEL_PROF_LINREC_COMPLEX_BWD, linrec_complex_bwd_kernel, dim3((C + TILE_C - 1) / TILE_C, B), dim3(NSEG * 64), (size_t)(L + 1) * sizeof(float), s,
                        vr, vi, lam_re, lam_im, gamma, start, h0r, h0i, hr, hi, dhr, dhi, dvr, dvi, (float*)workspace, B, L, C);
     // per-(row, segment) partials [B * NSEG][3][C] -> d lambda_re, d lambda_im, d gamma (fixed summation order)
     const float* part = (const float*)workspace;

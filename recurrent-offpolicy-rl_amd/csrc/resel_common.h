@@ -1,6 +1,7 @@
 // Shared device helpers for the gfx950 kernels (CDNA4: wave64, 160 KiB LDS/CU, 256 CUs in 8 XCDs).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include "../../include/resel_hip.h"
 
@@ -87,6 +88,26 @@ static __global__ void colsum_kernel(const float* __restrict__ part, int64_t ld,
 inline void launch_colsum(const float* part, int64_t ld, int K, int C, float* out, hipStream_t s, int KT = 1, int taps = 0,
                           int batch = 1) {
     hipLaunchKernelGGL(colsum_kernel, dim3((C + 15) / 16, batch), dim3(256), 0, s, part, ld, K, C, out, KT, taps);
+}
+
+// ---- per-dispatch timing (bench.py's roofline measurement) ---------------------------------------------------------
+// With profiling on, a kernel launched through launch_timed() is dispatched with hipExtLaunchKernelGGL and a (start, stop)
+// HIP event pair bound to THAT dispatch on the stream it runs on (a plain hipEventRecord pair around a launch also counts
+// queued predecessors on ROCm).  Slots are the RESEL_PROF_* ids of resel_hip.h; the registry lives in misc.hip.
+struct ProfEvents;
+void prof_push(int slot, hipEvent_t a, hipEvent_t b);
+bool prof_on();
+template <typename K, typename... Args>
+inline void launch_timed(int slot, K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t s, Args... args) {
+    if (!prof_on()) {
+        hipLaunchKernelGGL(kernel, grid, block, lds, s, args...);
+        return;
+    }
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    hipExtLaunchKernelGGL(kernel, grid, block, lds, s, a, b, 0, args...);
+    prof_push(slot, a, b);
 }
 
 inline int launch_status() { return hipGetLastError() == hipSuccess ? RESEL_OK : RESEL_ELAUNCH; }

@@ -28,27 +28,13 @@
 namespace {
 using namespace resel;
 
-// Diagnostics (off by default): when enabled, the scan kernels are dispatched with hipExtLaunchKernelGGL and a
-// (start, stop) HIP event pair bound to that dispatch, i.e. timed on the very stream they run on.
-struct ProfSlot { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; };
-bool g_prof_on = false;
+template <typename K, typename P>
+void launch_maybe_timed(int slot, K kernel, dim3 grid, dim3 block, hipStream_t s, const P& p) {
+    launch_timed(slot, kernel, grid, block, 0, s, p);
+}
 #ifdef SSCAN_STAMP
 unsigned long long* g_stamps = nullptr;
 #endif
-ProfSlot g_prof[2];                   // 0 = sscan_fwd_kernel, 1 = sscan_bwd_kernel
-
-template <typename K, typename P>
-void launch_maybe_timed(int slot, K kernel, dim3 grid, dim3 block, hipStream_t s, const P& p) {
-    if (!g_prof_on) {
-        hipLaunchKernelGGL(kernel, grid, block, 0, s, p);
-        return;
-    }
-    hipEvent_t a, b;
-    (void)hipEventCreate(&a);
-    (void)hipEventCreate(&b);
-    hipExtLaunchKernelGGL(kernel, grid, block, 0, s, a, b, 0, p);
-    g_prof[slot].ev.emplace_back(a, b);
-}
 
 #ifndef SSCAN_FWD_TC
 #define SSCAN_FWD_TC 32
@@ -1124,23 +1110,23 @@ template <int NS, int NW, int TC>
 int launch_fwd(const FwdParams& p, hipStream_t s) {
     const int bp = (p.B + 7) / 8 * 8;
 #ifdef SSCAN_FWD1
-    launch_maybe_timed(0, sscan_fwd_kernel<NS, NW, TC>, dim3(bp * p.nd), dim3(NW * 64), s, p);
+    launch_maybe_timed(RESEL_PROF_SSCAN_FWD, sscan_fwd_kernel<NS, NW, TC>, dim3(bp * p.nd), dim3(NW * 64), s, p);
 #else
     if constexpr (NS * NW == 32) {                   // two rows per workgroup (144 KB of LDS, one workgroup per CU): -DSSCAN_FWD_ROWS2
 #ifdef SSCAN_FWD_ROWS2
         const int bp2 = ((p.B + 1) / 2 + 7) / 8 * 8;
-        launch_maybe_timed(0, sscan_fwd2_kernel<NS, NW, TC, 2>, dim3(bp2 * p.nd), dim3(NW * 64 * 2), s, p);
+        launch_maybe_timed(RESEL_PROF_SSCAN_FWD, sscan_fwd2_kernel<NS, NW, TC, 2>, dim3(bp2 * p.nd), dim3(NW * 64 * 2), s, p);
         return launch_status();
 #endif
     }
-    launch_maybe_timed(0, sscan_fwd2_kernel<NS, NW, TC, 1>, dim3(bp * p.nd), dim3(NW * 64), s, p);
+    launch_maybe_timed(RESEL_PROF_SSCAN_FWD, sscan_fwd2_kernel<NS, NW, TC, 1>, dim3(bp * p.nd), dim3(NW * 64), s, p);
 #endif
     return launch_status();
 }
 template <int NS, int NW>
 int launch_bwd(const BwdParams& p, hipStream_t s) {
     const int bp = (p.B + 7) / 8 * 8;
-    launch_maybe_timed(1, sscan_bwd_kernel<NS, NW>, dim3(bp * p.nd), dim3(NW * 64), s, p);
+    launch_maybe_timed(RESEL_PROF_SSCAN_BWD, sscan_bwd_kernel<NS, NW>, dim3(bp * p.nd), dim3(NW * 64), s, p);
     return launch_status();
 }
 
@@ -1162,30 +1148,6 @@ inline BwdWs bwd_ws(int B, int L, int Di, int N) {
 }
 
 }  // namespace
-
-extern "C" int resel_profile_enable(int on) {
-    g_prof_on = on != 0;
-    return RESEL_OK;
-}
-
-extern "C" int resel_profile_collect(int kernel_id, double* total_us, int* launches) {
-    if (kernel_id < 0 || kernel_id > 1 || !total_us || !launches) return RESEL_EINVAL;
-    double tot = 0.0;
-    int n = 0;
-    for (auto& pr : g_prof[kernel_id].ev) {
-        float ms = 0.f;
-        if (hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
-            tot += 1e3 * ms;
-            ++n;
-        }
-        (void)hipEventDestroy(pr.first);
-        (void)hipEventDestroy(pr.second);
-    }
-    g_prof[kernel_id].ev.clear();
-    *total_us = tot;
-    *launches = n;
-    return RESEL_OK;
-}
 
 extern "C" size_t resel_selective_scan_ckpt_bytes(int B, int L, int Di, int N) {
     return (size_t)B * (size_t)(n_ckpt(L) > 0 ? n_ckpt(L) : 0) * (size_t)N * (size_t)Di * sizeof(float);

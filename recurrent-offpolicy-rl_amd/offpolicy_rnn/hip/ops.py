@@ -51,15 +51,20 @@ def _ws(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
 
+PROF_SLOTS = ('sscan_fwd_kernel', 'sscan_bwd_kernel', 'attn_fwd_kernel', 'attn_dq_kernel', 'attn_dkv_kernel', 'linrec_real_fwd_kernel',
+              'linrec_real_bwd_kernel', 'linrec_complex_fwd_kernel', 'linrec_complex_bwd_kernel', 'gru_fwd_kernel', 'gru_bwd_kernel',
+              'conv_fwd_kernel', 'conv_bwd_kernel')          # RESEL_PROF_* of include/resel_hip.h, in id order
+
+
 def profile_enable(on: bool):
-    """Bind a (start, stop) HIP event pair to every selective-scan dispatch (bench.py's roofline measurement)."""
+    """Bind a (start, stop) HIP event pair to every sequence-layer kernel dispatch (bench.py's roofline measurement)."""
     check(lib().resel_profile_enable(int(bool(on))), 'profile_enable')
 
 
 def profile_collect():
     """-> {kernel: (launches, avg_us)} for the dispatches recorded since the last call."""
     out = {}
-    for kid, name in ((0, 'sscan_fwd_kernel'), (1, 'sscan_bwd_kernel')):
+    for kid, name in enumerate(PROF_SLOTS):
         tot, n = ctypes.c_double(0.0), ctypes.c_int(0)
         check(lib().resel_profile_collect(kid, ctypes.byref(tot), ctypes.byref(n)), 'profile_collect')
         if n.value:

@@ -3,11 +3,13 @@
    (HBM bytes per launch of the hand-written scan kernels: FETCH_SIZE [KB] x 1024 x 2 - the gfx950 correction for wide
    coalesced reads, MI355X_MICROARCH.md 'HBM' - and WRITE_SIZE [KB] x 1024; separate --pmc passes)."""
 import collections, csv, json, os, shutil, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 tag = sys.argv[1]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(ROOT, 'gpurun_out', f'prof_{tag}'), os.path.join(ROOT, 'profiles')
 os.makedirs(dst, exist_ok=True)
 shutil.copy(os.path.join(src, f'{tag}_kernel_stats.csv'), os.path.join(dst, f'{tag}_kernel_stats.csv'))
+TRAFFIC_NAME = sys.argv[2] if len(sys.argv) > 2 else 'traffic.json'      # secondary workloads keep their own traffic file
 shutil.copy(os.path.join(src, f'{tag}_bench.json'), os.path.join(dst, f'{tag}_bench.json'))
 bench = json.loads(open(os.path.join(src, f'{tag}_bench.json')).read())
 n_upd = bench['steps'] + bench['warmup']
@@ -20,8 +22,12 @@ def pmc(name):
         return {}
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
-        for short in ('sscan_fwd_kernel', 'sscan_bwd_kernel', 'conv_fwd_kernel', 'conv_bwd_kernel', 'ln_fwd_kernel', 'ln_bwd_kernel'):
-            if short in k:
+        for short, pat in (('sscan_fwd_kernel', 'sscan_fwd'), ('sscan_bwd_kernel', 'sscan_bwd_kernel'), ('conv_fwd_kernel', 'conv_fwd_kernel'),
+                           ('conv_bwd_kernel', 'conv_bwd'), ('ln_fwd_kernel', 'ln_fwd_kernel'), ('ln_bwd_kernel', 'ln_bwd_kernel'),
+                           ('attn_fwd_kernel', 'attn_q_kernel<32, 0'), ('attn_dq_kernel', 'attn_q_kernel<32, 1'), ('attn_dkv_kernel', 'attn_dkv_kernel'),
+                           ('linrec_real_fwd_kernel', 'linrec_real_fwd'), ('linrec_real_bwd_kernel', 'linrec_real_bwd'),
+                           ('linrec_complex_fwd_kernel', 'linrec_complex_fwd'), ('linrec_complex_bwd_kernel', 'linrec_complex_bwd')):
+            if pat in k:
                 agg[short].append(float(r['Counter_Value']))
     return {k: sum(v) / len(v) for k, v in agg.items()}
 
@@ -31,9 +37,12 @@ traffic = {}
 for k in sorted(set(fetch) | set(write)):
     rd, wr = fetch.get(k, 0.0) * 1024 * 2, write.get(k, 0.0) * 1024
     traffic[k] = {'read_bytes': rd, 'write_bytes': wr, 'total': rd + wr}
+import bench as _bench
+cfgw = bench['config']['workload']
 json.dump({'source': f'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over `python3 bench.py` ({tag}); FETCH_SIZE KB x 1024 x 2 (gfx950), WRITE_SIZE KB x 1024',
+           'kernel_source_stamp': _bench.kernel_source_stamp(), 'rnn': cfgw.split(' ')[0], 'rows': bench['config']['global_rows'] // bench['n_gpus'],
            'per_launch_bytes': {k: v['total'] for k, v in traffic.items()}, 'detail': traffic},
-          open(os.path.join(dst, 'traffic.json'), 'w'), indent=1)
+          open(os.path.join(dst, TRAFFIC_NAME), 'w'), indent=1)
 rows = list(csv.DictReader(open(os.path.join(src, f'{tag}_kernel_stats.csv'))))
 tot = sum(float(r['TotalDurationNs']) for r in rows)
 gemm = sum(float(r['TotalDurationNs']) for r in rows if r['Name'].startswith('Cijk'))
