@@ -214,6 +214,14 @@ int resel_tanh_gaussian_bwd(const float* out2, const float* noise, const float* 
 int resel_sac_target(const float* q, const int32_t* subset, int m, const float* next_logp, const float* log_alpha,
                      const float* reward, const float* done, const float* mask, float gamma, float* guard,
                      float* target, float* stats, void* workspace, int E, int M, resel_stream_t stream);
+/* The same target in three phases for data-parallel runs: the Q-guard of the reference sees the extrema of the WHOLE batch
+ * (utility/q_value_guard.py:22-38), so between the phases the caller all-reduces (MAX) the two-float blocks of `extrema`
+ * [4] = {-min v, max v, -min(y mask), max(y mask)}: phase 0 writes [0:2] (rank-local), phase 1 initialises the guard from
+ * the (now global) [0:2], clamps, forms y and writes [2:4], phase 2 updates the guard from the (now global) [2:4].
+ * Same workspace for all phases of one target. */
+int resel_sac_target_phase(int phase, const float* q, const int32_t* subset, int m, const float* next_logp, const float* log_alpha,
+                           const float* reward, const float* done, const float* mask, float gamma, float* guard,
+                           float* target, float* stats, float* extrema, void* workspace, int E, int M, resel_stream_t stream);
 size_t resel_sac_target_workspace_bytes(int M);
 
 /* Flat-buffer optimizer tail.  All parameter / gradient / moment tensors of one network live in ONE fp32 buffer.

@@ -119,6 +119,35 @@ __global__ __launch_bounds__(256) void target_y_kernel(const float* __restrict__
     }
     block_reduce4(mn, mx, ma, sm, part + 4 * blockIdx.x);
 }
+// data-parallel form: the batch extrema are written out ({-min, max}: one MAX all-reduce serves both) so that every rank
+// initialises / updates its guard from the extrema of the GLOBAL batch
+__global__ __launch_bounds__(256) void extrema_out_kernel(const float* __restrict__ part, int nblk, float* __restrict__ ext, float* stats) {
+    float mn = INFINITY, mx = -INFINITY, ma = 0.f, sm = 0.f;
+    for (int i = threadIdx.x; i < nblk; i += 256) {
+        mn = fminf(mn, part[4 * i]); mx = fmaxf(mx, part[4 * i + 1]); ma = fmaxf(ma, part[4 * i + 2]); sm += part[4 * i + 3];
+    }
+    __shared__ float res[4];
+    block_reduce4(mn, mx, ma, sm, res);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ext[0] = -res[0]; ext[1] = res[1];
+        if (stats) { stats[0] = res[2]; stats[1] = res[3]; }
+    }
+}
+__global__ void guard_init_from_kernel(const float* __restrict__ ext, float* guard) {
+    if (threadIdx.x == 0 && guard[2] == 0.f) { guard[0] = -ext[0]; guard[1] = ext[1]; guard[2] = 1.f; }
+}
+__global__ void guard_update_from_kernel(const float* __restrict__ ext, float* guard) {
+    if (threadIdx.x == 0) {
+        const float decay = guard[3], bmin = -ext[0], bmax = ext[1];
+        float gmin = fminf(guard[0], bmin), gmax = fmaxf(guard[1], bmax);
+        if (decay < 1.f) {
+            gmin = decay * gmin + (1.f - decay) * bmin;
+            gmax = decay * gmax + (1.f - decay) * bmax;
+        }
+        guard[0] = gmin; guard[1] = gmax;
+    }
+}
 __global__ __launch_bounds__(256) void guard_update_kernel(const float* __restrict__ part, int nblk, float* guard, float* stats) {
     float mn = INFINITY, mx = -INFINITY, ma = 0.f, sm = 0.f;
     for (int i = threadIdx.x; i < nblk; i += 256) {
@@ -225,6 +254,30 @@ extern "C" int resel_sac_target(const float* q, const int32_t* subset, int m, co
     hipLaunchKernelGGL(guard_init_kernel, dim3(1), dim3(256), 0, s, part1, nblk, guard);
     hipLaunchKernelGGL(target_y_kernel, dim3(nblk), dim3(256), 0, s, v, reward, done, mask, gamma, guard, target, part2, M);
     hipLaunchKernelGGL(guard_update_kernel, dim3(1), dim3(256), 0, s, part2, nblk, guard, stats);
+    return launch_status();
+}
+
+extern "C" int resel_sac_target_phase(int phase, const float* q, const int32_t* subset, int m, const float* next_logp, const float* log_alpha,
+                                      const float* reward, const float* done, const float* mask, float gamma, float* guard,
+                                      float* target, float* stats, float* extrema, void* workspace, int E, int M, resel_stream_t stream) {
+    if (phase < 0 || phase > 2 || !guard || !extrema || !workspace || M <= 0) return RESEL_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    float* v = (float*)workspace;
+    float* part1 = v + M;
+    float* part2 = part1 + 4 * RED_BLOCKS;
+    const int nblk = (M + 255) / 256 < RED_BLOCKS ? (M + 255) / 256 : RED_BLOCKS;
+    if (phase == 0) {                  // v = min over the subset (- alpha log pi); extrema[0:2] = {-min v, max v} of this rank's rows
+        if (!q || !subset || m <= 0 || E <= 0 || (next_logp && !log_alpha)) return RESEL_EINVAL;
+        hipLaunchKernelGGL(target_v_kernel, dim3(nblk), dim3(256), 0, s, q, subset, m, next_logp, log_alpha, v, part1, E, M);
+        hipLaunchKernelGGL(extrema_out_kernel, dim3(1), dim3(256), 0, s, part1, nblk, extrema, (float*)nullptr);
+    } else if (phase == 1) {           // extrema[0:2] now global: first-call initialisation, clamp, y; extrema[2:4] = {-min, max} of y * mask
+        if (!reward || !done || !target) return RESEL_EINVAL;
+        hipLaunchKernelGGL(guard_init_from_kernel, dim3(1), dim3(64), 0, s, extrema, guard);
+        hipLaunchKernelGGL(target_y_kernel, dim3(nblk), dim3(256), 0, s, v, reward, done, mask, gamma, guard, target, part2, M);
+        hipLaunchKernelGGL(extrema_out_kernel, dim3(1), dim3(256), 0, s, part2, nblk, extrema + 2, stats);
+    } else {                           // extrema[2:4] now global: running min / max update
+        hipLaunchKernelGGL(guard_update_from_kernel, dim3(1), dim3(64), 0, s, extrema + 2, guard);
+    }
     return launch_status();
 }
 

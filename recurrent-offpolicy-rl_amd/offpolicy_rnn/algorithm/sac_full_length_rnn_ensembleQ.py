@@ -152,6 +152,7 @@ class SACFullLengthRNNEnsembleQ(SAC):
         self.target_policy.copy_weight_from(self.policy, tau=0.0)
         self.target_policy.eval()
         self.grad_sync = GradSync()
+        self._subset_rng = None                        # REDQ subset stream: None = numpy's global stream (see _subset_stream)
         self._pinned = PinnedRing(torch.float32)       # staging blocks of the host-built batch (one event per block)
         self._needs_seq_table = any(lid.startswith('cgpt') for net in (self.values[0].uni_network, self.values[0].embedding_network,
                                                                        self.policy.uni_network, self.policy.embedding_network)
@@ -314,6 +315,19 @@ class SACFullLengthRNNEnsembleQ(SAC):
     def _select_target_ensemble(self, num_ensemble: int) -> np.ndarray:
         return np.arange(num_ensemble)                               # plain ensemble-min (REDQ trainers override)
 
+    def _subset_stream(self):
+        """numpy stream of the REDQ subset draws.  One process: the global stream, draw for draw as the reference.  Data parallel:
+        a dedicated stream seeded identically on every rank (`parameter.seed`), so that all ranks take the minimum over the
+        SAME critics while each samples its own rows from its own global stream - the update then equals the single-process
+        update over the global batch (tests/test_data_parallel*.py)."""
+        if self.grad_sync.world > 1 and self._subset_rng is None:
+            self._subset_rng = np.random.RandomState(int(self.parameter.seed) + 7919)
+        return self._subset_rng if self._subset_rng is not None else np.random
+
+    def _guard_exchange(self):
+        """Data parallel: the Q-guard sees the extrema of the global batch (two 2-float MAX all-reduces inside the target)."""
+        return dict(reduce_max=self.grad_sync.all_reduce_max_) if self.grad_sync.world > 1 else {}
+
     def _target_Q_discrete(self, b, policy_hidden, target_hiddens, stats):
         """Discrete-action target (reference sac_full_length_rnn_redq.py:52-72): V(s') = sum_a pi(a|s') (min_subset Q'(s', a) -
         alpha log pi(a|s')); the last action enters the networks as a one-hot vector.  Guard clamp / update, done masking
@@ -332,7 +346,7 @@ class SACFullLengthRNNEnsembleQ(SAC):
             alpha = self.log_sac_alpha.detach().exp()
             v = ((q.min(dim=0).values - alpha * logp) * logp.exp()).sum(dim=-1, keepdim=True)
             return ops.sac_target(v.unsqueeze(0).contiguous(), self._subset_on_device(np.arange(1), 1), None, self.log_sac_alpha.detach(),
-                                  b['reward'], b['done'], b['mask'], self.parameter.gamma, self.Q_guard.state, stats)
+                                  b['reward'], b['done'], b['mask'], self.parameter.gamma, self.Q_guard.state, stats, **self._guard_exchange())
 
     def get_target_Q(self, b, policy_hidden, target_hiddens, stats):
         if self.discrete_env:
@@ -360,7 +374,7 @@ class SACFullLengthRNNEnsembleQ(SAC):
                 q = tv.forward(b['next_state'], b['state'], b['action'], sample, target_hiddens[0], b['reward'])[0]
                 idx = self._subset_on_device(subset, E)
             return ops.sac_target(q, idx, logp if self.base_algorithm == 'sac' else None, self.log_sac_alpha.detach(), b['reward'],
-                                  b['done'], b['mask'], self.parameter.gamma, self.Q_guard.state, stats)
+                                  b['done'], b['mask'], self.parameter.gamma, self.Q_guard.state, stats, **self._guard_exchange())
 
     # ------------------------------------------------------------------------------------------ losses
     def _q_for_policy(self, qs: torch.Tensor) -> torch.Tensor:
@@ -387,11 +401,17 @@ class SACFullLengthRNNEnsembleQ(SAC):
             gnorm = 0.0
         return gnorm
 
-    def _finish_step(self, optimizer, store, local_count):
-        """Exchange (sum) the flat gradient + the local valid count, then AdamW with grad / global count."""
+    def _finish_step(self, optimizer, store, local_count, overlap=None):
+        """Exchange (sum) the flat gradient + the local valid count, then AdamW with grad / global count.  Data parallel: the
+        all-reduce is issued on the exchange stream as soon as the last gradient is in the flat buffer; `overlap()` (work
+        that does not touch the gradient buffer: the step's log scalars) runs on the compute stream meanwhile, which
+        joins before anything reads the reduced buffer."""
         store.collect_grads()
         store.grad[store.numel] = local_count
-        self.grad_sync.all_reduce_(store.grad)
+        self.grad_sync.all_reduce_async_(store.grad)
+        if overlap is not None:
+            overlap()
+        self.grad_sync.wait()
         return 1.0 / store.grad[store.numel:store.numel + 1]
 
     # ------------------------------------------------------------------------------------------ the update
@@ -458,10 +478,10 @@ class SACFullLengthRNNEnsembleQ(SAC):
             q_loss_sum = ((q - target_Q.unsqueeze(0)).pow(2).sum(dim=0) * mask).sum()
             self.optimizer_value.zero_grad()
             q_loss_sum.backward()
-            scale = self._finish_step(self.optimizer_value, value.store, valid_num)
+            scale = self._finish_step(self.optimizer_value, value.store, valid_num,
+                                      overlap=lambda: scal.update(critic_loss=q_loss_sum.detach() / valid_num))
             q_grad_norm = self._clip(value.store, value, par.value_max_gradnorm, par.value_embedding_max_gradnorm, scale)
             self.optimizer_value.step(grad_scale=scale)
-            scal['critic_loss'] = q_loss_sum.detach() / valid_num
             host['value_grad_norm'] = q_grad_norm
 
             # 3. soft target update: one kernel over the flat buffers
@@ -497,7 +517,8 @@ class SACFullLengthRNNEnsembleQ(SAC):
                 tune_alpha = not par.no_alpha_auto_tune
                 if tune_alpha:     # d/d log_alpha of -sum(mask * log_alpha * (logp + H)) rides in the second spare slot
                     pstore.grad[pstore.numel + 1] = -((log_prob.detach() + self.target_entropy) * mask).sum()
-                scale = self._finish_step(self.optimizer_policy, pstore, valid_num)
+                scale = self._finish_step(self.optimizer_policy, pstore, valid_num, overlap=lambda: scal.update(
+                    log_prob=(log_prob.detach() * mask).sum() / valid_num, actor_loss=actor_sum.detach() / valid_num))
                 pi_grad_norm = self._clip(pstore, self.policy, par.policy_max_gradnorm, par.policy_embedding_max_gradnorm, scale)
                 self.optimizer_policy.step(grad_scale=scale)
                 if tune_alpha:
@@ -507,8 +528,6 @@ class SACFullLengthRNNEnsembleQ(SAC):
                     self.optimizer_alpha.step()
                     with torch.no_grad():
                         self.log_sac_alpha.clamp_max_(1)
-                scal['log_prob'] = (log_prob.detach() * mask).sum() / valid_num
-                scal['actor_loss'] = actor_sum.detach() / valid_num
                 scal['policy_l2_norm_square'] = self.policy.l2_norm_square()
                 host['policy_grad_norm'] = pi_grad_norm
                 policy_update_cnt += 1

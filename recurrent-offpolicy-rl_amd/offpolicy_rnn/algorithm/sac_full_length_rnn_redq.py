@@ -7,9 +7,8 @@ from .sac_full_length_rnn_ensembleQ import SACFullLengthRNNEnsembleQ
 
 class SACFullLengthRNNREDQ(SACFullLengthRNNEnsembleQ):
     def _select_target_ensemble(self, num_ensemble: int) -> np.ndarray:
-        # the global numpy stream, draw for draw as the reference.  Under data parallelism every rank draws its own subset
-        # for its own rows (independent REDQ samples per shard of the global batch); identically seeded ranks coincide.
-        return np.random.permutation(num_ensemble)[:self.parameter.redq_m]
+        # one process: the global numpy stream, draw for draw as the reference; data parallel: a stream shared by all ranks
+        return self._subset_stream().permutation(num_ensemble)[:self.parameter.redq_m]
 
     def _q_for_policy(self, qs):
         return qs.mean(dim=0)

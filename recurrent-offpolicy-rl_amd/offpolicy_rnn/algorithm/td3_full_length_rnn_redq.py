@@ -8,7 +8,7 @@ class TD3FullLengthRNNREDQ(TD3FullLengthRNNEnsembleQ):
     target_from_live_policy = True
 
     def _select_target_ensemble(self, num_ensemble: int) -> np.ndarray:
-        return np.random.permutation(num_ensemble)[:self.parameter.redq_m]
+        return self._subset_stream().permutation(num_ensemble)[:self.parameter.redq_m]
 
     def _q_for_policy(self, qs):
         return qs.mean(dim=0)

@@ -556,8 +556,10 @@ def tanh_gaussian(out2, noise):
 
 
 @torch.no_grad()
-def sac_target(q, subset, next_logp, log_alpha, reward, done, mask, gamma, guard, stats=None):
-    """q [E, ...]; subset int32 [m] (device); guard fp32[4] device state {min, max, initialised, decay}."""
+def sac_target(q, subset, next_logp, log_alpha, reward, done, mask, gamma, guard, stats=None, reduce_max=None):
+    """q [E, ...]; subset int32 [m] (device); guard fp32[4] device state {min, max, initialised, decay}.
+    reduce_max (data parallel): in-place MAX all-reduce of a small device tensor - the guard then sees the extrema of the
+    global batch, exactly as one process would (three phases with two 2-float exchanges, see resel_hip.h)."""
     _need_cuda('sac_target', q, reward, done, guard)
     E = q.shape[0]
     M = reward.numel()
@@ -566,6 +568,14 @@ def sac_target(q, subset, next_logp, log_alpha, reward, done, mask, gamma, guard
     ws = _ws(lib().resel_sac_target_workspace_bytes(M), q.device)
     f = lambda t: None if t is None else t.float().reshape(-1).contiguous()
     nl, rw, dn, mk = f(next_logp), f(reward), f(done), f(mask)
+    if reduce_max is not None:
+        ext = torch.empty(4, dtype=torch.float32, device=q.device)
+        for phase in range(3):
+            check(lib().resel_sac_target_phase(phase, _p(qf), _p(subset), int(subset.numel()), _p(nl), _p(log_alpha), _p(rw), _p(dn), _p(mk),
+                                               float(gamma), _p(guard), _p(target), _p(stats), _p(ext), _p(ws), E, M, _stream()), 'sac_target_phase')
+            if phase < 2:
+                reduce_max(ext[2 * phase:2 * phase + 2])
+        return target.reshape(reward.shape)
     check(lib().resel_sac_target(_p(qf), _p(subset), int(subset.numel()), _p(nl), _p(log_alpha), _p(rw), _p(dn), _p(mk),
                                  float(gamma), _p(guard), _p(target), _p(stats), _p(ws), E, M, _stream()), 'sac_target')
     return target.reshape(reward.shape)

@@ -16,10 +16,33 @@ class GradSync:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
+        self._stream, self._pending = None, None
 
     def all_reduce_(self, flat_grad: torch.Tensor):
         if self.world > 1:
             dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+
+    def all_reduce_async_(self, flat_grad: torch.Tensor):
+        """SUM all-reduce on a side stream (RCCL): returns at once, `wait()` makes the compute stream depend on its completion.
+        gloo (CPU tests, or CUDA tensors staged through the host) and single-process runs reduce in place synchronously."""
+        self._pending = None
+        if self.world <= 1:
+            return
+        if flat_grad.is_cuda and dist.get_backend(self.group) == 'nccl':
+            if self._stream is None:
+                self._stream = torch.cuda.Stream(device=flat_grad.device)
+            self._stream.wait_stream(torch.cuda.current_stream(flat_grad.device))
+            with torch.cuda.stream(self._stream):
+                dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+            flat_grad.record_stream(self._stream)
+            self._pending = flat_grad.device
+        else:
+            dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+
+    def wait(self):
+        if getattr(self, '_pending', None) is not None:
+            torch.cuda.current_stream(self._pending).wait_stream(self._stream)
+            self._pending = None
 
     def broadcast_(self, flat: torch.Tensor, src=0):
         if self.world > 1:

@@ -118,19 +118,26 @@ def tanh_gaussian(out2, noise):
 
 
 @torch.no_grad()
-def sac_target(q, subset, next_logp, log_alpha, reward, done, mask, gamma, guard, stats=None):
+def sac_target(q, subset, next_logp, log_alpha, reward, done, mask, gamma, guard, stats=None, reduce_max=None):
     idx = subset.long()
     v = q[idx].min(dim=0).values
     if next_logp is not None:
         v = v - log_alpha.exp() * next_logp
+    ext = torch.stack((-v.min(), v.max()))
+    if reduce_max is not None:
+        reduce_max(ext)
     if guard[2] == 0:
-        guard[0], guard[1], guard[2] = v.min(), v.max(), 1.0
+        guard[0], guard[1], guard[2] = -ext[0], ext[1], 1.0
     y = reward + (1 - done) * gamma * v.clamp(min=guard[0].item(), max=guard[1].item())
     ym = y * mask
-    lo, hi = torch.minimum(guard[0], ym.min()), torch.maximum(guard[1], ym.max())
+    ext = torch.stack((-ym.min(), ym.max()))
+    if reduce_max is not None:
+        reduce_max(ext)
+    bmin, bmax = -ext[0], ext[1]
+    lo, hi = torch.minimum(guard[0], bmin), torch.maximum(guard[1], bmax)
     decay = guard[3]
     if decay < 1:
-        lo, hi = decay * lo + (1 - decay) * ym.min(), decay * hi + (1 - decay) * ym.max()
+        lo, hi = decay * lo + (1 - decay) * bmin, decay * hi + (1 - decay) * bmax
     guard[0], guard[1] = lo, hi
     if stats is not None:
         stats[0], stats[1] = y.abs().max(), mask.sum()

@@ -1,7 +1,9 @@
 """world_size-2 data parallelism with the REAL HIP kernels: two processes share cuda:0 and exchange the flat gradient buffer
 through `gloo` (it stages CUDA tensors through the host; RCCL needs one GPU per rank and is exercised by the driver's
 multi-GPU bench).  Two ranks holding the SAME rows and the same actor noise must reproduce the single-process update -
-this pins the masked-sum losses + piggy-backed valid count + flat AdamW normalisation on the device path."""
+this pins the masked-sum losses + piggy-backed valid count + flat AdamW normalisation on the device path; two ranks holding
+DISJOINT trajectory sets (each trains on all of its own, actor noise off) must reproduce the single-process update over the
+UNION batch - this pins the shared REDQ subset stream and the global Q-guard (phased `resel_sac_target_phase`)."""
 import os
 import sys
 
@@ -15,20 +17,29 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 pytestmark = pytest.mark.gpu
 
 
-def _build(rnn):
+LENS = (12, 5, 7, 12, 9)
+SPLIT = ((0, 2, 4), (1, 3))
+
+
+def _build(rnn, keep=None, batch=30, quiet=False):
     sys.path[:0] = [HERE, os.path.dirname(HERE), os.path.join(os.path.dirname(HERE), 'recurrent-offpolicy-rl_amd')]
     from test_host_logic import _push, _synth, make_parameter
     from offpolicy_rnn import alg_init
+    from offpolicy_rnn.utility import rng
+    if quiet:
+        rng.randn = lambda shape, device, dtype=torch.float32: torch.zeros(tuple(shape), dtype=dtype, device=device)
     torch.manual_seed(0)
     np.random.seed(0)
-    alg = alg_init(make_parameter(rnn, sac_batch_size=30, cuda_inference=True))
+    alg = alg_init(make_parameter(rnn, sac_batch_size=batch, cuda_inference=True))
     rs = np.random.RandomState(3)
-    for n in (12, 5, 7, 12, 9):
+    for i, n in enumerate(LENS):
         o, a, r = _synth(rs, n, 5, 3)
-        _push(alg.replay_buffer, o, a, r, early_done=(n != 12))
+        if keep is None or i in keep:
+            _push(alg.replay_buffer, o, a, r, early_done=(n != 12))
     torch.manual_seed(11)
     torch.cuda.manual_seed_all(11)
     np.random.seed(11)
+    alg._subset_rng = np.random.RandomState(int(alg.parameter.seed) + 7919)     # the stream data-parallel ranks share
     return alg
 
 
@@ -42,11 +53,12 @@ def _run(alg, steps=2):
                 alpha=alg.log_sac_alpha.detach().cpu(), critic_loss=log['critic_loss'])
 
 
-def _worker(rank, world, port, rnn, out_dir):
+def _worker(rank, world, port, rnn, out_dir, union=False):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.cuda.set_device(0)
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    alg = _build(rnn)
+    alg = _build(rnn, keep=SPLIT[rank], batch=sum(LENS[i] for i in SPLIT[rank]), quiet=True) if union else _build(rnn)
+    alg._subset_rng = None                             # product default under world > 1: the shared stream
     alg.grad_sync.__init__()
     assert alg.grad_sync.world == world and alg.device.type == 'cuda'
     torch.save(_run(alg), os.path.join(out_dir, f'rank{rank}.pt'))
@@ -63,5 +75,19 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_process_update(tmp_path, rnn)
     for k in ('policy', 'value', 'alpha'):
         assert torch.equal(r0[k], r1[k]), f'{k} diverged across ranks'
     ref = _run(_build(rnn))                          # single process, same rows, same noise
+    for k in ('policy', 'value', 'alpha'):
+        np.testing.assert_allclose(r0[k].numpy(), ref[k].numpy(), rtol=2e-4, atol=2e-6, err_msg=k)
+
+
+@pytest.mark.parametrize('rnn', ['smamba_s8_c4_b1_nln', 'gilr'])
+def test_two_ranks_with_disjoint_rows_reproduce_the_union_batch_update(tmp_path, rnn):
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from test_data_parallel import _free_port
+    mp.spawn(_worker, args=(2, _free_port(), rnn, str(tmp_path), True), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(tmp_path, f'rank{i}.pt')) for i in range(2))
+    for k in ('policy', 'value', 'alpha'):
+        assert torch.equal(r0[k], r1[k]), f'{k} diverged across ranks'
+    ref = _run(_build(rnn, batch=sum(LENS), quiet=True))       # one process, all five trajectories in one batch
     for k in ('policy', 'value', 'alpha'):
         np.testing.assert_allclose(r0[k].numpy(), ref[k].numpy(), rtol=2e-4, atol=2e-6, err_msg=k)
