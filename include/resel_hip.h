@@ -260,6 +260,22 @@ size_t resel_ensemble_head_bwd_workspace_bytes(int64_t rows, int H, int64_t rows
 int resel_ensemble_head_bwd(const float* gq, const float* a, const float* w3, float* gy, float* db2, float* dw3, void* workspace,
                             int64_t rows, int H, int64_t rows_per_seg, resel_stream_t stream);
 
+/* ---- fp32 GEMM on the f32-input matrix cores (v_mfma_f32_32x32x2_f32: exact fp32), tails fused ------------------------
+ * C[b][m][n] = act( sum_k A[b](m, k) B[b](n, k) + bias[b][n] ),  b < batch (ensemble member; strides in floats).
+ * An operand is a [rows][K] matrix (x_kcontig = 1: activations, nn.Linear / EnsembleLinear weights [out][in]) or a [K][rows]
+ * matrix (x_kcontig = 0: the transposed use of an activation matrix in a weight gradient, of a weight in an input gradient):
+ *   forward  y = x W^T (+ bias, ELU)   A = x  (1), B = W (1)      torch.nn.Linear (models/rnn_base.py:101-105),
+ *   dgrad    dx = dy W                 A = dy (1), B = W (0)      EnsembleLinear (models/ensemble_linear_model.py:36-49)
+ *   wgrad    dW = dy^T x               A = dy (0), B = x (0)      K = number of tokens: split over blocks, partial tiles summed in
+ *                                                                  a fixed order (workspace: resel_gemm_f32_workspace_bytes)
+ * act: 0 none, 1 ELU.  The contiguous extent of each operand (K or rows) must be a multiple of 4, pointers 16-byte aligned. */
+size_t resel_gemm_f32_workspace_bytes(int M, int N, int K, int batch);
+int resel_gemm_f32(const float* A, int64_t lda, int64_t strideA, int a_kcontig,
+                   const float* B, int64_t ldb, int64_t strideB, int b_kcontig,
+                   const float* bias, int64_t strideBias, int act,
+                   float* C, int64_t ldc, int64_t strideC, void* workspace,
+                   int M, int N, int K, int batch, resel_stream_t stream);
+
 /* ---- packed trajectory batch from a device-resident replay ring --------------------------------------------------
  * Device counterpart of NestedMemoryArray.sample_trajs' packing loop (reference buffers/transition_buffer/
  * nested_replay_memory.py:140-176) plus the trainer's flag surgery (algorithm/sac_full_length_rnn_ensembleQ.py:338-342).

@@ -655,12 +655,25 @@ class LinearAct(torch.autograd.Function):
         g2 = g.reshape(y2.shape)
         gy, db = bias_act_bwd(g2, y2, y2.shape[0], ctx.act, ctx.has_bias and ctx.needs_input_grad[2])
         dx = torch.mm(gy, weight).view(ctx.xshape) if ctx.needs_input_grad[0] else None
-        dw = torch.mm(gy.t(), x2) if ctx.needs_input_grad[1] else None
+        dw = wgrad(gy, x2) if ctx.needs_input_grad[1] else None
         return dx, dw, None if db is None else db.reshape(-1), None
 
 
 def linear_act(x, weight, bias, act):
     return LinearAct.apply(x, weight, bias, act)
+
+
+def wgrad(gy, x2):
+    """dW [out, in] = gy[M, out]^T x2[M, in] over the M tokens of a pass.  Long reductions into a narrow output are where the
+    library's heuristics are weakest (a [128, 256] output from 66 752 tokens: 233 us = 19 TFLOP/s tuned) and where the
+    hand-written split-K kernel wins (89 us, `tools/bench_gemm_f32.py`); everything else stays a library GEMM."""
+    M, n_out = gy.shape
+    n_in = x2.shape[1]
+    if gy.is_cuda and M >= 16384 and n_out <= 128 and n_out % 4 == 0 and n_in % 4 == 0 and n_in >= 128 \
+            and gy.stride(1) == 1 and x2.stride(1) == 1 and gy.stride(0) % 4 == 0 and x2.stride(0) % 4 == 0 \
+            and gy.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0:
+        return gemm_f32(gy, x2, False, False)
+    return torch.mm(gy.t(), x2)
 
 
 @torch.no_grad()
@@ -689,6 +702,35 @@ def atb(wide, narrow, transposed=False):
     ws = _ws(lib().resel_atb_workspace_bytes(K, Wd, Nd), wide.device)
     check(lib().resel_atb(_p(wide), wide.stride(0), Wd, _p(narrow), narrow.stride(0), Nd, _p(out), int(bool(transposed)), _p(ws), K,
                           _stream()), 'atb')
+    return out
+
+
+@torch.no_grad()
+def gemm_f32(A, B, a_kcontig=True, b_kcontig=True, bias=None, act=None, out=None):
+    """C[b] = act(A[b] (.) B[b] + bias[b]) on the fp32 matrix cores (include/resel_hip.h `resel_gemm_f32`).
+    A: [M, K] (a_kcontig) or [K, M]; B: [N, K] (b_kcontig) or [K, N]; optionally a leading batch (ensemble) dimension on all of
+    A, B, bias [N] / [batch, N], out.  Row stride free (column stride 1); returns C [M, N] / [batch, M, N]."""
+    _need_cuda('gemm_f32', A, B)
+    batched = A.dim() == 3
+    A3, B3 = (A, B) if batched else (A.unsqueeze(0), B.unsqueeze(0))
+    assert A3.stride(-1) == 1 and B3.stride(-1) == 1 and A3.dtype == torch.float32 and B3.dtype == torch.float32
+    batch = A3.shape[0]
+    M, K = (A3.shape[1], A3.shape[2]) if a_kcontig else (A3.shape[2], A3.shape[1])
+    N = B3.shape[1] if b_kcontig else B3.shape[2]
+    assert (B3.shape[2] if b_kcontig else B3.shape[1]) == K and B3.shape[0] == batch
+    if out is None:
+        out = torch.empty((batch, M, N) if batched else (M, N), dtype=torch.float32, device=A.device)
+    C3 = out if batched else out.unsqueeze(0)
+    assert C3.stride(-1) == 1
+    nb = lib().resel_gemm_f32_workspace_bytes(M, N, K, batch)
+    ws = _ws(nb, A.device) if nb else None
+    bs = 0
+    if bias is not None:
+        bias = bias.reshape(batch, N) if batched else bias.reshape(N)
+        bs = bias.stride(0) if batched else 0
+    check(lib().resel_gemm_f32(_p(A3), A3.stride(1), A3.stride(0) if batch > 1 else 0, int(a_kcontig), _p(B3), B3.stride(1),
+                               B3.stride(0) if batch > 1 else 0, int(b_kcontig), _p(bias), bs, ACT_IDS[act], _p(C3), C3.stride(1),
+                               C3.stride(0) if batch > 1 else 0, _p(ws), M, N, K, batch, _stream()), 'gemm_f32')
     return out
 
 

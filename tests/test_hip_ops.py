@@ -546,3 +546,33 @@ def test_atb_long_reduction_gemm(ops, K, Wd, Nd, ldn, tr):
     ref = ref.t() if tr else ref
     close(got.cpu(), ref.float().cpu(), rtol=1e-4, atol_scale=2e-5, name='atb')
     assert torch.equal(got, ops.atb(wide, narrow, tr))           # fixed summation order
+
+
+# ------------------------------------------------------------------------------------------ fp32 MFMA GEMM
+@pytest.mark.parametrize('M,N,K,akc,bkc,bias,act,batch', [
+    (300, 256, 384, True, True, True, 'elu', 1),        # forward with the fused tail, ragged M
+    (1000, 132, 72, True, True, False, None, 1),        # ragged N / K tails
+    (513, 384, 256, True, False, False, None, 1),       # dgrad: weight read [K][rows]
+    (20000, 128, 256, False, False, False, None, 1),    # wgrad: split over the 20 000-long reduction
+    (260, 256, 256, True, False, True, 'elu', 8),       # per-member ensemble layer [E, in, out] with bias + ELU
+    (17000, 256, 256, False, False, False, None, 8),    # per-member weight gradient (batched split-K)
+])
+def test_gemm_f32_vs_fp64_product(ops, M, N, K, akc, bkc, bias, act, batch):
+    """resel_gemm_f32 (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulation) against an fp64 product: 1e-5 of the
+    largest output magnitude; both operand layouts, ragged edges, batch strides, fused bias + ELU, deterministic split-K."""
+    g = torch.Generator().manual_seed(M + N + K)
+    sh = (batch,) if batch > 1 else ()
+    A = torch.randn(*sh, *((M, K) if akc else (K, M)), generator=g)
+    B = torch.randn(*sh, *((N, K) if bkc else (K, N)), generator=g) / K ** 0.5
+    b = torch.randn(*sh, N, generator=g) if bias else None
+    Ad = A.double() if akc else A.double().transpose(-1, -2)
+    Bd = B.double().transpose(-1, -2) if bkc else B.double()
+    ref = Ad @ Bd
+    if bias:
+        ref = ref + b.double().unsqueeze(-2)
+    if act == 'elu':
+        ref = torch.nn.functional.elu(ref)
+    out = ops.gemm_f32(A.cuda(), B.cuda(), akc, bkc, None if b is None else b.cuda(), act)
+    close(out, ref.float(), rtol=1e-5, atol_scale=1e-6, name='gemm_f32')
+    out2 = ops.gemm_f32(A.cuda(), B.cuda(), akc, bkc, None if b is None else b.cuda(), act)
+    assert torch.equal(out, out2)                       # bitwise reproducible (no atomics)
