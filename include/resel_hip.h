@@ -62,20 +62,24 @@ int resel_profile_collect(int kernel_id, double* total_us, int* launches);
  * Supported: Di % 4 == 0, N in {4, 8, 16, 32, 64}.
  * ckpt (optional, for the backward): state checkpoints every RESEL_SSCAN_CKPT steps,
  *   resel_selective_scan_ckpt_bytes(B, L, Di, N) bytes.  last_state (optional): [B, Di, N].
+ * time_segments: 0 = the library decides (one workgroup scans a whole row when B * Di / 64 rows x tiles fill the chip; small
+ *   batches are cut into time segments scanned in parallel: local pass, carry of the segment states, final pass), 1 = never
+ *   split, k > 1 = k segments; workspace: resel_selective_scan_fwd_workspace_bytes(...) for the same arguments (NULL if 0).
  */
 #define RESEL_SSCAN_CKPT 16
 size_t resel_selective_scan_ckpt_bytes(int B, int L, int Di, int N);
+size_t resel_selective_scan_fwd_workspace_bytes(int B, int L, int Di, int N, int time_segments);
 int resel_selective_scan_fwd(const float* u, int64_t ld_u, const float* delta, int64_t ld_delta,
                              const float* z, int64_t ld_z, const float* A,
                              const float* Bm, int64_t ld_b, const float* Cm, int64_t ld_c,
                              const float* D, const float* delta_bias, const float* start,
-                             float* out, int64_t ld_out, float* ckpt, float* last_state,
-                             int B, int L, int Di, int N, int delta_softplus, resel_stream_t stream);
+                             float* out, int64_t ld_out, float* ckpt, float* last_state, void* workspace,
+                             int B, int L, int Di, int N, int delta_softplus, int time_segments, resel_stream_t stream);
 
 /* Backward of the above.  dout: [B*L, Di] (ld_dout).  Outputs: du, ddelta, dz: [B*L, Di] (dz may be NULL iff
  * z is NULL); dBm, dCm: [B*L, N]; dA: [Di, N]; dD, ddelta_bias: [Di] (NULL iff the input was NULL).
  * All outputs are overwritten (not accumulated).  workspace: resel_selective_scan_bwd_workspace_bytes(). */
-size_t resel_selective_scan_bwd_workspace_bytes(int B, int L, int Di, int N);
+size_t resel_selective_scan_bwd_workspace_bytes(int B, int L, int Di, int N, int time_segments);
 int resel_selective_scan_bwd(const float* u, int64_t ld_u, const float* delta, int64_t ld_delta,
                              const float* z, int64_t ld_z, const float* A,
                              const float* Bm, int64_t ld_b, const float* Cm, int64_t ld_c,
@@ -84,7 +88,7 @@ int resel_selective_scan_bwd(const float* u, int64_t ld_u, const float* delta, i
                              float* du, int64_t ld_du, float* ddelta, int64_t ld_ddelta, float* dz, int64_t ld_dz,
                              float* dBm, int64_t ld_db, float* dCm, int64_t ld_dc,
                              float* dA, float* dD, float* ddelta_bias, void* workspace,
-                             int B, int L, int Di, int N, int delta_softplus, resel_stream_t stream);
+                             int B, int L, int Di, int N, int delta_softplus, int time_segments, resel_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * smamba depthwise causal conv1d + bias + SiLU on the masked input.  Replaces `causal_conv1d_cuda.causal_conv1d_fwd/bwd`

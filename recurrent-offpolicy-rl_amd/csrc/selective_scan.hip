@@ -36,9 +36,6 @@ void launch_maybe_timed(int slot, K kernel, dim3 grid, dim3 block, hipStream_t s
 unsigned long long* g_stamps = nullptr;
 #endif
 
-#ifndef SSCAN_FWD_TC
-#define SSCAN_FWD_TC 32
-#endif
 constexpr int TILE_C = 64;            // channels per workgroup
 constexpr int CKS = RESEL_SSCAN_CKPT; // checkpoint stride
 constexpr int SC = 16;                // backward sub-chunk = one checkpoint interval staged in LDS
@@ -50,6 +47,8 @@ struct FwdParams {
     float *out, *ckpt, *last_state;
     int64_t ld_u, ld_delta, ld_z, ld_b, ld_c, ld_out;
     int B, L, Di, N, nck, softplus, nd, bc_vec;
+    int seg_len, nseg;              // time-parallel form (MODE 1 / 2): steps per segment (multiple of the chunk), segments per row
+    float *h_carry, *sdl;           // [B][nseg][N][Di] local end states -> entry states; [B][nseg][Di] delta sums
 #ifdef SSCAN_STAMP
     unsigned long long* stamps;     // diagnostic build only (tools/micro/sscan_lab.hip): per-wave phase cycle sums
 #endif
@@ -122,22 +121,49 @@ __device__ __forceinline__ float4 load_bc4(const float* base, int64_t tok, int64
     return make_float4(q[0], q[1], q[2], q[3]);
 }
 
-template <int NS, int NW, int TC>
-__global__ __launch_bounds__(NW * 64) void sscan_fwd_kernel(FwdParams p) {
+// ---------------------------------------------------------------------------------------------------------------------
+// Forward.  Ownership: workgroup = (row b, 64 channels[, time segment]), lane = channel, wave = NS-state group, time in
+// TC-step chunks staged through LDS.  What keeps the per-step overhead down (phase stamps / PMC: tools/micro/sscan_lab.hip):
+//   * resets are applied when the chunk is STAGED (delta := +inf at a start step, so exp2(delta * A) = 0): no select, no
+//     mask arithmetic in the step;
+//   * the step loop is straight-line over the whole chunk (rows past the end of the sequence are staged as identity steps:
+//     delta = 0, delta * u = 0), so the compiler software-pipelines across steps and pairs the y stores;
+//   * checkpoints are collected in LDS and leave with the output tile as whole 256-byte rows;
+//   * the prefetched tiles of the next chunk are waited for BEFORE this chunk's output stores are issued (hipcc otherwise
+//     guards their first use with s_waitcnt vmcnt(0) and every chunk eats a full store round trip), and the data registers
+//     of those stores stay live until the end of the next scan phase;
+//   * softplus / SiLU of the tile passes are branch-free.
+// MODE 0: one workgroup scans a whole row (B * Di / 64 workgroups: enough to fill the chip from B ~ 32 at Di = 512).
+// Time-parallel form for small batches (north_star: parallel scan over the sequence): the row is cut into `nseg` segments of
+// `seg_len` steps (a multiple of TC), each segment is its own workgroup and the scan becomes
+//   MODE 1  local pass: every segment scans from a zero state and leaves its end state h_loc and the sum S of its deltas
+//           (+inf after a reset) - no output, no checkpoints, no C operand;
+//   carry   (sscan_carry_kernel) per (row, channel, state): h_in[s] = state entering segment s, by the segment recurrence
+//           h_in[s + 1] = exp2(A2 * S[s]) * h_in[s] + h_loc[s]  (the product of a segment's decays is the exp of the sum);
+//   MODE 2  final pass: every segment rescans from its true entry state and produces outputs and checkpoints exactly as MODE 0.
+// ~1.9x the arithmetic of MODE 0 on nseg x the workgroups; chosen by the launcher when the one-pass grid cannot fill the CUs.
+template <int NS, int NW, int TC, int MODE>
+__global__ __launch_bounds__(NW * 64) void sscan_fwd2_kernel(FwdParams p) {
     constexpr int NT = NW * 64;
     constexpr int N = NS * NW;
-    constexpr int PER_T = (TC * 16 + NT - 1) / NT; // float4 tile items per thread (u / delta / z / out)
-    constexpr int BC_ITEMS = TC * N / 4;           // float4 items of a [TC][N] coefficient tile
+    constexpr int NP = (NS + 1) / 2;
+    constexpr int PER_T = (TC * 16 + NT - 1) / NT;
+    constexpr int BC_ITEMS = TC * N / 4;
     constexpr int PER_BC = (BC_ITEMS + NT - 1) / NT;
-    __shared__ __attribute__((aligned(16))) float s_dl[TC][TILE_C];
-    __shared__ __attribute__((aligned(16))) float s_du[TC][TILE_C];
-    __shared__ __attribute__((aligned(16))) float s_y[NW][TC][TILE_C];
+    static_assert(TC % 2 == 0 && (TC * 16) % NT == 0, "whole tile rows per thread pass");
+    __shared__ __attribute__((aligned(16))) float s_dl[TC][TILE_C];      // exp argument: softplus(delta + bias), +inf at a reset
+    __shared__ __attribute__((aligned(16))) float s_du[TC][TILE_C];      // softplus(delta + bias) * u
+    __shared__ __attribute__((aligned(16))) float s_y[MODE == 1 ? 1 : NW][TC][TILE_C];
     __shared__ __attribute__((aligned(16))) float s_B[TC][N];
-    __shared__ __attribute__((aligned(16))) float s_C[TC][N];
-    __shared__ float s_st[TC];
+    __shared__ __attribute__((aligned(16))) float s_C[MODE == 1 ? 1 : TC][N];
+    __shared__ __attribute__((aligned(16))) float s_ck[MODE == 1 ? 1 : TC / CKS][N][TILE_C];   // the chunk's checkpoints, stored with the output tile
 
     int b, dt;
     if (!decode_block(blockIdx.x, p.nd, p.B, b, dt)) return;
+    constexpr bool row_ok = true;
+    const int seg = MODE == 0 ? 0 : (int)blockIdx.y;
+    const int t_begin = MODE == 0 ? 0 : seg * p.seg_len;
+    const int t_end = MODE == 0 ? p.L : min(p.L, t_begin + p.seg_len);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -146,9 +172,6 @@ __global__ __launch_bounds__(NW * 64) void sscan_fwd_kernel(FwdParams p) {
     const bool d_ok = d < p.Di;
     const int64_t tok0 = (int64_t)b * p.L;
 
-    // per-lane recurrence constants: A (pre-scaled for exp2; clamped below zero so that the reset trick
-    // delta := +inf always yields exp2(-inf) = 0) for this lane's channel and this wave's states
-    constexpr int NP = (NS + 1) / 2;                // states are processed as float2 pairs (odd NS: padded lane is inert)
     f2 A2p[NP], hp[NP];
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
@@ -160,278 +183,12 @@ __global__ __launch_bounds__(NW * 64) void sscan_fwd_kernel(FwdParams p) {
         }
         A2p[k] = f2{a[0], a[1]};
         hp[k] = f2{0.f, 0.f};
+        if (MODE == 2 && d_ok) {                     // the state entering this segment (sscan_carry_kernel)
+            const float* hin = p.h_carry + (((int64_t)b * p.nseg + seg) * N + w * NS) * p.Di + d;
+            hp[k] = f2{2 * k < NS ? hin[(int64_t)(2 * k) * p.Di] : 0.f, 2 * k + 1 < NS ? hin[(int64_t)(2 * k + 1) * p.Di] : 0.f};
+        }
     }
-    const int tc4 = (tid & 15) * 4;
-    const int tr0 = tid >> 4;                       // first tile row of this thread
-    const bool c_ok = (d0 + tc4) < p.Di;
-    float4 Dv = make_float4(0.f, 0.f, 0.f, 0.f), bv = Dv;
-    if (c_ok) {
-        if (p.D) Dv = ld4(p.D + d0 + tc4);
-        if (p.delta_bias) bv = ld4(p.delta_bias + d0 + tc4);
-    }
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 pu[PER_T], pd[PER_T], pz[PER_T];         // register prefetch of the NEXT chunk's tiles
-    float4 pB[PER_BC], pC[PER_BC];
-    float pst = 0.f;
-    float4 u_r[PER_T], z_r[PER_T];
-
-    auto prefetch = [&](int c0) {
-#pragma unroll
-        for (int i = 0; i < PER_T; ++i) {
-            const int r = tr0 + i * (NT / 16);
-            const int t = c0 + r;
-            pu[i] = zero4; pd[i] = zero4; pz[i] = zero4;
-            if (r < TC && t < p.L && c_ok) {
-                const int64_t tok = tok0 + t;
-                pu[i] = ld4(p.u + tok * p.ld_u + d0 + tc4);
-                pd[i] = ld4(p.delta + tok * p.ld_delta + d0 + tc4);
-                if (p.z) pz[i] = ld4(p.z + tok * p.ld_z + d0 + tc4);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < PER_BC; ++i) {
-            const int it = tid + i * NT;
-            const int t = c0 + it / (N / 4), c = (it % (N / 4)) * 4;
-            pB[i] = zero4; pC[i] = zero4;
-            if (it < BC_ITEMS && t < p.L) {
-                pB[i] = load_bc4(p.Bm, tok0 + t, p.ld_b, c, p.bc_vec);
-                pC[i] = load_bc4(p.Cm, tok0 + t, p.ld_c, c, p.bc_vec);
-            }
-        }
-        pst = (p.start && tid < TC && c0 + tid < p.L) ? p.start[tok0 + c0 + tid] : 0.f;
-    };
-    prefetch(0);
-#ifdef SSCAN_STAMP
-    unsigned long long st_stage = 0, st_b1 = 0, st_scan = 0, st_b2 = 0, st_out = 0, st_last = 0, st_dummy = 0;
-    const unsigned long long st_r0 = __builtin_amdgcn_s_memrealtime();
-    STAMP(st_dummy, st_last);
-    const unsigned long long st_t0 = st_last;
-#endif
-
-    for (int c0 = 0; c0 < p.L; c0 += TC) {
-        // ---- stage: softplus(delta + bias), delta * u, B_t / C_t / start_t -> LDS; u and z stay in registers
-#pragma unroll
-        for (int i = 0; i < PER_T; ++i) {
-            const int r = tr0 + i * (NT / 16);
-            float4 dv = pd[i];
-            const float4 uv = pu[i];
-            dv.x += bv.x; dv.y += bv.y; dv.z += bv.z; dv.w += bv.w;
-            if (p.softplus) {
-                dv.x = softplusf_(dv.x); dv.y = softplusf_(dv.y); dv.z = softplusf_(dv.z); dv.w = softplusf_(dv.w);
-            }
-            if (c0 + r >= p.L) dv = zero4;              // past the end of the row: an identity step (exp2(0) = 1, delta * u = 0)
-            u_r[i] = uv;
-            z_r[i] = pz[i];
-            if (r < TC) {
-                st4(&s_dl[r][tc4], dv);
-                st4(&s_du[r][tc4], make_float4(dv.x * uv.x, dv.y * uv.y, dv.z * uv.z, dv.w * uv.w));
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < PER_BC; ++i) {
-            const int it = tid + i * NT;
-            if (it < BC_ITEMS) {
-                st4(&s_B[0][0] + it * 4, pB[i]);
-                st4(&s_C[0][0] + it * 4, pC[i]);
-            }
-        }
-        if (tid < TC) s_st[tid] = pst;
-        STAMP(st_stage, st_last);
-        __syncthreads();
-        STAMP(st_b1, st_last);
-        if (c0 + TC < p.L) prefetch(c0 + TC);        // in flight during the whole scan phase
-
-        // ---- scan: lane = channel, wave = state group, sequential in time.
-        // The lane's own column of the chunk (delta and delta*u of its channel, TC steps each) is pulled into registers
-        // up front - 2 TC independent LDS reads behind ONE wait - and the reset flags of the chunk become a bit mask in an
-        // SGPR pair, so the step loop (fully unrolled: register indices are static) reads only the wave-uniform B_t / C_t
-        // rows from LDS, one step ahead of their use (ping-pong sets pinned with sched_barrier).
-        // The per-state arithmetic is written on float2 pairs: on gfx950 a wave64 v_fma_f32 / v_mul_f32 issues every
-        // 4 cycles per SIMD and v_pk_fma_f32 / v_pk_mul_f32 every ~5.6 (tools/micro/valu_rate.hip), i.e. packed math
-        // is ~1.4x the scalar rate; v_exp_f32 (8 cycles) stays scalar.
-        static_assert(TC <= 64 && TC % 2 == 0, "one reset bit per step in a 64-bit mask; steps are processed in pairs");
-        const int nst = min(TC, p.L - c0);
-        float dlr[TC], dur[TC];
-#pragma unroll
-        for (int t = 0; t < TC; ++t) { dlr[t] = s_dl[t][lane]; dur[t] = s_du[t][lane]; }
-        const unsigned long long rmask = __ballot(lane < TC && s_st[lane < TC ? lane : 0] != 0.f);
-        f2 B0[NP], C0[NP], B1[NP], C1[NP];
-        auto fetch = [&](int t, f2 (&Bq)[NP], f2 (&Cq)[NP]) {
-#ifdef SSCAN_AB_NOBC
-            if (t == 0) {
-#endif
-            lds_coef2<NS>(&s_B[t][w * NS], Bq);
-            lds_coef2<NS>(&s_C[t][w * NS], Cq);
-#ifdef SSCAN_AB_NOBC
-            }
-#endif
-        };
-        auto step = [&](int t, const f2 (&Bq)[NP], const f2 (&Cq)[NP], float dlq, float duq) {
-#ifdef SSCAN_AB_NOSEL
-            const float dle = dlq;
-#else
-            const float dle = ((rmask >> t) & 1ull) ? __builtin_inff() : dlq;    // reset: exp2(-inf) = 0 wipes h_{t-1}
-#endif
-            const f2 dle2 = {dle, dle}, du2 = {duq, duq};
-            f2 yacc = {0.f, 0.f};
-#pragma unroll
-            for (int k = 0; k < NP; ++k) {
-                const f2 arg = dle2 * A2p[k];
-                f2 dA;
-                dA.x = fast_exp2(arg.x);
-                dA.y = fast_exp2(arg.y);
-                hp[k] = __builtin_elementwise_fma(dA, hp[k], du2 * Bq[k]);
-                yacc = __builtin_elementwise_fma(Cq[k], hp[k], yacc);
-            }
-#ifdef SSCAN_AB_NOY
-            { float yk = yacc.x + yacc.y; asm volatile("" :: "v"(yk)); }
-#else
-            s_y[w][t][lane] = yacc.x + yacc.y;
-#endif
-            const int tabs = c0 + t + 1;
-#ifdef SSCAN_AB_NOCK
-            if (false) {
-#else
-            if (p.ckpt != nullptr && (tabs % CKS) == 0 && tabs < p.L && d_ok) {
-#endif
-                float* ck = p.ckpt + (((int64_t)b * p.nck + (tabs / CKS - 1)) * N + w * NS) * p.Di + d;
-#pragma unroll
-                for (int j = 0; j < NS; ++j) ck[(int64_t)j * p.Di] = (j & 1) ? hp[j / 2].y : hp[j / 2].x;
-            }
-        };
-#ifdef SSCAN_FWD_FREE
-        // straight-line chunk: rows past the end of the sequence are staged as (delta, delta * u) = (0, 0), i.e. identity steps
-#pragma unroll
-        for (int t = 0; t < TC; ++t) {
-            fetch(t, B0, C0);
-            step(t, B0, C0, dlr[t], dur[t]);
-        }
-#else
-        fetch(0, B0, C0);
-#pragma unroll
-        for (int t = 0; t < TC; t += 2) {
-            if (t < nst) {
-                fetch(t + 1 < TC ? t + 1 : TC - 1, B1, C1);
-                __builtin_amdgcn_sched_barrier(0);
-                step(t, B0, C0, dlr[t], dur[t]);
-            }
-            if (t + 1 < nst) {
-                fetch(t + 2 < TC ? t + 2 : TC - 1, B0, C0);
-                __builtin_amdgcn_sched_barrier(0);
-                step(t + 1, B1, C1, dlr[t + 1 < TC ? t + 1 : TC - 1], dur[t + 1 < TC ? t + 1 : TC - 1]);
-            }
-        }
-#endif
-        STAMP(st_scan, st_last);
-        __syncthreads();
-        STAMP(st_b2, st_last);
-
-        // ---- output tile: sum the NW partials, skip term, gate, float4 store
-#pragma unroll
-        for (int i = 0; i < PER_T; ++i) {
-            const int r = tr0 + i * (NT / 16);
-            const int t = c0 + r;
-            if (r < TC && t < p.L && c_ok) {
-                float4 y = ld4(&s_y[0][r][tc4]);
-#pragma unroll
-                for (int ww = 1; ww < NW; ++ww) {
-                    const float4 q = ld4(&s_y[ww][r][tc4]);
-                    y.x += q.x; y.y += q.y; y.z += q.z; y.w += q.w;
-                }
-                const float4 uv = u_r[i];
-                y.x = __builtin_fmaf(Dv.x, uv.x, y.x); y.y = __builtin_fmaf(Dv.y, uv.y, y.y);
-                y.z = __builtin_fmaf(Dv.z, uv.z, y.z); y.w = __builtin_fmaf(Dv.w, uv.w, y.w);
-                if (p.z) {
-                    const float4 zv = z_r[i];
-                    y.x *= siluf_(zv.x); y.y *= siluf_(zv.y); y.z *= siluf_(zv.z); y.w *= siluf_(zv.w);
-                }
-                st4(p.out + (tok0 + t) * p.ld_out + d0 + tc4, y);
-            }
-        }
-        // no barrier needed here: the next stage only writes s_dl/s_du/s_B/s_C/s_st (last read before the barrier
-        // above), and s_y is rewritten only after the barrier that follows that stage.
-        STAMP(st_out, st_last);
-    }
-#ifdef SSCAN_STAMP
-    if (p.stamps && lane == 0) {
-        unsigned long long* o = p.stamps + ((size_t)blockIdx.x * NW + w) * 8;
-        o[0] = st_stage; o[1] = st_b1; o[2] = st_scan; o[3] = st_b2; o[4] = st_out;
-        o[5] = st_last - st_t0; o[6] = __builtin_amdgcn_s_memrealtime() - st_r0; o[7] = st_r0;
-    }
-#endif
-    if (p.last_state != nullptr && d_ok) {
-#pragma unroll
-        for (int j = 0; j < NS; ++j)
-            p.last_state[((int64_t)b * p.Di + d) * N + w * NS + j] = (j & 1) ? hp[j / 2].y : hp[j / 2].x;
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Forward, second edition.  Same ownership (workgroup = row b x 64 channels, lane = channel, wave = NS-state group, time in
-// TC-step chunks staged through LDS) with the per-step overheads the stamps of tools/micro/sscan_lab.hip showed removed:
-//   * resets are applied when the chunk is STAGED (delta := +inf at a start step, so exp2(delta * A) = 0): no select, no
-//     mask arithmetic in the step;
-//   * the step loop is straight-line over the whole chunk (rows past the end of the sequence are staged as identity steps:
-//     delta = 0, delta * u = 0), so the compiler software-pipelines across steps and pairs the y stores;
-//   * checkpoints leave through buffer stores (wave-uniform base in the descriptor, the per-event offset in an SGPR, the
-//     per-state offsets in registers set up once): no 64-bit address arithmetic in the loop;
-//   * the prefetched tiles of the next chunk are waited for BEFORE this chunk's output stores are issued - hipcc otherwise
-//     guards their first use with s_waitcnt vmcnt(0) and every chunk eats a full store round trip.
-// ROWS = 2: one workgroup of 2 NW waves carries TWO batch rows (rows 2k, 2k + 1 of the same channel tile), one per wave
-// quartet.  At one 256-thread workgroup per row two workgroups share a CU, the older one wins every VALU arbitration,
-// finishes ~30 % early and leaves the younger to run the rest of its row alone at one wave per SIMD (measured: 185 vs
-// 265 us); inside one workgroup the chunk barriers keep the two rows abreast.  Measured at B = 64: 276.7 us against 280.9 us
-// with one row per workgroup - the kernel is bound by total VALU work, not by the tail - so ROWS = 1 is what ships and
-// ROWS = 2 stays a build switch (SSCAN_FWD_ROWS2).
-template <int NS, int NW, int TC, int ROWS>
-__global__ __launch_bounds__(NW * 64 * ROWS) void sscan_fwd2_kernel(FwdParams p) {
-    constexpr int NT = NW * 64;
-    constexpr int N = NS * NW;
-    constexpr int NP = (NS + 1) / 2;
-    constexpr int PER_T = (TC * 16 + NT - 1) / NT;
-    constexpr int BC_ITEMS = TC * N / 4;
-    constexpr int PER_BC = (BC_ITEMS + NT - 1) / NT;
-    static_assert(TC % 2 == 0 && (TC * 16) % NT == 0, "whole tile rows per thread pass");
-    __shared__ __attribute__((aligned(16))) float sm_dl[ROWS][TC][TILE_C];      // exp argument: softplus(delta + bias), +inf at a reset
-    __shared__ __attribute__((aligned(16))) float sm_du[ROWS][TC][TILE_C];      // softplus(delta + bias) * u
-    __shared__ __attribute__((aligned(16))) float sm_y[ROWS][NW][TC][TILE_C];
-    __shared__ __attribute__((aligned(16))) float sm_B[ROWS][TC][N];
-    __shared__ __attribute__((aligned(16))) float sm_C[ROWS][TC][N];
-    __shared__ __attribute__((aligned(16))) float sm_ck[ROWS][TC / CKS][N][TILE_C];   // the chunk's checkpoints, stored with the output tile
-
-    int bpair, dt;
-    if (!decode_block(blockIdx.x, p.nd, (p.B + ROWS - 1) / ROWS, bpair, dt)) return;
-    const int row = __builtin_amdgcn_readfirstlane((int)threadIdx.x / (NW * 64));
-    const int b_raw = bpair * ROWS + row;
-    const bool row_ok = b_raw < p.B;                 // odd batch: the second row of the last pair idles (it still joins the barriers)
-    const int b = row_ok ? b_raw : p.B - 1;
-    float (*s_dl)[TILE_C] = sm_dl[row];
-    float (*s_du)[TILE_C] = sm_du[row];
-    float (*s_y)[TC][TILE_C] = sm_y[row];
-    float (*s_B)[N] = sm_B[row];
-    float (*s_C)[N] = sm_C[row];
-    float (*s_ck)[N][TILE_C] = sm_ck[row];
-    const int tid = threadIdx.x % (NW * 64);
-    const int lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int d0 = dt * TILE_C;
-    const int d = d0 + lane;
-    const bool d_ok = d < p.Di;
-    const int64_t tok0 = (int64_t)b * p.L;
-
-    f2 A2p[NP], hp[NP];
-#pragma unroll
-    for (int k = 0; k < NP; ++k) {
-        float a[2];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int j = 2 * k + e;
-            a[e] = (d_ok && j < NS) ? fminf(p.A[(int64_t)d * N + w * NS + j] * RESEL_LOG2E, -1e-30f) : -1.f;
-        }
-        A2p[k] = f2{a[0], a[1]};
-        hp[k] = f2{0.f, 0.f};
-    }
+    float sdl = 0.f;                                 // MODE 1: sum of this lane's deltas over the segment (+inf after a reset)
     const int tc4 = (tid & 15) * 4;
     const int tr0 = tid >> 4;
     const bool c_ok = (d0 + tc4) < p.Di;
@@ -451,12 +208,12 @@ __global__ __launch_bounds__(NW * 64 * ROWS) void sscan_fwd2_kernel(FwdParams p)
         for (int i = 0; i < PER_T; ++i) {
             const int t = c0 + tr0 + i * (NT / 16);
             pu[i] = zero4; pd[i] = zero4; pz[i] = zero4; pst[i] = 0.f;
-            if (t < p.L) {
+            if (t < t_end) {
                 const int64_t tok = tok0 + t;
                 if (c_ok) {
                     pu[i] = ld4(p.u + tok * p.ld_u + d0 + tc4);
                     pd[i] = ld4(p.delta + tok * p.ld_delta + d0 + tc4);
-                    if (p.z) pz[i] = ld4(p.z + tok * p.ld_z + d0 + tc4);
+                    if (MODE != 1 && p.z) pz[i] = ld4(p.z + tok * p.ld_z + d0 + tc4);
                 }
                 if (p.start) pst[i] = p.start[tok];
             }
@@ -466,13 +223,13 @@ __global__ __launch_bounds__(NW * 64 * ROWS) void sscan_fwd2_kernel(FwdParams p)
             const int it = tid + i * NT;
             const int t = c0 + it / (N / 4), c = (it % (N / 4)) * 4;
             pB[i] = zero4; pC[i] = zero4;
-            if (it < BC_ITEMS && t < p.L) {
+            if (it < BC_ITEMS && t < t_end) {
                 pB[i] = load_bc4(p.Bm, tok0 + t, p.ld_b, c, p.bc_vec);
-                pC[i] = load_bc4(p.Cm, tok0 + t, p.ld_c, c, p.bc_vec);
+                if (MODE != 1) pC[i] = load_bc4(p.Cm, tok0 + t, p.ld_c, c, p.bc_vec);
             }
         }
     };
-    prefetch(0);
+    prefetch(t_begin);
     auto retire_prefetch = [&]() {                 // make hipcc wait for the prefetched tiles HERE (see the header comment)
 #pragma unroll
         for (int i = 0; i < PER_T; ++i) asm volatile("" :: "v"(pu[i].x), "v"(pd[i].x), "v"(pz[i].x), "v"(pst[i]));
@@ -501,7 +258,7 @@ __global__ __launch_bounds__(NW * 64 * ROWS) void sscan_fwd2_kernel(FwdParams p)
     const unsigned long long st_t0 = st_last;
 #endif
 
-    for (int c0 = 0; c0 < p.L; c0 += TC) {
+    for (int c0 = t_begin; c0 < t_end; c0 += TC) {
         // ---- stage
 #pragma unroll
         for (int i = 0; i < PER_T; ++i) {
@@ -513,8 +270,8 @@ __global__ __launch_bounds__(NW * 64 * ROWS) void sscan_fwd2_kernel(FwdParams p)
                 dv.x = softplus_nb(dv.x); dv.y = softplus_nb(dv.y); dv.z = softplus_nb(dv.z); dv.w = softplus_nb(dv.w);
             }
             float4 du4 = make_float4(dv.x * uv.x, dv.y * uv.y, dv.z * uv.z, dv.w * uv.w);
-            if (c0 + TC > p.L) {                                              // last chunk only (uniform branch)
-                if (c0 + r >= p.L) { dv = zero4; du4 = zero4; }              // identity step past the end of the row
+            if (c0 + TC > t_end) {                                            // last chunk only (uniform branch)
+                if (c0 + r >= t_end) { dv = zero4; du4 = zero4; }            // identity step past the end of the row / segment
             }
             {                                                                 // reset: exp2(-inf * |A|) = 0 wipes the carried state
                 const bool rs = pst[i] != 0.f;
@@ -531,7 +288,7 @@ __global__ __launch_bounds__(NW * 64 * ROWS) void sscan_fwd2_kernel(FwdParams p)
             const int it = tid + i * NT;
             if (it < BC_ITEMS) {
                 st4(&s_B[0][0] + it * 4, pB[i]);
-                st4(&s_C[0][0] + it * 4, pC[i]);
+                if (MODE != 1) st4(&s_C[0][0] + it * 4, pC[i]);
             }
         }
         STAMP(st_stage, st_last);
@@ -546,12 +303,12 @@ __global__ __launch_bounds__(NW * 64 * ROWS) void sscan_fwd2_kernel(FwdParams p)
         const bool ck_on = p.ckpt != nullptr;
         f2 Bq[2][NP], Cq[2][NP];                      // operand rows one step ahead of their use (two register sets)
         lds_coef2<NS>(&s_B[0][w * NS], Bq[0]);
-        lds_coef2<NS>(&s_C[0][w * NS], Cq[0]);
+        if (MODE != 1) lds_coef2<NS>(&s_C[0][w * NS], Cq[0]);
 #pragma unroll
         for (int t = 0; t < TC; ++t) {
             if (t + 1 < TC) {
                 lds_coef2<NS>(&s_B[t + 1][w * NS], Bq[(t + 1) & 1]);
-                lds_coef2<NS>(&s_C[t + 1][w * NS], Cq[(t + 1) & 1]);
+                if (MODE != 1) lds_coef2<NS>(&s_C[t + 1][w * NS], Cq[(t + 1) & 1]);
             }
             const f2 dl2 = {dlr[t], dlr[t]}, du2 = {dur[t], dur[t]};
             f2 yacc = {0.f, 0.f};
@@ -562,12 +319,16 @@ __global__ __launch_bounds__(NW * 64 * ROWS) void sscan_fwd2_kernel(FwdParams p)
                 dA.x = fast_exp2(arg.x);
                 dA.y = fast_exp2(arg.y);
                 hp[k] = __builtin_elementwise_fma(dA, hp[k], du2 * Bq[t & 1][k]);
-                yacc = __builtin_elementwise_fma(Cq[t & 1][k], hp[k], yacc);
+                if (MODE != 1) yacc = __builtin_elementwise_fma(Cq[t & 1][k], hp[k], yacc);
             }
-            s_y[w][t][lane] = yacc.x + yacc.y;
-            if ((t + 1) % CKS == 0 && ck_on) {                               // c0 is a multiple of TC, TC of CKS
+            if (MODE == 1) {
+                sdl += dlr[t];
+            } else {
+                s_y[w][t][lane] = yacc.x + yacc.y;
+                if ((t + 1) % CKS == 0 && ck_on) {                           // c0 is a multiple of TC, TC of CKS
 #pragma unroll
-                for (int j = 0; j < NS; ++j) s_ck[t / CKS][w * NS + j][lane] = (j & 1) ? hp[j / 2].y : hp[j / 2].x;
+                    for (int j = 0; j < NS; ++j) s_ck[t / CKS][w * NS + j][lane] = (j & 1) ? hp[j / 2].y : hp[j / 2].x;
+                }
             }
         }
         // the next chunk's tiles have been in flight for the whole scan: retire them here, ahead of the output stores
@@ -578,11 +339,12 @@ __global__ __launch_bounds__(NW * 64 * ROWS) void sscan_fwd2_kernel(FwdParams p)
         STAMP(st_b2, st_last);
 
         // ---- output tile
+        if (MODE == 1) continue;
 #pragma unroll
         for (int i = 0; i < PER_T; ++i) {
             const int r = tr0 + i * (NT / 16);
             const int t = c0 + r;
-            if (t < p.L && c_ok && row_ok) {
+            if (t < t_end && c_ok && row_ok) {
                 float4 y = ld4(&s_y[0][r][tc4]);
 #pragma unroll
                 for (int ww = 1; ww < NW; ++ww) {
@@ -609,7 +371,7 @@ __global__ __launch_bounds__(NW * 64 * ROWS) void sscan_fwd2_kernel(FwdParams p)
                 for (int q = 0; q < (N * 16 + NT - 1) / NT; ++q) {
                     const int it = tid + q * NT;
                     const int n = it >> 4, c4 = (it & 15) * 4;
-                    if (tabs < p.L && it < N * 16 && d0 + c4 < p.Di && row_ok) {
+                    if (tabs < p.L && tabs <= t_end && it < N * 16 && d0 + c4 < p.Di && row_ok) {
                         ck_keep[e * ((N * 16 + NT - 1) / NT) + q] = ld4(&s_ck[e][n][c4]);
                         st4(dst + (int64_t)n * p.Di + c4, ck_keep[e * ((N * 16 + NT - 1) / NT) + q]);
                     }
@@ -625,10 +387,34 @@ __global__ __launch_bounds__(NW * 64 * ROWS) void sscan_fwd2_kernel(FwdParams p)
         o[5] = st_last - st_t0; o[6] = __builtin_amdgcn_s_memrealtime() - st_r0; o[7] = st_r0;
     }
 #endif
-    if (p.last_state != nullptr && d_ok && row_ok) {
+    if (MODE == 1) {                                 // local end state and delta sum of this segment
+        if (d_ok) {
+            float* ho = p.h_carry + (((int64_t)b * p.nseg + seg) * N + w * NS) * p.Di + d;
+#pragma unroll
+            for (int j = 0; j < NS; ++j) ho[(int64_t)j * p.Di] = (j & 1) ? hp[j / 2].y : hp[j / 2].x;
+            if (w == 0) p.sdl[((int64_t)b * p.nseg + seg) * p.Di + d] = sdl;
+        }
+        return;
+    }
+    if (p.last_state != nullptr && d_ok && row_ok && t_end == p.L) {
 #pragma unroll
         for (int j = 0; j < NS; ++j)
             p.last_state[((int64_t)b * p.Di + d) * N + w * NS + j] = (j & 1) ? hp[j / 2].y : hp[j / 2].x;
+    }
+}
+
+// h_carry[b][s] (local end states on entry) -> states ENTERING segment s; one thread per (row, state, channel)
+__global__ void sscan_carry_kernel(float* __restrict__ h_carry, const float* __restrict__ sdl, const float* __restrict__ A, int B, int nseg, int N, int Di) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * N * Di) return;
+    const int d = (int)(i % Di), n = (int)((i / Di) % N), b = (int)(i / ((int64_t)Di * N));
+    const float a2 = fminf(A[(int64_t)d * N + n] * RESEL_LOG2E, -1e-30f);
+    float h = 0.f;
+    for (int s = 0; s < nseg; ++s) {
+        float* q = h_carry + (((int64_t)b * nseg + s) * N + n) * Di + d;
+        const float loc = *q;
+        *q = h;
+        h = fast_exp2(a2 * sdl[((int64_t)b * nseg + s) * Di + d]) * h + loc;
     }
 }
 
@@ -641,6 +427,8 @@ struct BwdParams {
     float *dB_part, *dC_part, *dA_part, *dD_part, *dbias_part;     // workspace slabs
     int64_t ld_u, ld_delta, ld_z, ld_b, ld_c, ld_dout, ld_du, ld_ddelta, ld_dz;
     int B, L, Di, N, nck, softplus, nd, bc_vec;
+    int seg_len, nseg;              // time-parallel form: steps per segment (multiple of 32), segments per row (1 = whole row)
+    float *dh_carry, *sdl;          // [B][nseg][N][Di]: dL/dh flowing INTO the end of each segment; [B][nseg][Di] delta sums
 };
 
 // Cross-lane sums for the dB / dC channel reductions.
@@ -805,8 +593,20 @@ __global__ __launch_bounds__(NW * 64) void sscan_bwd_kernel(BwdParams p) {
         dh[k] = f2{0.f, 0.f};
         dAacc[k] = f2{0.f, 0.f};
     }
+    // time-parallel form: this workgroup owns sub-chunks [sc_begin, sc_end) of the row and starts from the adjoint state that
+    // the later segments send back (sscan_bwd_local_kernel + sscan_carry_rev_kernel)
+    const int seg = p.nseg > 1 ? (int)blockIdx.y : 0;
+    const int prow = b * p.nseg + seg;              // row of the per-(row, segment) partial slabs
+    if (p.nseg > 1 && d_ok) {
+        const float* q = p.dh_carry + ((int64_t)prow * N + w * NS) * p.Di + d;
+#pragma unroll
+        for (int k = 0; k < NP; ++k)
+            dh[k] = f2{2 * k < NS ? q[(int64_t)(2 * k) * p.Di] : 0.f, 2 * k + 1 < NS ? q[(int64_t)(2 * k + 1) * p.Di] : 0.f};
+    }
 
-    const int nsc = (p.L + SC - 1) / SC;
+    const int nsc_row = (p.L + SC - 1) / SC;
+    const int sc_begin = p.nseg > 1 ? seg * (p.seg_len / SC) : 0;
+    const int nsc = p.nseg > 1 ? min(nsc_row, sc_begin + p.seg_len / SC) : nsc_row;      // one past this segment's last sub-chunk
     // issue the LDS-DMA of sub-chunk sc into buffer sc & 1 (plus its start flags into a register)
     auto stage_issue = [&](int sc) {
         const int ts = sc * SC, buf = sc & 1;
@@ -867,7 +667,7 @@ __global__ __launch_bounds__(NW * 64) void sscan_bwd_kernel(BwdParams p) {
     issue_h0(nsc - 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // later iterations find their DMA retired by barrier_vm (C) / (E)
 
-    for (int sc = nsc - 1; sc >= 0; --sc) {
+    for (int sc = nsc - 1; sc >= sc_begin; --sc) {
         const int ts = sc * SC, buf = sc & 1;
         const int sl = min(SC, p.L - ts);                 // steps in this sub-chunk
         float (*s_u)[TILE_C] = s_raw[buf][0];
@@ -884,7 +684,7 @@ __global__ __launch_bounds__(NW * 64) void sscan_bwd_kernel(BwdParams p) {
             float4 dl4 = ld4(&s_dl[tr][tc4]);
             dl4.x += bv.x; dl4.y += bv.y; dl4.z += bv.z; dl4.w += bv.w;
             if (p.softplus) {
-                dl4.x = softplusf_(dl4.x); dl4.y = softplusf_(dl4.y); dl4.z = softplusf_(dl4.z); dl4.w = softplusf_(dl4.w);
+                dl4.x = softplus_nb(dl4.x); dl4.y = softplus_nb(dl4.y); dl4.z = softplus_nb(dl4.z); dl4.w = softplus_nb(dl4.w);
             }
             st4(&s_dl[tr][tc4], dl4);
             if (p.z) {
@@ -894,7 +694,7 @@ __global__ __launch_bounds__(NW * 64) void sscan_bwd_kernel(BwdParams p) {
             }
         }
         barrier_lds();                                     // (B)
-        if (sc > 0) stage_issue(sc - 1);                   // in flight during the whole replay / reverse phase
+        if (sc > sc_begin) stage_issue(sc - 1);            // in flight during the whole replay / reverse phase
 
         // ---------------- replay + reverse, in two halves of SCH steps (later half first) ----------------
         // The (h, dA) history of SCH = 8 steps x NS states lives in registers.  The second half starts from the state
@@ -1068,7 +868,7 @@ __global__ __launch_bounds__(NW * 64) void sscan_bwd_kernel(BwdParams p) {
             f2 h0[NP];
             read_h0(sc, h0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the checkpoint rows are in registers: their LDS slots may be refilled
-            if (sc > 0) issue_h0(sc - 1);
+            if (sc > sc_begin) issue_h0(sc - 1);
             half(0, min(sl, SCH), h0);
         }
         // (E) retires the checkpoint DMA (and, on a short tail sub-chunk that skipped (C), the tile DMA)
@@ -1079,7 +879,7 @@ __global__ __launch_bounds__(NW * 64) void sscan_bwd_kernel(BwdParams p) {
     if (d_ok) {
 #pragma unroll
         for (int j = 0; j < NS; ++j)
-            p.dA_part[((int64_t)b * p.Di + d) * N + w * NS + j] = (j & 1) ? dAacc[j / 2].y : dAacc[j / 2].x;
+            p.dA_part[((int64_t)prow * p.Di + d) * N + w * NS + j] = (j & 1) ? dAacc[j / 2].y : dAacc[j / 2].x;
     }
     __syncthreads();
     if (tid < 2 * TILE_C) {
@@ -1087,7 +887,119 @@ __global__ __launch_bounds__(NW * 64) void sscan_bwd_kernel(BwdParams p) {
         float acc = 0.f;
 #pragma unroll
         for (int r = 0; r < SCH; ++r) acc += s_acc[which][r][c];
-        if (d0 + c < p.Di) (which ? p.dbias_part : p.dD_part)[(int64_t)b * p.Di + d0 + c] = acc;
+        if (d0 + c < p.Di) (which ? p.dbias_part : p.dD_part)[(int64_t)prow * p.Di + d0 + c] = acc;
+    }
+}
+
+// ---- time-parallel backward, local pass: the adjoint recurrence alone (dL/dh_t = dy_t C_t + carried; carried = dL/dh_t * dA_t),
+// run over one time segment from a zero adjoint.  No state replay, no gradients: it leaves, per segment, the adjoint at the
+// segment's start (dh_loc) and the sum of the segment's deltas, from which sscan_carry_rev_kernel forms the adjoint entering
+// the END of every segment (the map across a segment is dh_start = exp2(A2 * S) * dh_end + dh_loc).  Same staging as the
+// forward: TC-step chunks, resets as delta = +inf (the decay 0 cuts the adjoint exactly where the forward cut the state).
+template <int NS, int NW, int TC>
+__global__ __launch_bounds__(NW * 64) void sscan_bwd_local_kernel(BwdParams p) {
+    constexpr int NT = NW * 64;
+    constexpr int N = NS * NW;
+    constexpr int NP = (NS + 1) / 2;
+    constexpr int PER_T = (TC * 16 + NT - 1) / NT;
+    constexpr int BC_ITEMS = TC * N / 4;
+    constexpr int PER_BC = (BC_ITEMS + NT - 1) / NT;
+    __shared__ __attribute__((aligned(16))) float s_dl[TC][TILE_C];
+    __shared__ __attribute__((aligned(16))) float s_dy[TC][TILE_C];
+    __shared__ __attribute__((aligned(16))) float s_C[TC][N];
+    int b, dt;
+    if (!decode_block(blockIdx.x, p.nd, p.B, b, dt)) return;
+    const int seg = blockIdx.y;
+    const int t_begin = seg * p.seg_len, t_end = min(p.L, t_begin + p.seg_len);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int d0 = dt * TILE_C, d = d0 + lane;
+    const bool d_ok = d < p.Di;
+    const int64_t tok0 = (int64_t)b * p.L;
+    f2 A2p[NP], dh[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        float a[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int j = 2 * k + e;
+            a[e] = (d_ok && j < NS) ? fminf(p.A[(int64_t)d * N + w * NS + j] * RESEL_LOG2E, -1e-30f) : -1.f;
+        }
+        A2p[k] = f2{a[0], a[1]};
+        dh[k] = f2{0.f, 0.f};
+    }
+    float sdl = 0.f;
+    const int tc4 = (tid & 15) * 4, tr0 = tid >> 4;
+    const bool c_ok = (d0 + tc4) < p.Di;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c_ok && p.delta_bias) bv = ld4(p.delta_bias + d0 + tc4);
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int nchunk = (t_end - t_begin + TC - 1) / TC;
+    for (int ci = nchunk - 1; ci >= 0; --ci) {
+        const int c0 = t_begin + ci * TC;
+        __syncthreads();                             // the previous chunk's tiles are consumed
+#pragma unroll
+        for (int i = 0; i < PER_T; ++i) {
+            const int r = tr0 + i * (NT / 16);
+            const int t = c0 + r;
+            float4 dv = zero4, dy = zero4;
+            if (r < TC && t < t_end && c_ok) {
+                const int64_t tok = tok0 + t;
+                dv = ld4(p.delta + tok * p.ld_delta + d0 + tc4);
+                dy = ld4(p.dout + tok * p.ld_dout + d0 + tc4);
+                dv.x += bv.x; dv.y += bv.y; dv.z += bv.z; dv.w += bv.w;
+                if (p.softplus) { dv.x = softplus_nb(dv.x); dv.y = softplus_nb(dv.y); dv.z = softplus_nb(dv.z); dv.w = softplus_nb(dv.w); }
+                if (p.z) {
+                    const float4 zv = ld4(p.z + tok * p.ld_z + d0 + tc4);
+                    dy.x *= silu_nb(zv.x); dy.y *= silu_nb(zv.y); dy.z *= silu_nb(zv.z); dy.w *= silu_nb(zv.w);
+                }
+                if (p.start && p.start[tok] != 0.f) { const float inf = __builtin_inff(); dv = make_float4(inf, inf, inf, inf); }
+            }
+            if (r < TC) { st4(&s_dl[r][tc4], dv); st4(&s_dy[r][tc4], dy); }
+        }
+#pragma unroll
+        for (int i = 0; i < PER_BC; ++i) {
+            const int it = tid + i * NT;
+            const int t = c0 + it / (N / 4), c = (it % (N / 4)) * 4;
+            if (it < BC_ITEMS) st4(&s_C[0][0] + it * 4, t < t_end ? load_bc4(p.Cm, tok0 + t, p.ld_c, c, p.bc_vec) : zero4);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = TC - 1; t >= 0; --t) {
+            f2 Cq[NP];
+            lds_coef2<NS>(&s_C[t][w * NS], Cq);
+            const float dl = s_dl[t][lane], dy = s_dy[t][lane];
+            const f2 dl2 = {dl, dl}, dy2 = {dy, dy};
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const f2 arg = dl2 * A2p[k];
+                f2 dA;
+                dA.x = fast_exp2(arg.x);
+                dA.y = fast_exp2(arg.y);
+                dh[k] = __builtin_elementwise_fma(dy2, Cq[k], dh[k]) * dA;
+            }
+            sdl += dl;
+        }
+    }
+    if (d_ok) {
+        float* ho = p.dh_carry + (((int64_t)b * p.nseg + seg) * N + w * NS) * p.Di + d;
+#pragma unroll
+        for (int j = 0; j < NS; ++j) ho[(int64_t)j * p.Di] = (j & 1) ? dh[j / 2].y : dh[j / 2].x;
+        if (w == 0) p.sdl[((int64_t)b * p.nseg + seg) * p.Di + d] = sdl;
+    }
+}
+// dh_carry[b][s] (adjoint at the START of segment s for a zero adjoint at its end) -> adjoint entering the END of segment s
+__global__ void sscan_carry_rev_kernel(float* __restrict__ dh_carry, const float* __restrict__ sdl, const float* __restrict__ A, int B, int nseg, int N, int Di) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * N * Di) return;
+    const int d = (int)(i % Di), n = (int)((i / Di) % N), b = (int)(i / ((int64_t)Di * N));
+    const float a2 = fminf(A[(int64_t)d * N + n] * RESEL_LOG2E, -1e-30f);
+    float carry = 0.f;
+    for (int s = nseg - 1; s >= 0; --s) {
+        float* q = dh_carry + (((int64_t)b * nseg + s) * N + n) * Di + d;
+        const float loc = *q;
+        *q = carry;
+        carry = fast_exp2(a2 * sdl[((int64_t)b * nseg + s) * Di + d]) * carry + loc;
     }
 }
 
@@ -1106,43 +1018,64 @@ __global__ void sscan_reduce_bc_kernel(const float* __restrict__ part, int nd, i
     float* o = out + tok * ld + c;
     o[0] = acc.x; o[1] = acc.y; o[2] = acc.z; o[3] = acc.w;
 }
+// Time segments of the forward: one pass while the one-pass grid (B * nd workgroups, two fit a CU) covers ~3/4 of the chip's
+// 512 slots, otherwise enough segments to fill them (each at least two chunks long).  `force` > 0 overrides (tests).
+inline int fwd_segments(int B, int L, int nd, int TC, int force) {
+    const int max_seg = L / (2 * TC) > 0 ? L / (2 * TC) : 1;
+    int nseg = force > 0 ? force : (B * nd >= 384 ? 1 : (512 + B * nd - 1) / (B * nd));
+    if (nseg > max_seg) nseg = max_seg;
+    if (nseg <= 1) return 1;
+    const int seg_len = ((L + nseg - 1) / nseg + TC - 1) / TC * TC;
+    return (L + seg_len - 1) / seg_len;
+}
 template <int NS, int NW, int TC>
-int launch_fwd(const FwdParams& p, hipStream_t s) {
+int launch_fwd(FwdParams p, int force_seg, void* workspace, hipStream_t s) {
     const int bp = (p.B + 7) / 8 * 8;
-#ifdef SSCAN_FWD1
-    launch_maybe_timed(RESEL_PROF_SSCAN_FWD, sscan_fwd_kernel<NS, NW, TC>, dim3(bp * p.nd), dim3(NW * 64), s, p);
-#else
-    if constexpr (NS * NW == 32) {                   // two rows per workgroup (144 KB of LDS, one workgroup per CU): -DSSCAN_FWD_ROWS2
-#ifdef SSCAN_FWD_ROWS2
-        const int bp2 = ((p.B + 1) / 2 + 7) / 8 * 8;
-        launch_maybe_timed(RESEL_PROF_SSCAN_FWD, sscan_fwd2_kernel<NS, NW, TC, 2>, dim3(bp2 * p.nd), dim3(NW * 64 * 2), s, p);
+    const int nseg = fwd_segments(p.B, p.L, p.nd, TC, force_seg);
+    if (nseg <= 1) {
+        launch_maybe_timed(RESEL_PROF_SSCAN_FWD, sscan_fwd2_kernel<NS, NW, TC, 0>, dim3(bp * p.nd), dim3(NW * 64), s, p);
         return launch_status();
-#endif
     }
-    launch_maybe_timed(RESEL_PROF_SSCAN_FWD, sscan_fwd2_kernel<NS, NW, TC, 1>, dim3(bp * p.nd), dim3(NW * 64), s, p);
-#endif
+    if (!workspace) return RESEL_EINVAL;
+    p.nseg = nseg;
+    p.seg_len = ((p.L + nseg - 1) / nseg + TC - 1) / TC * TC;
+    p.h_carry = (float*)workspace;
+    p.sdl = p.h_carry + (size_t)p.B * nseg * p.N * p.Di;
+    launch_maybe_timed(RESEL_PROF_SSCAN_FWD, sscan_fwd2_kernel<NS, NW, TC, 1>, dim3(bp * p.nd, nseg), dim3(NW * 64), s, p);
+    const int64_t n = (int64_t)p.B * p.N * p.Di;
+    hipLaunchKernelGGL(sscan_carry_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p.h_carry, p.sdl, p.A, p.B, nseg, p.N, p.Di);
+    launch_maybe_timed(RESEL_PROF_SSCAN_FWD, sscan_fwd2_kernel<NS, NW, TC, 2>, dim3(bp * p.nd, nseg), dim3(NW * 64), s, p);
     return launch_status();
 }
 template <int NS, int NW>
 int launch_bwd(const BwdParams& p, hipStream_t s) {
     const int bp = (p.B + 7) / 8 * 8;
-    launch_maybe_timed(RESEL_PROF_SSCAN_BWD, sscan_bwd_kernel<NS, NW>, dim3(bp * p.nd), dim3(NW * 64), s, p);
+    if (p.nseg > 1) {                                // time-parallel form: local adjoint pass, carry, then the full pass per segment
+        hipLaunchKernelGGL((sscan_bwd_local_kernel<NS, NW, 32>), dim3(bp * p.nd, p.nseg), dim3(NW * 64), 0, s, p);
+        const int64_t n = (int64_t)p.B * p.N * p.Di;
+        hipLaunchKernelGGL(sscan_carry_rev_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p.dh_carry, p.sdl, p.A, p.B, p.nseg, p.N, p.Di);
+    }
+    launch_maybe_timed(RESEL_PROF_SSCAN_BWD, sscan_bwd_kernel<NS, NW>, dim3(bp * p.nd, p.nseg), dim3(NW * 64), s, p);
     return launch_status();
 }
 
 inline int n_ckpt(int L) { return (L - 1) / CKS; }   // checkpoints after steps CKS, 2*CKS, ... (< L)
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-struct BwdWs { size_t dB, dC, dA, dD, dbias, total; };
-inline BwdWs bwd_ws(int B, int L, int Di, int N) {
+struct BwdWs { size_t dB, dC, dA, dD, dbias, carry, sdl, total; int nseg; };
+inline BwdWs bwd_ws(int B, int L, int Di, int N, int force_seg) {
     const size_t nd = (Di + TILE_C - 1) / TILE_C;
     BwdWs w;
+    w.nseg = fwd_segments(B, L, (int)nd, 32, force_seg);
+    const size_t rows = (size_t)B * w.nseg;          // per-(row, segment) partials of the parameter gradients
     size_t o = 0;
     w.dB = o; o += align256(nd * (size_t)B * L * N * 4);
     w.dC = o; o += align256(nd * (size_t)B * L * N * 4);
-    w.dA = o; o += align256((size_t)B * Di * N * 4);
-    w.dD = o; o += align256((size_t)B * Di * 4);
-    w.dbias = o; o += align256((size_t)B * Di * 4);
+    w.dA = o; o += align256(rows * Di * N * 4);
+    w.dD = o; o += align256(rows * Di * 4);
+    w.dbias = o; o += align256(rows * Di * 4);
+    w.carry = o; o += w.nseg > 1 ? align256(rows * N * Di * 4) : 0;
+    w.sdl = o; o += w.nseg > 1 ? align256(rows * Di * 4) : 0;
     w.total = o;
     return w;
 }
@@ -1153,12 +1086,17 @@ extern "C" size_t resel_selective_scan_ckpt_bytes(int B, int L, int Di, int N) {
     return (size_t)B * (size_t)(n_ckpt(L) > 0 ? n_ckpt(L) : 0) * (size_t)N * (size_t)Di * sizeof(float);
 }
 
+extern "C" size_t resel_selective_scan_fwd_workspace_bytes(int B, int L, int Di, int N, int time_segments) {
+    const int nseg = fwd_segments(B, L, (Di + TILE_C - 1) / TILE_C, 32, time_segments);
+    return nseg > 1 ? ((size_t)B * nseg * N * Di + (size_t)B * nseg * Di) * sizeof(float) : 0;
+}
+
 extern "C" int resel_selective_scan_fwd(const float* u, int64_t ld_u, const float* delta, int64_t ld_delta,
                                         const float* z, int64_t ld_z, const float* A,
                                         const float* Bm, int64_t ld_b, const float* Cm, int64_t ld_c,
                                         const float* D, const float* delta_bias, const float* start,
-                                        float* out, int64_t ld_out, float* ckpt, float* last_state,
-                                        int B, int L, int Di, int N, int delta_softplus, resel_stream_t stream) {
+                                        float* out, int64_t ld_out, float* ckpt, float* last_state, void* workspace,
+                                        int B, int L, int Di, int N, int delta_softplus, int time_segments, resel_stream_t stream) {
     if (!u || !delta || !A || !Bm || !Cm || !out || B <= 0 || L <= 0 || Di <= 0) return RESEL_EINVAL;
     if (Di % 4 != 0 || ld_u % 4 || ld_delta % 4 || ld_out % 4 || (z && ld_z % 4)) return RESEL_EINVAL;
     if (!aligned16(u) || !aligned16(delta) || !aligned16(out) || (z && !aligned16(z))) return RESEL_EINVAL;
@@ -1166,23 +1104,23 @@ extern "C" int resel_selective_scan_fwd(const float* u, int64_t ld_u, const floa
     FwdParams p{u, delta, z, A, Bm, Cm, D, delta_bias, start, out, ckpt, last_state,
                 ld_u, ld_delta, ld_z, ld_b, ld_c, ld_out, B, L, Di, N, n_ckpt(L), delta_softplus,
                 (Di + TILE_C - 1) / TILE_C,
-                (ld_b % 4 == 0 && ld_c % 4 == 0 && aligned16(Bm) && aligned16(Cm)) ? 1 : 0};
+                (ld_b % 4 == 0 && ld_c % 4 == 0 && aligned16(Bm) && aligned16(Cm)) ? 1 : 0, 0, 1, nullptr, nullptr};
 #ifdef SSCAN_STAMP
     p.stamps = g_stamps;
 #endif
     hipStream_t s = (hipStream_t)stream;
     switch (N) {
-        case 4: return launch_fwd<1, 4, 32>(p, s);
-        case 8: return launch_fwd<2, 4, 32>(p, s);
-        case 16: return launch_fwd<4, 4, 32>(p, s);
-        case 32: return launch_fwd<8, 4, SSCAN_FWD_TC>(p, s);
-        case 64: return launch_fwd<8, 8, 32>(p, s);
+        case 4: return launch_fwd<1, 4, 32>(p, time_segments, workspace, s);
+        case 8: return launch_fwd<2, 4, 32>(p, time_segments, workspace, s);
+        case 16: return launch_fwd<4, 4, 32>(p, time_segments, workspace, s);
+        case 32: return launch_fwd<8, 4, 32>(p, time_segments, workspace, s);
+        case 64: return launch_fwd<8, 8, 32>(p, time_segments, workspace, s);
         default: return RESEL_EINVAL;
     }
 }
 
-extern "C" size_t resel_selective_scan_bwd_workspace_bytes(int B, int L, int Di, int N) {
-    return bwd_ws(B, L, Di, N).total;
+extern "C" size_t resel_selective_scan_bwd_workspace_bytes(int B, int L, int Di, int N, int time_segments) {
+    return bwd_ws(B, L, Di, N, time_segments).total;
 }
 
 extern "C" int resel_selective_scan_bwd(const float* u, int64_t ld_u, const float* delta, int64_t ld_delta,
@@ -1193,7 +1131,7 @@ extern "C" int resel_selective_scan_bwd(const float* u, int64_t ld_u, const floa
                                         float* du, int64_t ld_du, float* ddelta, int64_t ld_ddelta,
                                         float* dz, int64_t ld_dz, float* dBm, int64_t ld_db, float* dCm, int64_t ld_dc,
                                         float* dA, float* dD, float* ddelta_bias, void* workspace,
-                                        int B, int L, int Di, int N, int delta_softplus, resel_stream_t stream) {
+                                        int B, int L, int Di, int N, int delta_softplus, int time_segments, resel_stream_t stream) {
     if (!u || !delta || !A || !Bm || !Cm || !dout || !du || !ddelta || !dBm || !dCm || !dA || !workspace)
         return RESEL_EINVAL;
     if (B <= 0 || L <= 0 || Di <= 0 || Di % 4 != 0 || N % 4 != 0) return RESEL_EINVAL;
@@ -1205,14 +1143,16 @@ extern "C" int resel_selective_scan_bwd(const float* u, int64_t ld_u, const floa
         (z && (!aligned16(z) || !aligned16(dz))) || (D && !aligned16(D)) || (delta_bias && !aligned16(delta_bias)) ||
         !aligned16(workspace))
         return RESEL_EINVAL;
-    const BwdWs ws = bwd_ws(B, L, Di, N);
+    const BwdWs ws = bwd_ws(B, L, Di, N, time_segments);
     char* base = (char*)workspace;
     BwdParams p{u, delta, z, A, Bm, Cm, D, delta_bias, start, dout, ckpt, du, ddelta, dz,
                 (float*)(base + ws.dB), (float*)(base + ws.dC), (float*)(base + ws.dA), (float*)(base + ws.dD),
                 (float*)(base + ws.dbias),
                 ld_u, ld_delta, ld_z, ld_b, ld_c, ld_dout, ld_du, ld_ddelta, ld_dz,
                 B, L, Di, N, n_ckpt(L), delta_softplus, (Di + TILE_C - 1) / TILE_C,
-                (ld_b % 4 == 0 && ld_c % 4 == 0 && aligned16(Bm) && aligned16(Cm)) ? 1 : 0};
+                (ld_b % 4 == 0 && ld_c % 4 == 0 && aligned16(Bm) && aligned16(Cm)) ? 1 : 0,
+                ws.nseg > 1 ? ((L + ws.nseg - 1) / ws.nseg + 31) / 32 * 32 : L, ws.nseg,
+                ws.nseg > 1 ? (float*)(base + ws.carry) : nullptr, ws.nseg > 1 ? (float*)(base + ws.sdl) : nullptr};
     hipStream_t s = (hipStream_t)stream;
     int rc;
     switch (N) {
@@ -1231,8 +1171,8 @@ extern "C" int resel_selective_scan_bwd(const float* u, int64_t ld_u, const floa
     hipLaunchKernelGGL(sscan_reduce_bc_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s,
                        p.dC_part, p.nd, ntok, N, dCm, ld_dc);
     const int64_t na = (int64_t)Di * N;
-    launch_colsum(p.dA_part, na, B, (int)na, dA, s);
-    if (dD) launch_colsum(p.dD_part, Di, B, Di, dD, s);
-    if (ddelta_bias) launch_colsum(p.dbias_part, Di, B, Di, ddelta_bias, s);
+    launch_colsum(p.dA_part, na, B * ws.nseg, (int)na, dA, s);
+    if (dD) launch_colsum(p.dD_part, Di, B * ws.nseg, Di, dD, s);
+    if (ddelta_bias) launch_colsum(p.dbias_part, Di, B * ws.nseg, Di, ddelta_bias, s);
     return launch_status();
 }

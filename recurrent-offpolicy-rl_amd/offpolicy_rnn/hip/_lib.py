@@ -9,7 +9,7 @@ from ctypes import c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libresel_hip.so')
-ABI_VERSION = 2
+ABI_VERSION = 3
 _lib = None
 
 P, I, L, F, S, U = c_void_p, c_int, c_int64, c_float, c_void_p, c_uint64
@@ -21,10 +21,11 @@ SIGNATURES = {
     'resel_profile_enable': (c_int, [I]),
     'resel_profile_collect': (c_int, [I, P, P]),
     'resel_selective_scan_ckpt_bytes': (c_size_t, [I, I, I, I]),
-    'resel_selective_scan_fwd': (c_int, [P, L, P, L, P, L, P, P, L, P, L, P, P, P, P, L, P, P, I, I, I, I, I, S]),
-    'resel_selective_scan_bwd_workspace_bytes': (c_size_t, [I, I, I, I]),
+    'resel_selective_scan_fwd_workspace_bytes': (c_size_t, [I, I, I, I, I]),
+    'resel_selective_scan_fwd': (c_int, [P, L, P, L, P, L, P, P, L, P, L, P, P, P, P, L, P, P, P, I, I, I, I, I, I, S]),
+    'resel_selective_scan_bwd_workspace_bytes': (c_size_t, [I, I, I, I, I]),
     'resel_selective_scan_bwd': (c_int, [P, L, P, L, P, L, P, P, L, P, L, P, P, P, P, L, P,
-                                         P, L, P, L, P, L, P, L, P, L, P, P, P, P, I, I, I, I, I, S]),
+                                         P, L, P, L, P, L, P, L, P, L, P, P, P, P, I, I, I, I, I, I, S]),
     'resel_causal_conv1d_fwd': (c_int, [P, L, P, P, P, P, L, I, I, I, I, I, S]),
     'resel_causal_conv1d_bwd_workspace_bytes': (c_size_t, [I, I, I, I]),
     'resel_causal_conv1d_bwd': (c_int, [P, L, P, P, P, P, L, P, L, P, P, P, I, I, I, I, I, S]),

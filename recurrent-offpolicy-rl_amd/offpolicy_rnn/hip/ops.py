@@ -8,6 +8,7 @@ Layout: activations are token-major `[B, L, C]` (channel stride 1).  Column slic
 tensor (e.g. the `x` / `z` halves of `in_proj`'s output) are passed by stride, never copied.
 """
 import ctypes
+import os
 from typing import Optional
 
 import torch
@@ -73,6 +74,10 @@ def profile_collect():
 
 
 # ---------------------------------------------------------------------------------------------- selective scan
+# 0: the library cuts small batches into time segments scanned in parallel (resel_hip.h); 1: never; k > 1: k segments (tests)
+SSCAN_TIME_SEGMENTS = int(os.environ.get('RESEL_SSCAN_TIME_SEGMENTS', '0'))
+
+
 class SelectiveScanFn(torch.autograd.Function):
     """Token-major selective scan with start resets.  Interface counterpart of the reference's
     `SelectiveScanFn` (mamba_ssm/ops/selective_scan_interface_new.py:19-84)."""
@@ -94,11 +99,12 @@ class SelectiveScanFn(torch.autograd.Function):
         if need_grad:
             ck = _ws(lib().resel_selective_scan_ckpt_bytes(Bsz, L, Di, N), u.device)
         last = torch.empty(Bsz, Di, N, dtype=torch.float32, device=u.device) if return_last_state else None
+        nb = lib().resel_selective_scan_fwd_workspace_bytes(Bsz, L, Di, N, SSCAN_TIME_SEGMENTS)
         check(lib().resel_selective_scan_fwd(
             _p(u), u.stride(1), _p(delta), delta.stride(1), _p(z), 0 if z is None else z.stride(1), _p(A),
             _p(Bm), Bm.stride(1), _p(Cm), Cm.stride(1), _p(D), _p(delta_bias), _p(start),
-            _p(out), out.stride(1), _p(ck), _p(last), Bsz, L, Di, N, int(bool(delta_softplus)), _stream()),
-            'selective_scan_fwd')
+            _p(out), out.stride(1), _p(ck), _p(last), _p(_ws(nb, u.device) if nb else None), Bsz, L, Di, N, int(bool(delta_softplus)),
+            SSCAN_TIME_SEGMENTS, _stream()), 'selective_scan_fwd')
         ctx.save_for_backward(u, delta, A, Bm, Cm, D, z, delta_bias, start, ck)
         ctx.softplus = bool(delta_softplus)
         if return_last_state:
@@ -121,14 +127,14 @@ class SelectiveScanFn(torch.autograd.Function):
         dA = torch.empty(Di, N, dtype=torch.float32, device=dev)
         dD = torch.empty(Di, dtype=torch.float32, device=dev) if D is not None else None
         dbias = torch.empty(Di, dtype=torch.float32, device=dev) if delta_bias is not None else None
-        ws = _ws(lib().resel_selective_scan_bwd_workspace_bytes(Bsz, L, Di, N), dev)
+        ws = _ws(lib().resel_selective_scan_bwd_workspace_bytes(Bsz, L, Di, N, SSCAN_TIME_SEGMENTS), dev)
         check(lib().resel_selective_scan_bwd(
             _p(u), u.stride(1), _p(delta), delta.stride(1), _p(z), 0 if z is None else z.stride(1), _p(A),
             _p(Bm), Bm.stride(1), _p(Cm), Cm.stride(1), _p(D), _p(delta_bias), _p(start),
             _p(dout), dout.stride(1), _p(ck),
             _p(du), du.stride(1), _p(ddelta), ddelta.stride(1), _p(dz), 0 if dz is None else dz.stride(1),
             _p(dB), dB.stride(1), _p(dC), dC.stride(1), _p(dA), _p(dD), _p(dbias), _p(ws),
-            Bsz, L, Di, N, int(ctx.softplus), _stream()), 'selective_scan_bwd')
+            Bsz, L, Di, N, int(ctx.softplus), SSCAN_TIME_SEGMENTS, _stream()), 'selective_scan_bwd')
         return du, ddelta, dA, dB, dC, dD, dz, dbias, None, None, None
 
 
@@ -182,9 +188,10 @@ class MambaInnerFn(torch.autograd.Function):
         y = torch.empty(M, Di, dtype=torch.float32, device=x.device)
         zptr = ctypes.c_void_p(xz.data_ptr() + 4 * Di)
         bptr, cptr = ctypes.c_void_p(x_dbl.data_ptr() + 4 * R), ctypes.c_void_p(x_dbl.data_ptr() + 4 * (R + N))
+        nb = lib().resel_selective_scan_fwd_workspace_bytes(Bsz, L, Di, N, SSCAN_TIME_SEGMENTS)
         check(lib().resel_selective_scan_fwd(_p(xc), Di, _p(dt), Di, zptr, 2 * Di, _p(A), bptr, R + 2 * N, cptr, R + 2 * N,
-                                             _p(D), _p(dt_b), _p(startf), _p(y), Di, _p(ck), None, Bsz, L, Di, N, 1, _stream()),
-              'selective_scan_fwd')
+                                             _p(D), _p(dt_b), _p(startf), _p(y), Di, _p(ck), None, _p(_ws(nb, x.device) if nb else None),
+                                             Bsz, L, Di, N, 1, SSCAN_TIME_SEGMENTS, _stream()), 'selective_scan_fwd')
         out = torch.mm(y, out_w.t())
         ctx.save_for_backward(x2, in_w, cw, conv_b, xproj_w, dt_w, dt_b, A, D, out_w, maskf, startf, xz, xc, x_dbl, dt, y, ck)
         ctx.dims = (Bsz, L, Dm, Di, N, R, K, conv_w.shape)
@@ -208,13 +215,13 @@ class MambaInnerFn(torch.autograd.Function):
         dA = torch.empty(Di, N, dtype=torch.float32, device=dev)
         dD = torch.empty(Di, dtype=torch.float32, device=dev)
         ddt_b = torch.empty(Di, dtype=torch.float32, device=dev)
-        ws = _ws(lib().resel_selective_scan_bwd_workspace_bytes(Bsz, L, Di, N), dev)
+        ws = _ws(lib().resel_selective_scan_bwd_workspace_bytes(Bsz, L, Di, N, SSCAN_TIME_SEGMENTS), dev)
         P = lambda t, off: ctypes.c_void_p(t.data_ptr() + 4 * off)
         check(lib().resel_selective_scan_bwd(
             _p(xc), Di, _p(dt), Di, P(xz, Di), 2 * Di, _p(A), P(x_dbl, R), R + 2 * N, P(x_dbl, R + N), R + 2 * N,
             _p(D), _p(dt_b), _p(startf), _p(dy), Di, _p(ck),
             _p(dxc), Di, _p(ddt), Di, P(dxz, Di), 2 * Di, P(dx_dbl, R), R + 2 * N, P(dx_dbl, R + N), R + 2 * N,
-            _p(dA), _p(dD), _p(ddt_b), _p(ws), Bsz, L, Di, N, 1, _stream()), 'selective_scan_bwd')
+            _p(dA), _p(dD), _p(ddt_b), _p(ws), Bsz, L, Di, N, 1, SSCAN_TIME_SEGMENTS, _stream()), 'selective_scan_bwd')
         # [Di, R] with a 66 752-long reduction: hand-written MFMA kernel (the library reaches 7 TFLOP/s on this shape)
         d_dt_w = atb(ddt, x_dbl[:, :R]) if R <= 32 and Di % 4 == 0 and ddt.stride(1) == 1 and ddt.stride(0) % 4 == 0 \
             else torch.mm(ddt.t(), x_dbl[:, :R])

@@ -576,3 +576,37 @@ def test_gemm_f32_vs_fp64_product(ops, M, N, K, akc, bkc, bias, act, batch):
     close(out, ref.float(), rtol=1e-5, atol_scale=1e-6, name='gemm_f32')
     out2 = ops.gemm_f32(A.cuda(), B.cuda(), akc, bkc, None if b is None else b.cuda(), act)
     assert torch.equal(out, out2)                       # bitwise reproducible (no atomics)
+
+
+# ------------------------------------------------------------------------------------------ time-parallel selective scan
+@pytest.mark.parametrize('B,L,Di,N,segs', [(2, 333, 128, 32, 4), (1, 200, 64, 16, 3), (3, 1043, 64, 32, 0), (2, 97, 64, 8, 2)])
+def test_selective_scan_time_segments_equal_the_one_pass_scan(ops, monkeypatch, B, L, Di, N, segs):
+    """Small batches are cut into time segments scanned in parallel (local pass, carry of the segment states, final pass; the
+    backward: local adjoint pass, reverse carry, full pass per segment).  Forward, every gradient and the oracle agree;
+    resets fall inside and on the edges of segments; segs = 0 lets the library choose (it splits at these sizes)."""
+    g = torch.Generator().manual_seed(B * L + N)
+    u, delta, z = rnd(B, L, Di, g=g), rnd(B, L, Di, g=g, scale=0.5), rnd(B, L, Di, g=g)
+    Bm, Cm = rnd(B, L, N, g=g), rnd(B, L, N, g=g)
+    A, D, db = -torch.exp(rnd(Di, N, g=g, scale=0.3)), rnd(Di, g=g), rnd(Di, g=g, scale=0.1)
+    start = make_start(B, L, g, p=0.02)
+    start[0, 32] = 1
+    start[-1, min(L - 1, 64)] = 1
+    w = rnd(B, L, Di, g=g)
+    outs = []
+    for mode in (1, segs):
+        monkeypatch.setattr(ops, 'SSCAN_TIME_SEGMENTS', mode)
+        ins = [t.clone().cuda().requires_grad_(True) for t in (u, delta, A, Bm, Cm, D, z, db)]
+        out, last = ops.selective_scan_tm(*ins, start.cuda(), True, return_last_state=True)
+        (out * w.cuda()).sum().backward()
+        outs.append((out.detach(), last.detach(), [t.grad for t in ins]))
+    (o1, l1, g1), (o2, l2, g2) = outs
+    close(o2, o1.cpu(), rtol=1e-5, atol_scale=1e-6, name='out')
+    close(l2, l1.cpu(), rtol=1e-5, atol_scale=1e-6, name='last_state')
+    for a, b, nm in zip(g2, g1, ('du', 'ddelta', 'dA', 'dB', 'dC', 'dD', 'dz', 'dbias')):
+        close(a, b.cpu(), rtol=1e-4, atol_scale=1e-5, name=nm)
+    ref_in = [t.clone().requires_grad_(True) for t in (u, delta, A, Bm, Cm, D, z, db)]
+    ref, _ = K.selective_scan_ref(*ref_in, start, True)
+    (ref * w).sum().backward()
+    close(o2, ref, name='out vs oracle')
+    for a, b, nm in zip(g2, ref_in, ('du', 'ddelta', 'dA', 'dB', 'dC', 'dD', 'dz', 'dbias')):
+        close(a, b.grad, rtol=2e-4, atol_scale=5e-5, name=nm + ' vs oracle')

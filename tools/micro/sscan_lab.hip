@@ -2,8 +2,9 @@
 // configs[1] size without torch, checks a few (row, channel) columns against a double-precision host recurrence and times
 // the launches with HIP events.  Lets kernel variants (-D switches) be compared in seconds on a gpurun box.
 // Build (here or on the box): hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize tools/micro/sscan_lab.hip -o tools/micro/bin/sscan_lab
-// Run: sscan_lab [B=64] [L=1043] [Di=512] [N=32] [reps=20] [bwd=1]
+// Run: sscan_lab [B=64] [L=1043] [Di=512] [N=32] [reps=20] [bwd=1] [time segments: 0 auto, 1 off, k]
 #include "../../recurrent-offpolicy-rl_amd/csrc/selective_scan.hip"
+#include "../../recurrent-offpolicy-rl_amd/csrc/misc.hip"          // the per-dispatch timing registry the launches refer to
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -20,6 +21,7 @@ int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 64, L = argc > 2 ? atoi(argv[2]) : 1043, Di = argc > 3 ? atoi(argv[3]) : 512,
               N = argc > 4 ? atoi(argv[4]) : 32, reps = argc > 5 ? atoi(argv[5]) : 20, do_bwd = argc > 6 ? atoi(argv[6]) : 1;
     const int R = 16, ldx = 2 * Di, ldb = R + 2 * N;
+    const int tseg = argc > 7 ? atoi(argv[7]) : 0;
     std::mt19937 g(1);
     std::normal_distribution<float> nd(0.f, 1.f);
     std::vector<float> xz((size_t)B * L * ldx), xdbl((size_t)B * L * ldb), delta((size_t)B * L * Di), A((size_t)Di * N), Dp(Di), db(Di),
@@ -46,16 +48,18 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&d_ddelta, (size_t)B * L * Di * 4));
     CK(hipMalloc(&d_dxdbl, (size_t)B * L * ldb * 4));
     CK(hipMalloc(&d_dA, (size_t)Di * N * 4)); CK(hipMalloc(&d_dD, Di * 4)); CK(hipMalloc(&d_ddb, Di * 4));
-    CK(hipMalloc(&d_ws, resel_selective_scan_bwd_workspace_bytes(B, L, Di, N)));
+    CK(hipMalloc(&d_ws, resel_selective_scan_bwd_workspace_bytes(B, L, Di, N, argc > 7 ? atoi(argv[7]) : 0)));
     hipStream_t s = 0;
+    void* d_fws = nullptr;
+    { const size_t nb = resel_selective_scan_fwd_workspace_bytes(B, L, Di, N, tseg); if (nb) CK(hipMalloc(&d_fws, nb)); printf("forward time segments workspace: %zu bytes\n", nb); }
     auto fwd = [&]() {
         return resel_selective_scan_fwd(d_xz, ldx, d_delta, Di, d_xz + Di, ldx, d_A, d_xdbl + R, ldb, d_xdbl + R + N, ldb, d_D, d_db, d_start,
-                                        d_out, Di, d_ckpt, nullptr, B, L, Di, N, 1, s);
+                                        d_out, Di, d_ckpt, nullptr, d_fws, B, L, Di, N, 1, tseg, s);
     };
     auto bwd = [&]() {
         return resel_selective_scan_bwd(d_xz, ldx, d_delta, Di, d_xz + Di, ldx, d_A, d_xdbl + R, ldb, d_xdbl + R + N, ldb, d_D, d_db, d_start,
                                         d_dout, Di, d_ckpt, d_dxz, ldx, d_ddelta, Di, d_dxz + Di, ldx, d_dxdbl + R, ldb, d_dxdbl + R + N, ldb,
-                                        d_dA, d_dD, d_ddb, d_ws, B, L, Di, N, 1, s);
+                                        d_dA, d_dD, d_ddb, d_ws, B, L, Di, N, 1, tseg, s);
     };
 #ifdef SSCAN_STAMP
     const size_t nst = (size_t)((B + 7) / 8 * 8) * ((Di + 63) / 64) * 8 * 8;
@@ -155,7 +159,10 @@ int main(int argc, char** argv) {
         for (size_t i = 0; i < dde.size(); i += 101) c2 += dde[i];
         for (size_t tok = 0; tok < (size_t)B * L; tok += 7) for (int n = 0; n < 2 * N; ++n) c3 += dxd[tok * ldb + R + n];
         for (size_t i = 0; i < dA.size(); ++i) c4 += dA[i];
-        printf("bwd checksums: dxz %.6f ddelta %.6f dBC %.6f dA %.6f\n", c1, c2, c3, c4);
+        std::vector<float> dDv(Di), ddbv(Di);
+        CK(hipMemcpy(dDv.data(), d_dD, Di * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(ddbv.data(), d_ddb, Di * 4, hipMemcpyDeviceToHost));
+        double c5 = 0, c6 = 0; for (int i = 0; i < Di; ++i) { c5 += dDv[i]; c6 += ddbv[i]; }
+        printf("bwd checksums: dxz %.6f ddelta %.6f dBC %.6f dA %.6f dD %.6f dbias %.6f\n", c1, c2, c3, c4, c5, c6);
         for (int i = 0; i < 2; ++i) bwd();
         CK(hipEventRecord(e0, s));
         for (int i = 0; i < reps; ++i) bwd();
