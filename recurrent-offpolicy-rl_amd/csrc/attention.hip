@@ -207,10 +207,16 @@ __global__ __launch_bounds__(256) void attn_q_kernel(AttnParams p) {
     f32x16 acc[ND];
 #pragma unroll
     for (int t = 0; t < ND; ++t) acc[t] = zero16();
-    // ALiBi: -slope * (q - key) = slope * row(i) - slope * (q - k0); the first term is a per-lane constant per register
+    // The score accumulator STARTS from the constants of its row and tile, in raw (pre-scale) units: the ALiBi term
+    // -slope (q - key) = slope row(i) - slope (q - k0) (a per-lane constant per register + a per-tile scalar) and, in the dQ
+    // pass, -lse; exp2(acc * c1 [- m]) then needs one multiply-add per score and no separate bias / lse arithmetic (the
+    // constants replace the zero fill, instruction for instruction).  dP starts from -delta the same way.
+    const float inv_c1 = 1.f / c1;
     float crow[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) crow[i] = slope2 * (float)acc_row(i, hh);
+    for (int i = 0; i < 16; ++i) crow[i] = slope2 * inv_c1 * (float)acc_row(i, hh);
+    const float lse_c = MODE == 1 ? lse2 * inv_c1 : 0.f;
+    constexpr float RESCALE_THR = 5.f;              // forward: rescale the running sums only when a maximum grows by > 2^5
 
     // dropout: per-lane query word and the four key-quad offsets of a tile (rows 8g + 4hh + {0..3} = keys of one quad)
     uint32_t dq_word = 0, dk_off[4] = {0, 0, 0, 0};
@@ -232,28 +238,17 @@ __global__ __launch_bounds__(256) void attn_q_kernel(AttnParams p) {
       for (int sub = 0; sub < KTB / KT; ++sub) {
         const int k0 = kb + sub * KT, ko = sub * KT;
         if (k0 > wq_hi || k0 >= nkeys) break;                    // the rest lies in this wave's future (uniform per wave)
-        f32x16 st = zero16();
+        const bool masked = (k0 + KT - 1 > wq_lo) || (wq_hi >= len);          // tile crosses the diagonal / the sequence end
+        const float base = -slope2 * inv_c1 * (float)(q - k0) - lse_c;
+        f32x16 st;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) st[i] = crow[i] + base;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
             st = mfma(*reinterpret_cast<const bf16x8*>(&k_lds[ko + r][16 * ks + 8 * hh]), qf[ks], st);
-        // scaled + biased (+ masked) scores, base 2
-        const bool masked = (k0 + KT - 1 > wq_lo) || (wq_hi >= len);          // tile crosses the diagonal / the sequence end
-        const float off = -slope2 * (float)(q - k0);
-        float sc[16];
-        float mloc = NEG_BIG;
         if (masked) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const bool ok = q_ok && (k0 + acc_row(i, hh)) <= q;       // (key <= q < len)
-                sc[i] = ok ? __builtin_fmaf(st[i], c1, crow[i] + off) : NEG_BIG;
-                mloc = fmaxf(mloc, sc[i]);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                sc[i] = __builtin_fmaf(st[i], c1, crow[i] + off);
-                mloc = fmaxf(mloc, sc[i]);
-            }
+            for (int i = 0; i < 16; ++i) st[i] = (q_ok && (k0 + acc_row(i, hh)) <= q) ? st[i] : NEG_BIG;      // (key <= q < len)
         }
         uint32_t dw[4] = {0, 0, 0, 0};
         if (DROP) {
@@ -263,58 +258,47 @@ __global__ __launch_bounds__(256) void attn_q_kernel(AttnParams p) {
         }
         f32x16 pt;
         if (MODE == 0) {
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-            const float mnew = fmaxf(m, mloc);
-            float psum = 0.f;
-            if (masked) {
+            float mloc = fmaxf(fmaxf(st[0], st[1]), st[2]);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float e = sc[i] > 0.5f * NEG_BIG ? fast_exp2(sc[i] - mnew) : 0.f;
-                    pt[i] = e;
-                    psum += e;
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float e = fast_exp2(sc[i] - mnew);
-                    pt[i] = e;
-                    psum += e;
-                }
-            }
-            if (__any(mnew != m)) {                              // some lane's maximum moved: rescale the running sums
+            for (int i = 3; i < 15; i += 2) mloc = fmaxf(fmaxf(mloc, st[i]), st[i + 1]);
+            mloc = fmaxf(mloc, st[15]);
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64)) * c1;
+            if (__any(mloc > m + RESCALE_THR)) {                 // some lane's maximum grew past the threshold: rescale the running sums
+                const float mnew = fmaxf(m, mloc);
                 const float alpha = fast_exp2(m - mnew);
                 l *= alpha;
 #pragma unroll
                 for (int t = 0; t < ND; ++t)
 #pragma unroll
                     for (int i = 0; i < 16; ++i) acc[t][i] *= alpha;
+                m = mnew;
+            }
+            const float negm = -m;
+            float psum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {                       // masked scores (-1e30) give exp2(-huge) = 0 by themselves
+                pt[i] = fast_exp2(__builtin_fmaf(st[i], c1, negm));
+                psum += pt[i];
             }
             l += psum;
-            m = mnew;
             if (DROP) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) pt[i] = ((dw[i >> 2] >> (8 * (i & 3))) & 0xffu) < p.thr ? pt[i] : 0.f;
             }
         } else {
-            // dP^T = V dO^T ; dS^T = P^T (dP^T - delta) * scale
-            f32x16 dp = zero16();
+            // dP^T = V dO^T ; dS^T = P^T (dP^T - delta)   (the 1/sqrt(d) factor of dS is applied once, to dQ, in the epilogue)
+            f32x16 dp;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dp[i] = DROP ? 0.f : -dlt;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
                 dp = mfma(*reinterpret_cast<const bf16x8*>(&v_lds[ko + r][16 * ks + 8 * hh]), dof[ks], dp);
-            if (DROP) {                                          // dP = mask / (1 - p) * (dO V^T)
+            if (DROP) {                                          // dP = mask / (1 - p) * (dO V^T), then - delta
 #pragma unroll
-                for (int i = 0; i < 16; ++i) dp[i] = ((dw[i >> 2] >> (8 * (i & 3))) & 0xffu) < p.thr ? dp[i] * p.rp : 0.f;
+                for (int i = 0; i < 16; ++i) dp[i] = (((dw[i >> 2] >> (8 * (i & 3))) & 0xffu) < p.thr ? dp[i] * p.rp : 0.f) - dlt;
             }
-            if (masked) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float e = sc[i] > 0.5f * NEG_BIG ? fast_exp2(sc[i] - lse2) : 0.f;
-                    pt[i] = e * (dp[i] - dlt) * p.scale;
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) pt[i] = fast_exp2(sc[i] - lse2) * (dp[i] - dlt) * p.scale;
-            }
+            for (int i = 0; i < 16; ++i) pt[i] = fast_exp2(st[i] * c1) * dp[i];
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -325,7 +309,7 @@ __global__ __launch_bounds__(256) void attn_q_kernel(AttnParams p) {
       }
     }
     // epilogue: acc[t][reg] = X^T[d = 32t + row(reg)][q]
-    float inv = 1.f;
+    float inv = MODE == 1 ? p.scale : 1.f;
     if (MODE == 0) {
         const float ltot = l + __shfl_xor(l, 32, 64);
         inv = ltot > 0.f ? (DROP ? p.rp : 1.f) / ltot : 0.f;
@@ -392,9 +376,12 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnParams p) {
     f32x16 dkt[ND], dvt[ND];
 #pragma unroll
     for (int t = 0; t < ND; ++t) { dkt[t] = zero16(); dvt[t] = zero16(); }
-    float crow[16];                                              // ALiBi: -slope (q - key) = -slope row(i) - slope (q0 - key)
+    // as in attn_q_kernel the accumulators start from the row constants (raw units): ALiBi -slope (q - key) = -slope row(i) -
+    // slope (q0 - key), -lse of the query row (staged per tile as -lse / c1) for the scores and -delta for dP
+    const float inv_c1 = 1.f / c1;
+    float crow[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) crow[i] = -slope2 * (float)acc_row(i, hh);
+    for (int i = 0; i < 16; ++i) crow[i] = -slope2 * inv_c1 * (float)acc_row(i, hh);
     // dropout: the word of (query row, this lane's key quad) serves the four lanes of a quad, one byte each; a lane
     // hashes the rows with (row & 3) == (lane & 3) and the quad exchanges them by DPP
     uint32_t dk_word = 0, dq_off[4] = {0, 0, 0, 0};
@@ -428,7 +415,7 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnParams p) {
             dlq = p.delta[(int64_t)h * p.T + t0 + qa];
         }
         __syncthreads();                                         // previous iteration's transposed tiles fully consumed
-        if (hh == 0) { s_lse[w][r] = l2q; s_dlt[w][r] = dlq; }
+        if (hh == 0) { s_lse[w][r] = -l2q * inv_c1; s_dlt[w][r] = -dlq; }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -438,11 +425,18 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnParams p) {
             }
         __syncthreads();
         if (!active) continue;
-        f32x16 sacc = zero16(), dp = zero16();
+        const float offk = -slope2 * inv_c1 * (float)(q0 - key);
+        f32x16 sacc, dp;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = acc_row(i, hh);
+            sacc[i] = crow[i] + offk + s_lse[w][row];
+            dp[i] = DROP ? 0.f : s_dlt[w][row];
+        }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            sacc = mfma(qa_f[ks], kf[ks], sacc);                 // S[q][key]
-            dp = mfma(doa_f[ks], vf[ks], dp);                    // dP[q][key]
+            sacc = mfma(qa_f[ks], kf[ks], sacc);                 // S[q][key] (+ ALiBi - lse, raw units)
+            dp = mfma(doa_f[ks], vf[ks], dp);                    // dP[q][key] - delta
         }
         f32x16 pm, ds;
         bool keep[16];
@@ -459,26 +453,24 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnParams p) {
                 keep[4 * g + 3] = ((quad_bcast<3>(mine[g]) >> dsh) & 0xffu) < p.thr;
             }
 #pragma unroll
-            for (int i = 0; i < 16; ++i) dp[i] = keep[i] ? dp[i] * p.rp : 0.f;
+            for (int i = 0; i < 16; ++i) dp[i] = (keep[i] ? dp[i] * p.rp : 0.f) + s_dlt[w][acc_row(i, hh)];
         }
         const bool masked = (q0 < k0 + KT - 1) || (q0 + KT > len) || (k0 + KT > len);      // diagonal tile or ragged end (wave-uniform)
-        const float off = -slope2 * (float)(q0 - key);
         if (masked) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int row = acc_row(i, hh), qq = q0 + row;
+                const int qq = q0 + acc_row(i, hh);
                 const bool ok = k_ok && qq < len && key <= qq;
-                const float e = ok ? fast_exp2(__builtin_fmaf(sacc[i], c1, crow[i] + off) - s_lse[w][row]) : 0.f;
+                const float e = ok ? fast_exp2(sacc[i] * c1) : 0.f;
                 pm[i] = e;
-                ds[i] = e * (dp[i] - s_dlt[w][row]) * p.scale;
+                ds[i] = e * dp[i];
             }
         } else {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int row = acc_row(i, hh);
-                const float e = fast_exp2(__builtin_fmaf(sacc[i], c1, crow[i] + off) - s_lse[w][row]);
+                const float e = fast_exp2(sacc[i] * c1);
                 pm[i] = e;
-                ds[i] = e * (dp[i] - s_dlt[w][row]) * p.scale;
+                ds[i] = e * dp[i];
             }
         }
         if (DROP) {                                              // dV sees the dropped, rescaled probabilities
@@ -515,7 +507,8 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnParams p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int i = 4 * g + e;
-                v[e] = (s_red[0][pair][i][lane] + s_red[1][pair][i][lane]) + (s_red[2][pair][i][lane] + s_red[3][pair][i][lane]);
+                v[e] = ((s_red[0][pair][i][lane] + s_red[1][pair][i][lane]) + (s_red[2][pair][i][lane] + s_red[3][pair][i][lane])) *
+                       (which == 1 ? p.scale : 1.f);                  // dK carries the 1/sqrt(d) of dS
             }
             *reinterpret_cast<bf16x4*>(dst + 8 * g + 4 * hh) = __builtin_convertvector(v, bf16x4);
         }
