@@ -160,7 +160,6 @@ __global__ __launch_bounds__(NW * 64) void sscan_fwd2_kernel(FwdParams p) {
 
     int b, dt;
     if (!decode_block(blockIdx.x, p.nd, p.B, b, dt)) return;
-    constexpr bool row_ok = true;
     const int seg = MODE == 0 ? 0 : (int)blockIdx.y;
     const int t_begin = MODE == 0 ? 0 : seg * p.seg_len;
     const int t_end = MODE == 0 ? p.L : min(p.L, t_begin + p.seg_len);
@@ -344,7 +343,7 @@ __global__ __launch_bounds__(NW * 64) void sscan_fwd2_kernel(FwdParams p) {
         for (int i = 0; i < PER_T; ++i) {
             const int r = tr0 + i * (NT / 16);
             const int t = c0 + r;
-            if (t < t_end && c_ok && row_ok) {
+            if (t < t_end && c_ok) {
                 float4 y = ld4(&s_y[0][r][tc4]);
 #pragma unroll
                 for (int ww = 1; ww < NW; ++ww) {
@@ -371,7 +370,7 @@ __global__ __launch_bounds__(NW * 64) void sscan_fwd2_kernel(FwdParams p) {
                 for (int q = 0; q < (N * 16 + NT - 1) / NT; ++q) {
                     const int it = tid + q * NT;
                     const int n = it >> 4, c4 = (it & 15) * 4;
-                    if (tabs < p.L && tabs <= t_end && it < N * 16 && d0 + c4 < p.Di && row_ok) {
+                    if (tabs < p.L && tabs <= t_end && it < N * 16 && d0 + c4 < p.Di) {
                         ck_keep[e * ((N * 16 + NT - 1) / NT) + q] = ld4(&s_ck[e][n][c4]);
                         st4(dst + (int64_t)n * p.Di + c4, ck_keep[e * ((N * 16 + NT - 1) / NT) + q]);
                     }
@@ -396,7 +395,7 @@ __global__ __launch_bounds__(NW * 64) void sscan_fwd2_kernel(FwdParams p) {
         }
         return;
     }
-    if (p.last_state != nullptr && d_ok && row_ok && t_end == p.L) {
+    if (p.last_state != nullptr && d_ok && t_end == p.L) {
 #pragma unroll
         for (int j = 0; j < NS; ++j)
             p.last_state[((int64_t)b * p.Di + d) * N + w * NS + j] = (j & 1) ? hp[j / 2].y : hp[j / 2].x;
