@@ -7,13 +7,15 @@
 // the affine map h_out = a * h_in + c, the 16 maps are composed through LDS, pass 2 replays the segment from
 // its true incoming state and writes the result.  The composition is exact algebra on the same fp32
 // operations, start-resets are folded into the gate (f := 0), and nothing is atomic.
+// Small batches (configs[4]: B = 16, C = 256 is 64 such workgroups on 256 CUs): the lanes of a wave are split CL channels x
+// 64 / CL time segments (CL = 64, 32 or 16, chosen by the launcher so that (C / CL) * B workgroups fill the chip): a workgroup
+// then owns CL channels and 16 * 64 / CL time segments; a wave access is 64 / CL row pieces of 4 CL bytes.
 #include "resel_common.h"
 
 namespace {
 using namespace resel;
 
 constexpr int NSEG = 16;            // waves (= time segments) per workgroup
-constexpr int TILE_C = 64;
 
 __device__ __forceinline__ float tanhf_(float x) {
     const float e = fast_exp(-2.0f * fabsf(x));                 // tanh|x| = (1 - e) / (1 + e)
@@ -24,8 +26,9 @@ __device__ __forceinline__ float tanhf_(float x) {
 struct Seg {
     int t0, t1;
 };
+template <int NST>
 __device__ __forceinline__ Seg segment(int w, int L) {
-    const int len = (L + NSEG - 1) / NSEG;
+    const int len = (L + NST - 1) / NST;
     Seg s;
     s.t0 = min(L, w * len);
     s.t1 = min(L, s.t0 + len);
@@ -46,19 +49,20 @@ __device__ __forceinline__ void gilr_gate(float vraw, float fraw, float keep, in
     fe = (act ? sigmoidf_(fraw) : fraw) * keep;
 }
 
-template <bool ACT>
+template <bool ACT, int CL>
 __global__ __launch_bounds__(NSEG * 64) void linrec_real_fwd_kernel(const float* __restrict__ v, const float* __restrict__ f,
                                                                     const float* __restrict__ start, const float* __restrict__ h0,
                                                                     float* __restrict__ h, int B, int L, int C) {
     constexpr int act = ACT ? 1 : 0;
-    __shared__ float s_a[NSEG][TILE_C], s_c[NSEG][TILE_C];
+    constexpr int NST = NSEG * 64 / CL;                          // time segments of this workgroup
+    __shared__ float s_a[NST][CL], s_c[NST][CL];
     extern __shared__ float s_keep[];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int b = blockIdx.y, c = blockIdx.x * TILE_C + lane;
+    const int lane = threadIdx.x & (CL - 1), w = (threadIdx.x >> 6) * (64 / CL) + ((threadIdx.x & 63) / CL);   // channel, time segment
+    const int b = blockIdx.y, c = blockIdx.x * CL + lane;
     stage_keep(s_keep, start, b, L);
     const bool ok = c < C;
     const int64_t base = (int64_t)b * L * C + c;
-    const Seg sg = segment(w, L);
+    const Seg sg = segment<NST>(w, L);
     float a = 1.f, hl = 0.f;
     if (ok) {
 #pragma unroll 8
@@ -87,21 +91,22 @@ __global__ __launch_bounds__(NSEG * 64) void linrec_real_fwd_kernel(const float*
 }
 
 // g_t = dh_t + f_{t+1} g_{t+1} ;  dv_t = g_t (1 - f_t) ;  df_t = g_t (h_{t-1} - v_t)   (then through tanh / sigmoid)
-template <bool ACT>
+template <bool ACT, int CL>
 __global__ __launch_bounds__(NSEG * 64) void linrec_real_bwd_kernel(const float* __restrict__ v, const float* __restrict__ f,
                                                                     const float* __restrict__ start, const float* __restrict__ h0,
                                                                     const float* __restrict__ h, const float* __restrict__ dh,
                                                                     float* __restrict__ dv, float* __restrict__ df,
                                                                     int B, int L, int C) {
     constexpr int act = ACT ? 1 : 0;
-    __shared__ float s_a[NSEG][TILE_C], s_c[NSEG][TILE_C];
+    constexpr int NST = NSEG * 64 / CL;                          // time segments of this workgroup
+    __shared__ float s_a[NST][CL], s_c[NST][CL];
     extern __shared__ float s_keep[];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int b = blockIdx.y, c = blockIdx.x * TILE_C + lane;
+    const int lane = threadIdx.x & (CL - 1), w = (threadIdx.x >> 6) * (64 / CL) + ((threadIdx.x & 63) / CL);   // channel, time segment
+    const int b = blockIdx.y, c = blockIdx.x * CL + lane;
     stage_keep(s_keep, start, b, L);
     const bool ok = c < C;
     const int64_t base = (int64_t)b * L * C + c;
-    const Seg sg = segment(w, L);
+    const Seg sg = segment<NST>(w, L);
     auto gate_f = [&](int t) -> float {                          // effective gate f_t (0 beyond the row end: keep sentinel)
         const float fr = f[base + (int64_t)min(t, L - 1) * C];
         return (act ? sigmoidf_(fr) : fr) * s_keep[t];
@@ -120,7 +125,7 @@ __global__ __launch_bounds__(NSEG * 64) void linrec_real_bwd_kernel(const float*
     s_c[w][lane] = gl;
     __syncthreads();
     float gin = 0.f;                                              // g just right of this segment
-    for (int ww = NSEG - 1; ww > w; --ww) gin = __builtin_fmaf(s_a[ww][lane], gin, s_c[ww][lane]);
+    for (int ww = NST - 1; ww > w; --ww) gin = __builtin_fmaf(s_a[ww][lane], gin, s_c[ww][lane]);
     if (ok && sg.t1 > sg.t0) {
         float g = gin;
         float fnext = gate_f(sg.t1);
@@ -149,19 +154,21 @@ __global__ __launch_bounds__(NSEG * 64) void linrec_real_bwd_kernel(const float*
 }
 
 // --------------------------------------------------------------------------------------- complex (lru)
+template <int CL>
 __global__ __launch_bounds__(NSEG * 64) void linrec_complex_fwd_kernel(const float* __restrict__ vr, const float* __restrict__ vi,
                                                                        const float* __restrict__ lam_re, const float* __restrict__ lam_im,
                                                                        const float* __restrict__ gamma, const float* __restrict__ start,
                                                                        const float* __restrict__ h0r, const float* __restrict__ h0i,
                                                                        float* __restrict__ hr, float* __restrict__ hi, int B, int L, int C) {
-    __shared__ float s_ar[NSEG][TILE_C], s_ai[NSEG][TILE_C], s_cr[NSEG][TILE_C], s_ci[NSEG][TILE_C];
+    constexpr int NST = NSEG * 64 / CL;
+    __shared__ float s_ar[NST][CL], s_ai[NST][CL], s_cr[NST][CL], s_ci[NST][CL];
     extern __shared__ float s_keep[];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int b = blockIdx.y, c = blockIdx.x * TILE_C + lane;
+    const int lane = threadIdx.x & (CL - 1), w = (threadIdx.x >> 6) * (64 / CL) + ((threadIdx.x & 63) / CL);   // channel, time segment
+    const int b = blockIdx.y, c = blockIdx.x * CL + lane;
     stage_keep(s_keep, start, b, L);
     const bool ok = c < C;
     const int64_t base = (int64_t)b * L * C + c;
-    const Seg sg = segment(w, L);
+    const Seg sg = segment<NST>(w, L);
     const float lr = ok ? lam_re[c] : 0.f, li = ok ? lam_im[c] : 0.f, gm = (ok && gamma) ? gamma[c] : 1.f;
     float ar = 1.f, ai = 0.f, cr = 0.f, ci = 0.f;
     if (ok) {
@@ -200,6 +207,7 @@ __global__ __launch_bounds__(NSEG * 64) void linrec_complex_fwd_kernel(const flo
 }
 
 // g_t = dh_t + conj(f_{t+1}) g_{t+1} ; dv = gamma g ; dgamma += Re(g conj(v_raw)) ; dlambda += (1 - s_t) g conj(h_{t-1})
+template <int CL>
 __global__ __launch_bounds__(NSEG * 64) void linrec_complex_bwd_kernel(const float* __restrict__ vr, const float* __restrict__ vi,
                                                                        const float* __restrict__ lam_re, const float* __restrict__ lam_im,
                                                                        const float* __restrict__ gamma, const float* __restrict__ start,
@@ -208,14 +216,15 @@ __global__ __launch_bounds__(NSEG * 64) void linrec_complex_bwd_kernel(const flo
                                                                        const float* __restrict__ dhr, const float* __restrict__ dhi,
                                                                        float* __restrict__ dvr, float* __restrict__ dvi,
                                                                        float* __restrict__ part, int B, int L, int C) {
-    __shared__ float s_ar[NSEG][TILE_C], s_ai[NSEG][TILE_C], s_cr[NSEG][TILE_C], s_ci[NSEG][TILE_C];
+    constexpr int NST = NSEG * 64 / CL;
+    __shared__ float s_ar[NST][CL], s_ai[NST][CL], s_cr[NST][CL], s_ci[NST][CL];
     extern __shared__ float s_keep[];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int b = blockIdx.y, c = blockIdx.x * TILE_C + lane;
+    const int lane = threadIdx.x & (CL - 1), w = (threadIdx.x >> 6) * (64 / CL) + ((threadIdx.x & 63) / CL);   // channel, time segment
+    const int b = blockIdx.y, c = blockIdx.x * CL + lane;
     stage_keep(s_keep, start, b, L);
     const bool ok = c < C;
     const int64_t base = (int64_t)b * L * C + c;
-    const Seg sg = segment(w, L);
+    const Seg sg = segment<NST>(w, L);
     const float lr = ok ? lam_re[c] : 0.f, li = ok ? lam_im[c] : 0.f, gm = (ok && gamma) ? gamma[c] : 1.f;
     auto keep_at = [&](int t) -> float { return s_keep[t]; };          // sentinel slot L holds 0
     float ar = 1.f, ai = 0.f, gr = 0.f, gi = 0.f;
@@ -234,7 +243,7 @@ __global__ __launch_bounds__(NSEG * 64) void linrec_complex_bwd_kernel(const flo
     s_ar[w][lane] = ar; s_ai[w][lane] = ai; s_cr[w][lane] = gr; s_ci[w][lane] = gi;
     __syncthreads();
     float xr0 = 0.f, xi0 = 0.f;
-    for (int ww = NSEG - 1; ww > w; --ww) {
+    for (int ww = NST - 1; ww > w; --ww) {
         const float pr = s_ar[ww][lane], pi = s_ai[ww][lane];
         const float nr = pr * xr0 - pi * xi0 + s_cr[ww][lane], ni = pr * xi0 + pi * xr0 + s_ci[ww][lane];
         xr0 = nr; xi0 = ni;
@@ -260,22 +269,33 @@ __global__ __launch_bounds__(NSEG * 64) void linrec_complex_bwd_kernel(const flo
             kn = kt;
         }
     }
-    // per-(b, segment) partials of the per-channel parameter gradients: [B, NSEG, 3, C]
+    // per-(b, segment) partials of the per-channel parameter gradients: [B, NST, 3, C]
     if (ok) {
-        float* o = part + (((int64_t)b * NSEG + w) * 3) * C + c;
+        float* o = part + (((int64_t)b * NST + w) * 3) * C + c;
         o[0] = dlr; o[(int64_t)C] = dli; o[2 * (int64_t)C] = dgm;
     }
 }
+
+// channels per wave: the widest split whose grid still fills the chip
+inline int pick_cl(int B, int C) {
+    if ((int64_t)((C + 63) / 64) * B >= 256) return 64;
+    if ((int64_t)((C + 31) / 32) * B >= 256) return 32;
+    return 16;
+}
+#define LINREC_DISPATCH(CLV, CALL) do { if ((CLV) == 64) { constexpr int CL = 64; CALL; } else if ((CLV) == 32) { constexpr int CL = 32; CALL; } \
+                                        else { constexpr int CL = 16; CALL; } } while (0)
 
 }  // namespace
 
 extern "C" int resel_linrec_real_fwd(const float* v, const float* f, const float* start, const float* h0, float* h,
                                      int B, int L, int C, int fuse_act, resel_stream_t stream) {
     if (!v || !f || !h || B <= 0 || L <= 0 || C <= 0) return RESEL_EINVAL;
-    const dim3 grid((C + TILE_C - 1) / TILE_C, B), blk(NSEG * 64);
+    const int cl = pick_cl(B, C);
+    const dim3 grid((C + cl - 1) / cl, B), blk(NSEG * 64);
     const size_t lds = (size_t)(L + 1) * sizeof(float);          // keep table (dynamic LDS)
-    if (fuse_act) launch_timed(RESEL_PROF_LINREC_REAL_FWD, linrec_real_fwd_kernel<true>, grid, blk, lds, (hipStream_t)stream, v, f, start, h0, h, B, L, C);
-    else launch_timed(RESEL_PROF_LINREC_REAL_FWD, linrec_real_fwd_kernel<false>, grid, blk, lds, (hipStream_t)stream, v, f, start, h0, h, B, L, C);
+    hipStream_t s = (hipStream_t)stream;
+    if (fuse_act) LINREC_DISPATCH(cl, (launch_timed(RESEL_PROF_LINREC_REAL_FWD, linrec_real_fwd_kernel<true, CL>, grid, blk, lds, s, v, f, start, h0, h, B, L, C)));
+    else LINREC_DISPATCH(cl, (launch_timed(RESEL_PROF_LINREC_REAL_FWD, linrec_real_fwd_kernel<false, CL>, grid, blk, lds, s, v, f, start, h0, h, B, L, C)));
     return launch_status();
 }
 
@@ -283,10 +303,12 @@ extern "C" int resel_linrec_real_bwd(const float* v, const float* f, const float
                                      const float* dh, float* dv, float* df, int B, int L, int C, int fuse_act,
                                      resel_stream_t stream) {
     if (!v || !f || !h || !dh || !dv || !df || B <= 0 || L <= 0 || C <= 0) return RESEL_EINVAL;
-    const dim3 grid((C + TILE_C - 1) / TILE_C, B), blk(NSEG * 64);
+    const int cl = pick_cl(B, C);
+    const dim3 grid((C + cl - 1) / cl, B), blk(NSEG * 64);
     const size_t lds = (size_t)(L + 1) * sizeof(float);
-    if (fuse_act) launch_timed(RESEL_PROF_LINREC_REAL_BWD, linrec_real_bwd_kernel<true>, grid, blk, lds, (hipStream_t)stream, v, f, start, h0, h, dh, dv, df, B, L, C);
-    else launch_timed(RESEL_PROF_LINREC_REAL_BWD, linrec_real_bwd_kernel<false>, grid, blk, lds, (hipStream_t)stream, v, f, start, h0, h, dh, dv, df, B, L, C);
+    hipStream_t s = (hipStream_t)stream;
+    if (fuse_act) LINREC_DISPATCH(cl, (launch_timed(RESEL_PROF_LINREC_REAL_BWD, linrec_real_bwd_kernel<true, CL>, grid, blk, lds, s, v, f, start, h0, h, dh, dv, df, B, L, C)));
+    else LINREC_DISPATCH(cl, (launch_timed(RESEL_PROF_LINREC_REAL_BWD, linrec_real_bwd_kernel<false, CL>, grid, blk, lds, s, v, f, start, h0, h, dh, dv, df, B, L, C)));
     return launch_status();
 }
 
@@ -294,14 +316,15 @@ extern "C" int resel_linrec_complex_fwd(const float* vr, const float* vi, const 
                                         const float* gamma, const float* start, const float* h0r, const float* h0i,
                                         float* hr, float* hi, int B, int L, int C, resel_stream_t stream) {
     if (!vr || !vi || !lam_re || !lam_im || !hr || !hi || B <= 0 || L <= 0 || C <= 0) return RESEL_EINVAL;
-    launch_timed(RESEL_PROF_LINREC_COMPLEX_FWD, linrec_complex_fwd_kernel, dim3((C + TILE_C - 1) / TILE_C, B), dim3(NSEG * 64), (size_t)(L + 1) * sizeof(float),
-                       (hipStream_t)stream, vr, vi, lam_re, lam_im, gamma, start, h0r, h0i, hr, hi, B, L, C);
+    const int cl = pick_cl(B, C);
+    LINREC_DISPATCH(cl, (launch_timed(RESEL_PROF_LINREC_COMPLEX_FWD, linrec_complex_fwd_kernel<CL>, dim3((C + cl - 1) / cl, B), dim3(NSEG * 64),
+                                      (size_t)(L + 1) * sizeof(float), (hipStream_t)stream, vr, vi, lam_re, lam_im, gamma, start, h0r, h0i, hr, hi, B, L, C)));
     return launch_status();
 }
 
 extern "C" size_t resel_linrec_complex_bwd_workspace_bytes(int B, int L, int C) {
     (void)L;
-    return (size_t)B * NSEG * 3 * C * sizeof(float);
+    return (size_t)B * (NSEG * 4) * 3 * C * sizeof(float);      // up to 64 time segments per row (CL = 16)
 }
 
 extern "C" int resel_linrec_complex_bwd(const float* vr, const float* vi, const float* lam_re, const float* lam_im,
@@ -313,12 +336,14 @@ extern "C" int resel_linrec_complex_bwd(const float* vr, const float* vi, const 
         B <= 0 || L <= 0 || C <= 0)
         return RESEL_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    launch_timed(RESEL_PROF_LINREC_COMPLEX_BWD, linrec_complex_bwd_kernel, dim3((C + TILE_C - 1) / TILE_C, B), dim3(NSEG * 64), (size_t)(L + 1) * sizeof(float), s,
-                       vr, vi, lam_re, lam_im, gamma, start, h0r, h0i, hr, hi, dhr, dhi, dvr, dvi, (float*)workspace, B, L, C);
-    // per-(row, segment) partials [B * NSEG][3][C] -> d lambda_re, d lambda_im, d gamma (fixed summation order)
+    const int cl = pick_cl(B, C), nst = NSEG * 64 / cl;
+    LINREC_DISPATCH(cl, (launch_timed(RESEL_PROF_LINREC_COMPLEX_BWD, linrec_complex_bwd_kernel<CL>, dim3((C + cl - 1) / cl, B), dim3(NSEG * 64),
+                                      (size_t)(L + 1) * sizeof(float), s, vr, vi, lam_re, lam_im, gamma, start, h0r, h0i, hr, hi, dhr, dhi, dvr, dvi,
+                                      (float*)workspace, B, L, C)));
+    // per-(row, segment) partials [B * nst][3][C] -> d lambda_re, d lambda_im, d gamma (fixed summation order)
     const float* part = (const float*)workspace;
-    launch_colsum(part, 3 * (int64_t)C, B * NSEG, C, dlam_re, s);
-    launch_colsum(part + C, 3 * (int64_t)C, B * NSEG, C, dlam_im, s);
-    if (dgamma) launch_colsum(part + 2 * (int64_t)C, 3 * (int64_t)C, B * NSEG, C, dgamma, s);
+    launch_colsum(part, 3 * (int64_t)C, B * nst, C, dlam_re, s);
+    launch_colsum(part + C, 3 * (int64_t)C, B * nst, C, dlam_im, s);
+    if (dgamma) launch_colsum(part + 2 * (int64_t)C, 3 * (int64_t)C, B * nst, C, dgamma, s);
     return launch_status();
 }

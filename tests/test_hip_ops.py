@@ -170,7 +170,8 @@ def test_add_layernorm_fwd_bwd(ops, M, C, rms, prenorm):
 
 
 # ------------------------------------------------------------------------------------------------ linear recurrences
-@pytest.mark.parametrize('B,L,C', [(2, 33, 64), (3, 500, 96), (1, 2003, 256), (2, 7, 32)])
+# (64, 40, 256): 64 channels per wave; (16, 45, 512): 32 x 2 time segments; the small batches: 16 channels x 4 segments per wave
+@pytest.mark.parametrize('B,L,C', [(2, 33, 64), (3, 500, 96), (1, 2003, 256), (2, 7, 32), (64, 40, 256), (16, 45, 512)])
 @pytest.mark.parametrize('fuse', [True, False])
 def test_gilr_scan_fwd_bwd(ops, B, L, C, fuse):
     g = torch.Generator().manual_seed(L + C)
@@ -194,7 +195,7 @@ def test_gilr_scan_fwd_bwd(ops, B, L, C, fuse):
     close(g_gpu[1], g_ref[1], rtol=2e-4, atol_scale=5e-5, name='df')
 
 
-@pytest.mark.parametrize('B,L,C', [(2, 33, 64), (3, 500, 96), (1, 2003, 256)])
+@pytest.mark.parametrize('B,L,C', [(2, 33, 64), (3, 500, 96), (1, 2003, 256), (64, 40, 256), (16, 45, 512)])
 def test_lru_scan_fwd_bwd(ops, B, L, C):
     g = torch.Generator().manual_seed(L + C + 1)
     vr, vi = rnd(B, L, C, g=g), rnd(B, L, C, g=g)
