@@ -14,187 +14,349 @@
 // Tiling: 128 x 128 block tile, 4 waves as 2 x 2, wave tile 64 x 64 = 2 x 2 MFMA tiles (64 accumulator registers), K step 32.
 // A 32x32x2 MFMA takes one A and one B value per lane: lane (i = l & 31, h = l >> 5) supplies A(i, k_h) and B(j = i, k_h).  A
 // group of four MFMAs covers 8 consecutive k with the assignment k = 8 g + 4 h + e (e = MFMA in the group) - the sum over k is
-// order-free per output, and with it a lane's four A values are CONTIGUOUS in k: for a [rows][K] operand the LDS image keeps
-// k contiguous (rows padded to 36 floats) and one ds_read_b128 feeds four MFMAs; for a [K][rows] operand the image is
-// k-major and the four values are four ds_read_b32 of 32 consecutive floats.  At 64 cycles per MFMA either way is far
-// below the LDS rate - no transposes anywhere, global loads are float4 along the operand's contiguous axis in both forms.
-// Global -> LDS goes through registers one K step ahead (the loads of step s + 1 are in flight during the 64 MFMAs of step
-// s), LDS is double-buffered, one barrier per step.  72 KB of LDS per block: two blocks (two waves per SIMD) per CU.
-// Split-K (wgrad): blockIdx.y = K slice, partial tiles go to a slab [slice][M][N] summed in fixed order by a second kernel
-// (deterministic, no atomics).  Block ids are XCD-aware: the n-tiles of one m-tile share an L2.
+// order-free per output, and with it a lane's four operand values are CONTIGUOUS in k: the LDS image of either operand is
+// [row][k] (rows padded to 36 floats: conflict-free ds_read_b128, 256 B/clk) and one ds_read_b128 feeds four MFMAs.
+// A [K][rows] operand is transposed on its way in: a thread loads a 4 (k) x 4 (rows) patch as four float4 along rows and
+// stores its four COLUMNS as ds_write_b128 - the 4 x 4 transpose is register naming.
+//
+// Pipeline (one barrier per K step, LDS double-buffered, global -> registers -> LDS two steps ahead):
+//     step s:  MFMA g0 | ds_write(step s+1) | MFMA g1 | global loads(step s+2) | MFMA g2 | barrier | ds_read frags(s+1) g0..g2
+//              | MFMA g3 | ds_read frags(s+1) g3
+// so the matrix pipe always has 16 MFMAs (1024 cycles) queued behind the barrier and the LDS round trip of the next step's
+// fragments.  History (66 752 x 2048 x 384, PMC in DESIGN.md): fragments re-read next to each group of 8 MFMAs (the compiler's
+// placement) 67 % pipe-busy, 102 TFLOP/s; all 16 reads hoisted above the 64 MFMAs 113 TFLOP/s; this pipeline: see DESIGN.md.
+//
+// Blocks are persistent: block b walks the items b, b + G, ... (G = 512 = two blocks per CU); the loads of an item's first
+// steps and its epilogue stores overlap the neighbouring items' MFMAs.  An item is a whole output tile or - for the LAST,
+// partly filled round of tiles, and for weight gradients (few tiles, K = 66 752) - a K slice of a tile whose partial sums go
+// to a workspace slab; a fix-up kernel adds the slices in fixed order (deterministic, no atomics) and applies bias/activation.
+// Without that the last round cost a full tile time at 4 % occupancy (1044 tiles on 512 slots: 68 % efficiency).
+// Tile ids are XCD-aware: the n-tiles of one m-tile share an L2.
 #include "resel_common.h"
+#include <algorithm>
 
 namespace {
 using namespace resel;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int BN = 128, BK = 32;        // block tile BM x 128, BM = 128 or 64 (template): see pick_bm
-constexpr int LDK = BK + 4;           // [row][k] image: 36 floats per row (16-byte aligned rows, conflict-free ds_read_b128)
-template <int ROWS> constexpr int ldr() { return ROWS + 4; }     // [k][row] image: ROWS + 4 floats per k
+constexpr int BM = 128, BN = 128, BK = 32, NG = BK / 8;
+constexpr int LDK = BK + 4;           // LDS image [row][k]: 36 floats per row
+constexpr int GRID = 512;             // persistent blocks: two per CU
+constexpr int TILE = BM * BN;
 
 struct GemmParams {
     const float *A, *B, *bias;
-    float* C;
+    float *C, *slab;
     int64_t lda, ldb, ldc, sA, sB, sC, sBias;    // leading dimensions (floats) and per-batch strides
-    int M, N, K, kslice;                          // kslice: K range per blockIdx.y (multiple of BK), = K without split-K
+    int M, N, K;
     int act;                                      // 0 none, 1 ELU
-    int mt, nt;                                   // tile counts
+    int mt, nt;                                   // tiles along m and n
+    int nfull;                                    // items [0, nfull): whole tiles; then nsplit tiles x nsl K slices of kslice
+    int nsplit, nsl, kslice;
 };
 
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : fast_exp(x) - 1.f; }
 
-// stage one 128 x 32 operand tile: registers <- global (float4 along the contiguous axis, zero beyond the edges)
-template <bool KC, int ROWS>
-__device__ __forceinline__ void tile_load(const float* __restrict__ P, int64_t ld, int rows, int K, int r0, int k0, int kend, int tid,
-                                          float4 (&r)[ROWS / 32]) {
-#pragma unroll
-    for (int i = 0; i < ROWS / 32; ++i) {
-        r[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (KC) {                                  // P[row][k]: thread -> (row = tid / 8 + 32 i, k = 4 (tid % 8))
-            const int row = r0 + (tid >> 3) + 32 * i, k = k0 + 4 * (tid & 7);
-            if (row < rows && k < kend) r[i] = ld4(P + (int64_t)row * ld + k);
-        } else {                                   // P[k][row]: ROWS / 4 threads per k
-            constexpr int TPK = ROWS / 4, KPP = 256 / TPK;
-            const int k = k0 + tid / TPK + KPP * i, row = r0 + 4 * (tid % TPK);
-            if (k < kend && row < rows) r[i] = ld4(P + (int64_t)k * ld + row);
-        }
-    }
-}
-template <bool KC, int ROWS>
-__device__ __forceinline__ void tile_store(float* __restrict__ S, int tid, const float4 (&r)[ROWS / 32]) {
-#pragma unroll
-    for (int i = 0; i < ROWS / 32; ++i) {
-        if (KC) st4(S + ((tid >> 3) + 32 * i) * LDK + 4 * (tid & 7), r[i]);
-        else {
-            constexpr int TPK = ROWS / 4, KPP = 256 / TPK;
-            st4(S + (tid / TPK + KPP * i) * ldr<ROWS>() + 4 * (tid % TPK), r[i]);
-        }
-    }
-}
-// the four operand values of lane (i, h) for k-group g of a 32-row sub-tile starting at row rb
-template <bool KC, int ROWS>
-__device__ __forceinline__ float4 frag(const float* __restrict__ S, int rb, int g, int i, int h) {
-    if (KC) return ld4(S + (rb + i) * LDK + 8 * g + 4 * h);
-    constexpr int LDR = ldr<ROWS>();
-    const float* q = S + (8 * g + 4 * h) * LDR + rb + i;
-    return make_float4(q[0], q[LDR], q[2 * LDR], q[3 * LDR]);
-}
-
-template <bool AKC, bool BKC, int BM>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
-    constexpr int TM = BM / 64;                    // MFMA tiles per wave along m (wave tile 32 TM x 64)
-    constexpr int ASZ = AKC ? BM * LDK : BK * ldr<BM>(), BSZ = BKC ? BN * LDK : BK * ldr<BN>();
-    __shared__ __attribute__((aligned(16))) float lds[2 * (ASZ + BSZ)];
-    // XCD-aware tile id: ids congruent mod 8 share an XCD; give each XCD whole m-tiles (their n-tiles reuse the A rows in L2)
+// tile t (member-major) -> member z, tile origin (m0, n0).  XCD-aware: the tiles of one XCD (ids congruent mod 8) walk the
+// n-tiles of one m-tile after another.
+__device__ __forceinline__ void tile_origin(const GemmParams& p, int t, int& z, int& m0, int& n0) {
     const int ntile = p.mt * p.nt;
-    int bid = blockIdx.x;
-    {
-        const int q = ntile / 8, r = ntile % 8, x = bid & 7, j = bid >> 3;
-        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+    z = t / ntile;
+    const int tt = t - z * ntile;
+    const int q = ntile / 8, r = ntile % 8, x = tt & 7, j = tt >> 3;
+    const int bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+    m0 = (bid / p.nt) * BM;
+    n0 = (bid % p.nt) * BN;
+}
+
+struct Item { int m0, n0, z, kbeg, kend, split; };     // split: index of the slab tile + 1, 0 for a whole tile
+__device__ __forceinline__ Item decode(const GemmParams& p, int it) {
+    Item o;
+    int t = it;
+    o.kbeg = 0; o.kend = p.K; o.split = 0;
+    if (it >= p.nfull) {
+        const int idx = it - p.nfull, tr = idx / p.nsl, sl = idx - tr * p.nsl;
+        t = p.nfull + tr;
+        o.kbeg = sl * p.kslice; o.kend = min(p.K, o.kbeg + p.kslice); o.split = idx + 1;
     }
-    const int tm = bid / p.nt, tn = bid % p.nt;
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int kbeg = blockIdx.y * p.kslice, kend = min(p.K, kbeg + p.kslice);
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wm = (w >> 1) * (32 * TM), wn = (w & 1) * 64;
-    const int li = lane & 31, lh = lane >> 5;
-    const float* A = p.A + (int64_t)blockIdx.z * p.sA;
-    const float* B = p.B + (int64_t)blockIdx.z * p.sB;
+    tile_origin(p, t, o.z, o.m0, o.n0);
+    return o;
+}
 
-    f32x16 acc[TM][2];
+// One operand's share of a thread in a K step: four float4 along the operand's contiguous axis.
+//   KC  (P[row][k]):  piece i = row (tid / 8 + 32 i), k = 4 (tid % 8) .. + 3
+//   !KC (P[k][row]):  piece j = k (4 (tid % 8) + j), rows 4 (tid / 8) .. + 3
+// Rows beyond the operand's extent are read from row 0 instead (their products land in output rows / columns that are never
+// stored); k beyond the slice end must contribute zeros and is the only guarded case (last step of a K not a multiple of 32).
+template <bool KC>
+struct Src {
+    const char* base;                              // uniform (SGPR pair): operand + member + tile origin + K position
+    uint32_t off[4];                               // this thread's byte offsets of its four pieces from `base`
+    int64_t step;                                  // bytes per K step
+    int kofs;                                      // k of piece 0 inside the step
+    __device__ __forceinline__ void init(const float* P, int64_t ld, int rows, int r0, int k0, int tid) {
+        kofs = 4 * (tid & 7);
+        if (KC) {
+            base = (const char*)(P + (int64_t)r0 * ld + k0);
 #pragma unroll
-    for (int a = 0; a < TM; ++a)
+            for (int i = 0; i < 4; ++i) {
+                const int rl = (tid >> 3) + 32 * i;
+                off[i] = (uint32_t)(((r0 + rl < rows ? rl : 0) * ld + kofs) * 4);
+            }
+            step = BK * 4;
+        } else {
+            base = (const char*)(P + (int64_t)k0 * ld + r0);
+            const int rl = 4 * (tid >> 3);
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-
-    float4 ra[BM / 32], rb[BN / 32];
-    tile_load<AKC, BM>(A, p.lda, p.M, p.K, m0, kbeg, kend, tid, ra);
-    tile_load<BKC, BN>(B, p.ldb, p.N, p.K, n0, kbeg, kend, tid, rb);
-    int buf = 0;
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        float* As = lds + buf * (ASZ + BSZ);
-        float* Bs = As + ASZ;
-        tile_store<AKC, BM>(As, tid, ra);
-        tile_store<BKC, BN>(Bs, tid, rb);
-        __syncthreads();
-        if (k0 + BK < kend) {                       // next step's operands: in flight during this step's MFMAs
-            tile_load<AKC, BM>(A, p.lda, p.M, p.K, m0, k0 + BK, kend, tid, ra);
-            tile_load<BKC, BN>(B, p.ldb, p.N, p.K, n0, k0 + BK, kend, tid, rb);
+            for (int j = 0; j < 4; ++j) off[j] = (uint32_t)(((kofs + j) * ld + (r0 + rl < rows ? rl : 0)) * 4);
+            step = (int64_t)BK * ld * 4;
         }
+    }
+    __device__ __forceinline__ void load(float4 (&r)[4], int k0, int kend) {
+        if (k0 + BK <= kend) {
 #pragma unroll
-        for (int g = 0; g < BK / 8; ++g) {
-            float4 fa[TM], fb[2];
+            for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const float4*>(base + off[i]);
+        } else {
 #pragma unroll
-            for (int t = 0; t < TM; ++t) fa[t] = frag<AKC, BM>(As, wm + 32 * t, g, li, lh);
+            for (int i = 0; i < 4; ++i) {
+                r[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k0 + kofs + (KC ? 0 : i) < kend) r[i] = *reinterpret_cast<const float4*>(base + off[i]);
+            }
+        }
+        base += step;
+    }
+};
+template <bool KC>
+__device__ __forceinline__ void tile_store(float* __restrict__ S, int tid, const float4 (&r)[4]) {
+    if (KC) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t) fb[t] = frag<BKC, BN>(Bs, wn + 32 * t, g, li, lh);
+        for (int i = 0; i < 4; ++i) st4(S + ((tid >> 3) + 32 * i) * LDK + 4 * (tid & 7), r[i]);
+    } else {
+        float* q = S + (4 * (tid >> 3)) * LDK + 4 * (tid & 7);
+        st4(q, make_float4(r[0].x, r[1].x, r[2].x, r[3].x));
+        st4(q + LDK, make_float4(r[0].y, r[1].y, r[2].y, r[3].y));
+        st4(q + 2 * LDK, make_float4(r[0].z, r[1].z, r[2].z, r[3].z));
+        st4(q + 3 * LDK, make_float4(r[0].w, r[1].w, r[2].w, r[3].w));
+    }
+}
+
+struct Frags { float4 a[NG][2], b[NG][2]; };
+__device__ __forceinline__ void read_frags(Frags& f, const float* __restrict__ As, const float* __restrict__ Bs, int g) {
+    // As / Bs already point at (wave row block + lane row, 4 * lane half)
 #pragma unroll
-            for (int a = 0; a < TM; ++a)
+    for (int t = 0; t < 2; ++t) {
+        f.a[g][t] = ld4(As + 32 * t * LDK + 8 * g);
+        f.b[g][t] = ld4(Bs + 32 * t * LDK + 8 * g);
+    }
+}
+__device__ __forceinline__ void mfma_group(f32x16 (&acc)[2][2], const Frags& f, int g) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[g][a].x, f.b[g][b].x, acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[g][a].y, f.b[g][b].y, acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[g][a].z, f.b[g][b].z, acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[g][a].w, f.b[g][b].w, acc[a][b], 0, 0, 0);
+        }
+}
+#define RESEL_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
+    constexpr int ASZ = BM * LDK, BSZ = BN * LDK;
+    __shared__ __attribute__((aligned(16))) float lds[2 * (ASZ + BSZ)];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
+    const int li = lane & 31, lh = lane >> 5;
+    const int total = p.nfull + p.nsplit * p.nsl;
+    const int G = gridDim.x;
+    if ((int)blockIdx.x >= total) return;
+
+    // producer: global -> registers, two steps ahead of the MFMAs
+    Src<AKC> sa;
+    Src<BKC> sb;
+    float4 ra[4], rb[4];
+    int p_item = blockIdx.x, p_k0, p_kend;
+    bool p_live = true;
+    auto p_open = [&]() {
+        const Item it = decode(p, p_item);
+        sa.init(p.A + (int64_t)it.z * p.sA, p.lda, p.M, it.m0, it.kbeg, tid);
+        sb.init(p.B + (int64_t)it.z * p.sB, p.ldb, p.N, it.n0, it.kbeg, tid);
+        p_k0 = it.kbeg; p_kend = it.kend;
+    };
+    auto produce = [&]() {
+        if (!p_live) return;
+        sa.load(ra, p_k0, p_kend);
+        sb.load(rb, p_k0, p_kend);
+        p_k0 += BK;
+        if (p_k0 >= p_kend) {
+            p_item += G;
+            if (p_item < total) p_open(); else p_live = false;
+        }
+    };
+    // consumer
+    int c_item = blockIdx.x;
+    float* const lA = lds + (wm + li) * LDK + 4 * lh;              // this lane's fragment rows in buffer 0
+    float* const lB = lds + ASZ + (wn + li) * LDK + 4 * lh;
+    Frags f;
+    p_open();
+    produce();
+    tile_store<AKC>(lds, tid, ra);
+    tile_store<BKC>(lds + ASZ, tid, rb);
+    produce();
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < NG; ++g) read_frags(f, lA, lB, g);
+    int nb = ASZ + BSZ;                                             // offset of the buffer the NEXT step goes to
+    for (; c_item < total; c_item += G) {
+        const Item cur = decode(p, c_item);
+        float zero = 0.f;
+        asm volatile("" : "+v"(zero));              // opaque: or 64 registers of hoisted zeros stay live across the K loop
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[a][b][e] = zero;
+        float bv[2] = {0.f, 0.f};
+        for (int c_k0 = cur.kbeg; c_k0 < cur.kend; c_k0 += BK) {
+            RESEL_FENCE();
+            mfma_group(acc, f, 0);
+            RESEL_FENCE();
+            tile_store<AKC>(lds + nb, tid, ra);
+            tile_store<BKC>(lds + nb + ASZ, tid, rb);
+            RESEL_FENCE();
+            mfma_group(acc, f, 1);
+            RESEL_FENCE();
+            if (c_k0 + BK >= cur.kend && p.bias && !cur.split) {    // requested most of a step before the epilogue needs them
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].x, fb[b].x, acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].y, fb[b].y, acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].z, fb[b].z, acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].w, fb[b].w, acc[a][b], 0, 0, 0);
-                }
-        }
-        buf ^= 1;                                   // the other buffer was last read before the barrier above
-    }
-    // epilogue: D layout col = lane & 31 (n), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (m)
-    float* C = p.C + (int64_t)blockIdx.z * p.sC + (int64_t)blockIdx.y * gridDim.z * p.M * p.ldc;   // split-K: slab [slice][batch][M][N]
-    const float* bias = p.bias ? p.bias + (int64_t)blockIdx.z * p.sBias : nullptr;
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int n = n0 + wn + 32 * b + li;
-        if (n >= p.N) continue;
-        const float bv = bias ? bias[n] : 0.f;
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm + 32 * a + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (m < p.M) {
-                    float v = acc[a][b][e] + bv;
-                    if (p.act == 1) v = elu1(v);
-                    C[(int64_t)m * p.ldc + n] = v;
+                    const int n = cur.n0 + wn + 32 * b + li;
+                    bv[b] = p.bias[(int64_t)cur.z * p.sBias + (n < p.N ? n : 0)];
                 }
             }
+            produce();
+            RESEL_FENCE();
+            mfma_group(acc, f, 2);
+            RESEL_FENCE();
+            __syncthreads();
+            read_frags(f, lA + nb, lB + nb, 0);
+            read_frags(f, lA + nb, lB + nb, 1);
+            read_frags(f, lA + nb, lB + nb, 2);
+            RESEL_FENCE();
+            mfma_group(acc, f, 3);
+            RESEL_FENCE();
+            read_frags(f, lA + nb, lB + nb, 3);
+            RESEL_FENCE();
+            nb = ASZ + BSZ - nb;
+        }
+        // epilogue: D layout col = lane & 31 (n), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (m)
+        if (cur.split) {                                            // partial sums: dense 128 x 128 slab tile
+            float* o = p.slab + (int64_t)(cur.split - 1) * TILE + (wm + 4 * lh) * BN + wn + li;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) o[(32 * a + (e & 3) + 8 * (e >> 2)) * BN + 32 * b] = acc[a][b][e];
+        } else {
+            float* C = p.C + (int64_t)cur.z * p.sC;
+            const bool full_m = cur.m0 + BM <= p.M;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int n = cur.n0 + wn + 32 * b + li;
+                if (n >= p.N) continue;
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    float v[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) v[e] = acc[a][b][e] + bv[b];
+                    if (p.act == 1) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) v[e] = elu1(v[e]);
+                    }
+                    const int mb = cur.m0 + wm + 32 * a + 4 * lh;
+                    float* crow = C + (int64_t)mb * p.ldc + n;
+                    if (full_m) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) crow[(int64_t)((e & 3) + 8 * (e >> 2)) * p.ldc] = v[e];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int dm = (e & 3) + 8 * (e >> 2);
+                            if (mb + dm < p.M) crow[(int64_t)dm * p.ldc] = v[e];
+                        }
+                    }
+                }
+            }
+        }
     }
 }
 
-// out[i] = sum_s slab[s][i]  (fixed order; float4 per thread)
-__global__ void splitk_sum_kernel(const float* __restrict__ slab, int nslice, int64_t n, float* __restrict__ out) {
-    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (i >= n) return;
-    float4 acc = ld4(slab + i);
-    for (int s = 1; s < nslice; ++s) {
-        const float4 v = ld4(slab + (int64_t)s * n + i);
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+// C tile = epi(sum over the K slices of a split tile).  Fixed summation order (deterministic): four interleaved slice groups
+// (threadIdx.y) accumulate slices q, q + 4, ... each, then ((g0 + g1) + (g2 + g3)).  grid (TILE / 4 / 64, split tiles), block (64, 4).
+__global__ __launch_bounds__(256) void gemm_fixup_kernel(GemmParams p) {
+    __shared__ float4 part[3][64];
+    const int tr = blockIdx.y, q = threadIdx.y;
+    const int e = blockIdx.x * 64 + threadIdx.x, ml = e >> 5, nl = 4 * (e & 31);
+    const float* s = p.slab + (int64_t)tr * p.nsl * TILE + ml * BN + nl;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    int i = q;
+    for (; i + 12 < p.nsl; i += 16) {                     // four loads in flight per thread
+        const float4 u0 = ld4(s + (int64_t)i * TILE), u1 = ld4(s + (int64_t)(i + 4) * TILE);
+        const float4 u2 = ld4(s + (int64_t)(i + 8) * TILE), u3 = ld4(s + (int64_t)(i + 12) * TILE);
+        v.x = (((v.x + u0.x) + u1.x) + u2.x) + u3.x; v.y = (((v.y + u0.y) + u1.y) + u2.y) + u3.y;
+        v.z = (((v.z + u0.z) + u1.z) + u2.z) + u3.z; v.w = (((v.w + u0.w) + u1.w) + u2.w) + u3.w;
     }
-    st4(out + i, acc);
+    for (; i < p.nsl; i += 4) {
+        const float4 u = ld4(s + (int64_t)i * TILE);
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    if (q) part[q - 1][threadIdx.x] = v;
+    __syncthreads();
+    if (q) return;
+    const float4 g1 = part[0][threadIdx.x], g2 = part[1][threadIdx.x], g3 = part[2][threadIdx.x];
+    float o[4] = {(v.x + g1.x) + (g2.x + g3.x), (v.y + g1.y) + (g2.y + g3.y), (v.z + g1.z) + (g2.z + g3.z), (v.w + g1.w) + (g2.w + g3.w)};
+    int z, m0, n0;
+    tile_origin(p, p.nfull + tr, z, m0, n0);
+    const int m = m0 + ml, n = n0 + nl;
+    if (m >= p.M || n >= p.N) return;
+    float* c = p.C + (int64_t)z * p.sC + (int64_t)m * p.ldc + n;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (n + j >= p.N) break;
+        float x = o[j] + (p.bias ? p.bias[(int64_t)z * p.sBias + n + j] : 0.f);
+        if (p.act == 1) x = elu1(x);
+        c[j] = x;
+    }
 }
 
-// 128-row tiles unless they would leave the 512 block slots (2 per CU) badly quantised: fewer than ~6 rounds of tiles
-inline int pick_bm(int M, int N, int batch) {
-    const long tiles = (long)((M + 127) / 128) * ((N + BN - 1) / BN) * batch;
-    return tiles >= 3072 ? 128 : 64;
-}
-inline int pick_slices(int M, int N, int K, int batch) {
-    const int BM = pick_bm(M, N, batch);
-    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN) * batch;
-    if (tiles >= 256 || K < 2048) return 1;
-    int s = (512 + tiles - 1) / tiles;              // ~two blocks per CU
-    const int maxs = K / 256 > 0 ? K / 256 : 1;     // at least 8 K steps per slice
-    return s < maxs ? s : maxs;
+// How the output tiles become items: whole tiles for the full rounds of the 512 block slots; the remaining r tiles are cut
+// into K slices so that they fill the slots once more (at least two K steps per slice), also when r is everything (weight
+// gradients: 6 tiles, K = 66 752).  r > 256 tiles are left whole (a split could not even double the blocks).
+struct Plan { int nfull, nsplit, nsl, kslice; };
+inline Plan make_plan(int M, int N, int K, int batch) {
+    const long nbt = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN) * batch;
+    const int ksteps = (K + BK - 1) / BK;
+    Plan pl{(int)nbt, 0, 1, ksteps * BK};
+    const int r = (int)(nbt % GRID);
+    if (r == 0 || r > GRID / 2 || ksteps < 4) return pl;
+    int s = std::min(GRID / r, ksteps / 2);
+    const int per = (ksteps + s - 1) / s;           // K steps per slice
+    s = (ksteps + per - 1) / per;                   // no empty slices
+    if (s < 2) return pl;
+    pl.nfull = (int)(nbt - r); pl.nsplit = r; pl.nsl = s; pl.kslice = per * BK;
+    return pl;
 }
 
 }  // namespace
 
 extern "C" size_t resel_gemm_f32_workspace_bytes(int M, int N, int K, int batch) {
-    const int s = pick_slices(M, N, K, batch);
-    return s > 1 ? (size_t)s * batch * M * N * sizeof(float) : 0;
+    if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return 0;
+    const Plan pl = make_plan(M, N, K, batch);
+    return (size_t)pl.nsplit * pl.nsl * TILE * sizeof(float);
 }
 
 extern "C" int resel_gemm_f32(const float* A, int64_t lda, int64_t strideA, int a_kcontig,
@@ -206,28 +368,17 @@ extern "C" int resel_gemm_f32(const float* A, int64_t lda, int64_t strideA, int 
     if (lda % 4 || ldb % 4 || strideA % 4 || strideB % 4 || !aligned16(A) || !aligned16(B)) return RESEL_EINVAL;
     // float4 loads run along the contiguous axis: its extent must be a multiple of 4 (K for [rows][K] operands, rows otherwise)
     if ((a_kcontig ? K : M) % 4 || (b_kcontig ? K : N) % 4) return RESEL_EINVAL;
-    const int slices = pick_slices(M, N, K, batch);
-    // split-K output: dense [batch][M][N] (the slabs are summed as flat arrays)
-    if (slices > 1 && (bias || act || !workspace || ldc != N || (batch > 1 && strideC != (int64_t)M * N) || (N % 4) || !aligned16(C) ||
-                       !aligned16(workspace))) return RESEL_EINVAL;
-    const int BM = pick_bm(M, N, batch);
-    GemmParams p{A, B, bias, slices > 1 ? (float*)workspace : C, lda, ldb, slices > 1 ? (int64_t)N : ldc, strideA, strideB,
-                 slices > 1 ? (int64_t)M * N : strideC, strideBias, M, N, K, 0, act, (M + BM - 1) / BM, (N + BN - 1) / BN};
-    p.kslice = slices > 1 ? ((K + slices - 1) / slices + BK - 1) / BK * BK : (K + BK - 1) / BK * BK;
-    const int nsl = (K + p.kslice - 1) / p.kslice;
-    dim3 grid(p.mt * p.nt, nsl, batch);
+    const Plan pl = make_plan(M, N, K, batch);
+    if (pl.nsplit && (!workspace || !aligned16(workspace))) return RESEL_EINVAL;
+    GemmParams p{A, B, bias, C, (float*)workspace, lda, ldb, ldc, strideA, strideB, strideC, strideBias, M, N, K, act,
+                 (M + BM - 1) / BM, (N + BN - 1) / BN, pl.nfull, pl.nsplit, pl.nsl, pl.kslice};
+    const int64_t total = (int64_t)pl.nfull + (int64_t)pl.nsplit * pl.nsl;
+    dim3 grid((unsigned)std::min<int64_t>(total, GRID));
     hipStream_t s = (hipStream_t)stream;
-#define RESEL_GEMM_LAUNCH(AK, BK_) \
-    do { if (BM == 128) hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, 128>), grid, dim3(256), 0, s, p); \
-         else hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, 64>), grid, dim3(256), 0, s, p); } while (0)
-    if (a_kcontig && b_kcontig) RESEL_GEMM_LAUNCH(true, true);
-    else if (a_kcontig) RESEL_GEMM_LAUNCH(true, false);
-    else if (b_kcontig) RESEL_GEMM_LAUNCH(false, true);
-    else RESEL_GEMM_LAUNCH(false, false);
-#undef RESEL_GEMM_LAUNCH
-    if (slices > 1) {
-        const int64_t n = (int64_t)batch * M * N;
-        hipLaunchKernelGGL(splitk_sum_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, (const float*)workspace, nsl, n, C);
-    }
+    if (a_kcontig && b_kcontig) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, s, p);
+    else if (a_kcontig) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, s, p);
+    else if (b_kcontig) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, s, p);
+    if (pl.nsplit) hipLaunchKernelGGL(gemm_fixup_kernel, dim3(TILE / 4 / 64, pl.nsplit), dim3(64, 4), 0, s, p);
     return launch_status();
 }

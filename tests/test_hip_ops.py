@@ -560,6 +560,10 @@ def test_atb_long_reduction_gemm(ops, K, Wd, Nd, ldn, tr):
     (20000, 128, 256, False, False, False, None, 1),    # wgrad: split over the 20 000-long reduction
     (260, 256, 256, True, False, True, 'elu', 8),       # per-member ensemble layer [E, in, out] with bias + ELU
     (17000, 256, 256, False, False, False, None, 8),    # per-member weight gradient (batched split-K)
+    (16640, 512, 136, True, True, True, 'elu', 1),      # 520 tiles on 512 block slots: the last 8 are K-split, tail + bias + ELU in the fix-up
+    (600, 260, 99, False, False, False, None, 1),       # both operands [K][rows], odd K (guarded last step)
+    (600, 260, 100, True, False, True, None, 2),        # mixed layouts, batch of 2, K tail
+    (66752, 256, 64, True, True, True, None, 1),        # two K steps per item: the persistent pipeline crosses items every other step
 ])
 def test_gemm_f32_vs_fp64_product(ops, M, N, K, akc, bkc, bias, act, batch):
     """resel_gemm_f32 (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulation) against an fp64 product: 1e-5 of the

@@ -1,0 +1,21 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/pmc_gemm
+rm -rf $OUT; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+SETS=("SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
+      "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS" \
+      "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM SQ_IFETCH SQ_INSTS_VALU_MFMA_F32 GRBM_GUI_ACTIVE")
+for i in 0 1 2; do
+  timeout 200 rocprofv3 --pmc ${SETS[$i]} -d $OUT -o p$i --output-format csv -- python3 $R/tools/prof_gemm.py "$@" > $OUT/p$i.log 2>&1
+  tail -2 $OUT/p$i.log
+done
+python3 - <<PY
+import csv, glob, collections
+tot = collections.defaultdict(float); cnt = collections.defaultdict(int)
+for f in glob.glob('$OUT/**/*counter_collection.csv', recursive=True):
+    for r in csv.DictReader(open(f)):
+        if 'gemm_f32_kernel' in r['Kernel_Name']:
+            tot[r['Counter_Name']] += float(r['Counter_Value']); cnt[r['Counter_Name']] += 1
+for c in sorted(tot): print('   %-30s %16.0f per launch' % (c, tot[c] / cnt[c]))
+PY

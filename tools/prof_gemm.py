@@ -1,0 +1,21 @@
+"""One shape of resel_gemm_f32, many repetitions (PMC / stats driver).  python tools/prof_gemm.py M N K [akc bkc] [reps]"""
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'recurrent-offpolicy-rl_amd')]
+import torch
+from offpolicy_rnn.hip import ops
+M, N, K = (int(a) for a in sys.argv[1:4])
+akc, bkc = (bool(int(sys.argv[4])), bool(int(sys.argv[5]))) if len(sys.argv) > 5 else (True, True)
+reps = int(sys.argv[6]) if len(sys.argv) > 6 else 20
+A = torch.randn((M, K) if akc else (K, M), device='cuda')
+B = torch.randn((N, K) if bkc else (K, N), device='cuda')
+for _ in range(reps):
+    C = ops.gemm_f32(A, B, akc, bkc)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(reps):
+    C = ops.gemm_f32(A, B, akc, bkc)
+e1.record(); torch.cuda.synchronize()
+us = e0.elapsed_time(e1) / reps * 1e3
+print(f'gemm_f32 {M}x{N}x{K}: {us:.1f} us, {2.0 * M * N * K / us / 1e6:.1f} TFLOP/s')
