@@ -264,7 +264,7 @@ size_t resel_ensemble_head_bwd_workspace_bytes(int64_t rows, int H, int64_t rows
 int resel_ensemble_head_bwd(const float* gq, const float* a, const float* w3, float* gy, float* db2, float* dw3, void* workspace,
                             int64_t rows, int H, int64_t rows_per_seg, resel_stream_t stream);
 
-/* ---- fp32 GEMM on the f32-input matrix cores (v_mfma_f32_32x32x2_f32: exact fp32), tails fused ------------------------
+/* ---- fp32 GEMM on the matrix cores, tails fused --------------------------------------------------------------------------
  * C[b][m][n] = act( sum_k A[b](m, k) B[b](n, k) + bias[b][n] ),  b < batch (ensemble member; strides in floats).
  * An operand is a [rows][K] matrix (x_kcontig = 1: activations, nn.Linear / EnsembleLinear weights [out][in]) or a [K][rows]
  * matrix (x_kcontig = 0: the transposed use of an activation matrix in a weight gradient, of a weight in an input gradient):
@@ -272,13 +272,18 @@ int resel_ensemble_head_bwd(const float* gq, const float* a, const float* w3, fl
  *   dgrad    dx = dy W                 A = dy (1), B = W (0)      EnsembleLinear (models/ensemble_linear_model.py:36-49)
  *   wgrad    dW = dy^T x               A = dy (0), B = x (0)      K = number of tokens: split over blocks, partial tiles summed in
  *                                                                  a fixed order (workspace: resel_gemm_f32_workspace_bytes)
- * act: 0 none, 1 ELU.  The contiguous extent of each operand (K or rows) must be a multiple of 4, pointers 16-byte aligned. */
+ * act: 0 none, 1 ELU.  The contiguous extent of each operand (K or rows) must be a multiple of 4, pointers 16-byte aligned.
+ * split selects how the fp32 products are formed (inputs, accumulation and outputs are fp32 in every mode):
+ *   0  v_mfma_f32_32x32x2_f32 (fp32 operands, exact products);
+ *   9  each operand split EXACTLY into three bf16 planes (8 + 8 + 8 significant bits), all nine plane products - each exact -
+ *      accumulated in fp32 by v_mfma_f32_32x32x16_bf16: the product a b is represented exactly, as in mode 0;
+ *   6  as 9 without the three smallest terms (each <= 2^-24 |a b|, the size of one fp32 rounding of the product). */
 size_t resel_gemm_f32_workspace_bytes(int M, int N, int K, int batch);
 int resel_gemm_f32(const float* A, int64_t lda, int64_t strideA, int a_kcontig,
                    const float* B, int64_t ldb, int64_t strideB, int b_kcontig,
                    const float* bias, int64_t strideBias, int act,
                    float* C, int64_t ldc, int64_t strideC, void* workspace,
-                   int M, int N, int K, int batch, resel_stream_t stream);
+                   int M, int N, int K, int batch, int split, resel_stream_t stream);
 
 /* ---- packed trajectory batch from a device-resident replay ring --------------------------------------------------
  * Device counterpart of NestedMemoryArray.sample_trajs' packing loop (reference buffers/transition_buffer/

@@ -141,14 +141,21 @@ __device__ __forceinline__ void tile_store(float* __restrict__ S, int tid, const
 }
 
 struct Frags { float4 a[NG][2], b[NG][2]; };
+struct Planes;
+// slot g of the lane's fragments.  fp32 MFMA: k = 8 g + 4 h .. + 3 (As / Bs point at the lane's row + 4 h).  SPLIT: the lane
+// owns k = 16 s + 8 h .. + 7 of slab s in slots 2 s and 2 s + 1 (As / Bs point at the lane's row + 8 h).
+template <int SPLIT>
 __device__ __forceinline__ void read_frags(Frags& f, const float* __restrict__ As, const float* __restrict__ Bs, int g) {
-    // As / Bs already point at (wave row block + lane row, 4 * lane half)
+    const int ko = SPLIT ? 16 * (g >> 1) + 4 * (g & 1) : 8 * g;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        f.a[g][t] = ld4(As + 32 * t * LDK + 8 * g);
-        f.b[g][t] = ld4(Bs + 32 * t * LDK + 8 * g);
+        f.a[g][t] = ld4(As + 32 * t * LDK + ko);
+        f.b[g][t] = ld4(Bs + 32 * t * LDK + ko);
     }
 }
+// quarter q of a K step's matrix work
+template <int SPLIT>
+__device__ __forceinline__ void quarter(f32x16 (&acc)[2][2], const Frags& f, Planes& pl, int q);
 __device__ __forceinline__ void mfma_group(f32x16 (&acc)[2][2], const Frags& f, int g) {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -160,9 +167,71 @@ __device__ __forceinline__ void mfma_group(f32x16 (&acc)[2][2], const Frags& f, 
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[g][a].w, f.b[g][b].w, acc[a][b], 0, 0, 0);
         }
 }
+// ---- SPLIT mode: fp32 operands as three bf16 planes, products on the bf16 matrix cores -------------------------------------
+// x = x1 + x2 + x3 EXACTLY, each plane a bf16 (8 significant bits) obtained by truncation: x1 = top 16 bits of x, x2 = top 16
+// bits of (x - x1) (exact difference), x3 = x - x1 - x2 (at most 8 significant bits left: exact).  A bf16 x bf16 product is
+// exact in fp32, so  a b = sum_{p,q} a_p b_q  term by term; v_mfma_f32_32x32x16_bf16 accumulates the terms in fp32 like the
+// fp32 MFMA accumulates a b itself.  SPLIT = 9 keeps all nine terms (the product is represented exactly: the same contract as
+// the fp32 instruction, with nine accumulator roundings in place of one); SPLIT = 6 drops a2 b3, a3 b2, a3 b3 (each at most
+// 2^-24 |a b|: the size of ONE fp32 rounding of the product).  8 k per lane and instruction at 32 cycles against 2 k at 64:
+// 6 terms cost 192 cycles per 32 x 32 x 16 block where the fp32 instruction needs 512 (9 terms: 288).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+struct Planes { bf16x8 a[3][2], b[3][2]; };                        // [plane][tile]
+
+__device__ __forceinline__ void split8(const float4& lo, const float4& hi, bf16x8& p1, bf16x8& p2, bf16x8& p3) {
+    const float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    uint32_t w1[4], w2[4], w3[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t u0 = __float_as_uint(x[2 * q]), u1 = __float_as_uint(x[2 * q + 1]);
+        w1[q] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);        // {hi16(x1), hi16(x0)}: element 2q in the low half
+        const float r0 = x[2 * q] - __uint_as_float(u0 & 0xffff0000u), r1 = x[2 * q + 1] - __uint_as_float(u1 & 0xffff0000u);
+        const uint32_t v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+        w2[q] = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+        const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
+        w3[q] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+    }
+    p1 = __builtin_bit_cast(bf16x8, make_uint4(w1[0], w1[1], w1[2], w1[3]));
+    p2 = __builtin_bit_cast(bf16x8, make_uint4(w2[0], w2[1], w2[2], w2[3]));
+    p3 = __builtin_bit_cast(bf16x8, make_uint4(w3[0], w3[1], w3[2], w3[3]));
+}
+// planes of slab s (k = 16 s .. 16 s + 15; fragment slots 2 s and 2 s + 1 hold the lane's 8 consecutive k)
+__device__ __forceinline__ void split_slab(Planes& pl, const Frags& f, int s) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        split8(f.a[2 * s][t], f.a[2 * s + 1][t], pl.a[0][t], pl.a[1][t], pl.a[2][t]);
+        split8(f.b[2 * s][t], f.b[2 * s + 1][t], pl.b[0][t], pl.b[1][t], pl.b[2][t]);
+    }
+}
+// one term a_P b_Q on the four 32 x 32 tiles of the wave (each accumulator is touched every fourth instruction)
+template <int P, int Q>
+__device__ __forceinline__ void mfma_term(f32x16 (&acc)[2][2], const Planes& pl) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pl.a[P][a], pl.b[Q][b], acc[a][b], 0, 0, 0);
+}
+// half 0: the small terms (added first), half 1: the leading ones
+template <int SPLIT>
+__device__ __forceinline__ void mfma_terms(f32x16 (&acc)[2][2], const Planes& pl, int half) {
+    if (half == 0) {
+        if (SPLIT == 9) { mfma_term<2, 2>(acc, pl); mfma_term<2, 1>(acc, pl); mfma_term<1, 2>(acc, pl); }
+        mfma_term<2, 0>(acc, pl); mfma_term<0, 2>(acc, pl); mfma_term<1, 1>(acc, pl);
+    } else {
+        mfma_term<1, 0>(acc, pl); mfma_term<0, 1>(acc, pl); mfma_term<0, 0>(acc, pl);
+    }
+}
+
+template <int SPLIT>
+__device__ __forceinline__ void quarter(f32x16 (&acc)[2][2], const Frags& f, Planes& pl, int q) {
+    if (SPLIT == 0) { mfma_group(acc, f, q); return; }
+    if ((q & 1) == 0) split_slab(pl, f, q >> 1);
+    mfma_terms<SPLIT>(acc, pl, q & 1);
+}
+
 #define RESEL_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-template <bool AKC, bool BKC>
+template <bool AKC, bool BKC, int SPLIT>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
     constexpr int ASZ = BM * LDK, BSZ = BN * LDK;
     __shared__ __attribute__((aligned(16))) float lds[2 * (ASZ + BSZ)];
@@ -197,9 +266,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
     };
     // consumer
     int c_item = blockIdx.x;
-    float* const lA = lds + (wm + li) * LDK + 4 * lh;              // this lane's fragment rows in buffer 0
-    float* const lB = lds + ASZ + (wn + li) * LDK + 4 * lh;
+    float* const lA = lds + (wm + li) * LDK + (SPLIT ? 8 : 4) * lh;              // this lane's fragment rows in buffer 0
+    float* const lB = lds + ASZ + (wn + li) * LDK + (SPLIT ? 8 : 4) * lh;
     Frags f;
+    Planes pl;
     p_open();
     produce();
     tile_store<AKC>(lds, tid, ra);
@@ -207,7 +277,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
     produce();
     __syncthreads();
 #pragma unroll
-    for (int g = 0; g < NG; ++g) read_frags(f, lA, lB, g);
+    for (int g = 0; g < NG; ++g) read_frags<SPLIT>(f, lA, lB, g);
     int nb = ASZ + BSZ;                                             // offset of the buffer the NEXT step goes to
     for (; c_item < total; c_item += G) {
         const Item cur = decode(p, c_item);
@@ -223,12 +293,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
         float bv[2] = {0.f, 0.f};
         for (int c_k0 = cur.kbeg; c_k0 < cur.kend; c_k0 += BK) {
             RESEL_FENCE();
-            mfma_group(acc, f, 0);
+            quarter<SPLIT>(acc, f, pl, 0);
             RESEL_FENCE();
             tile_store<AKC>(lds + nb, tid, ra);
             tile_store<BKC>(lds + nb + ASZ, tid, rb);
             RESEL_FENCE();
-            mfma_group(acc, f, 1);
+            quarter<SPLIT>(acc, f, pl, 1);
             RESEL_FENCE();
             if (c_k0 + BK >= cur.kend && p.bias && !cur.split) {    // requested most of a step before the epilogue needs them
 #pragma unroll
@@ -239,16 +309,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
             }
             produce();
             RESEL_FENCE();
-            mfma_group(acc, f, 2);
+            quarter<SPLIT>(acc, f, pl, 2);
             RESEL_FENCE();
             __syncthreads();
-            read_frags(f, lA + nb, lB + nb, 0);
-            read_frags(f, lA + nb, lB + nb, 1);
-            read_frags(f, lA + nb, lB + nb, 2);
+            read_frags<SPLIT>(f, lA + nb, lB + nb, 0);
+            read_frags<SPLIT>(f, lA + nb, lB + nb, 1);
+            read_frags<SPLIT>(f, lA + nb, lB + nb, 2);
             RESEL_FENCE();
-            mfma_group(acc, f, 3);
+            quarter<SPLIT>(acc, f, pl, 3);
             RESEL_FENCE();
-            read_frags(f, lA + nb, lB + nb, 3);
+            read_frags<SPLIT>(f, lA + nb, lB + nb, 3);
             RESEL_FENCE();
             nb = ASZ + BSZ - nb;
         }
@@ -363,8 +433,9 @@ extern "C" int resel_gemm_f32(const float* A, int64_t lda, int64_t strideA, int 
                               const float* B, int64_t ldb, int64_t strideB, int b_kcontig,
                               const float* bias, int64_t strideBias, int act,
                               float* C, int64_t ldc, int64_t strideC, void* workspace,
-                              int M, int N, int K, int batch, resel_stream_t stream) {
+                              int M, int N, int K, int batch, int split, resel_stream_t stream) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || act < 0 || act > 1) return RESEL_EINVAL;
+    if (split != 0 && split != 6 && split != 9) return RESEL_EINVAL;
     if (lda % 4 || ldb % 4 || strideA % 4 || strideB % 4 || !aligned16(A) || !aligned16(B)) return RESEL_EINVAL;
     // float4 loads run along the contiguous axis: its extent must be a multiple of 4 (K for [rows][K] operands, rows otherwise)
     if ((a_kcontig ? K : M) % 4 || (b_kcontig ? K : N) % 4) return RESEL_EINVAL;
@@ -375,10 +446,15 @@ extern "C" int resel_gemm_f32(const float* A, int64_t lda, int64_t strideA, int 
     const int64_t total = (int64_t)pl.nfull + (int64_t)pl.nsplit * pl.nsl;
     dim3 grid((unsigned)std::min<int64_t>(total, GRID));
     hipStream_t s = (hipStream_t)stream;
-    if (a_kcontig && b_kcontig) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, s, p);
-    else if (a_kcontig) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, s, p);
-    else if (b_kcontig) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, s, p);
+#define RESEL_GEMM_LAUNCH(SP) \
+    do { if (a_kcontig && b_kcontig) hipLaunchKernelGGL((gemm_f32_kernel<true, true, SP>), grid, dim3(256), 0, s, p); \
+         else if (a_kcontig) hipLaunchKernelGGL((gemm_f32_kernel<true, false, SP>), grid, dim3(256), 0, s, p); \
+         else if (b_kcontig) hipLaunchKernelGGL((gemm_f32_kernel<false, true, SP>), grid, dim3(256), 0, s, p); \
+         else hipLaunchKernelGGL((gemm_f32_kernel<false, false, SP>), grid, dim3(256), 0, s, p); } while (0)
+    if (split == 6) RESEL_GEMM_LAUNCH(6);
+    else if (split == 9) RESEL_GEMM_LAUNCH(9);
+    else RESEL_GEMM_LAUNCH(0);
+#undef RESEL_GEMM_LAUNCH
     if (pl.nsplit) hipLaunchKernelGGL(gemm_fixup_kernel, dim3(TILE / 4 / 64, pl.nsplit), dim3(64, 4), 0, s, p);
     return launch_status();
 }

@@ -9,7 +9,7 @@ from ctypes import c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libresel_hip.so')
-ABI_VERSION = 3
+ABI_VERSION = 4
 _lib = None
 
 P, I, L, F, S, U = c_void_p, c_int, c_int64, c_float, c_void_p, c_uint64
@@ -60,7 +60,7 @@ SIGNATURES = {
     'resel_ensemble_head_bwd_workspace_bytes': (c_size_t, [L, I, L]),
     'resel_ensemble_head_bwd': (c_int, [P, P, P, P, P, P, P, L, I, L, S]),
     'resel_gemm_f32_workspace_bytes': (c_size_t, [I, I, I, I]),
-    'resel_gemm_f32': (c_int, [P, L, L, I, P, L, L, I, P, L, I, P, L, L, P, I, I, I, I, S]),
+    'resel_gemm_f32': (c_int, [P, L, L, I, P, L, L, I, P, L, I, P, L, L, P, I, I, I, I, I, S]),
     'resel_gather_trajs': (c_int, [P, I, L, P, I, I, I, I, I, I, I, I, I, P, I, P, S]),
     'resel_mamba_conv_step': (c_int, [P, L, P, L, P, L, L, L, I, P, P, P, I, I, I, I, S]),
     'resel_selective_state_update': (c_int, [P, L, P, L, P, P, L, P, P, P, P, P, L, P, I, I, I, I, S]),

@@ -163,7 +163,7 @@ class MambaInnerFn(torch.autograd.Function):
     only exists for d_conv <= 4).  Everything is token-major; the backward writes every gradient straight into its slot of
     two buffers - dxz [M, 2Di] (conv backward fills the x half, scan backward the z half) and dx_dbl [M, R+2N] (scan
     backward fills the B / C columns) - through the kernels' token strides, so autograd's slice-backward zero-fill + copy +
-    add passes (8 x 273 MB per update at config 2) disappear.  GEMMs are library calls (torch.mm)."""
+    add passes (8 x 273 MB per update at config 2) disappear.  GEMMs: `mm_nt` / `mm_nn` / `wgrad` (hand-written for long passes, library otherwise)."""
 
     @staticmethod
     def forward(ctx, x, in_w, conv_w, conv_b, xproj_w, dt_w, dt_b, A_log, D, out_w, mask, start):
@@ -175,12 +175,12 @@ class MambaInnerFn(torch.autograd.Function):
         M = Bsz * L
         x2 = x.reshape(M, Dm)
         maskf, startf = _flags(mask, Bsz, L), _flags(start, Bsz, L)
-        xz = torch.mm(x2, in_w.t())                                        # [M, 2Di] = (x | z)
+        xz = mm_nt(x2, in_w)                                               # [M, 2Di] = (x | z)
         cw = conv_w.reshape(Di, K).contiguous()
         xc = torch.empty(M, Di, dtype=torch.float32, device=x.device)
         check(lib().resel_causal_conv1d_fwd(_p(xz), 2 * Di, _p(cw), _p(conv_b), _p(maskf), _p(xc), Di, Bsz, L, Di, K, 1, _stream()),
               'causal_conv1d_fwd')
-        x_dbl = torch.mm(xc, xproj_w.t())                                  # [M, R + 2N] = (delta_r | B | C)
+        x_dbl = mm_nt(xc, xproj_w)                                         # [M, R + 2N] = (delta_r | B | C)
         dt = torch.mm(x_dbl[:, :R], dt_w.t())                              # [M, Di]; bias enters the scan as delta_bias
         A = -torch.exp(A_log.float())
         need_grad = any(ctx.needs_input_grad)
@@ -192,7 +192,7 @@ class MambaInnerFn(torch.autograd.Function):
         check(lib().resel_selective_scan_fwd(_p(xc), Di, _p(dt), Di, zptr, 2 * Di, _p(A), bptr, R + 2 * N, cptr, R + 2 * N,
                                              _p(D), _p(dt_b), _p(startf), _p(y), Di, _p(ck), None, _p(_ws(nb, x.device) if nb else None),
                                              Bsz, L, Di, N, 1, SSCAN_TIME_SEGMENTS, _stream()), 'selective_scan_fwd')
-        out = torch.mm(y, out_w.t())
+        out = mm_nt(y, out_w)
         ctx.save_for_backward(x2, in_w, cw, conv_b, xproj_w, dt_w, dt_b, A, D, out_w, maskf, startf, xz, xc, x_dbl, dt, y, ck)
         ctx.dims = (Bsz, L, Dm, Di, N, R, K, conv_w.shape)
         return out.view(Bsz, L, -1)
@@ -206,8 +206,8 @@ class MambaInnerFn(torch.autograd.Function):
         do2 = dout.reshape(M, -1)
         if not do2.is_contiguous():
             do2 = do2.contiguous()
-        d_out_w = torch.mm(do2.t(), y)
-        dy = torch.mm(do2, out_w)                                          # [M, Di]
+        d_out_w = wgrad(do2, y)
+        dy = mm_nn(do2, out_w)                                             # [M, Di]
         dxz = torch.empty(M, 2 * Di, dtype=torch.float32, device=dev)      # fully written: conv bwd -> [:, :Di], scan bwd -> [:, Di:]
         dx_dbl = torch.empty(M, R + 2 * N, dtype=torch.float32, device=dev)
         dxc = torch.empty(M, Di, dtype=torch.float32, device=dev)
@@ -226,15 +226,15 @@ class MambaInnerFn(torch.autograd.Function):
         d_dt_w = atb(ddt, x_dbl[:, :R]) if R <= 32 and Di % 4 == 0 and ddt.stride(1) == 1 and ddt.stride(0) % 4 == 0 \
             else torch.mm(ddt.t(), x_dbl[:, :R])
         dx_dbl[:, :R] = torch.mm(ddt, dt_w)
-        d_xproj_w = torch.mm(dx_dbl.t(), xc)
+        d_xproj_w = wgrad(dx_dbl, xc)
         dxc.addmm_(dx_dbl, xproj_w)                                        # conv output receives scan (du) + x_proj gradients
         dcw = torch.empty(Di, K, dtype=torch.float32, device=dev)
         dcb = torch.empty(Di, dtype=torch.float32, device=dev) if conv_b is not None else None
         ws2 = _ws(lib().resel_causal_conv1d_bwd_workspace_bytes(Bsz, L, Di, K), dev)
         check(lib().resel_causal_conv1d_bwd(_p(xz), 2 * Di, _p(cw), _p(conv_b), _p(maskf), _p(dxc), Di, _p(dxz), 2 * Di, _p(dcw), _p(dcb),
                                             _p(ws2), Bsz, L, Di, K, 1, _stream()), 'causal_conv1d_bwd')
-        d_in_w = torch.mm(dxz.t(), x2)
-        dx = torch.mm(dxz, in_w).view(Bsz, L, Dm) if ctx.needs_input_grad[0] else None
+        d_in_w = wgrad(dxz, x2)
+        dx = mm_nn(dxz, in_w).view(Bsz, L, Dm) if ctx.needs_input_grad[0] else None
         return (dx, d_in_w, dcw.reshape(cw_shape), dcb, d_xproj_w, d_dt_w, ddt_b, dA * A, dD, d_out_w, None, None)
 
 
@@ -645,13 +645,13 @@ def ensemble_head_bwd(gq, a3, w3):
 
 class LinearAct(torch.autograd.Function):
     """act(x W^T + b) for nn.Linear weights (reference rnn_base.py:462-474: `fc` layer followed by its activation module):
-    library GEMM + one in-place bias/activation pass; the backward needs the layer OUTPUT only."""
+    one GEMM with the bias / activation tail (`mm_nt`); the backward needs the layer OUTPUT only."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, act):
         x2 = x.reshape(-1, x.shape[-1])
-        y2 = torch.mm(x2, weight.t())
-        bias_act_(y2, None if bias is None else bias.reshape(1, -1).contiguous(), y2.shape[0], act)
+        x2 = x2 if x2.stride(-1) == 1 else x2.contiguous()
+        y2 = mm_nt(x2, weight, bias, act)
         ctx.save_for_backward(x2, weight, y2)
         ctx.act, ctx.has_bias, ctx.xshape = act, bias is not None, x.shape
         return y2.view(*x.shape[:-1], weight.shape[0])
@@ -660,8 +660,13 @@ class LinearAct(torch.autograd.Function):
     def backward(ctx, g):
         x2, weight, y2 = ctx.saved_tensors
         g2 = g.reshape(y2.shape)
-        gy, db = bias_act_bwd(g2, y2, y2.shape[0], ctx.act, ctx.has_bias and ctx.needs_input_grad[2])
-        dx = torch.mm(gy, weight).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        need_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.act is None and y2.shape[1] % 4:                       # narrow heads (6-wide action mean): plain column sum
+            g2 = g2 if g2.is_contiguous() else g2.contiguous()
+            gy, db = g2, (g2.sum(dim=0) if need_db else None)
+        else:
+            gy, db = bias_act_bwd(g2, y2, y2.shape[0], ctx.act, need_db)
+        dx = mm_nn(gy, weight).view(ctx.xshape) if ctx.needs_input_grad[0] else None
         dw = wgrad(gy, x2) if ctx.needs_input_grad[1] else None
         return dx, dw, None if db is None else db.reshape(-1), None
 
@@ -670,15 +675,47 @@ def linear_act(x, weight, bias, act):
     return LinearAct.apply(x, weight, bias, act)
 
 
+# tokens per pass from which the hand-written GEMM is used (measured at 66 752: tools/bench_gemm_f32.py); the environment
+# variable is the A/B switch of the profiles (a huge value = library GEMMs everywhere)
+GEMM_F32_MIN_ROWS = int(os.environ.get('RESEL_GEMM_F32_MIN_ROWS', 16384))
+
+
+def gemm_f32_ok(rows, *mats):
+    """True when `resel_gemm_f32` may take these operands: a long pass on the GPU, fp32, unit column stride, 16-byte aligned rows."""
+    return rows >= GEMM_F32_MIN_ROWS and all(
+        t.is_cuda and t.dtype == torch.float32 and t.stride(-1) == 1 and t.data_ptr() % 16 == 0 and t.shape[-1] % 4 == 0
+        and all(st % 4 == 0 for st in t.stride()[:-1]) for t in mats)
+
+
+GEMM_F32_MIN_DIM = 64        # narrower outputs / shorter reductions (dt_proj's rank 16, the 6-wide heads) stay with the library
+
+
+def _mine(rows, n, k, *mats):
+    return min(n, k) >= GEMM_F32_MIN_DIM and gemm_f32_ok(rows, *mats)
+
+
+def mm_nt(x2, w, bias=None, act=None):
+    """act(x2 [M, K] w[N, K]^T + bias): forward of an nn.Linear-shaped layer over the tokens of a pass.  Hand-written GEMM with
+    the bias / ELU in its epilogue when the pass is long enough (`gemm_f32_ok`), else library GEMM (+ one in-place tail pass)."""
+    if act in (None, 'elu') and _mine(x2.shape[0], w.shape[0], w.shape[1], x2, w):
+        return gemm_f32(x2, w, True, True, bias, act)
+    if act is None:
+        return torch.addmm(bias, x2, w.t()) if bias is not None else torch.mm(x2, w.t())
+    y2 = torch.mm(x2, w.t())
+    return bias_act_(y2, None if bias is None else bias.reshape(1, -1).contiguous(), y2.shape[0], act)
+
+
+def mm_nn(g2, w):
+    """g2 [M, N] w[N, K] -> [M, K]: input gradient of such a layer."""
+    if _mine(g2.shape[0], w.shape[1], w.shape[0], g2, w):
+        return gemm_f32(g2, w, True, False)
+    return torch.mm(g2, w)
+
+
 def wgrad(gy, x2):
-    """dW [out, in] = gy[M, out]^T x2[M, in] over the M tokens of a pass.  Long reductions into a narrow output are where the
-    library's heuristics are weakest (a [128, 256] output from 66 752 tokens: 233 us = 19 TFLOP/s tuned) and where the
-    hand-written split-K kernel wins (89 us, `tools/bench_gemm_f32.py`); everything else stays a library GEMM."""
-    M, n_out = gy.shape
-    n_in = x2.shape[1]
-    if gy.is_cuda and M >= 16384 and n_out <= 128 and n_out % 4 == 0 and n_in % 4 == 0 and n_in >= 128 \
-            and gy.stride(1) == 1 and x2.stride(1) == 1 and gy.stride(0) % 4 == 0 and x2.stride(0) % 4 == 0 \
-            and gy.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0:
+    """dW [out, in] = gy[M, out]^T x2[M, in] over the M tokens of a pass: the hand-written K-split GEMM (at 66 752 tokens:
+    [128, 256] 49 us against the library's 234, [2048, 384] 731 against 1217, [256, 256] 86 against 123; `tools/bench_gemm_f32.py`)."""
+    if _mine(gy.shape[0], gy.shape[1], x2.shape[1], gy, x2):
         return gemm_f32(gy, x2, False, False)
     return torch.mm(gy.t(), x2)
 
@@ -712,8 +749,12 @@ def atb(wide, narrow, transposed=False):
     return out
 
 
+# product formation of resel_gemm_f32 (include/resel_hip.h): 0 fp32 MFMA, 9 / 6 exact three-way bf16 split on the bf16 MFMA
+GEMM_SPLIT = int(os.environ.get('RESEL_GEMM_SPLIT', 6))
+
+
 @torch.no_grad()
-def gemm_f32(A, B, a_kcontig=True, b_kcontig=True, bias=None, act=None, out=None):
+def gemm_f32(A, B, a_kcontig=True, b_kcontig=True, bias=None, act=None, out=None, split=None):
     """C[b] = act(A[b] (.) B[b] + bias[b]) on the fp32 matrix cores (include/resel_hip.h `resel_gemm_f32`).
     A: [M, K] (a_kcontig) or [K, M]; B: [N, K] (b_kcontig) or [K, N]; optionally a leading batch (ensemble) dimension on all of
     A, B, bias [N] / [batch, N], out.  Row stride free (column stride 1); returns C [M, N] / [batch, M, N]."""
@@ -737,7 +778,7 @@ def gemm_f32(A, B, a_kcontig=True, b_kcontig=True, bias=None, act=None, out=None
         bs = bias.stride(0) if batched else 0
     check(lib().resel_gemm_f32(_p(A3), A3.stride(1), A3.stride(0) if batch > 1 else 0, int(a_kcontig), _p(B3), B3.stride(1),
                                B3.stride(0) if batch > 1 else 0, int(b_kcontig), _p(bias), bs, ACT_IDS[act], _p(C3), C3.stride(1),
-                               C3.stride(0) if batch > 1 else 0, _p(ws), M, N, K, batch, _stream()), 'gemm_f32')
+                               C3.stride(0) if batch > 1 else 0, _p(ws), M, N, K, batch, GEMM_SPLIT if split is None else int(split), _stream()), 'gemm_f32')
     return out
 
 

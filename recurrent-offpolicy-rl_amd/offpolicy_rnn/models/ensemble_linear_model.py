@@ -24,7 +24,10 @@ class _SharedInput(torch.autograd.Function):
     def forward(ctx, x2, weight, bias, act, x_part=None, col0=0):
         E, n_in, n_out = weight.shape
         w_cat = weight.permute(1, 0, 2).reshape(n_in, E * n_out)                 # [in, E*out] (weights only: tiny copy)
-        if act is None:
+        if min(n_in, E * n_out) >= ops.GEMM_F32_MIN_DIM and ops.gemm_f32_ok(x2.shape[0], x2, w_cat):
+            # hand-written fp32 MFMA GEMM, bias + ELU in its epilogue (837 us against 995 at 66 752 x 384 -> 2048)
+            y2 = ops.gemm_f32(x2, w_cat, True, False, None if bias is None else bias.reshape(E * n_out), act)
+        elif act is None:
             y2 = torch.addmm(bias.reshape(E * n_out), x2, w_cat) if bias is not None else torch.mm(x2, w_cat)
         else:                               # GEMM, then bias + activation in one in-place pass
             y2 = torch.mm(x2, w_cat)
@@ -44,31 +47,53 @@ class _SharedInput(torch.autograd.Function):
             g2, db = ops.bias_act_bwd(g2, y2, g2.shape[0], act, need_db)
         else:
             db = g2.sum(dim=0, keepdim=True) if need_db else None
-        dx = torch.mm(g2, w_cat.t()) if ctx.needs_input_grad[0] else None        # sums over the ensemble
-        dw = torch.mm(x2.t(), g2).view(n_in, E, n_out).permute(1, 0, 2) if ctx.needs_input_grad[1] else None
+        mine = min(n_in, E * n_out) >= ops.GEMM_F32_MIN_DIM and ops.gemm_f32_ok(g2.shape[0], g2, x2, w_cat)
+        dx = None
+        if ctx.needs_input_grad[0]:                                               # sums over the ensemble
+            dx = ops.gemm_f32(g2, w_cat, True, True) if mine else torch.mm(g2, w_cat.t())
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = ops.gemm_f32(x2, g2, False, False) if mine else torch.mm(x2.t(), g2)
+            dw = dw.view(n_in, E, n_out).permute(1, 0, 2)
         dpart = None
         if ctx.part is not None and ctx.needs_input_grad[4]:
             col0, k, shape = ctx.part
-            dpart = torch.mm(g2, w_cat[col0:col0 + k].t()).view(shape)
+            wp = w_cat[col0:col0 + k]
+            dpart = (ops.gemm_f32(g2, wp, True, True) if mine and k >= ops.GEMM_F32_MIN_DIM else torch.mm(g2, wp.t())).view(shape)
         return dx, dw, None if db is None else db.view(E, 1, n_out), None, dpart, None
 
 
 def _member_wgrad(x3, gy):
-    """dW[e] = x3[e]^T gy[e] for the per-member layers: the hand-written split-K fp32 MFMA kernel (737 us against the tuned
-    strided-batched library GEMM's 840 us at 8 x 66 752 x 256 x 256, `tools/bench_gemm_f32.py`) when the layout allows."""
-    E, M, n_in = x3.shape
-    n_out = gy.shape[2]
-    if x3.is_cuda and M >= 16384 and n_in % 4 == 0 and n_out % 4 == 0 and x3.stride(2) == 1 and gy.stride(2) == 1 \
-            and all(t.stride(0) % 4 == 0 and t.stride(1) % 4 == 0 and t.data_ptr() % 16 == 0 for t in (x3, gy)):
+    """dW[e] = x3[e]^T gy[e] for the per-member layers: the hand-written K-split fp32 MFMA kernel (676 us against the tuned
+    strided-batched library GEMM's 833 us at 8 x 66 752 x 256 x 256, `tools/bench_gemm_f32.py`) when the layout allows."""
+    if min(x3.shape[2], gy.shape[2]) >= ops.GEMM_F32_MIN_DIM and ops.gemm_f32_ok(x3.shape[1], x3, gy):
         return ops.gemm_f32(x3, gy, False, False)
     return torch.bmm(x3.transpose(1, 2), gy)
+
+
+def _member_dgrad(gy, weight, like):
+    """dx[e] = gy[e] W[e]^T.  When the layer's input was the [E, M, in] VIEW of a shared-input layer's [M, E*in] output
+    (`like.stride(0) < like.stride(1)`), dx is written in that same memory layout, so that the producer's backward reads it as
+    the [M, E*in] matrix it needs - no transposing copy.  649 us hand-written against 674 (8 x 66 752 x 256 x 256)."""
+    E, M, _ = gy.shape
+    n_in = weight.shape[1]
+    if like.stride(0) < like.stride(1):
+        dx = torch.empty(M, E, n_in, dtype=gy.dtype, device=gy.device).transpose(0, 1)
+    else:
+        dx = torch.empty(E, M, n_in, dtype=gy.dtype, device=gy.device)
+    if min(n_in, weight.shape[2]) >= ops.GEMM_F32_MIN_DIM and ops.gemm_f32_ok(M, gy, weight, dx):
+        return ops.gemm_f32(gy, weight, True, True, out=dx)
+    return torch.bmm(gy, weight.transpose(1, 2), out=dx)
 
 
 class _PerMember(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x3, weight, bias, act):
         E, M, _ = x3.shape
-        if act is None and (bias is None or weight.shape[2] < 4):
+        if min(weight.shape[1:]) >= ops.GEMM_F32_MIN_DIM and act in (None, 'elu') and ops.gemm_f32_ok(M, x3, weight):
+            # bias + ELU in the GEMM epilogue: 583 us against the library's 605 + a 140 us tail pass (8 x 66 752 x 256 x 256)
+            y = ops.gemm_f32(x3, weight, True, False, bias, act)
+        elif act is None and (bias is None or weight.shape[2] < 4):
             y = torch.baddbmm(bias, x3, weight) if bias is not None else torch.bmm(x3, weight)
         else:                               # baddbmm would first materialise the broadcast bias as a full [E, M, out] copy
             y = torch.bmm(x3, weight)
@@ -89,15 +114,7 @@ class _PerMember(torch.autograd.Function):
             db = None if db is None else db.view(E, 1, n_out)
         else:
             gy, db = g, (g.sum(dim=1, keepdim=True) if need_db else None)
-        dx = None
-        if ctx.needs_input_grad[0]:
-            if x3.stride(0) < x3.stride(1):
-                # the input was the [E, M, in] VIEW of a shared-input layer's [M, E*in] output: write dx in that same memory
-                # layout, so that the producer's backward reads it as the [M, E*in] matrix it needs - no transposing copy
-                dx = torch.empty(M, E, weight.shape[1], dtype=g.dtype, device=g.device).transpose(0, 1)
-                torch.bmm(gy, weight.transpose(1, 2), out=dx)
-            else:
-                dx = torch.bmm(gy, weight.transpose(1, 2))
+        dx = _member_dgrad(gy, weight, x3) if ctx.needs_input_grad[0] else None
         dw = _member_wgrad(x3, gy) if ctx.needs_input_grad[1] else None
         return dx, dw, db, None
 
@@ -112,7 +129,8 @@ class _Head(torch.autograd.Function):
     def forward(ctx, x3, w2, b2, w3, b3):
         E, M, _ = x3.shape
         H = w2.shape[2]
-        a = torch.bmm(x3, w2)
+        a = ops.gemm_f32(x3, w2, True, False) if min(w2.shape[1:]) >= ops.GEMM_F32_MIN_DIM and ops.gemm_f32_ok(M, x3, w2) \
+            else torch.bmm(x3, w2)
         w3v = w3.reshape(E, H)
         q = ops.ensemble_head_fwd_(a, b2.reshape(E, H), w3v, None if b3 is None else b3.reshape(E))
         ctx.save_for_backward(x3, w2, w3v, a)
@@ -125,13 +143,7 @@ class _Head(torch.autograd.Function):
         E, M, H = a.shape
         gq2 = gq.reshape(E, M)
         gy, db2, dw3 = ops.ensemble_head_bwd(gq2, a, w3v)
-        dx = None
-        if ctx.needs_input_grad[0]:
-            if x3.stride(0) < x3.stride(1):          # same layout rule as _PerMember.backward
-                dx = torch.empty(M, E, w2.shape[1], dtype=gy.dtype, device=gy.device).transpose(0, 1)
-                torch.bmm(gy, w2.transpose(1, 2), out=dx)
-            else:
-                dx = torch.bmm(gy, w2.transpose(1, 2))
+        dx = _member_dgrad(gy, w2, x3) if ctx.needs_input_grad[0] else None
         dw2 = _member_wgrad(x3, gy)
         db3 = gq2.sum(dim=1).view(E, 1, 1) if ctx.has_b3 else None
         return dx, dw2, db2.view(E, 1, H), dw3.view(E, H, 1), db3

@@ -287,7 +287,8 @@ class RNNBase(torch.nn.Module):
                 assert not (ind == 0 and first_grad_part is not None), 'first_grad_part needs an efc first layer with ELU'
 
                 if isinstance(layer, torch.nn.Linear) and x.dim() > 2:    # 2-D call: the bias rides in the GEMM epilogue (addmm)
-                    x = torch.nn.functional.linear(x.reshape(-1, x.shape[-1]), layer.weight, layer.bias).view(*x.shape[:-1], -1)
+                    x = ops.linear_act(x, layer.weight, layer.bias, None) if x.is_cuda and x.dtype == torch.float32 else \
+                        torch.nn.functional.linear(x.reshape(-1, x.shape[-1]), layer.weight, layer.bias).view(*x.shape[:-1], -1)
                 else:
                     x = layer(x)
             if isinstance(act, torch.nn.ModuleList):

@@ -565,9 +565,11 @@ def test_atb_long_reduction_gemm(ops, K, Wd, Nd, ldn, tr):
     (600, 260, 100, True, False, True, None, 2),        # mixed layouts, batch of 2, K tail
     (66752, 256, 64, True, True, True, None, 1),        # two K steps per item: the persistent pipeline crosses items every other step
 ])
-def test_gemm_f32_vs_fp64_product(ops, M, N, K, akc, bkc, bias, act, batch):
-    """resel_gemm_f32 (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulation) against an fp64 product: 1e-5 of the
-    largest output magnitude; both operand layouts, ragged edges, batch strides, fused bias + ELU, deterministic split-K."""
+@pytest.mark.parametrize('split', [0, 6, 9])
+def test_gemm_f32_vs_fp64_product(ops, M, N, K, akc, bkc, bias, act, batch, split):
+    """resel_gemm_f32 against an fp64 product: 1e-5 of the largest output magnitude in every product mode (0: fp32 MFMA, exact
+    products; 9 / 6: exact three-way bf16 operand split on the bf16 MFMA, all nine / the six leading plane products); both
+    operand layouts, ragged edges, batch strides, fused bias + ELU, deterministic K split."""
     g = torch.Generator().manual_seed(M + N + K)
     sh = (batch,) if batch > 1 else ()
     A = torch.randn(*sh, *((M, K) if akc else (K, M)), generator=g)
@@ -580,10 +582,31 @@ def test_gemm_f32_vs_fp64_product(ops, M, N, K, akc, bkc, bias, act, batch):
         ref = ref + b.double().unsqueeze(-2)
     if act == 'elu':
         ref = torch.nn.functional.elu(ref)
-    out = ops.gemm_f32(A.cuda(), B.cuda(), akc, bkc, None if b is None else b.cuda(), act)
+    out = ops.gemm_f32(A.cuda(), B.cuda(), akc, bkc, None if b is None else b.cuda(), act, split=split)
     close(out, ref.float(), rtol=1e-5, atol_scale=1e-6, name='gemm_f32')
-    out2 = ops.gemm_f32(A.cuda(), B.cuda(), akc, bkc, None if b is None else b.cuda(), act)
+    out2 = ops.gemm_f32(A.cuda(), B.cuda(), akc, bkc, None if b is None else b.cuda(), act, split=split)
     assert torch.equal(out, out2)                       # bitwise reproducible (no atomics)
+
+
+def test_gemm_f32_split_modes_error_against_fp64(ops):
+    """The bf16-split product modes are as accurate as the fp32 instruction: mean and maximum error against an fp64 product, on
+    operands with a wide dynamic range (6 decades), K = 4096.  Mode 9 represents every product exactly (as mode 0 does): its
+    error is the accumulation's; mode 6 adds at most one product rounding per term."""
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 512, 384, 4096
+    A = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, K, generator=g) * 2.0)).cuda()
+    B = (torch.randn(N, K, generator=g) * torch.exp(torch.randn(N, K, generator=g) * 2.0)).cuda()
+    ref = A.double() @ B.double().t()
+    scale = (A.double().abs() @ B.double().abs().t())          # sum |a b|: the natural error scale of a dot product
+    err = {}
+    for split in (0, 6, 9):
+        e = ((ops.gemm_f32(A, B, True, True, split=split).double() - ref).abs() / scale)
+        err[split] = (e.mean().item(), e.max().item())
+    lib = (((A @ B.t()).double() - ref).abs() / scale)
+    print('relative to sum|ab|: mean / max', err, 'library fp32 GEMM', (lib.mean().item(), lib.max().item()))
+    for split in (6, 9):
+        assert err[split][0] <= 1.5 * err[0][0] + 1e-9 and err[split][1] <= 2.0 * err[0][1] + 1e-9, err
+    assert err[6][1] < 1e-6
 
 
 # ------------------------------------------------------------------------------------------ time-parallel selective scan

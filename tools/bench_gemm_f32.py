@@ -9,6 +9,9 @@ from offpolicy_rnn.hip.gemm_select import enable_tuned_gemms
 enable_tuned_gemms()
 dev = 'cuda'
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 66752
+if len(sys.argv) > 2:
+    ops.GEMM_SPLIT = int(sys.argv[2])
+print('tokens', T, 'product mode (split)', ops.GEMM_SPLIT)
 
 
 def timeit(fn, n=10, warm=3):
