@@ -91,13 +91,14 @@ __device__ __forceinline__ Item decode(const GemmParams& p, int it) {
 template <bool KC>
 struct Src {
     const char* base;                              // uniform (SGPR pair): operand + member + tile origin + K position
+    const char* base0;                             // ... at the item's first K step
     uint32_t off[4];                               // this thread's byte offsets of its four pieces from `base`
     int64_t step;                                  // bytes per K step
     int kofs;                                      // k of piece 0 inside the step
     __device__ __forceinline__ void init(const float* P, int64_t ld, int rows, int r0, int k0, int tid) {
         kofs = 4 * (tid & 7);
         if (KC) {
-            base = (const char*)(P + (int64_t)r0 * ld + k0);
+            base = base0 = (const char*)(P + (int64_t)r0 * ld + k0);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int rl = (tid >> 3) + 32 * i;
@@ -105,12 +106,21 @@ struct Src {
             }
             step = BK * 4;
         } else {
-            base = (const char*)(P + (int64_t)k0 * ld + r0);
+            base = base0 = (const char*)(P + (int64_t)k0 * ld + r0);
             const int rl = 4 * (tid >> 3);
 #pragma unroll
             for (int j = 0; j < 4; ++j) off[j] = (uint32_t)(((kofs + j) * ld + (r0 + rl < rows ? rl : 0)) * 4);
             step = (int64_t)BK * ld * 4;
         }
+    }
+    // Branch-free load for the scheduled region of the SPLIT loop: `full` (uniform) = a whole K step is due - load it and
+    // advance; otherwise (K tail, or nothing left to fetch) the same instructions re-read the item's first step, a valid
+    // address (the host sends K < 32 to the fp32 kernel), and the caller's guarded `load` then provides the real data.
+    __device__ __forceinline__ void load_sched(float4 (&r)[4], bool full) {
+        const char* b = full ? base : base0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const float4*>(b + off[i]);
+        if (full) base += step;
     }
     __device__ __forceinline__ void load(float4 (&r)[4], int k0, int kend) {
         if (k0 + BK <= kend) {
@@ -153,9 +163,17 @@ __device__ __forceinline__ void read_frags(Frags& f, const float* __restrict__ A
         f.b[g][t] = ld4(Bs + 32 * t * LDK + ko);
     }
 }
+__device__ __forceinline__ void read_a(Frags& f, const float* __restrict__ As, int g) {      // SPLIT-mode slot g of A / of B
+#pragma unroll
+    for (int t = 0; t < 2; ++t) f.a[g][t] = ld4(As + 32 * t * LDK + 16 * (g >> 1) + 4 * (g & 1));
+}
+__device__ __forceinline__ void read_b(Frags& f, const float* __restrict__ Bs, int g) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) f.b[g][t] = ld4(Bs + 32 * t * LDK + 16 * (g >> 1) + 4 * (g & 1));
+}
 // quarter q of a K step's matrix work
 template <int SPLIT>
-__device__ __forceinline__ void quarter(f32x16 (&acc)[2][2], const Frags& f, Planes& pl, int q);
+__device__ __forceinline__ void quarter(f32x16 (&acc)[2][2], const Frags& f, Planes (&pl)[2], int q);
 __device__ __forceinline__ void mfma_group(f32x16 (&acc)[2][2], const Frags& f, int g) {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -179,6 +197,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 struct Planes { bf16x8 a[3][2], b[3][2]; };                        // [plane][tile]
 
 __device__ __forceinline__ void split8(const float4& lo, const float4& hi, bf16x8& p1, bf16x8& p2, bf16x8& p3) {
+#ifdef GEMM_AB_NOSPLIT                 // ablation (wrong results): no vector work, the matrix instructions and everything else stay
+    p1 = __builtin_bit_cast(bf16x8, lo); p2 = __builtin_bit_cast(bf16x8, hi); p3 = p1;
+    return;
+#endif
     const float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
     uint32_t w1[4], w2[4], w3[4];
 #pragma unroll
@@ -195,12 +217,30 @@ __device__ __forceinline__ void split8(const float4& lo, const float4& hi, bf16x
     p2 = __builtin_bit_cast(bf16x8, make_uint4(w2[0], w2[1], w2[2], w2[3]));
     p3 = __builtin_bit_cast(bf16x8, make_uint4(w3[0], w3[1], w3[2], w3[3]));
 }
-// planes of slab s (k = 16 s .. 16 s + 15; fragment slots 2 s and 2 s + 1 hold the lane's 8 consecutive k)
-__device__ __forceinline__ void split_slab(Planes& pl, const Frags& f, int s) {
+// planes of slab s (k = 16 s .. 16 s + 15; fragment slots 2 s and 2 s + 1 hold the lane's 8 consecutive k), one operand at a time
+__device__ __forceinline__ void split_a(Planes& pl, const Frags& f, int s) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        split8(f.a[2 * s][t], f.a[2 * s + 1][t], pl.a[0][t], pl.a[1][t], pl.a[2][t]);
-        split8(f.b[2 * s][t], f.b[2 * s + 1][t], pl.b[0][t], pl.b[1][t], pl.b[2][t]);
+    for (int t = 0; t < 2; ++t) split8(f.a[2 * s][t], f.a[2 * s + 1][t], pl.a[0][t], pl.a[1][t], pl.a[2][t]);
+}
+__device__ __forceinline__ void split_b(Planes& pl, const Frags& f, int s) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) split8(f.b[2 * s][t], f.b[2 * s + 1][t], pl.b[0][t], pl.b[1][t], pl.b[2][t]);
+}
+// Program order IS issue order within a wave: twelve MFMAs written back to back hold the wave's issue slot for 12 x 32 cycles
+// and the vector work behind them then runs with the matrix pipe idle (PMC: MFMA busy 50 % + VALU issue 56 % = the whole
+// kernel).  Ask the scheduler for MFMA, NV vector instructions, MFMA, ... (tools/micro/mfma_valu_overlap.hip: five to six
+// vector instructions hide completely behind one 32-cycle MFMA, the rest cost 4.75 cycles each).
+// MEM: what else rides in the region - 2: eight LDS writes, eight global loads (each refills the register the write released),
+// four LDS reads; 3: four LDS reads
+template <int NM, int NV, int MEM = 0>
+__device__ __forceinline__ void interleave_mfma_valu() {
+#pragma unroll
+    for (int i = 0; i < NM; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
+        if (MEM == 2 && i < 8) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        if (MEM == 2 && i < 8) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        if (MEM != 0 && i >= 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
 }
 // one term a_P b_Q on the four 32 x 32 tiles of the wave (each accumulator is touched every fourth instruction)
@@ -209,7 +249,13 @@ __device__ __forceinline__ void mfma_term(f32x16 (&acc)[2][2], const Planes& pl)
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pl.a[P][a], pl.b[Q][b], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < 2; ++b) {
+#ifdef GEMM_AB_NOMFMA                  // ablation (wrong results): the operands are consumed, no matrix instruction is issued
+            asm volatile("" :: "v"(pl.a[P][a]), "v"(pl.b[Q][b]));
+#else
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pl.a[P][a], pl.b[Q][b], acc[a][b], 0, 0, 0);
+#endif
+        }
 }
 // half 0: the small terms (added first), half 1: the leading ones
 template <int SPLIT>
@@ -222,14 +268,43 @@ __device__ __forceinline__ void mfma_terms(f32x16 (&acc)[2][2], const Planes& pl
     }
 }
 
+// quarter q of a K step's matrix work.  fp32 MFMA: k group q.  SPLIT: slab q / 2, small terms (even q) or leading terms (odd q),
+// interleaved with a quarter of the operand splitting the NEXT slab needs: B then A of slab 1 during q = 0, 1; A then B of the
+// next step's slab 0 during q = 2, 3 (their fragments are read right after the barrier that precedes q = 2).
 template <int SPLIT>
-__device__ __forceinline__ void quarter(f32x16 (&acc)[2][2], const Frags& f, Planes& pl, int q) {
-    if (SPLIT == 0) { mfma_group(acc, f, q); return; }
-    if ((q & 1) == 0) split_slab(pl, f, q >> 1);
-    mfma_terms<SPLIT>(acc, pl, q & 1);
+__device__ __forceinline__ void quarter(f32x16 (&acc)[2][2], const Frags& f, Planes (&pl)[2], int q) {
+    mfma_group(acc, f, q);
+}
+// SPLIT-mode quarter q: slab q / 2, small terms (even q) or leading terms (odd q), interleaved with a quarter of the operand
+// splitting the NEXT slab needs - B then A of slab 1 during q = 0, 1; A then B of the next step's slab 0 during q = 2, 3 -
+// and with the memory instructions of the step (MEM, see interleave_mfma_valu), all in one scheduling region.
+template <int SPLIT, int Q, int MEM>
+__device__ __forceinline__ void split_quarter(f32x16 (&acc)[2][2], const Frags& f, Planes (&pl)[2]) {
+    if (Q == 0) split_b(pl[1], f, 1);
+    if (Q == 1) split_a(pl[1], f, 1);
+    if (Q == 2) split_a(pl[0], f, 0);
+    if (Q == 3) split_b(pl[0], f, 0);
+    mfma_terms<SPLIT>(acc, pl[Q >> 1], Q & 1);
+    // pin the planes to THIS region (the optimiser otherwise sinks their computation to the block of their first use)
+    Planes& np = pl[Q < 2 ? 1 : 0];
+#pragma unroll
+    for (int pi = 0; pi < 3; ++pi)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (Q == 0 || Q == 3) asm volatile("" : "+v"(np.b[pi][t]));
+            else asm volatile("" : "+v"(np.a[pi][t]));
+        }
+    if (SPLIT == 6 || (Q & 1)) interleave_mfma_valu<12, 8, MEM>();
+    else interleave_mfma_valu<24, 4, MEM>();
 }
 
 #define RESEL_FENCE() __builtin_amdgcn_sched_barrier(0)
+#ifdef GEMM_STAMP                      // issue-time stamps of one wave (block 0, wave 0) at the phase boundaries of its K steps
+__device__ unsigned long long g_gemm_stamps[64 * 16];
+#define STAMP(i) do { if (stamp_on && stamp_step < 64) g_gemm_stamps[stamp_step * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 
 template <bool AKC, bool BKC, int SPLIT>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
@@ -269,16 +344,26 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
     float* const lA = lds + (wm + li) * LDK + (SPLIT ? 8 : 4) * lh;              // this lane's fragment rows in buffer 0
     float* const lB = lds + ASZ + (wn + li) * LDK + (SPLIT ? 8 : 4) * lh;
     Frags f;
-    Planes pl;
+    Planes pl[2];
     p_open();
     produce();
     tile_store<AKC>(lds, tid, ra);
     tile_store<BKC>(lds + ASZ, tid, rb);
     produce();
+    if (SPLIT) {                                    // SPLIT runs one step further ahead: both LDS buffers filled, a third tile in registers
+        tile_store<AKC>(lds + ASZ + BSZ, tid, ra);
+        tile_store<BKC>(lds + ASZ + BSZ + ASZ, tid, rb);
+        produce();
+    }
     __syncthreads();
 #pragma unroll
     for (int g = 0; g < NG; ++g) read_frags<SPLIT>(f, lA, lB, g);
+    if (SPLIT) { split_a(pl[0], f, 0); split_b(pl[0], f, 0); }     // the loop keeps slab 0 split and slab 1's B fragments read
     int nb = ASZ + BSZ;                                             // offset of the buffer the NEXT step goes to
+#ifdef GEMM_STAMP
+    const bool stamp_on = blockIdx.x == 0 && tid == 0;
+    int stamp_step = 0;
+#endif
     for (; c_item < total; c_item += G) {
         const Item cur = decode(p, c_item);
         float zero = 0.f;
@@ -292,34 +377,92 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
                 for (int e = 0; e < 16; ++e) acc[a][b][e] = zero;
         float bv[2] = {0.f, 0.f};
         for (int c_k0 = cur.kbeg; c_k0 < cur.kend; c_k0 += BK) {
-            RESEL_FENCE();
-            quarter<SPLIT>(acc, f, pl, 0);
-            RESEL_FENCE();
-            tile_store<AKC>(lds + nb, tid, ra);
-            tile_store<BKC>(lds + nb + ASZ, tid, rb);
-            RESEL_FENCE();
-            quarter<SPLIT>(acc, f, pl, 1);
-            RESEL_FENCE();
-            if (c_k0 + BK >= cur.kend && p.bias && !cur.split) {    // requested most of a step before the epilogue needs them
+            if (SPLIT) {
+                // A: q0 | barrier | B: q1 + LDS write of the tile for step s + 2 (into the buffer step s was read from, free
+                // once every wave has passed the barrier) + global loads for step s + 3 into the same registers | C: q2 | D: q3.
+                // Every quarter also reads the 16 fragment registers the NEXT quarter splits (just in time: 32 raw registers
+                // live instead of 64).  Nothing but the barrier is issued outside the shadow of a matrix instruction
+                // (issue-time stamps of the version with the memory phases between the quarters: 4 x 620 cycles of quarters
+                // + 1600 of ds_write / loads / reads / barrier).
+                const int cb = ASZ + BSZ - nb;                          // offset of the buffer this step's tile is in
+                RESEL_FENCE();
+                STAMP(0);
+                read_a(f, lA + cb, 2); read_a(f, lA + cb, 3);           // this step's slab 1, A
+                split_quarter<SPLIT, 0, 3>(acc, f, pl);
+                RESEL_FENCE();
+                STAMP(1);
+                __syncthreads();
+                STAMP(2);
+                if (c_k0 + BK >= cur.kend && p.bias && !cur.split) {    // requested most of a step before the epilogue needs them
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const int n = cur.n0 + wn + 32 * b + li;
-                    bv[b] = p.bias[(int64_t)cur.z * p.sBias + (n < p.N ? n : 0)];
+                    for (int b = 0; b < 2; ++b) {
+                        const int n = cur.n0 + wn + 32 * b + li;
+                        bv[b] = p.bias[(int64_t)cur.z * p.sBias + (n < p.N ? n : 0)];
+                    }
                 }
+                const float* nA = lA + nb;
+                const float* nB = lB + nb;
+                const bool fast = p_live && p_k0 + BK <= p_kend;
+                RESEL_FENCE();
+                tile_store<AKC>(lds + cb, tid, ra);
+                tile_store<BKC>(lds + cb + ASZ, tid, rb);
+                sa.load_sched(ra, fast);
+                sb.load_sched(rb, fast);
+                read_a(f, nA, 0); read_a(f, nA, 1);
+                split_quarter<SPLIT, 1, 2>(acc, f, pl);
+                RESEL_FENCE();
+                if (fast) {
+                    p_k0 += BK;
+                    if (p_k0 >= p_kend) {
+                        p_item += G;
+                        if (p_item < total) p_open(); else p_live = false;
+                    }
+                } else {
+                    produce();
+                }
+                RESEL_FENCE();
+                STAMP(3);
+                read_b(f, nB, 0); read_b(f, nB, 1);
+                split_quarter<SPLIT, 2, 3>(acc, f, pl);
+                RESEL_FENCE();
+                STAMP(4);
+                read_b(f, nB, 2); read_b(f, nB, 3);
+                split_quarter<SPLIT, 3, 3>(acc, f, pl);
+                RESEL_FENCE();
+                STAMP(5);
+#ifdef GEMM_STAMP
+                ++stamp_step;
+#endif
+            } else {
+                RESEL_FENCE();
+                quarter<SPLIT>(acc, f, pl, 0);
+                RESEL_FENCE();
+                tile_store<AKC>(lds + nb, tid, ra);
+                tile_store<BKC>(lds + nb + ASZ, tid, rb);
+                RESEL_FENCE();
+                quarter<SPLIT>(acc, f, pl, 1);
+                RESEL_FENCE();
+                if (c_k0 + BK >= cur.kend && p.bias && !cur.split) {    // requested most of a step before the epilogue needs them
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const int n = cur.n0 + wn + 32 * b + li;
+                        bv[b] = p.bias[(int64_t)cur.z * p.sBias + (n < p.N ? n : 0)];
+                    }
+                }
+                produce();
+                RESEL_FENCE();
+                quarter<SPLIT>(acc, f, pl, 2);
+                RESEL_FENCE();
+                __syncthreads();
+                read_frags<SPLIT>(f, lA + nb, lB + nb, 0);
+                read_frags<SPLIT>(f, lA + nb, lB + nb, 1);
+                read_frags<SPLIT>(f, lA + nb, lB + nb, 2);
+                RESEL_FENCE();
+                quarter<SPLIT>(acc, f, pl, 3);
+                RESEL_FENCE();
+                read_frags<SPLIT>(f, lA + nb, lB + nb, 3);
+                RESEL_FENCE();
             }
-            produce();
-            RESEL_FENCE();
-            quarter<SPLIT>(acc, f, pl, 2);
-            RESEL_FENCE();
-            __syncthreads();
-            read_frags<SPLIT>(f, lA + nb, lB + nb, 0);
-            read_frags<SPLIT>(f, lA + nb, lB + nb, 1);
-            read_frags<SPLIT>(f, lA + nb, lB + nb, 2);
-            RESEL_FENCE();
-            quarter<SPLIT>(acc, f, pl, 3);
-            RESEL_FENCE();
-            read_frags<SPLIT>(f, lA + nb, lB + nb, 3);
-            RESEL_FENCE();
             nb = ASZ + BSZ - nb;
         }
         // epilogue: D layout col = lane & 31 (n), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (m)
@@ -423,6 +566,12 @@ inline Plan make_plan(int M, int N, int K, int batch) {
 
 }  // namespace
 
+#ifdef GEMM_STAMP
+extern "C" int resel_gemm_debug_stamps(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_gemm_stamps), sizeof(unsigned long long) * 64 * 16);
+}
+#endif
+
 extern "C" size_t resel_gemm_f32_workspace_bytes(int M, int N, int K, int batch) {
     if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return 0;
     const Plan pl = make_plan(M, N, K, batch);
@@ -436,6 +585,7 @@ extern "C" int resel_gemm_f32(const float* A, int64_t lda, int64_t strideA, int 
                               int M, int N, int K, int batch, int split, resel_stream_t stream) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || act < 0 || act > 1) return RESEL_EINVAL;
     if (split != 0 && split != 6 && split != 9) return RESEL_EINVAL;
+    if (K < BK) split = 0;                         // the split kernels' scheduled loads assume one whole K step per item
     if (lda % 4 || ldb % 4 || strideA % 4 || strideB % 4 || !aligned16(A) || !aligned16(B)) return RESEL_EINVAL;
     // float4 loads run along the contiguous axis: its extent must be a multiple of 4 (K for [rows][K] operands, rows otherwise)
     if ((a_kcontig ? K : M) % 4 || (b_kcontig ? K : N) % 4) return RESEL_EINVAL;

@@ -8,7 +8,7 @@ import os
 from ctypes import c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libresel_hip.so')
+LIB_PATH = os.environ.get('RESEL_HIP_LIBRARY') or os.path.join(_HERE, 'libresel_hip.so')      # override: ablation builds (tools/gemm_ablate.sh)
 ABI_VERSION = 4
 _lib = None
 

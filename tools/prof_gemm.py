@@ -7,6 +7,8 @@ from offpolicy_rnn.hip import ops
 M, N, K = (int(a) for a in sys.argv[1:4])
 akc, bkc = (bool(int(sys.argv[4])), bool(int(sys.argv[5]))) if len(sys.argv) > 5 else (True, True)
 reps = int(sys.argv[6]) if len(sys.argv) > 6 else 20
+if len(sys.argv) > 7:
+    ops.GEMM_SPLIT = int(sys.argv[7])
 A = torch.randn((M, K) if akc else (K, M), device='cuda')
 B = torch.randn((N, K) if bkc else (K, N), device='cuda')
 for _ in range(reps):
@@ -19,3 +21,15 @@ for _ in range(reps):
 e1.record(); torch.cuda.synchronize()
 us = e0.elapsed_time(e1) / reps * 1e3
 print(f'gemm_f32 {M}x{N}x{K}: {us:.1f} us, {2.0 * M * N * K / us / 1e6:.1f} TFLOP/s')
+
+if os.environ.get('RESEL_GEMM_STAMPS'):
+    import ctypes, numpy as np
+    from offpolicy_rnn.hip._lib import lib
+    buf = np.zeros(64 * 16, dtype=np.uint64)
+    rc = lib().resel_gemm_debug_stamps(ctypes.c_void_p(buf.ctypes.data))
+    st = buf.reshape(64, 16)[:, :9].astype(np.int64)
+    names = ['q0', 'ds_write', 'q1', 'produce', 'barrier', 'frag reads', 'q2', 'q3', '-> next step']
+    print('rc', rc, 'phases:', names)
+    for i in range(2, 26):
+        d = np.diff(st[i]).tolist() + [int(st[i + 1][0] - st[i][8])]
+        print(f'step {i:2d}: ' + ' '.join(f'{x:5d}' for x in d) + f' | total {int(st[i + 1][0] - st[i][0])}')
