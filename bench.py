@@ -263,6 +263,7 @@ def main():
                          '(BASELINE configs[3]: 512)')
     ap.add_argument('--horizon', type=int, default=1024)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-strict-leg', action='store_true', help='skip the 4 extra updates that time the fp32-MFMA product mode')
     ap.add_argument('--envs', type=int, default=1, help='rollout mode: also time one graph replay over this many environments')
     args = ap.parse_args()
     if args.mode == 'rollout':
@@ -296,6 +297,7 @@ def main():
         alg.train_one_batch()
         alg.grad_num += 1
     ops.profile_enable(True)                            # HIP event pair bound to each scan dispatch, timed region only
+    ops.GEMM_FLOPS[0] = 0.0
     sync()
     t0 = time.perf_counter()
     trained = 0
@@ -306,6 +308,21 @@ def main():
     dt = time.perf_counter() - t0
     prof = ops.profile_collect()
     ops.profile_enable(False)
+    gemm_flops = ops.GEMM_FLOPS[0]
+    strict_ms = None
+    if ops.GEMM_SPLIT != 0 and not args.no_strict_leg:
+        # the same update with the GEMM products formed by the fp32 MFMA instruction (reported beside the headline, never as it)
+        mode, ops.GEMM_SPLIT = ops.GEMM_SPLIT, 0
+        alg.train_one_batch()
+        alg.grad_num += 1
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            alg.train_one_batch()
+            alg.grad_num += 1
+        sync()
+        strict_ms = 1e3 * (time.perf_counter() - t1) / 3
+        ops.GEMM_SPLIT = mode
     stat = torch.tensor([dt, float(trained)], dtype=torch.float64, device='cuda')
     if world > 1:
         tmax = stat[:1].clone()
@@ -330,6 +347,17 @@ def main():
         out['roofline'] = lines[0]
     if len(lines) > 1:
         out['roofline_other'] = lines[1:]
+    if 'gemm_f32_kernel' in kern:
+        g = kern['gemm_f32_kernel']
+        tf = gemm_flops / (g['launches'] * g['avg_us'] * 1e-6) / 1e12
+        mode = ops.GEMM_SPLIT
+        # fp32-equivalent FLOP (2 M N K); peak: the fp32 MFMA rate (mode 0) or the bf16 MFMA rate / the number of plane products
+        peak = 2500.0 / mode if mode else 157.3
+        out['gemm'] = {'kernel': 'gemm_f32_kernel', 'bound': 'mfma', 'achieved': tf, 'peak': peak, 'unit': 'TFLOP/s (fp32-equivalent)', 'frac': tf / peak,
+                       'launches': g['launches'], 'avg_us': g['avg_us'], 'flops_per_update': gemm_flops / args.steps,
+                       'products': {0: 'v_mfma_f32_32x32x2_f32', 6: 'exact 3-way bf16 operand split, 6 leading plane products, fp32 accumulate',
+                                    9: 'exact 3-way bf16 operand split, all 9 plane products, fp32 accumulate'}[mode],
+                       'ms_per_step_with_fp32_mfma_products': strict_ms}
     out['kernels'] = kern
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline('gru')      # of record: north_star's CPU GRU trainer at the full B=64, T=1024

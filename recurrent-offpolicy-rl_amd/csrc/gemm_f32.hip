@@ -597,10 +597,10 @@ extern "C" int resel_gemm_f32(const float* A, int64_t lda, int64_t strideA, int 
     dim3 grid((unsigned)std::min<int64_t>(total, GRID));
     hipStream_t s = (hipStream_t)stream;
 #define RESEL_GEMM_LAUNCH(SP) \
-    do { if (a_kcontig && b_kcontig) hipLaunchKernelGGL((gemm_f32_kernel<true, true, SP>), grid, dim3(256), 0, s, p); \
-         else if (a_kcontig) hipLaunchKernelGGL((gemm_f32_kernel<true, false, SP>), grid, dim3(256), 0, s, p); \
-         else if (b_kcontig) hipLaunchKernelGGL((gemm_f32_kernel<false, true, SP>), grid, dim3(256), 0, s, p); \
-         else hipLaunchKernelGGL((gemm_f32_kernel<false, false, SP>), grid, dim3(256), 0, s, p); } while (0)
+    do { if (a_kcontig && b_kcontig) launch_timed(RESEL_PROF_GEMM, gemm_f32_kernel<true, true, SP>, grid, dim3(256), 0, s, p); \
+         else if (a_kcontig) launch_timed(RESEL_PROF_GEMM, gemm_f32_kernel<true, false, SP>, grid, dim3(256), 0, s, p); \
+         else if (b_kcontig) launch_timed(RESEL_PROF_GEMM, gemm_f32_kernel<false, true, SP>, grid, dim3(256), 0, s, p); \
+         else launch_timed(RESEL_PROF_GEMM, gemm_f32_kernel<false, false, SP>, grid, dim3(256), 0, s, p); } while (0)
     if (split == 6) RESEL_GEMM_LAUNCH(6);
     else if (split == 9) RESEL_GEMM_LAUNCH(9);
     else RESEL_GEMM_LAUNCH(0);

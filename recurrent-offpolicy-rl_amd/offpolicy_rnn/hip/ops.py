@@ -54,7 +54,8 @@ def _ws(nbytes: int, device) -> torch.Tensor:
 
 PROF_SLOTS = ('sscan_fwd_kernel', 'sscan_bwd_kernel', 'attn_fwd_kernel', 'attn_dq_kernel', 'attn_dkv_kernel', 'linrec_real_fwd_kernel',
               'linrec_real_bwd_kernel', 'linrec_complex_fwd_kernel', 'linrec_complex_bwd_kernel', 'gru_fwd_kernel', 'gru_bwd_kernel',
-              'conv_fwd_kernel', 'conv_bwd_kernel')          # RESEL_PROF_* of include/resel_hip.h, in id order
+              'conv_fwd_kernel', 'conv_bwd_kernel', 'gemm_f32_kernel')          # RESEL_PROF_* of include/resel_hip.h, in id order
+GEMM_FLOPS = [0.0]            # 2 M N K of every resel_gemm_f32 call since the caller last reset it (bench.py's GEMM line)
 
 
 def profile_enable(on: bool):
@@ -675,9 +676,9 @@ def linear_act(x, weight, bias, act):
     return LinearAct.apply(x, weight, bias, act)
 
 
-# tokens per pass from which the hand-written GEMM is used (measured at 66 752: tools/bench_gemm_f32.py); the environment
+# tokens per pass from which the hand-written GEMM is used (measured at 66 752 and 8 344: tools/bench_gemm_f32.py); the environment
 # variable is the A/B switch of the profiles (a huge value = library GEMMs everywhere)
-GEMM_F32_MIN_ROWS = int(os.environ.get('RESEL_GEMM_F32_MIN_ROWS', 16384))
+GEMM_F32_MIN_ROWS = int(os.environ.get('RESEL_GEMM_F32_MIN_ROWS', 4096))
 
 
 def gemm_f32_ok(rows, *mats):
@@ -770,6 +771,7 @@ def gemm_f32(A, B, a_kcontig=True, b_kcontig=True, bias=None, act=None, out=None
         out = torch.empty((batch, M, N) if batched else (M, N), dtype=torch.float32, device=A.device)
     C3 = out if batched else out.unsqueeze(0)
     assert C3.stride(-1) == 1
+    GEMM_FLOPS[0] += 2.0 * M * N * K * batch
     nb = lib().resel_gemm_f32_workspace_bytes(M, N, K, batch)
     ws = _ws(nb, A.device) if nb else None
     bs = 0
