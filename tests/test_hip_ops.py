@@ -411,12 +411,16 @@ def test_bias_act_fwd_bwd(ops, rows, C, nseg, act):
     close(db, br.grad, rtol=2e-4, atol_scale=5e-5, name='dbias')
 
 
-def test_ensemble_mlp_fused_tail_vs_torch(ops):
+@pytest.mark.parametrize('R,T,n_in,H', [(3, 50, 24, 32), (3, 1500, 128, 128)])
+def test_ensemble_mlp_fused_tail_vs_torch(ops, R, T, n_in, H):
     """shared-input layer -> per-member layer -> per-member head, ELU fused into the first two (efc-8 critic head,
-    reference contextual_sac_value.py via rnn_base.py:462-474) against plain torch autograd on the CPU."""
+    reference contextual_sac_value.py via rnn_base.py:462-474) against plain torch autograd on the CPU.  The second size
+    (4500 tokens, 128-wide) is past the thresholds of `ops.gemm_f32_ok`: every contraction of the three nodes - forward with the
+    bias / ELU epilogue, input gradients, weight gradients - then runs in `resel_gemm_f32` instead of the library."""
     from offpolicy_rnn.models.ensemble_linear_model import EnsembleLinear
     torch.manual_seed(3)
-    E, R, T, n_in, H = 4, 3, 50, 24, 32
+    E = 4
+    flops0 = ops.GEMM_FLOPS[0]
     l1, l2, l3 = EnsembleLinear(n_in, H, E), EnsembleLinear(H, H, E, desire_ndim=4), EnsembleLinear(H, 1, E, desire_ndim=4)
     for l in (l1, l2, l3):
         torch.nn.init.normal_(l.bias, std=0.3)
@@ -455,6 +459,30 @@ def test_ensemble_mlp_fused_tail_vs_torch(ops):
             close(a, b, rtol=2e-4, atol_scale=5e-5, name=f'fused_head={fused_head} tensor {i}')
         for l in (l1, l2, l3):
             l.zero_grad()
+    assert (ops.GEMM_FLOPS[0] > flops0) == (R * T >= ops.GEMM_F32_MIN_ROWS), 'hand-written GEMM routing'
+
+
+@pytest.mark.parametrize('act', [None, 'elu'])
+@pytest.mark.parametrize('rows,n_in,n_out', [(5000, 128, 256), (5000, 96, 64), (300, 128, 256), (5000, 128, 6)])
+def test_linear_act_fwd_bwd_long_pass_vs_torch(ops, rows, n_in, n_out, act):
+    """`ops.linear_act` (fc layer + activation module, reference rnn_base.py:462-474): output, dx, dW, db against torch autograd;
+    long passes run in the hand-written GEMM (forward epilogue, mm_nn, wgrad), short ones and the 6-wide head in the library."""
+    g = torch.Generator().manual_seed(rows + n_out)
+    x, W, b = rnd(2, rows // 2, n_in, g=g), rnd(n_out, n_in, g=g, scale=n_in ** -0.5), rnd(n_out, g=g, scale=0.3)
+    w = rnd(2, rows // 2, n_out, g=g)
+    xr, Wr, br = (t.clone().requires_grad_(True) for t in (x, W, b))
+    yr = torch.nn.functional.linear(xr, Wr, br)
+    yr = torch.nn.functional.elu(yr) if act else yr
+    (yr * w).sum().backward()
+    xs, Ws, bs = (t.clone().cuda().requires_grad_(True) for t in (x, W, b))
+    flops0 = ops.GEMM_FLOPS[0]
+    y = ops.linear_act(xs, Ws, bs, act)
+    (y * w.cuda()).sum().backward()
+    close(y, yr.detach(), name='y')
+    close(xs.grad, xr.grad, name='dx')
+    close(Ws.grad, Wr.grad, rtol=2e-4, atol_scale=5e-5, name='dW')
+    close(bs.grad, br.grad, rtol=2e-4, atol_scale=5e-5, name='db')
+    assert (ops.GEMM_FLOPS[0] > flops0) == (rows >= ops.GEMM_F32_MIN_ROWS and min(n_in, n_out) >= ops.GEMM_F32_MIN_DIM)
 
 
 def test_linear_act_vs_torch(ops):
