@@ -677,6 +677,14 @@ def linear_act(x, weight, bias, act):
     return LinearAct.apply(x, weight, bias, act)
 
 
+def linear(x, weight, bias=None):
+    """x W^T + b for an fp32 nn.Linear over the tokens of a training pass: the `LinearAct` node (hand-written GEMM forward, input
+    and weight gradients) when the pass is long enough to take it, `F.linear` otherwise (rollout steps, CPU, narrow layers)."""
+    if x.is_cuda and x.dtype == torch.float32 and x.numel() // x.shape[-1] >= GEMM_F32_MIN_ROWS and min(weight.shape) >= GEMM_F32_MIN_DIM:
+        return LinearAct.apply(x, weight, bias, None)
+    return torch.nn.functional.linear(x, weight, bias)
+
+
 # tokens per pass from which the hand-written GEMM is used (measured at 66 752 and 8 344: tools/bench_gemm_f32.py); the environment
 # variable is the A/B switch of the profiles (a huge value = library GEMMs everywhere)
 GEMM_F32_MIN_ROWS = int(os.environ.get('RESEL_GEMM_F32_MIN_ROWS', 4096))

@@ -20,8 +20,8 @@ class PositionWiseFeedForward(nn.Module):
         self.layer_norm = nn.LayerNorm(d_model, eps=eps)
 
     def forward(self, x):
-        y = self.dropout(self.activation(self.w_1(x)))
-        return ops.layer_norm_fn(self.dropout(self.w_2(y)), self.layer_norm.weight, self.layer_norm.bias, residual=x,
+        y = self.dropout(self.activation(ops.linear(x, self.w_1.weight, self.w_1.bias)))
+        return ops.layer_norm_fn(self.dropout(ops.linear(y, self.w_2.weight, self.w_2.bias)), self.layer_norm.weight, self.layer_norm.bias, residual=x,
                                  eps=self.layer_norm.eps)        # fused add + LayerNorm
 
 
@@ -45,7 +45,7 @@ class GILRLayer(nn.Module):
         u = self.in_proj(x)                                         # [2, B, T, C]
         h0 = None if hidden is None else hidden[0]
         h = ops.gilr_scan(u[0], u[1], rnn_start, h0, True)
-        out = self.out_proj(h)
+        out = ops.linear(h, self.out_proj.weight, self.out_proj.bias)
         if self.use_ff:
             out = self.ff(out)
         return out, h[:, -1:, :].transpose(0, 1)

@@ -24,7 +24,7 @@ class GRU(nn.Module):
 
     def forward(self, x, hidden=None):
         """x [B, T, in]; hidden [1, B, H] -> (y [B, T, H], last hidden [1, B, H])."""
-        gi = F.linear(x, self.weight_ih_l0, self.bias_ih_l0)
+        gi = ops.linear(x, self.weight_ih_l0, self.bias_ih_l0)
         h0 = None if hidden is None else hidden[0]
         y = ops.gru_seq(gi, self.weight_hh_l0, self.bias_hh_l0, h0)
         return y, y[:, -1:, :].transpose(0, 1)
