@@ -121,6 +121,17 @@ def kernel_source_stamp():
     return h.hexdigest()[:16]
 
 
+def load_traffic(args, Bsz):
+    """HBM bytes per launch from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile_bench.sh -> profiles/traffic.json),
+    only when that file was produced from THESE kernel sources on THIS workload (sha256 stamp, layer id, rows) - else {}."""
+    tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        if tj.get('kernel_source_stamp') == kernel_source_stamp() and tj.get('rnn', 'smamba_s32_c16_b2_nln') == args.rnn and tj.get('rows', 64) == Bsz:
+            return tj.get('per_launch_bytes', {})
+    return {}
+
+
 def roofline_lines(args, kern, Bsz, Tp):
     """One roofline object per hand-written sequence kernel timed in the run (HIP event pair bound to each dispatch, on the
     launch stream).  Algorithmic bytes / flops per launch = SURVEY.md 8(d)'s per-unit figures x the units of one launch
@@ -147,13 +158,7 @@ def roofline_lines(args, kern, Bsz, Tp):
     elif fam == 'gru':
         alg['gru_fwd_kernel'] = ('hbm', 4 * Bsz * Tp * D * 4)      # gi (3H) in, h out: the recurrence itself is latency-bound (see us_per_step)
         alg['gru_bwd_kernel'] = ('hbm', 4 * Bsz * Tp * D * 8)
-    traffic, tstamp = {}, None
-    tpath = os.path.join(ROOT, 'profiles', 'traffic.json')           # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile_bench.sh)
-    if os.path.exists(tpath):
-        tj = json.load(open(tpath))
-        tstamp = tj.get('kernel_source_stamp')
-        if tstamp == kernel_source_stamp() and tj.get('rnn', 'smamba_s32_c16_b2_nln') == args.rnn and tj.get('rows', 64) == Bsz:
-            traffic = tj.get('per_launch_bytes', {})               # only when the PMC passes profiled THESE kernels on THIS workload
+    traffic = load_traffic(args, Bsz)
     lines = []
     for name, (bound, units) in alg.items():
         if name not in kern or kern[name]['launches'] <= 0:
@@ -354,7 +359,7 @@ def main():
         # fp32-equivalent FLOP (2 M N K); peak: the fp32 MFMA rate (mode 0) or the bf16 MFMA rate / the number of plane products
         peak = 2500.0 / mode if mode else 157.3
         out['gemm'] = {'kernel': 'gemm_f32_kernel', 'bound': 'mfma', 'achieved': tf, 'peak': peak, 'unit': 'TFLOP/s (fp32-equivalent)', 'frac': tf / peak,
-                       'launches': g['launches'], 'avg_us': g['avg_us'], 'flops_per_update': gemm_flops / args.steps,
+                       'traffic': load_traffic(args, Bsz).get('gemm_f32_kernel'), 'launches': g['launches'], 'avg_us': g['avg_us'], 'flops_per_update': gemm_flops / args.steps,
                        'products': {0: 'v_mfma_f32_32x32x2_f32', 6: 'exact 3-way bf16 operand split, 6 leading plane products, fp32 accumulate',
                                     9: 'exact 3-way bf16 operand split, all 9 plane products, fp32 accumulate'}[mode],
                        'ms_per_step_with_fp32_mfma_products': strict_ms}
