@@ -680,7 +680,8 @@ def linear_act(x, weight, bias, act):
 def linear(x, weight, bias=None):
     """x W^T + b for an fp32 nn.Linear over the tokens of a training pass: the `LinearAct` node (hand-written GEMM forward, input
     and weight gradients) when the pass is long enough to take it, `F.linear` otherwise (rollout steps, CPU, narrow layers)."""
-    if x.is_cuda and x.dtype == torch.float32 and x.numel() // x.shape[-1] >= GEMM_F32_MIN_ROWS and min(weight.shape) >= GEMM_F32_MIN_DIM:
+    if x.is_cuda and x.dtype == torch.float32 and x.numel() // x.shape[-1] >= GEMM_F32_MIN_ROWS and weight.shape[0] >= GEMM_F32_MIN_DIM \
+            and weight.shape[1] >= GEMM_F32_MIN_K and weight.shape[1] % 4 == 0:
         return LinearAct.apply(x, weight, bias, None)
     return torch.nn.functional.linear(x, weight, bias)
 
@@ -697,11 +698,14 @@ def gemm_f32_ok(rows, *mats):
         and all(st % 4 == 0 for st in t.stride()[:-1]) for t in mats)
 
 
-GEMM_F32_MIN_DIM = 64        # narrower outputs / shorter reductions (dt_proj's rank 16, the 6-wide heads) stay with the library
+GEMM_F32_MIN_DIM = 64        # narrower outputs (dt_proj's rank-16 input gradient, the 6-wide heads) stay with the library
+GEMM_F32_MIN_K = 32          # ... and so do reductions shorter than one K step (dt_proj forward, K = 16: 23 us library, 39 here)
 
 
 def _mine(rows, n, k, *mats):
-    return min(n, k) >= GEMM_F32_MIN_DIM and gemm_f32_ok(rows, *mats)
+    """n: the output extent that is not the token count, k: the other extent of the weight (measured at 66 752 tokens,
+    `tools/bench_skinny.py`: 44 -> 384 encoder forward 35 us against the library's 97, its weight gradient 58 against 222)."""
+    return n >= GEMM_F32_MIN_DIM and k >= GEMM_F32_MIN_K and gemm_f32_ok(rows, *mats)
 
 
 def mm_nt(x2, w, bias=None, act=None):
