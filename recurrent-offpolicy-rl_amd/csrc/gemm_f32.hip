@@ -1,5 +1,7 @@
-// fp32 GEMM on the f32-input matrix cores of gfx950 (v_mfma_f32_32x32x2_f32: exact fp32 products and sums, 64 FLOP/clk/SIMD),
-// with the tails of the fc / efc-E layers fused into the epilogue.
+// fp32 GEMM (fp32 in, fp32 accumulate, fp32 out) on the matrix cores of gfx950, with the tails of the fc / efc-E layers fused into
+// the epilogue.  The products are formed either by the f32-input instruction (v_mfma_f32_32x32x2_f32: exact fp32 products and
+// sums, 64 FLOP/clk/SIMD) or - 'SPLIT' modes, the default - from an exact three-way bf16 split of both operands on the bf16
+// instruction (v_mfma_f32_32x32x16_bf16); see the SPLIT section below and DESIGN.md 4 'The GEMMs'.
 //
 //     C[b][m][n] = epi( sum_k A[b](m, k) * B[b](n, k) )            b = ensemble member (blockIdx.z), strides per operand
 //
