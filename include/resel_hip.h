@@ -197,6 +197,12 @@ int resel_attn_varlen_bwd(const uint16_t* qkv, const int32_t* cu_seqlens, const 
  * decoder block (TransformerFlashAttention.py:48,52,72,84-85) in training-mode passes; the backward is the same call on dy
  * with the same (seed, offset).  In place (y == x) allowed. */
 int resel_dropout(const float* x, float* y, int64_t n, float p_drop, uint64_t seed, uint64_t offset, resel_stream_t stream);
+/* y = dropout(gelu(x)) (erf form) in one pass and its backward dx = dy * keep / (1 - p) * gelu'(x) from the pre-activation x; same
+ * counter-keyed mask as resel_dropout (p_drop = 0: plain GELU).  FFN hidden of the cgpt block (reference
+ * models/flash_attention/TransformerFlashAttention.py:46-53: nn.GELU() followed by nn.Dropout). */
+int resel_gelu_dropout_fwd(const float* x, float* y, int64_t n, float p_drop, uint64_t seed, uint64_t offset, resel_stream_t stream);
+int resel_gelu_dropout_bwd(const float* x, const float* dy, float* dx, int64_t n, float p_drop, uint64_t seed, uint64_t offset,
+                           resel_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * SAC / TD3 head, target and loss arithmetic + optimizer tail (the "fusions" of SURVEY.md section 8 row a16-a18).

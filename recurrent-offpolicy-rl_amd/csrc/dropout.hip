@@ -40,7 +40,64 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
     }
 }
 
+// FFN hidden of the cgpt block: y = dropout(gelu(x)) in ONE pass (reference TransformerFlashAttention.py:46-53: `nn.GELU()` then
+// `nn.Dropout`; erf form), and its backward dx = dy * keep / (1 - p) * gelu'(x) from the saved pre-activation x - the mask is
+// regenerated from the counter, never stored.  BWD = false: (x) -> y;  BWD = true: (x, dy) -> dx.  thr16 = 65536 keeps everything.
+template <bool BWD>
+__device__ __forceinline__ float gelu_or_grad(float x, float g) {
+    const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
+    if (!BWD) return x * cdf;
+    const float pdf = __expf(-0.5f * x * x) * 0.39894228040143267794f;
+    return g * (cdf + x * pdf);
+}
+template <bool BWD>
+__global__ __launch_bounds__(256) void gelu_dropout_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ out,
+                                                           int64_t n, uint32_t thr16, float rp, uint64_t seed, uint64_t offset) {
+    const uint32_t key = stream_key(seed, offset);
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t w0 = mix32(((uint32_t)(2 * i) * 0x9E3779B1u) ^ key), w1 = mix32(((uint32_t)(2 * i + 1) * 0x9E3779B1u) ^ key);
+        const float4 v = ld4(x + 4 * i);
+        float4 g = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (BWD) g = ld4(dy + 4 * i);
+        float4 o;
+        o.x = (w0 & 0xffffu) < thr16 ? gelu_or_grad<BWD>(v.x, g.x) * rp : 0.f;
+        o.y = (w0 >> 16) < thr16 ? gelu_or_grad<BWD>(v.y, g.y) * rp : 0.f;
+        o.z = (w1 & 0xffffu) < thr16 ? gelu_or_grad<BWD>(v.z, g.z) * rp : 0.f;
+        o.w = (w1 >> 16) < thr16 ? gelu_or_grad<BWD>(v.w, g.w) * rp : 0.f;
+        st4(out + 4 * i, o);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {                 // ragged tail
+        const int64_t i = (n4 << 2) + threadIdx.x;
+        const uint32_t w = mix32(((uint32_t)(i >> 1) * 0x9E3779B1u) ^ key);
+        out[i] = ((i & 1) ? (w >> 16) : (w & 0xffffu)) < thr16 ? gelu_or_grad<BWD>(x[i], BWD ? dy[i] : 1.f) * rp : 0.f;
+    }
+}
+
 }  // namespace
+
+extern "C" int resel_gelu_dropout_fwd(const float* x, float* y, int64_t n, float p_drop, uint64_t seed, uint64_t offset, resel_stream_t stream) {
+    if (!x || !y || n < 0 || !(p_drop >= 0.f && p_drop < 1.f) || !aligned16(x) || !aligned16(y)) return RESEL_EINVAL;
+    if (n == 0) return RESEL_OK;
+    const uint32_t thr16 = (uint32_t)lrintf((1.f - p_drop) * 65536.f);
+    const int64_t n4 = (n + 3) >> 2;
+    const int blocks = (int)(n4 + 255) / 256 < 2048 ? (int)((n4 + 255) / 256) : 2048;
+    hipLaunchKernelGGL(gelu_dropout_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (const float*)nullptr, y, n, thr16,
+                       1.f / (1.f - p_drop), seed, offset);
+    return launch_status();
+}
+
+extern "C" int resel_gelu_dropout_bwd(const float* x, const float* dy, float* dx, int64_t n, float p_drop, uint64_t seed, uint64_t offset,
+                                      resel_stream_t stream) {
+    if (!x || !dy || !dx || n < 0 || !(p_drop >= 0.f && p_drop < 1.f) || !aligned16(x) || !aligned16(dy) || !aligned16(dx)) return RESEL_EINVAL;
+    if (n == 0) return RESEL_OK;
+    const uint32_t thr16 = (uint32_t)lrintf((1.f - p_drop) * 65536.f);
+    const int64_t n4 = (n + 3) >> 2;
+    const int blocks = (int)(n4 + 255) / 256 < 2048 ? (int)((n4 + 255) / 256) : 2048;
+    hipLaunchKernelGGL(gelu_dropout_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, dy, dx, n, thr16, 1.f / (1.f - p_drop), seed,
+                       offset);
+    return launch_status();
+}
 
 extern "C" int resel_dropout(const float* x, float* y, int64_t n, float p_drop, uint64_t seed, uint64_t offset, resel_stream_t stream) {
     if (!x || !y || n < 0 || !(p_drop >= 0.f && p_drop < 1.f) || !aligned16(x) || !aligned16(y)) return RESEL_EINVAL;

@@ -528,6 +528,35 @@ def counter_dropout(x, p_drop, seed=None, offset=None):
     return CounterDropoutFn.apply(x, p_drop, seed, offset)
 
 
+class GeluDropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p_drop, seed, offset):
+        _need_cuda('gelu_dropout', x)
+        assert x.dtype == torch.float32
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        check(lib().resel_gelu_dropout_fwd(_p(x), _p(y), x.numel(), float(p_drop), int(seed), int(offset), _stream()), 'gelu_dropout_fwd')
+        ctx.save_for_backward(x)
+        ctx.drop = (float(p_drop), int(seed), int(offset))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        check(lib().resel_gelu_dropout_bwd(_p(x), _p(dy), _p(dx), dy.numel(), *ctx.drop, _stream()), 'gelu_dropout_bwd')
+        return dx, None, None, None
+
+
+def gelu_dropout(x, p_drop, seed=None, offset=None):
+    """dropout(gelu(x)) (erf GELU) as one kernel forward and one backward; the mask is the `counter_dropout` mask of the same
+    (seed, offset) - one `dropout_counter` draw when p_drop > 0, none otherwise (plain GELU)."""
+    if p_drop > 0.0 and seed is None:
+        seed, offset = dropout_counter(x.device)
+    return GeluDropoutFn.apply(x, p_drop if p_drop > 0.0 else 0.0, seed or 0, offset or 0)
+
+
 # ---------------------------------------------------------------------------------------------- SAC / TD3 arithmetic
 class TanhGaussianFn(torch.autograd.Function):
     @staticmethod

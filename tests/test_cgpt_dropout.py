@@ -321,3 +321,32 @@ def test_config2_td3_update_full_size_finite_and_first_rows_vs_oracle():
     with torch.no_grad():
         y = net.meta_forward(x.cuda(), hid)[0]
     _close(y, ref, 3e-2, 'configs[2] rows 0-1')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('p', [0.0, 0.1, 0.5])
+@pytest.mark.parametrize('shape', [(257, 1024), (33, 7)])
+def test_fused_gelu_dropout_equals_gelu_then_counter_dropout(p, shape):
+    """`resel_gelu_dropout_fwd / _bwd` (FFN hidden of the cgpt block, reference TransformerFlashAttention.py:46-53) against torch's erf
+    GELU followed by the element-wise counter dropout with the SAME (seed, offset): identical keep mask (zeros at the same elements),
+    values and input gradient at 1e-6; p = 0 is plain GELU."""
+    import torch
+    from offpolicy_rnn.hip import ops
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn(*shape, generator=g) * 2.0).cuda()
+    w = torch.randn(*shape, generator=g).cuda()
+    seed, offset = 1234567, 8
+    xr = x.clone().requires_grad_(True)
+    ref = torch.nn.functional.gelu(xr)
+    ref = ops.counter_dropout(ref, p, seed, offset)
+    (ref * w).sum().backward()
+    xs = x.clone().requires_grad_(True)
+    out = ops.gelu_dropout(xs, p, seed, offset)
+    (out * w).sum().backward()
+    if p > 0:
+        assert torch.equal(out == 0, ref == 0) or ((out == 0) ^ (ref == 0)).sum().item() <= 2      # gelu(x) == 0 exactly is the only other zero
+        keep = (ref != 0).float().mean().item()
+        assert x.numel() < 100000 or abs(keep - (1 - p)) < 0.01
+    scale = ref.abs().max().item()
+    assert (out - ref).abs().max().item() <= 2e-6 * scale
+    assert (xs.grad - xr.grad).abs().max().item() <= 2e-6 * xr.grad.abs().max().item()
