@@ -591,6 +591,8 @@ extern "C" int resel_gemm_f32(const float* A, int64_t lda, int64_t strideA, int 
     if (lda % 4 || ldb % 4 || strideA % 4 || strideB % 4 || !aligned16(A) || !aligned16(B)) return RESEL_EINVAL;
     // float4 loads run along the contiguous axis: its extent must be a multiple of 4 (K for [rows][K] operands, rows otherwise)
     if ((a_kcontig ? K : M) % 4 || (b_kcontig ? K : N) % 4) return RESEL_EINVAL;
+    // a thread's piece offsets inside a tile are 32-bit byte offsets: 128 rows (or 32 k) of the leading dimension must fit
+    if (lda <= 0 || ldb <= 0 || ldc <= 0 || lda >= (int64_t)1 << 22 || ldb >= (int64_t)1 << 22) return RESEL_EINVAL;
     const Plan pl = make_plan(M, N, K, batch);
     if (pl.nsplit && (!workspace || !aligned16(workspace))) return RESEL_EINVAL;
     GemmParams p{A, B, bias, C, (float*)workspace, lda, ldb, ldc, strideA, strideB, strideC, strideBias, M, N, K, act,

@@ -724,7 +724,7 @@ def gemm_f32_ok(rows, *mats):
     """True when `resel_gemm_f32` may take these operands: a long pass on the GPU, fp32, unit column stride, 16-byte aligned rows."""
     return rows >= GEMM_F32_MIN_ROWS and all(
         t.is_cuda and t.dtype == torch.float32 and t.stride(-1) == 1 and t.data_ptr() % 16 == 0 and t.shape[-1] % 4 == 0
-        and all(st % 4 == 0 for st in t.stride()[:-1]) for t in mats)
+        and all(st % 4 == 0 for st in t.stride()[:-1]) and (t.dim() < 2 or t.stride(-2) < (1 << 22)) for t in mats)
 
 
 GEMM_F32_MIN_DIM = 64        # narrower outputs (dt_proj's rank-16 input gradient, the 6-wide heads) stay with the library
