@@ -70,8 +70,18 @@ static __global__ void colsum_kernel(const float* __restrict__ part, int64_t ld,
     part += (int64_t)blockIdx.y * K * ld;
     out += (int64_t)blockIdx.y * C;
     float acc = 0.f;
-    if (c < C)
-        for (int k = rg; k < K; k += 16) acc += part[(int64_t)k * ld + c];
+    if (c < C) {                                   // four loads in flight per thread, fixed summation order
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int k = rg;
+        for (; k + 48 < K; k += 64) {
+            a0 += part[(int64_t)k * ld + c];
+            a1 += part[(int64_t)(k + 16) * ld + c];
+            a2 += part[(int64_t)(k + 32) * ld + c];
+            a3 += part[(int64_t)(k + 48) * ld + c];
+        }
+        for (; k < K; k += 16) a0 += part[(int64_t)k * ld + c];
+        acc = (a0 + a1) + (a2 + a3);
+    }
     s_acc[rg][cl] = acc;
     __syncthreads();
     if (rg == 0 && c < C) {

@@ -797,33 +797,41 @@ def atb(wide, narrow, transposed=False):
 GEMM_SPLIT = int(os.environ.get('RESEL_GEMM_SPLIT', 6))
 
 
+_GEMM_WS_BYTES = {}           # (M, N, K, batch) -> workspace bytes of resel_gemm_f32 (a pure function of the shape)
+
+
 @torch.no_grad()
 def gemm_f32(A, B, a_kcontig=True, b_kcontig=True, bias=None, act=None, out=None, split=None):
-    """C[b] = act(A[b] (.) B[b] + bias[b]) on the fp32 matrix cores (include/resel_hip.h `resel_gemm_f32`).
+    """C[b] = act(A[b] (.) B[b] + bias[b]) on the matrix cores, fp32 in / out (include/resel_hip.h `resel_gemm_f32`).
     A: [M, K] (a_kcontig) or [K, M]; B: [N, K] (b_kcontig) or [K, N]; optionally a leading batch (ensemble) dimension on all of
-    A, B, bias [N] / [batch, N], out.  Row stride free (column stride 1); returns C [M, N] / [batch, M, N]."""
+    A, B, bias [N] / [batch, N], out.  Row stride free (column stride 1); returns C [M, N] / [batch, M, N].
+    (The wrapper is on the host's critical path at small batches: 79 calls per update - no temporary views, cached sizes.)"""
     _need_cuda('gemm_f32', A, B)
     batched = A.dim() == 3
-    A3, B3 = (A, B) if batched else (A.unsqueeze(0), B.unsqueeze(0))
-    assert A3.stride(-1) == 1 and B3.stride(-1) == 1 and A3.dtype == torch.float32 and B3.dtype == torch.float32
-    batch = A3.shape[0]
-    M, K = (A3.shape[1], A3.shape[2]) if a_kcontig else (A3.shape[2], A3.shape[1])
-    N = B3.shape[1] if b_kcontig else B3.shape[2]
-    assert (B3.shape[2] if b_kcontig else B3.shape[1]) == K and B3.shape[0] == batch
+    assert A.stride(-1) == 1 and B.stride(-1) == 1 and A.dtype == torch.float32 and B.dtype == torch.float32
+    sa_, sb_ = A.shape, B.shape
+    batch = sa_[0] if batched else 1
+    M, K = (sa_[-2], sa_[-1]) if a_kcontig else (sa_[-1], sa_[-2])
+    N = sb_[-2] if b_kcontig else sb_[-1]
+    assert (sb_[-1] if b_kcontig else sb_[-2]) == K and (not batched or sb_[0] == batch)
     if out is None:
         out = torch.empty((batch, M, N) if batched else (M, N), dtype=torch.float32, device=A.device)
-    C3 = out if batched else out.unsqueeze(0)
-    assert C3.stride(-1) == 1
+    assert out.stride(-1) == 1
     GEMM_FLOPS[0] += 2.0 * M * N * K * batch
-    nb = lib().resel_gemm_f32_workspace_bytes(M, N, K, batch)
+    L = lib()
+    key = (M, N, K, batch)
+    nb = _GEMM_WS_BYTES.get(key)
+    if nb is None:
+        nb = _GEMM_WS_BYTES[key] = L.resel_gemm_f32_workspace_bytes(M, N, K, batch)
     ws = _ws(nb, A.device) if nb else None
     bs = 0
     if bias is not None:
         bias = bias.reshape(batch, N) if batched else bias.reshape(N)
         bs = bias.stride(0) if batched else 0
-    check(lib().resel_gemm_f32(_p(A3), A3.stride(1), A3.stride(0) if batch > 1 else 0, int(a_kcontig), _p(B3), B3.stride(1),
-                               B3.stride(0) if batch > 1 else 0, int(b_kcontig), _p(bias), bs, ACT_IDS[act], _p(C3), C3.stride(1),
-                               C3.stride(0) if batch > 1 else 0, _p(ws), M, N, K, batch, GEMM_SPLIT if split is None else int(split), _stream()), 'gemm_f32')
+    multi = batch > 1
+    check(L.resel_gemm_f32(_p(A), A.stride(-2), A.stride(0) if multi else 0, int(a_kcontig), _p(B), B.stride(-2),
+                           B.stride(0) if multi else 0, int(b_kcontig), _p(bias), bs, ACT_IDS[act], _p(out), out.stride(-2),
+                           out.stride(0) if multi else 0, _p(ws), M, N, K, batch, GEMM_SPLIT if split is None else int(split), _stream()), 'gemm_f32')
     return out
 
 
