@@ -28,7 +28,9 @@ def _p(t: Optional[torch.Tensor]):
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """Raw handle of the current HIP stream of the current device (the two private C calls are what
+    `torch.cuda.current_stream().cuda_stream` wraps in a Stream object: 11 us per call there, ~1700 calls per update)."""
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
 def _tok_major(t: torch.Tensor) -> torch.Tensor:

@@ -17,4 +17,5 @@ for _ in range(20):
 torch.cuda.synchronize()
 pr.disable()
 st = pstats.Stats(pr)
-st.sort_stats('tottime').print_stats(28)
+st.sort_stats('tottime').print_stats(22)
+st.sort_stats('cumtime').print_stats('offpolicy_rnn', 30)
