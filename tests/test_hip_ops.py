@@ -580,6 +580,36 @@ def test_atb_long_reduction_gemm(ops, K, Wd, Nd, ldn, tr):
     assert torch.equal(got, ops.atb(wide, narrow, tr))           # fixed summation order
 
 
+def test_encode_concat_padded_block_diagonal_gemm_vs_separate_linears(ops):
+    """`policy_value_models/_inputs.encode_concat` (reference contextual_sac_value.py:90-99: cat of per-input Linear encoders): the
+    41-column input is zero-padded to 44 so that the hand-written GEMM takes the long pass; output and every gradient against the
+    plain `cat([enc(x)])` on the CPU, at a library-sized and a hand-written-GEMM-sized batch."""
+    from offpolicy_rnn.policy_value_models._inputs import encode_concat
+    torch.manual_seed(4)
+    dims = (17, 17, 6, 1)
+    for rows in (6, 80):                                   # x 64 tokens: 384 and 5120 tokens
+        mods = [torch.nn.Linear(d, 128) for d in dims]
+        xs = [torch.randn(rows, 64, d) for d in dims]
+        xs[2].requires_grad_(True)                         # the action input carries a gradient in the actor step
+        ref = torch.cat([m(x) for m, x in zip(mods, xs)], dim=-1)
+        w = torch.randn_like(ref)
+        (ref * w).sum().backward()
+        expect = [ref.detach(), xs[2].grad.clone()] + [p.grad.clone() for m in mods for p in (m.weight, m.bias)]
+        xs[2].grad = None
+        for m in mods:
+            m.zero_grad()
+            m.cuda()
+        xc = [x.detach().cuda() for x in xs]
+        xc[2].requires_grad_(True)
+        flops0 = ops.GEMM_FLOPS[0]
+        out = encode_concat(list(zip(mods, xc)))
+        (out * w.cuda()).sum().backward()
+        got = [out, xc[2].grad] + [p.grad for m in mods for p in (m.weight, m.bias)]
+        for i, (a, b) in enumerate(zip(got, expect)):
+            close(a, b, rtol=2e-4, atol_scale=5e-5, name=f'rows={rows} tensor {i}')
+        assert (ops.GEMM_FLOPS[0] > flops0) == (rows * 64 >= ops.GEMM_F32_MIN_ROWS)
+
+
 # ------------------------------------------------------------------------------------------ fp32 MFMA GEMM
 @pytest.mark.parametrize('M,N,K,akc,bkc,bias,act,batch', [
     (300, 256, 384, True, True, True, 'elu', 1),        # forward with the fused tail, ragged M
