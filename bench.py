@@ -342,7 +342,7 @@ def main():
     out = {
         'metric': 'env-steps/sec trained', 'value': trained / dt, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'strong' if args.global_rows else 'weak', 'vs_baseline': None,
-        'dtype': 'f32', 'data': 'synthetic',
+        'dtype': 'f32', 'dtype_note': ('inputs, accumulators and outputs of every kernel are fp32; GEMM products: ' + {0: 'fp32 MFMA instruction', 6: 'exact 3-way bf16 split of both fp32 operands, 6 leading plane products on the bf16 MFMA (as accurate vs fp64 as the fp32 instruction: DESIGN.md 4)', 9: 'exact 3-way bf16 split of both fp32 operands, all 9 plane products on the bf16 MFMA'}[ops.GEMM_SPLIT]), 'data': 'synthetic',
         'config': {'workload': f'{args.rnn} {args.algo.upper()}-REDQ full-trajectory update, B={Bsz}/GPU, T={args.horizon} (row length {Tp}), obs={OBS}, act={ACT}, '
                                f'D=256, efc-8 critic ({baseline_config(args)})',
                    'global_rows': Bsz * world, 'parallelism': f'dp{world}'},
