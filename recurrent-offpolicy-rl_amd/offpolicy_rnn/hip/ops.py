@@ -488,6 +488,8 @@ def dropout_counter(device):
     """(seed, offset) for one counter-keyed dropout mask, taken from the device's default torch generator the way ATen's
     own dropout kernels reserve Philox offsets: host-side bookkeeping only (no sync), deterministic under
     `torch.manual_seed`, and every call gets a fresh offset."""
+    if not torch.cuda.default_generators:            # first CUDA touch of the process: the generator tuple is filled by the lazy init
+        torch.cuda.init()
     gen = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
     off = gen.get_offset()
     gen.set_offset(off + 4)
