@@ -622,6 +622,8 @@ def test_encode_concat_padded_block_diagonal_gemm_vs_separate_linears(ops):
     (600, 260, 99, False, False, False, None, 1),       # both operands [K][rows], odd K (guarded last step)
     (600, 260, 100, True, False, True, None, 2),        # mixed layouts, batch of 2, K tail
     (66752, 256, 64, True, True, True, None, 1),        # two K steps per item: the persistent pipeline crosses items every other step
+    (5000, 256, 16, True, True, True, None, 1),         # K shorter than one K step (every mode runs the fp32 kernel there)
+    (1024, 128, 28, False, True, False, None, 1),
 ])
 @pytest.mark.parametrize('split', [0, 6, 9])
 def test_gemm_f32_vs_fp64_product(ops, M, N, K, akc, bkc, bias, act, batch, split):
