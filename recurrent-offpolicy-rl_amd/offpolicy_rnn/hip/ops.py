@@ -27,10 +27,14 @@ def _p(t: Optional[torch.Tensor]):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
-def _stream():
-    """Raw handle of the current HIP stream of the current device (the two private C calls are what
-    `torch.cuda.current_stream().cuda_stream` wraps in a Stream object: 11 us per call there, ~1700 calls per update)."""
-    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+if hasattr(torch._C, '_cuda_getCurrentRawStream') and hasattr(torch._C, '_cuda_getDevice'):
+    def _stream():
+        """Raw handle of the current HIP stream of the current device (the two C calls are what
+        `torch.cuda.current_stream().cuda_stream` wraps in a Stream object: 11 us per call there, ~1700 calls per update)."""
+        return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+else:                                                   # another torch build: the public (slower) spelling
+    def _stream():
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def _tok_major(t: torch.Tensor) -> torch.Tensor:
