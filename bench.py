@@ -287,7 +287,7 @@ def main():
     alg = build_trainer(args.rnn, args.rows, args.horizon, seed=rank, algo=args.algo)
     alg.defer_log = True          # log scalars: one async D2H copy per update (inside the timed region), read on demand
     alg.grad_sync.__init__()                            # pick up the process group
-    if world > 1:
+    if alg.grad_sync.active:
         for net in [alg.policy] + alg.values + alg.target_values:
             alg.grad_sync.broadcast_(net.store.flat)
     from offpolicy_rnn.hip import ops

@@ -320,13 +320,13 @@ class SACFullLengthRNNEnsembleQ(SAC):
         a dedicated stream seeded identically on every rank (`parameter.seed`), so that all ranks take the minimum over the
         SAME critics while each samples its own rows from its own global stream - the update then equals the single-process
         update over the global batch (tests/test_data_parallel*.py)."""
-        if self.grad_sync.world > 1 and self._subset_rng is None:
+        if self.grad_sync.active and self._subset_rng is None:
             self._subset_rng = np.random.RandomState(int(self.parameter.seed) + 7919)
         return self._subset_rng if self._subset_rng is not None else np.random
 
     def _guard_exchange(self):
         """Data parallel: the Q-guard sees the extrema of the global batch (two 2-float MAX all-reduces inside the target)."""
-        return dict(reduce_max=self.grad_sync.all_reduce_max_) if self.grad_sync.world > 1 else {}
+        return dict(reduce_max=self.grad_sync.all_reduce_max_) if self.grad_sync.active else {}
 
     def _target_Q_discrete(self, b, policy_hidden, target_hiddens, stats):
         """Discrete-action target (reference sac_full_length_rnn_redq.py:52-72): V(s') = sum_a pi(a|s') (min_subset Q'(s', a) -

@@ -16,17 +16,21 @@ class GradSync:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
+        # `active`: the collectives are issued.  RESEL_DP_FORCE_COLLECTIVES=1 issues them in a one-rank group too (identity
+        # results): the way to exercise the RCCL plumbing - side-stream all-reduce, broadcast, the guard's MAX all-reduces - on a
+        # single-GPU box (`torchrun --nproc-per-node 1 bench.py --gpus 1`).
+        self.active = self.world > 1 or (dist.is_available() and dist.is_initialized() and os.environ.get('RESEL_DP_FORCE_COLLECTIVES') == '1')
         self._stream, self._pending = None, None
 
     def all_reduce_(self, flat_grad: torch.Tensor):
-        if self.world > 1:
+        if self.active:
             dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
 
     def all_reduce_async_(self, flat_grad: torch.Tensor):
         """SUM all-reduce on a side stream (RCCL): returns at once, `wait()` makes the compute stream depend on its completion.
         gloo (CPU tests, or CUDA tensors staged through the host) and single-process runs reduce in place synchronously."""
         self._pending = None
-        if self.world <= 1:
+        if not self.active:
             return
         if flat_grad.is_cuda and dist.get_backend(self.group) == 'nccl':
             if self._stream is None:
@@ -45,11 +49,11 @@ class GradSync:
             self._pending = None
 
     def broadcast_(self, flat: torch.Tensor, src=0):
-        if self.world > 1:
+        if self.active:
             dist.broadcast(flat, src=src, group=self.group)
 
     def all_reduce_max_(self, t: torch.Tensor):
-        if self.world > 1:
+        if self.active:
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
 
 

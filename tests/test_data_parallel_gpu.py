@@ -91,3 +91,23 @@ def test_two_ranks_with_disjoint_rows_reproduce_the_union_batch_update(tmp_path,
     ref = _run(_build(rnn, batch=sum(LENS), quiet=True))       # one process, all five trajectories in one batch
     for k in ('policy', 'value', 'alpha'):
         np.testing.assert_allclose(r0[k].numpy(), ref[k].numpy(), rtol=2e-4, atol=2e-6, err_msg=k)
+
+
+@pytest.mark.gpu
+def test_rccl_collectives_in_a_one_rank_group_under_torchrun():
+    """The RCCL plumbing on real hardware with the one GPU a test box has: `bench.py` under torch.distributed.run with one rank and
+    RESEL_DP_FORCE_COLLECTIVES=1 issues every collective of the data-parallel update - parameter broadcast, the flat-gradient
+    all-reduce on the exchange stream, the Q-guard's two MAX all-reduces inside the target - through backend `nccl` (= RCCL);
+    in a one-rank group they are identities, so the run must finish with finite numbers at the single-process speed."""
+    import json
+    import subprocess
+    root = os.path.dirname(HERE)
+    port = _free_port() if '_free_port' in globals() else 29533
+    env = dict(os.environ, RESEL_DP_FORCE_COLLECTIVES='1', MASTER_ADDR='127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1', '--rows', '8',
+           '--no-cpu-baseline', '--no-strict-leg']
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['n_gpus'] == 1 and np.isfinite(line['value']) and line['value'] > 0
