@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """bench.py - env-steps/sec trained by the full-trajectory recurrent SAC update on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]            (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N > 1: one rank per GPU over RCCL.  Under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` the ranks are
+torchrun's; a plain `python bench.py --gpus N` starts its own N ranks as child processes (before this process touches a GPU),
+relays rank 0's JSON line and exits non-zero if any rank fails.
 
 A "step" is one `train_one_batch()` (sample B trajectories -> H2D -> target -> critic step -> soft update -> actor +
 alpha step) on synthetic Gaussian trajectories.  Workload at N = 1 = BASELINE.json configs[1]:
@@ -253,6 +257,142 @@ def rollout_mode(args):
     print(json.dumps(out))
 
 
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` without a torchrun environment: start the N ranks here.  Nothing in this (parent) process has
+    touched a GPU - `import torch` and `torch.cuda.device_count()` do not initialise HIP on this image - and the ranks are plain child
+    processes (never an exec of this one).  Rank 0's stdout is relayed (its last JSON line is THE bench line); the other ranks'
+    output goes to stderr.  The first rank that fails takes the others down (by pid) and the exit code is non-zero."""
+    import subprocess
+    from offpolicy_rnn.parallel.data_parallel import free_port
+    N = args.gpus
+    if not args.spawn_dry_run:
+        have = torch.cuda.device_count()
+        if have < N:
+            print(f'bench.py: --gpus {N} but this node shows {have} GPU(s)', file=sys.stderr)
+            return 2
+    port = free_port()
+    cores = os.cpu_count() or 1
+    procs = []
+    for r in range(N):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(N), LOCAL_WORLD_SIZE=str(N), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), RESEL_BENCH_SPAWNED='1')
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')                 # dmabuf IPC: RCCL's intra-node transport needs it on this image
+        env.setdefault('OMP_NUM_THREADS', str(max(1, min(16, cores // N))))   # N ranks share the host cores
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE,
+                                      stderr=None, text=True))
+    import threading
+    lines = [[] for _ in range(N)]
+
+    def pump(r):
+        for ln in procs[r].stdout:
+            lines[r].append(ln)
+            if r:
+                sys.stderr.write(f'[rank {r}] {ln}')
+    threads = [threading.Thread(target=pump, args=(r,), daemon=True) for r in range(N)]
+    for t in threads:
+        t.start()
+    deadline = time.time() + args.spawn_timeout
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0):
+                failed = (r, p.returncode)
+        if time.time() > deadline:
+            failed = (-1, 'timeout')
+        time.sleep(0.05)
+    for r, p in enumerate(procs):
+        if failed is None and p.returncode != 0:
+            failed = (r, p.returncode)
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()                                 # exactly the pids started above
+        for p in procs:
+            p.wait()
+    for t in threads:
+        t.join(timeout=5)
+    out0 = ''.join(lines[0])
+    if failed is not None:
+        sys.stderr.write(out0)
+        print(f'bench.py: rank {failed[0]} failed ({failed[1]}); no result', file=sys.stderr)
+        return 1
+    js = [l for l in out0.splitlines() if l.startswith('{')]
+    sys.stdout.write(''.join(l + '\n' for l in out0.splitlines() if not l.startswith('{')))
+    if not js:
+        print('bench.py: rank 0 printed no JSON line', file=sys.stderr)
+        return 1
+    line = json.loads(js[-1])
+    line['launcher'] = 'bench.py spawned its own ranks (subprocess children, env rendezvous on 127.0.0.1)'
+    print(json.dumps(line))
+    return 0
+
+
+def dry_run_rank(args):
+    """`--spawn-dry-run`: the launcher's plumbing without a GPU.  Every rank joins a gloo group from the environment the launcher
+    (this file's or torchrun) gave it, the ranks all-reduce their row counts, and rank 0 prints the line the real run would carry
+    its numbers in."""
+    import torch.distributed as dist
+    from offpolicy_rnn.parallel.data_parallel import GradSync, init_from_env
+    if os.environ.get('RESEL_BENCH_DRY_FAIL_RANK') == os.environ.get('RANK', '0'):      # launcher test: a rank that dies before the rendezvous
+        sys.exit(7)
+    rank, world, local = init_from_env(backend='gloo')
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    rows = args.rows
+    if args.global_rows:
+        assert args.global_rows % world == 0, f'--global-rows {args.global_rows} does not split over {world} ranks'
+        rows = args.global_rows // world
+    gs = GradSync()
+    t = torch.tensor([float(rows), float(local)])
+    gs.all_reduce_(t)
+    if rank == 0:
+        print(json.dumps({'dry_run': True, 'n_gpus': world, 'rows_per_rank': rows, 'global_rows': int(t[0].item()), 'local_rank_sum': int(t[1].item()),
+                          'rccl_ranks': gs.world, 'backend': gs.backend, 'collectives': gs.calls,
+                          'scaling': 'strong' if args.global_rows else 'weak', 'steps': args.steps, 'warmup': args.warmup}))
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+def rccl_one_rank_leg(args):
+    """N = 1 only: the same update in a child process whose ONE rank forms an RCCL communicator and issues every collective of the
+    data-parallel step (parameter broadcast, flat-gradient all-reduce on the exchange stream, the Q-guard's MAX all-reduces).  The
+    results are identities; what the leg shows is that the calls run on this hardware, how many there are per update and what they cost."""
+    import subprocess
+    env = dict(os.environ, RESEL_DP_FORCE_COLLECTIVES='1', RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1')
+    env.pop('MASTER_PORT', None)
+    cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--steps', '5', '--warmup', '2', '--rnn', args.rnn, '--algo', args.algo,
+           '--rows', str(args.rows), '--horizon', str(args.horizon), '--no-cpu-baseline', '--no-strict-leg', '--no-rccl-leg', '--no-suite']
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+        line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+        return {k: line[k] for k in ('ms_per_step', 'rccl_ranks', 'backend', 'collectives_per_step', 'collective_bytes_per_step')}
+    except Exception as e:
+        return {'failed': repr(e)[:200]}
+
+
+SUITE = (('configs[2]', ['--rnn', 'cgpt_h8_l6_p0.1_ml1024_rms', '--algo', 'td3', '--rows', '32', '--horizon', '1024']),
+         ('configs[4] gilr', ['--rnn', 'gilr', '--algo', 'sac', '--rows', '16', '--horizon', '2000']),
+         ('configs[4] lru', ['--rnn', 'lru', '--algo', 'sac', '--rows', '16', '--horizon', '2000']))
+
+
+def suite_legs(args):
+    """The other single-GPU BASELINE configs, each as a child run of this file (same timed region, same JSON line), so that their
+    ms_per_step and dominant-kernel roofline are in the driver's record and not only in builder-run profiles.  The headline stays configs[1]."""
+    import subprocess
+    out = {}
+    for name, extra in SUITE:
+        cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--steps', '10', '--warmup', '3', '--no-cpu-baseline', '--no-strict-leg',
+               '--no-rccl-leg', '--no-suite'] + extra
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+            out[name] = {k: line.get(k) for k in ('value', 'unit', 'ms_per_step', 'steps', 'dtype', 'config', 'roofline', 'roofline_other')}
+        except Exception as e:
+            out[name] = {'failed': repr(e)[:200]}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--mode', default='update', choices=['update', 'rollout'],
@@ -270,9 +410,18 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-strict-leg', action='store_true', help='skip the 4 extra updates that time the fp32-MFMA product mode')
     ap.add_argument('--envs', type=int, default=1, help='rollout mode: also time one graph replay over this many environments')
+    ap.add_argument('--spawn-timeout', type=float, default=1500.0, help='self-launched ranks: wall-clock limit in seconds')
+    ap.add_argument('--spawn-dry-run', action='store_true',
+                    help='launcher check without GPUs: every rank reports its rendezvous environment and row split over a gloo group, no kernels')
+    ap.add_argument('--no-suite', action='store_true', help='default workload at N = 1: skip the child runs of BASELINE configs[2] and configs[4]')
+    ap.add_argument('--no-rccl-leg', action='store_true', help='N = 1: skip the child run that issues the data-parallel collectives in a one-rank RCCL group')
     args = ap.parse_args()
     if args.mode == 'rollout':
         return rollout_mode(args)
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return spawn_ranks(args, sys.argv[1:])
+    if args.spawn_dry_run:
+        return dry_run_rank(args)
 
     from offpolicy_rnn.parallel.data_parallel import init_from_env
     import torch.distributed as dist
@@ -287,9 +436,12 @@ def main():
     alg = build_trainer(args.rnn, args.rows, args.horizon, seed=rank, algo=args.algo)
     alg.defer_log = True          # log scalars: one async D2H copy per update (inside the timed region), read on demand
     alg.grad_sync.__init__()                            # pick up the process group
+    bcast = 0
     if alg.grad_sync.active:
         for net in [alg.policy] + alg.values + alg.target_values:
             alg.grad_sync.broadcast_(net.store.flat)
+        alg.grad_sync.broadcast_(alg.log_sac_alpha.data)
+        bcast = alg.grad_sync.calls['broadcast']
     from offpolicy_rnn.hip import ops
 
     def sync():
@@ -303,6 +455,7 @@ def main():
         alg.grad_num += 1
     ops.profile_enable(True)                            # HIP event pair bound to each scan dispatch, timed region only
     ops.GEMM_FLOPS[0] = 0.0
+    alg.grad_sync.reset_counters()
     sync()
     t0 = time.perf_counter()
     trained = 0
@@ -311,6 +464,8 @@ def main():
         alg.grad_num += 1
     sync()
     dt = time.perf_counter() - t0
+    coll = {k: v / args.steps for k, v in alg.grad_sync.calls.items() if k != 'broadcast'}
+    coll_bytes = {k: v / args.steps for k, v in alg.grad_sync.bytes.items() if k != 'broadcast'}
     prof = ops.profile_collect()
     ops.profile_enable(False)
     gemm_flops = ops.GEMM_FLOPS[0]
@@ -346,6 +501,9 @@ def main():
         'config': {'workload': f'{args.rnn} {args.algo.upper()}-REDQ full-trajectory update, B={Bsz}/GPU, T={args.horizon} (row length {Tp}), obs={OBS}, act={ACT}, '
                                f'D=256, efc-8 critic ({baseline_config(args)})',
                    'global_rows': Bsz * world, 'parallelism': f'dp{world}'},
+        # collectives the timed updates ISSUED (counted where they are called, parallel/data_parallel.py), per update
+        'rccl_ranks': alg.grad_sync.world if alg.grad_sync.active else 0, 'backend': alg.grad_sync.backend,
+        'collectives_per_step': coll, 'collective_bytes_per_step': coll_bytes, 'parameter_broadcasts': bcast,
     }
     lines = roofline_lines(args, kern, Bsz, Tp)          # hand-written sequence kernels, largest total time first
     ranked = [(o['avg_us'] * o['launches'], o) for o in lines]
@@ -374,6 +532,13 @@ def main():
     if len(lines) > 1:
         out['roofline_other'] = lines[1:]
     out['kernels'] = kern
+    if world == 1 and not alg.grad_sync.active and not args.no_rccl_leg:
+        out['rccl_one_rank_leg'] = rccl_one_rank_leg(args)
+    default_workload = args.rnn == 'smamba_s32_c16_b2_nln' and args.rows == 64 and args.horizon == 1024 and args.algo == 'sac'
+    if world == 1 and default_workload and not args.no_suite:
+        del alg
+        torch.cuda.empty_cache()
+        out['suite'] = suite_legs(args)
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline('gru')      # of record: north_star's CPU GRU trainer at the full B=64, T=1024
         if args.rnn != 'gru':
@@ -382,4 +547,4 @@ def main():
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main() or 0)

@@ -107,3 +107,77 @@ def test_two_rank_update(tmp_path, mode, monkeypatch):
         n = alg.values[0].store.numel
         np.testing.assert_allclose(r0['value'][:n], alg.values[0].store.flat[:n], rtol=1e-5, atol=1e-7)
         np.testing.assert_allclose(r0['alpha'], alg.log_sac_alpha.detach(), rtol=1e-6)
+
+
+# ---- the launcher: `python bench.py --gpus N` starts its own ranks; the torchrun form keeps working (no GPU needed: --spawn-dry-run) ----
+
+ROOT = os.path.dirname(HERE)
+
+
+def _bench(args, env=None, launcher=()):
+    import json
+    import subprocess
+    cmd = [sys.executable, *launcher, os.path.join(ROOT, 'bench.py'), *args]
+    e = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
+    e.update(env or {})
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT, env=e)
+    js = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    return r, (json.loads(js[-1]) if js else None)
+
+
+def test_bench_starts_its_own_ranks_and_splits_a_global_batch():
+    r, line = _bench(['--gpus', '2', '--global-rows', '128', '--steps', '7', '--warmup', '2', '--spawn-dry-run'])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line['n_gpus'] == 2 and line['rows_per_rank'] == 64 and line['global_rows'] == 128 and line['scaling'] == 'strong'
+    assert line['local_rank_sum'] == 1 and line['rccl_ranks'] == 2 and line['collectives']['all_reduce_sum'] == 1
+    assert line['steps'] == 7 and line['warmup'] == 2 and 'spawned its own ranks' in line['launcher']
+    assert len([l for l in r.stdout.splitlines() if l.startswith('{')]) == 1          # ONE JSON line on stdout
+
+
+def test_bench_weak_scaling_rows_per_rank_under_the_launcher():
+    r, line = _bench(['--gpus', '4', '--spawn-dry-run'])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line['n_gpus'] == 4 and line['rows_per_rank'] == 64 and line['global_rows'] == 256 and line['scaling'] == 'weak'
+    assert line['local_rank_sum'] == 0 + 1 + 2 + 3
+
+
+def test_bench_exits_non_zero_when_a_rank_fails():
+    import time
+    t0 = time.time()
+    r, line = _bench(['--gpus', '2', '--spawn-dry-run'], env={'RESEL_BENCH_DRY_FAIL_RANK': '1'})
+    assert r.returncode != 0 and line is None and 'rank 1 failed' in r.stderr
+    assert time.time() - t0 < 120                    # the surviving rank (blocked in the rendezvous) was taken down, not waited for
+    r, line = _bench(['--gpus', '3', '--global-rows', '128', '--spawn-dry-run'])
+    assert r.returncode != 0 and line is None and 'does not split' in r.stderr
+
+
+def test_bench_under_torchrun_keeps_working():
+    r, line = _bench(['--gpus', '2', '--global-rows', '32', '--spawn-dry-run'],
+                     launcher=('-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                               '--master-port', str(_free_port())))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line['n_gpus'] == 2 and line['rows_per_rank'] == 16 and 'launcher' not in line
+
+
+def test_one_rank_group_issues_and_counts_collectives(monkeypatch):
+    """RESEL_DP_FORCE_COLLECTIVES=1: init_from_env creates a ONE-rank group and GradSync issues (and counts) every collective in it."""
+    from offpolicy_rnn.parallel.data_parallel import GradSync, init_from_env
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT'):
+        monkeypatch.delenv(k, raising=False)
+    assert not GradSync().active
+    monkeypatch.setenv('RESEL_DP_FORCE_COLLECTIVES', '1')
+    assert init_from_env(backend='gloo') == (0, 1, 0) and dist.is_initialized()
+    try:
+        gs = GradSync()
+        assert gs.active and gs.world == 1 and gs.backend == 'gloo'
+        t = torch.arange(6.0)
+        gs.all_reduce_async_(t)
+        gs.wait()
+        gs.all_reduce_max_(t[:2])
+        gs.broadcast_(t)
+        assert torch.equal(t, torch.arange(6.0))
+        assert gs.calls == dict(all_reduce_sum=1, all_reduce_max=1, broadcast=1) and gs.bytes['all_reduce_sum'] == 24
+        gs.reset_counters()
+        assert sum(gs.calls.values()) == 0
+    finally:
+        dist.destroy_process_group()

@@ -1,6 +1,6 @@
 """world_size-2 data parallelism with the REAL HIP kernels: two processes share cuda:0 and exchange the flat gradient buffer
-through `gloo` (it stages CUDA tensors through the host; RCCL needs one GPU per rank and is exercised by the driver's
-multi-GPU bench).  Two ranks holding the SAME rows and the same actor noise must reproduce the single-process update -
+through `gloo` (it stages CUDA tensors through the host; RCCL needs one GPU per rank: the two-rank `nccl` test below runs where two
+GPUs exist and skips itself on a one-GPU box, where the one-rank RCCL group test is what runs).  Two ranks holding the SAME rows and the same actor noise must reproduce the single-process update -
 this pins the masked-sum losses + piggy-backed valid count + flat AdamW normalisation on the device path; two ranks holding
 DISJOINT trajectory sets (each trains on all of its own, actor noise off) must reproduce the single-process update over the
 UNION batch - this pins the shared REDQ subset stream and the global Q-guard (phased `resel_sac_target_phase`)."""
@@ -21,13 +21,18 @@ LENS = (12, 5, 7, 12, 9)
 SPLIT = ((0, 2, 4), (1, 3))
 
 
-def _build(rnn, keep=None, batch=30, quiet=False):
+class _Patch:                                        # worker processes patch for good; the pytest process passes monkeypatch
+    def setattr(self, obj, name, val):
+        setattr(obj, name, val)
+
+
+def _build(rnn, keep=None, batch=30, quiet=False, patcher=None):
     sys.path[:0] = [HERE, os.path.dirname(HERE), os.path.join(os.path.dirname(HERE), 'recurrent-offpolicy-rl_amd')]
     from test_host_logic import _push, _synth, make_parameter
     from offpolicy_rnn import alg_init
     from offpolicy_rnn.utility import rng
     if quiet:
-        rng.randn = lambda shape, device, dtype=torch.float32: torch.zeros(tuple(shape), dtype=dtype, device=device)
+        (patcher or _Patch()).setattr(rng, 'randn', lambda shape, device, dtype=torch.float32: torch.zeros(tuple(shape), dtype=dtype, device=device))
     torch.manual_seed(0)
     np.random.seed(0)
     alg = alg_init(make_parameter(rnn, sac_batch_size=batch, cuda_inference=True))
@@ -53,15 +58,18 @@ def _run(alg, steps=2):
                 alpha=alg.log_sac_alpha.detach().cpu(), critic_loss=log['critic_loss'])
 
 
-def _worker(rank, world, port, rnn, out_dir, union=False):
+def _worker(rank, world, port, rnn, out_dir, union=False, backend='gloo'):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    torch.cuda.set_device(0)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.set_device(rank if backend == 'nccl' else 0)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     alg = _build(rnn, keep=SPLIT[rank], batch=sum(LENS[i] for i in SPLIT[rank]), quiet=True) if union else _build(rnn)
     alg._subset_rng = None                             # product default under world > 1: the shared stream
     alg.grad_sync.__init__()
-    assert alg.grad_sync.world == world and alg.device.type == 'cuda'
-    torch.save(_run(alg), os.path.join(out_dir, f'rank{rank}.pt'))
+    assert alg.grad_sync.world == world and alg.device.type == 'cuda' and alg.grad_sync.backend == backend
+    res = _run(alg)
+    res['calls'] = dict(alg.grad_sync.calls)
+    torch.save(res, os.path.join(out_dir, f'rank{rank}.pt'))
     dist.destroy_process_group()
 
 
@@ -80,7 +88,7 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_process_update(tmp_path, rnn)
 
 
 @pytest.mark.parametrize('rnn', ['smamba_s8_c4_b1_nln', 'gilr'])
-def test_two_ranks_with_disjoint_rows_reproduce_the_union_batch_update(tmp_path, rnn):
+def test_two_ranks_with_disjoint_rows_reproduce_the_union_batch_update(tmp_path, rnn, monkeypatch):
     if not torch.cuda.is_available():
         pytest.skip('needs a GPU')
     from test_data_parallel import _free_port
@@ -88,26 +96,74 @@ def test_two_ranks_with_disjoint_rows_reproduce_the_union_batch_update(tmp_path,
     r0, r1 = (torch.load(os.path.join(tmp_path, f'rank{i}.pt')) for i in range(2))
     for k in ('policy', 'value', 'alpha'):
         assert torch.equal(r0[k], r1[k]), f'{k} diverged across ranks'
-    ref = _run(_build(rnn, batch=sum(LENS), quiet=True))       # one process, all five trajectories in one batch
+    # 2 updates x (critic step + actor step) flat-gradient all-reduces, 2 x 2 MAX all-reduces of the guard extrema
+    assert r0['calls']['all_reduce_sum'] == 4 and r0['calls']['all_reduce_max'] == 4, r0['calls']
+    ref = _run(_build(rnn, batch=sum(LENS), quiet=True, patcher=monkeypatch))       # one process, all five trajectories in one batch
     for k in ('policy', 'value', 'alpha'):
         np.testing.assert_allclose(r0[k].numpy(), ref[k].numpy(), rtol=2e-4, atol=2e-6, err_msg=k)
 
 
-@pytest.mark.gpu
-def test_rccl_collectives_in_a_one_rank_group_under_torchrun():
-    """The RCCL plumbing on real hardware with the one GPU a test box has: `bench.py` under torch.distributed.run with one rank and
-    RESEL_DP_FORCE_COLLECTIVES=1 issues every collective of the data-parallel update - parameter broadcast, the flat-gradient
-    all-reduce on the exchange stream, the Q-guard's two MAX all-reduces inside the target - through backend `nccl` (= RCCL);
-    in a one-rank group they are identities, so the run must finish with finite numbers at the single-process speed."""
+def test_two_ranks_over_rccl_reproduce_the_union_batch_update(tmp_path, monkeypatch):
+    """Two GPUs, backend `nccl` (= RCCL): the exchange-stream branch of `all_reduce_async_` with a real peer.  Skips itself on a
+    one-GPU box (RCCL refuses two ranks on one device)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs two GPUs (RCCL: one rank per device)')
+    from test_data_parallel import _free_port
+    rnn = 'smamba_s8_c4_b1_nln'
+    mp.spawn(_worker, args=(2, _free_port(), rnn, str(tmp_path), True, 'nccl'), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(tmp_path, f'rank{i}.pt')) for i in range(2))
+    for k in ('policy', 'value', 'alpha'):
+        assert torch.equal(r0[k], r1[k]), f'{k} diverged across ranks'
+    assert r0['calls']['all_reduce_sum'] == 4 and r0['calls']['all_reduce_max'] == 4, r0['calls']
+    ref = _run(_build(rnn, batch=sum(LENS), quiet=True, patcher=monkeypatch))
+    for k in ('policy', 'value', 'alpha'):
+        np.testing.assert_allclose(r0[k].numpy(), ref[k].numpy(), rtol=2e-4, atol=2e-6, err_msg=k)
+
+
+def _one_rank_bench(launcher, extra_env=None):
     import json
     import subprocess
     root = os.path.dirname(HERE)
-    port = _free_port() if '_free_port' in globals() else 29533
-    env = dict(os.environ, RESEL_DP_FORCE_COLLECTIVES='1', MASTER_ADDR='127.0.0.1')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1', '--rows', '8',
-           '--no-cpu-baseline', '--no-strict-leg']
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
+    env.update(RESEL_DP_FORCE_COLLECTIVES='1', MASTER_ADDR='127.0.0.1', **(extra_env or {}))
+    cmd = [sys.executable, *launcher, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1', '--rows', '8',
+           '--no-cpu-baseline', '--no-strict-leg', '--no-rccl-leg', '--no-suite']
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
-    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+
+
+def _assert_collectives_ran(line):
     assert line['n_gpus'] == 1 and np.isfinite(line['value']) and line['value'] > 0
+    assert line['backend'] == 'nccl' and line['rccl_ranks'] == 1
+    # per update: critic step + actor step = 2 flat-gradient all-reduces; the target's Q-guard = 2 MAX all-reduces
+    assert line['collectives_per_step']['all_reduce_sum'] == 2 and line['collectives_per_step']['all_reduce_max'] == 2, line['collectives_per_step']
+    assert line['parameter_broadcasts'] >= 3 and line['collective_bytes_per_step']['all_reduce_sum'] > 1e6
+
+
+def test_rccl_collectives_in_a_one_rank_group_under_torchrun():
+    """The RCCL plumbing on real hardware with the one GPU a test box has: `bench.py` under torch.distributed.run with one rank and
+    RESEL_DP_FORCE_COLLECTIVES=1 forms a one-rank `nccl` (= RCCL) group and ISSUES every collective of the data-parallel update -
+    parameter broadcast, the flat-gradient all-reduce on the exchange stream, the Q-guard's two MAX all-reduces inside the target.
+    They are identities in a one-rank group; the bench line reports how many were issued (counted at the call sites)."""
+    from test_data_parallel import _free_port
+    line = _one_rank_bench(('-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+                            '--master-port', str(_free_port())))
+    _assert_collectives_ran(line)
+
+
+def test_rccl_collectives_in_a_one_rank_group_without_a_launcher():
+    """Same, started as a plain `python bench.py --gpus 1`: init_from_env creates the one-rank group itself (free local port)."""
+    _assert_collectives_ran(_one_rank_bench(()))
+
+
+def test_bench_line_without_a_group_reports_no_collectives():
+    import json
+    import subprocess
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'RESEL_DP_FORCE_COLLECTIVES')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '2', '--warmup', '1', '--rows', '8', '--no-cpu-baseline',
+                        '--no-strict-leg', '--no-rccl-leg', '--no-suite'], capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['rccl_ranks'] == 0 and line['backend'] is None and sum(line['collectives_per_step'].values()) == 0
