@@ -45,7 +45,9 @@ const char* resel_build_info(void);     /* "gfx950 <date> ..." */
 enum {
     RESEL_PROF_SSCAN_FWD = 0, RESEL_PROF_SSCAN_BWD = 1, RESEL_PROF_ATTN_FWD = 2, RESEL_PROF_ATTN_DQ = 3, RESEL_PROF_ATTN_DKV = 4,
     RESEL_PROF_LINREC_REAL_FWD = 5, RESEL_PROF_LINREC_REAL_BWD = 6, RESEL_PROF_LINREC_COMPLEX_FWD = 7, RESEL_PROF_LINREC_COMPLEX_BWD = 8,
-    RESEL_PROF_GRU_FWD = 9, RESEL_PROF_GRU_BWD = 10, RESEL_PROF_CONV_FWD = 11, RESEL_PROF_CONV_BWD = 12, RESEL_PROF_GEMM = 13, RESEL_PROF_NSLOTS = 14
+    RESEL_PROF_GRU_FWD = 9, RESEL_PROF_GRU_BWD = 10, RESEL_PROF_CONV_FWD = 11, RESEL_PROF_CONV_BWD = 12, RESEL_PROF_GEMM = 13,
+    RESEL_PROF_SSCAN_FWD_LOCAL = 14, RESEL_PROF_SSCAN_BWD_LOCAL = 15,   /* time-parallel form: the local passes (+ carry) of a call */
+    RESEL_PROF_NSLOTS = 16
 };
 int resel_profile_enable(int on);
 int resel_profile_collect(int kernel_id, double* total_us, int* launches);

@@ -93,14 +93,15 @@ __device__ __forceinline__ Item decode(const GemmParams& p, int it) {
 template <bool KC>
 struct Src {
     const char* base;                              // uniform (SGPR pair): operand + member + tile origin + K position
-    const char* base0;                             // ... at the item's first K step
+    const char* base0;                             // ... at k = 0 of the operand (always a whole, valid K step: K >= 32 here)
     uint32_t off[4];                               // this thread's byte offsets of its four pieces from `base`
     int64_t step;                                  // bytes per K step
     int kofs;                                      // k of piece 0 inside the step
     __device__ __forceinline__ void init(const float* P, int64_t ld, int rows, int r0, int k0, int tid) {
         kofs = 4 * (tid & 7);
         if (KC) {
-            base = base0 = (const char*)(P + (int64_t)r0 * ld + k0);
+            base = (const char*)(P + (int64_t)r0 * ld + k0);
+            base0 = (const char*)(P + (int64_t)r0 * ld);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int rl = (tid >> 3) + 32 * i;
@@ -108,7 +109,8 @@ struct Src {
             }
             step = BK * 4;
         } else {
-            base = base0 = (const char*)(P + (int64_t)k0 * ld + r0);
+            base = (const char*)(P + (int64_t)k0 * ld + r0);
+            base0 = (const char*)(P + r0);
             const int rl = 4 * (tid >> 3);
 #pragma unroll
             for (int j = 0; j < 4; ++j) off[j] = (uint32_t)(((kofs + j) * ld + (r0 + rl < rows ? rl : 0)) * 4);
@@ -116,8 +118,9 @@ struct Src {
         }
     }
     // Branch-free load for the scheduled region of the SPLIT loop: `full` (uniform) = a whole K step is due - load it and
-    // advance; otherwise (K tail, or nothing left to fetch) the same instructions re-read the item's first step, a valid
-    // address (the host sends K < 32 to the fp32 kernel), and the caller's guarded `load` then provides the real data.
+    // advance; otherwise (K tail, or nothing left to fetch) the same instructions re-read the tile's step at k = 0 - in bounds
+    // for every item, also a K slice shorter than one step (the host sends K < 32 to the fp32 kernel) - and the caller's
+    // guarded `load` then provides the real data.
     __device__ __forceinline__ void load_sched(float4 (&r)[4], bool full) {
         const char* b = full ? base : base0;
 #pragma unroll

@@ -1040,7 +1040,7 @@ int launch_fwd(FwdParams p, int force_seg, void* workspace, hipStream_t s) {
     p.seg_len = ((p.L + nseg - 1) / nseg + TC - 1) / TC * TC;
     p.h_carry = (float*)workspace;
     p.sdl = p.h_carry + (size_t)p.B * nseg * p.N * p.Di;
-    launch_maybe_timed(RESEL_PROF_SSCAN_FWD, sscan_fwd2_kernel<NS, NW, TC, 1>, dim3(bp * p.nd, nseg), dim3(NW * 64), s, p);
+    launch_maybe_timed(RESEL_PROF_SSCAN_FWD_LOCAL, sscan_fwd2_kernel<NS, NW, TC, 1>, dim3(bp * p.nd, nseg), dim3(NW * 64), s, p);
     const int64_t n = (int64_t)p.B * p.N * p.Di;
     hipLaunchKernelGGL(sscan_carry_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p.h_carry, p.sdl, p.A, p.B, nseg, p.N, p.Di);
     launch_maybe_timed(RESEL_PROF_SSCAN_FWD, sscan_fwd2_kernel<NS, NW, TC, 2>, dim3(bp * p.nd, nseg), dim3(NW * 64), s, p);
@@ -1050,7 +1050,7 @@ template <int NS, int NW>
 int launch_bwd(const BwdParams& p, hipStream_t s) {
     const int bp = (p.B + 7) / 8 * 8;
     if (p.nseg > 1) {                                // time-parallel form: local adjoint pass, carry, then the full pass per segment
-        hipLaunchKernelGGL((sscan_bwd_local_kernel<NS, NW, 32>), dim3(bp * p.nd, p.nseg), dim3(NW * 64), 0, s, p);
+        launch_maybe_timed(RESEL_PROF_SSCAN_BWD_LOCAL, sscan_bwd_local_kernel<NS, NW, 32>, dim3(bp * p.nd, p.nseg), dim3(NW * 64), s, p);
         const int64_t n = (int64_t)p.B * p.N * p.Di;
         hipLaunchKernelGGL(sscan_carry_rev_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p.dh_carry, p.sdl, p.A, p.B, p.nseg, p.N, p.Di);
     }

@@ -60,7 +60,8 @@ def _ws(nbytes: int, device) -> torch.Tensor:
 
 PROF_SLOTS = ('sscan_fwd_kernel', 'sscan_bwd_kernel', 'attn_fwd_kernel', 'attn_dq_kernel', 'attn_dkv_kernel', 'linrec_real_fwd_kernel',
               'linrec_real_bwd_kernel', 'linrec_complex_fwd_kernel', 'linrec_complex_bwd_kernel', 'gru_fwd_kernel', 'gru_bwd_kernel',
-              'conv_fwd_kernel', 'conv_bwd_kernel', 'gemm_f32_kernel')          # RESEL_PROF_* of include/resel_hip.h, in id order
+              'conv_fwd_kernel', 'conv_bwd_kernel', 'gemm_f32_kernel', 'sscan_fwd_local_kernel',
+              'sscan_bwd_local_kernel')                                         # RESEL_PROF_* of include/resel_hip.h, in id order
 GEMM_FLOPS = [0.0]            # 2 M N K of every resel_gemm_f32 call since the caller last reset it (bench.py's GEMM line)
 
 

@@ -77,6 +77,67 @@ def test_selective_scan_fwd_bwd(ops, B, L, Di, N, with_z):
         close(a, b, rtol=2e-4, atol_scale=5e-5, name=nm)
 
 
+def _slow_decay_case(B, L, Di, N, seed):
+    """Mamba's real initialisation range: A in [-1, -0.01] (log-uniform), delta = softplus(pre + bias) in [1e-3, 0.1] (log-uniform,
+    mamba_simple's dt_min / dt_max) - a state survives hundreds of steps, so every carry across chunks, checkpoints and time
+    segments contributes at full weight (with delta ~ 0.5, A ~ -1 a 64-step segment decays by e^-30 and the carry is invisible)."""
+    g = torch.Generator().manual_seed(seed)
+    u, z = rnd(B, L, Di, g=g), rnd(B, L, Di, g=g)
+    Bm, Cm = rnd(B, L, N, g=g), rnd(B, L, N, g=g)
+    A = -torch.exp(torch.rand(Di, N, generator=g) * math.log(100.0) + math.log(0.01))
+    db = rnd(Di, g=g, scale=0.1)
+    dt = torch.exp(torch.rand(B, L, Di, generator=g) * math.log(100.0) + math.log(1e-3))
+    delta = torch.log(torch.expm1(dt)) - db                     # softplus(delta + bias) = dt
+    D = rnd(Di, g=g)
+    start = torch.zeros(B, L)
+    start[:, 0] = 1
+    if L > 700:
+        start[0, 700] = 1                                       # one reset deep inside a row; the other rows run L steps unbroken
+    w = rnd(B, L, Di, g=g)
+    return (u, delta, A, Bm, Cm, D, z, db), start, w
+
+
+@pytest.mark.parametrize('B,L,Di,N,segs', [(2, 1043, 64, 32, 1), (2, 1043, 64, 32, 11), (3, 1043, 64, 32, 0), (1, 1043, 128, 16, 1),
+                                            (1, 1043, 128, 16, 5), (2, 300, 64, 64, 1), (2, 300, 64, 8, 3)])
+def test_selective_scan_slow_decay_vs_oracle(ops, monkeypatch, B, L, Di, N, segs):
+    """Forward, last state and every gradient against the oracle at the BASELINE row length with slowly decaying states, with the
+    one-pass kernels forced (segs = 1: the B = 64 bench path), the time-parallel kernels forced (segs > 1) and the library's
+    own choice (segs = 0)."""
+    ins, start, w = _slow_decay_case(B, L, Di, N, seed=L + N + segs)
+    ref_in = [t.clone().requires_grad_(True) for t in ins]
+    ref, ref_last = K.selective_scan_ref(*ref_in, start, True)
+    (ref * w).sum().backward()
+    monkeypatch.setattr(ops, 'SSCAN_TIME_SEGMENTS', segs)
+    dev_in = [t.clone().cuda().requires_grad_(True) for t in ins]
+    out, last = ops.selective_scan_tm(*dev_in, start.cuda(), True, return_last_state=True)
+    (out * w.cuda()).sum().backward()
+    # the carried state matters: the output with the state cut at every 32-step chunk would be far away from the reference
+    assert ref_last.abs().max().item() > 1.0
+    close(out, ref, name='out')
+    close(last, ref_last, name='last_state')
+    for a, b, nm in zip(dev_in, ref_in, ('du', 'ddelta', 'dA', 'dB', 'dC', 'dD', 'dz', 'dbias')):
+        close(a.grad, b.grad, rtol=2e-4, atol_scale=5e-5, name=nm)
+
+
+def test_selective_scan_slow_decay_carry_is_load_bearing(ops, monkeypatch):
+    """The test data above does exercise the cross-segment carry: zeroing the state at the segment edges (extra resets at the
+    11 segment starts) changes the output by far more than the parity tolerance, and the segmented kernels agree with the
+    one-pass kernels to 1e-5 WITHOUT those resets."""
+    ins, start, w = _slow_decay_case(2, 1043, 64, 32, seed=5)
+    dev = [t.cuda() for t in ins]
+    outs = {}
+    for segs in (1, 11):
+        monkeypatch.setattr(ops, 'SSCAN_TIME_SEGMENTS', segs)
+        outs[segs] = ops.selective_scan_tm(*dev, start.cuda(), True)
+    close(outs[11], outs[1].cpu(), rtol=1e-5, atol_scale=1e-6, name='segmented vs one pass')
+    cut = start.clone()
+    cut[:, ::96] = 1                                              # 11 segments of 96 steps at L = 1043
+    monkeypatch.setattr(ops, 'SSCAN_TIME_SEGMENTS', 1)
+    o_cut = ops.selective_scan_tm(*dev, cut.cuda(), True)
+    rel = (o_cut - outs[1]).abs().max().item() / outs[1].abs().max().item()
+    assert rel > 1e-2, f'cutting the carry changed the output by only {rel:.2e}'
+
+
 def test_selective_scan_golden_reference_vectors(ops):
     """The reference's own selective_scan_ref outputs (tests/golden/selective_scan.npz), channel-major signature."""
     gold = load_golden('selective_scan.npz')
@@ -501,7 +562,7 @@ def test_linear_act_vs_torch(ops):
 
 
 # ------------------------------------------------------------------------------------------ BASELINE-size properties
-def test_selective_scan_full_size_properties(ops):
+def test_selective_scan_full_size_properties(ops, monkeypatch):
     """Config-2 shapes (B 64, T' 1043, d_inner 512, N 32: too big for the CPU oracle in a test) through size-independent
     properties of the recurrence: (1) y is linear in u for fixed delta / B / C (no gate), forward and in the u-gradient;
     (2) a `start` reset makes the rest of the row independent of everything before it - the suffix of a packed row
@@ -528,8 +589,12 @@ def test_selective_scan_full_size_properties(ops):
     assert (y12 - (y1 + 2 * y2)).abs().max().item() <= 2e-5 * scale, 'linearity in u'
     tail = run(u1, sl=slice(cut, None))
     assert (tail - y1[:, cut:]).abs().max().item() <= 2e-5 * scale, 'reset isolation / packing'
+    # (3) row independence, bit for bit - for the right reason: BOTH sides on the one-pass kernels (a batch of one would otherwise be
+    # cut into time segments, whose arithmetic differs from the one-pass scan in the last bits whenever the carried state matters)
+    monkeypatch.setattr(ops, 'SSCAN_TIME_SEGMENTS', 1)
     one = run(u1, rows=slice(B - 1, B))
     assert torch.equal(one, y1[B - 1:]), 'row independence must be bit-exact'
+    monkeypatch.setattr(ops, 'SSCAN_TIME_SEGMENTS', 0)
     # backward: d/du of sum(w * y) is linear in w
     uu = u1.clone().requires_grad_(True)
     w1, w2 = rnd(B, L, Di, g=g).to(dev), rnd(B, L, Di, g=g).to(dev)
