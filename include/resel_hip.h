@@ -285,7 +285,9 @@ int resel_ensemble_head_bwd(const float* gq, const float* a, const float* w3, fl
  *   0  v_mfma_f32_32x32x2_f32 (fp32 operands, exact products);
  *   9  each operand split EXACTLY into three bf16 planes (8 + 8 + 8 significant bits), all nine plane products - each exact -
  *      accumulated in fp32 by v_mfma_f32_32x32x16_bf16: the product a b is represented exactly, as in mode 0;
- *   6  as 9 without the three smallest terms (each <= 2^-24 |a b|, the size of one fp32 rounding of the product). */
+ *   6  as 9 without the three smallest terms (each <= 2^-24 |a b|, the size of one fp32 rounding of the product);
+ *   106 / 109  modes 6 / 9 on the first-edition kernel (every wave splits the fragments it reads; kept for A/B measurements).
+ * Modes 6 / 9 split each operand element once per block on its way into LDS (csrc/gemm_bf3.hip, 256 x 128 tiles). */
 size_t resel_gemm_f32_workspace_bytes(int M, int N, int K, int batch);
 int resel_gemm_f32(const float* A, int64_t lda, int64_t strideA, int a_kcontig,
                    const float* B, int64_t ldb, int64_t strideB, int b_kcontig,

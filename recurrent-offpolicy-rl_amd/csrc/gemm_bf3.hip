@@ -1,0 +1,545 @@
+// fp32 GEMM on the bf16 matrix cores of gfx950, second edition: the operands are split ONCE PER BLOCK, on their way into LDS.
+//
+//     C[b][m][n] = epi( sum_k A[b](m, k) * B[b](n, k) )          same contract and operand layouts as gemm_f32.hip
+//
+// Product formation (resel_gemm_f32 modes 6 / 9, gemm_f32.hip 'SPLIT'): every fp32 operand element x is written exactly as
+// x1 + x2 + x3, three bf16 values obtained by truncation; a bf16 x bf16 product is exact in fp32 and v_mfma_f32_32x32x16_bf16
+// accumulates the plane products in fp32.  Mode 9 keeps all nine plane products, mode 6 drops a2 b3, a3 b2, a3 b3 (each at
+// most 2^-24 |a b|).  The first edition kept fp32 tiles in LDS and every wave split the fragments it read: with 2 x 2 waves
+// per block each element was split twice, 352 vector instructions per wave and K step beside 48 matrix instructions - the
+// vector pipe, not the matrix pipe, set the pace (PMC: matrix pipe 50 % busy, profiles/r02_gemm.md).  Here
+//   * the thread that LOADS an element splits it (22 vector instructions per four elements, once) and stores the three planes
+//     to LDS as bf16; fragments are read from LDS as finished MFMA operands (ds_read_b128 = 8 k of one plane);
+//   * the block tile is 256 x 128 (8 waves as 4 x 2, wave tile 64 x 64 = four 32 x 32 tiles): a thread splits 24 elements per
+//     K step (132 vector instructions) against 48 matrix instructions of 32 cycles - inside their shadow;
+//   * LDS image per plane: [row][32 k] bf16 = 64 bytes per row, no padding; the 16-byte chunk index is XOR-ed with bits 2..3
+//     of the row and rows 4..7 of every 8 swap inside their pairs, which makes the fragment reads (ds_read_b128), the
+//     [rows][K] stores (ds_write_b64) and the transposed [K][rows] stores conflict-free or 2-way at worst;
+//     2 stages x (3 x 16 KB + 3 x 8 KB) = 144 KB: one block of 512 threads per CU, two waves per SIMD.
+// Pipeline per K step s (one barrier): MFMAs of k slab 0 | split + LDS stores of step s + 1 (its global loads were issued a step
+// earlier) | fragment reads of slab 1 | global loads of step s + 2 | first half of slab 1's MFMAs | barrier | fragment reads of
+// step s + 1's slab 0 under the second half of slab 1's MFMAs.
+// Blocks are persistent (256 = one per CU) and walk items exactly as in gemm_f32.hip: whole tiles, and K slices for the last
+// partly filled round and for weight gradients, summed by a fix-up kernel in a fixed order (deterministic, no atomics).
+#include "resel_common.h"
+#include <algorithm>
+
+namespace {
+using namespace resel;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int BM = 256, BN = 128, BK = 32;
+constexpr int NTH = 512;
+constexpr int GRID = 256;
+constexpr int TILE = BM * BN;
+constexpr int ROWB = 64;                         // bytes of one row of one plane: 32 k x bf16
+constexpr int PLA = BM * ROWB, PLB = BN * ROWB;  // one plane of the A / B tile
+constexpr int STAGE = 3 * PLA + 3 * PLB;         // 73 728 bytes
+
+struct Params {
+    const float *A, *B, *bias;
+    float *C, *slab;
+    int64_t lda, ldb, ldc, sA, sB, sC, sBias;
+    int M, N, K;
+    int act;
+    int mt, nt;
+    int nfull, nsplit, nsl, kslice;
+};
+
+__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : fast_exp(x) - 1.f; }
+
+__device__ __forceinline__ void tile_origin(const Params& p, int t, int& z, int& m0, int& n0) {
+    const int ntile = p.mt * p.nt;
+    z = t / ntile;
+    const int tt = t - z * ntile;
+    const int q = ntile / 8, r = ntile % 8, x = tt & 7, j = tt >> 3;
+    const int bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+    m0 = (bid / p.nt) * BM;
+    n0 = (bid % p.nt) * BN;
+}
+struct Item { int m0, n0, z, kbeg, kend, split; };
+__device__ __forceinline__ Item decode(const Params& p, int it) {
+    Item o;
+    int t = it;
+    o.kbeg = 0; o.kend = p.K; o.split = 0;
+    if (it >= p.nfull) {
+        const int idx = it - p.nfull, tr = idx / p.nsl, sl = idx - tr * p.nsl;
+        t = p.nfull + tr;
+        o.kbeg = sl * p.kslice; o.kend = min(p.K, o.kbeg + p.kslice); o.split = idx + 1;
+    }
+    tile_origin(p, t, o.z, o.m0, o.n0);
+    return o;
+}
+
+// byte offset of (row, 16-byte chunk c = k / 8) inside one plane
+__device__ __forceinline__ int plane_off(int row, int c) {
+    const int q = row >> 2;
+    return ((row ^ (q & 1)) << 6) + ((c ^ (q & 3)) << 4);
+}
+
+// ---- four fp32 values -> three planes of four bf16 (8 bytes each)
+struct P3 { uint2 p1, p2, p3; };
+__device__ __forceinline__ P3 split4(const float4& v) {
+#ifdef BF3_AB_NOSPLIT                  // ablation (wrong results): no vector work for the split
+    return P3{make_uint2(__float_as_uint(v.x), __float_as_uint(v.y)), make_uint2(__float_as_uint(v.z), __float_as_uint(v.w)),
+              make_uint2(__float_as_uint(v.x), __float_as_uint(v.w))};
+#endif
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    uint32_t w1[2], w2[2], w3[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const uint32_t u0 = __float_as_uint(x[2 * q]), u1 = __float_as_uint(x[2 * q + 1]);
+        w1[q] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);        // {hi16(x[2q+1]), hi16(x[2q])}: element 2q in the low half
+        const float r0 = x[2 * q] - __uint_as_float(u0 & 0xffff0000u), r1 = x[2 * q + 1] - __uint_as_float(u1 & 0xffff0000u);
+        const uint32_t v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+        w2[q] = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+        const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
+        w3[q] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+    }
+    return P3{make_uint2(w1[0], w1[1]), make_uint2(w2[0], w2[1]), make_uint2(w3[0], w3[1])};
+}
+struct P3h { uint32_t p1, p2, p3; };                 // two values -> three planes of two bf16
+__device__ __forceinline__ P3h split2(float x0, float x1) {
+    const uint32_t u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+    P3h o;
+    o.p1 = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+    const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u), r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
+    const uint32_t v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+    o.p2 = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
+    o.p3 = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+    return o;
+}
+
+// ---- one operand's share of a thread in a K step.
+// KC (P[row][k]): NPC pieces, piece i = row (tid / 8 + 64 i), k = 4 (tid % 8) .. + 3 (one float4, 8 bytes per plane).
+// !KC (P[k][row]), the 256-row operand: one 4 (k) x 4 (rows) patch, rows 4 g .., k = 4 k4 ..: four float4 along rows,
+//   transposed in registers, four ds_write_b64 per plane.  tid = [g_lo:3][k4:3][g_hi:3]: a wave-load covers 8 k rows x 128 B.
+// !KC, the 128-row operand: one 2 (k) x 4 (rows) patch, k = 2 k2 ..: two float4, four ds_write_b32 per plane.
+//   tid = [g_lo:3][k2:4][g_hi:2].
+// Rows beyond the operand's extent are read from row 0 (their products land in rows / columns that are never stored); k beyond
+// the slice end contributes zeros (guarded loads on the last step of a K that is not a multiple of 32).
+template <bool KC, int ROWS>
+struct Src {
+    static constexpr int NPC = ROWS / 64;          // KC pieces
+    static constexpr int NR = KC ? NPC : (ROWS == 256 ? 4 : 2);
+    const char* base;
+    const char* base0;                             // the tile's step at k = 0: always a whole, valid K step (K >= 32)
+    uint32_t off[NR];
+    uint32_t loff[KC ? NPC : 4];                   // LDS byte offsets inside a plane (KC: per piece; !KC: per patch row)
+    int64_t step;
+    int kofs;
+    float4 r[NR];
+    __device__ __forceinline__ void init(const float* P, int64_t ld, int rows, int r0, int k0, int tid) {
+        if (KC) {
+            kofs = 4 * (tid & 7);
+            base = (const char*)(P + (int64_t)r0 * ld + k0);
+            base0 = (const char*)(P + (int64_t)r0 * ld);
+#pragma unroll
+            for (int i = 0; i < NPC; ++i) {
+                const int rl = (tid >> 3) + 64 * i;
+                off[i] = (uint32_t)(((r0 + rl < rows ? rl : 0) * ld + kofs) * 4);
+            }
+            step = BK * 4;
+        } else {
+            const int g = ROWS == 256 ? (tid & 7) + 8 * (tid >> 6) : (tid & 7) + 8 * (tid >> 7);
+            kofs = ROWS == 256 ? 4 * ((tid >> 3) & 7) : 2 * ((tid >> 3) & 15);
+            base = (const char*)(P + (int64_t)k0 * ld + r0);
+            base0 = (const char*)(P + r0);
+            const int rl = 4 * g;
+#pragma unroll
+            for (int j = 0; j < NR; ++j) off[j] = (uint32_t)(((kofs + j) * ld + (r0 + rl < rows ? rl : 0)) * 4);
+            step = (int64_t)BK * ld * 4;
+        }
+    }
+    __device__ __forceinline__ void init_lds(int tid) {
+        if (KC) {
+#pragma unroll
+            for (int i = 0; i < NPC; ++i) loff[i] = plane_off((tid >> 3) + 64 * i, (tid & 7) >> 1) + 8 * (tid & 1);
+        } else if (ROWS == 256) {
+            const int g = (tid & 7) + 8 * (tid >> 6), k4 = (tid >> 3) & 7;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) loff[j] = plane_off(4 * g + j, k4 >> 1) + 8 * (k4 & 1);
+        } else {
+            const int g = (tid & 7) + 8 * (tid >> 7), k2 = (tid >> 3) & 15;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) loff[j] = plane_off(4 * g + j, k2 >> 2) + 4 * (k2 & 3);
+        }
+    }
+    // branch-free form for the scheduled region of the K loop: `full` (uniform) = a whole K step is due - load it and advance;
+    // otherwise the same instructions re-read the tile's step at k = 0 (in bounds) and the caller's guarded `load` follows
+    __device__ __forceinline__ void load_sched(bool full) {
+        const char* b = full ? base : base0;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) r[i] = *reinterpret_cast<const float4*>(b + off[i]);
+        if (full) base += step;
+    }
+    __device__ __forceinline__ void load(int k0, int kend) {
+        if (k0 + BK <= kend) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) r[i] = *reinterpret_cast<const float4*>(base + off[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                r[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k0 + kofs + (KC ? 0 : i) < kend) r[i] = *reinterpret_cast<const float4*>(base + off[i]);
+            }
+        }
+        base += step;
+    }
+    // split the staged values and store the planes of this thread's pieces into the plane set at `pl` (plane stride PL bytes)
+    template <int PL>
+    __device__ __forceinline__ void store(char* pl) const {
+        if (KC) {
+#pragma unroll
+            for (int i = 0; i < NPC; ++i) {
+                const P3 s = split4(r[i]);
+                *reinterpret_cast<uint2*>(pl + loff[i]) = s.p1;
+                *reinterpret_cast<uint2*>(pl + PL + loff[i]) = s.p2;
+                *reinterpret_cast<uint2*>(pl + 2 * PL + loff[i]) = s.p3;
+            }
+        } else if (ROWS == 256) {
+            const float c[4][4] = {{r[0].x, r[1].x, r[2].x, r[3].x}, {r[0].y, r[1].y, r[2].y, r[3].y},
+                                   {r[0].z, r[1].z, r[2].z, r[3].z}, {r[0].w, r[1].w, r[2].w, r[3].w}};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const P3 s = split4(make_float4(c[j][0], c[j][1], c[j][2], c[j][3]));
+                *reinterpret_cast<uint2*>(pl + loff[j]) = s.p1;
+                *reinterpret_cast<uint2*>(pl + PL + loff[j]) = s.p2;
+                *reinterpret_cast<uint2*>(pl + 2 * PL + loff[j]) = s.p3;
+            }
+        } else {
+            const float c[4][2] = {{r[0].x, r[1].x}, {r[0].y, r[1].y}, {r[0].z, r[1].z}, {r[0].w, r[1].w}};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const P3h s = split2(c[j][0], c[j][1]);
+                *reinterpret_cast<uint32_t*>(pl + loff[j]) = s.p1;
+                *reinterpret_cast<uint32_t*>(pl + PL + loff[j]) = s.p2;
+                *reinterpret_cast<uint32_t*>(pl + 2 * PL + loff[j]) = s.p3;
+            }
+        }
+    }
+};
+
+struct Frag { bf16x8 a[3][2], b[3][2]; };            // [plane][32-row tile] of one k slab (16 k)
+
+__device__ __forceinline__ bf16x8 lds16(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
+// fa / fb: this lane's fragment address of slab `s` in plane 0, tile 0 of the stage (byte pointers into LDS)
+__device__ __forceinline__ void read_a(Frag& f, const char* fa) {
+#pragma unroll
+    for (int pi = 0; pi < 3; ++pi)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) f.a[pi][t] = lds16(fa + pi * PLA + t * 32 * ROWB);
+}
+__device__ __forceinline__ void read_b(Frag& f, const char* fb) {
+#pragma unroll
+    for (int pi = 0; pi < 3; ++pi)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) f.b[pi][t] = lds16(fb + pi * PLB + t * 32 * ROWB);
+}
+template <int P, int Q>
+__device__ __forceinline__ void mfma_term(f32x16 (&acc)[2][2], const Frag& f) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+#ifdef BF3_AB_NOMFMA                   // ablation (wrong results): operands consumed, no matrix instruction
+            asm volatile("" :: "v"(f.a[P][a]), "v"(f.b[Q][b]));
+#else
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[P][a], f.b[Q][b], acc[a][b], 0, 0, 0);
+#endif
+        }
+}
+// the small terms are added first
+template <int SPLIT>
+__device__ __forceinline__ void mfma_small(f32x16 (&acc)[2][2], const Frag& f) {
+    if (SPLIT == 9) { mfma_term<2, 2>(acc, f); mfma_term<2, 1>(acc, f); mfma_term<1, 2>(acc, f); }
+    mfma_term<2, 0>(acc, f); mfma_term<0, 2>(acc, f); mfma_term<1, 1>(acc, f);
+}
+__device__ __forceinline__ void mfma_lead(f32x16 (&acc)[2][2], const Frag& f) {
+    mfma_term<1, 0>(acc, f); mfma_term<0, 1>(acc, f); mfma_term<0, 0>(acc, f);
+}
+
+#define BF3_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+template <bool AKC, bool BKC, int SPLIT>
+__global__ __launch_bounds__(NTH, 2) void gemm_bf3_kernel(Params p) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];           // 2 stages
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
+    const int li = lane & 31, lh = lane >> 5;
+    const int total = p.nfull + p.nsplit * p.nsl;
+    const int G = gridDim.x;
+    if ((int)blockIdx.x >= total) return;
+
+    Src<AKC, BM> sa;
+    Src<BKC, BN> sb;
+    sa.init_lds(tid);
+    sb.init_lds(tid);
+    int p_item = blockIdx.x, p_k0, p_kend;
+    bool p_live = true;
+    auto p_open = [&]() {
+        const Item it = decode(p, p_item);
+        sa.init(p.A + (int64_t)it.z * p.sA, p.lda, p.M, it.m0, it.kbeg, tid);
+        sb.init(p.B + (int64_t)it.z * p.sB, p.ldb, p.N, it.n0, it.kbeg, tid);
+        p_k0 = it.kbeg; p_kend = it.kend;
+    };
+    auto produce = [&]() {                          // global loads of the next K step in program order (also across items)
+        if (!p_live) return;
+        sa.load(p_k0, p_kend);
+        sb.load(p_k0, p_kend);
+        p_k0 += BK;
+        if (p_k0 >= p_kend) {
+            p_item += G;
+            if (p_item < total) p_open(); else p_live = false;
+        }
+    };
+    auto stage_store = [&](int st) {
+        sa.template store<PLA>(lds + st * STAGE);
+        sb.template store<PLB>(lds + st * STAGE + 3 * PLA);
+    };
+    // fragment addresses: slab s of the lane = chunk 2 s + lh of row li of the wave's tile rows
+    const char* fa[2];
+    const char* fb[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        fa[s] = lds + wm * ROWB + plane_off(li, 2 * s + lh);
+        fb[s] = lds + 3 * PLA + wn * ROWB + plane_off(li, 2 * s + lh);
+    }
+
+#ifdef BF3_AB_STAGGER                     // experiment: BF3_AB_STAGGER groups of CUs start a fraction of a tile time apart (write bursts desynchronised)
+    {
+        const int grp = ((int)blockIdx.x >> 3) % BF3_AB_STAGGER;
+        const long long wait = (long long)((p.K + BK - 1) / BK) * 5300 * grp / BF3_AB_STAGGER;
+        const long long t0 = __builtin_amdgcn_s_memtime();
+        while ((long long)__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+    }
+#endif
+    Frag f0, f1;
+    p_open();
+    produce();
+    stage_store(0);
+    produce();
+    __syncthreads();
+    read_a(f0, fa[0]); read_b(f0, fb[0]);
+    int cur_st = 0;
+    for (int c_item = blockIdx.x; c_item < total; c_item += G) {
+        const Item cur = decode(p, c_item);
+        float zero = 0.f;
+        asm volatile("" : "+v"(zero));              // opaque: or 64 registers of hoisted zeros stay live across the K loop
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[a][b][e] = zero;
+        float bv[2] = {0.f, 0.f};
+
+        for (int c_k0 = cur.kbeg; c_k0 < cur.kend; c_k0 += BK) {
+            const int so = cur_st * STAGE, sn = (cur_st ^ 1) * STAGE;
+            const bool fast = p_live && p_k0 + BK <= p_kend;
+            if (c_k0 + BK >= cur.kend && p.bias && !cur.split) {        // requested most of a step before the epilogue needs them
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int n = cur.n0 + wn + 32 * b + li;
+                    bv[b] = p.bias[(int64_t)cur.z * p.sBias + (n < p.N ? n : 0)];
+                }
+            }
+            BF3_FENCE();
+            // ---- region A: 36 (54) matrix instructions; in their shadow slab 1's fragment reads, the split + LDS stores of step
+            // s + 1's tile and the global loads of step s + 2 into the registers the split has just released
+            read_a(f1, fa[1] + so); read_b(f1, fb[1] + so);
+            mfma_small<SPLIT>(acc, f0);
+            stage_store(cur_st ^ 1);
+            mfma_lead(acc, f0);
+            sa.load_sched(fast);
+            sb.load_sched(fast);
+            mfma_small<SPLIT>(acc, f1);
+            {
+                constexpr int NMA = SPLIT == 9 ? 60 : 36;
+#pragma unroll
+                for (int i = 0; i < NMA; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 // one MFMA
+                    if (i < 12) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // one LDS read
+                    __builtin_amdgcn_sched_group_barrier(0x002, SPLIT == 9 ? 3 : 5, 0);   // vector instructions
+                    if (i >= 4 && i < 4 + 18) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // one LDS write
+                    if (i >= NMA - 8) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);          // one global load
+                }
+            }
+            BF3_FENCE();
+#ifdef BF3_AB_NOBAR                    // ablation (wrong results)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // stage s + 1 is complete; every wave has read stage s
+#endif
+            BF3_FENCE();
+            // ---- region B: the leading terms of slab 1 with the fragment reads of step s + 1's slab 0
+            read_a(f0, fa[0] + sn); read_b(f0, fb[0] + sn);
+            mfma_lead(acc, f1);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            BF3_FENCE();
+            if (fast) {
+                p_k0 += BK;
+                if (p_k0 >= p_kend) {
+                    p_item += G;
+                    if (p_item < total) p_open(); else p_live = false;
+                }
+            } else {
+                produce();
+            }
+            BF3_FENCE();
+            cur_st ^= 1;
+        }
+#ifdef BF3_AB_NOEPI                    // ablation (wrong results): one store per wave and tile keeps the accumulators alive
+        if (lane == 0) p.C[(int64_t)cur.m0 * p.ldc + cur.n0 + w] = acc[0][0][0] + acc[0][1][1] + acc[1][0][2] + acc[1][1][3];
+        continue;
+#endif
+        // epilogue: D layout col = lane & 31 (n), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (m).  One dword per lane and store:
+        // 32 consecutive n of one row = a full 128-byte line (x 2 rows per instruction).  The transposed form (B fragment as the
+        // first MFMA operand: four consecutive n per lane, 16 float4 stores instead of 64 dword stores) was measured SLOWER
+        // (583 -> 618 us at 66 752 x 2048 x 384): a store costs per line touched (32 rows x 32 bytes per instruction there).
+        if (cur.split) {
+            float* o = p.slab + (int64_t)(cur.split - 1) * TILE + (wm + 4 * lh) * BN + wn + li;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) o[(32 * a + (e & 3) + 8 * (e >> 2)) * BN + 32 * b] = acc[a][b][e];
+        } else {
+            float* C = p.C + (int64_t)cur.z * p.sC;
+            const bool full_m = cur.m0 + BM <= p.M;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int n = cur.n0 + wn + 32 * b + li;
+                if (n >= p.N) continue;
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    float v[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) v[e] = acc[a][b][e] + bv[b];
+                    if (p.act == 1) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) v[e] = elu1(v[e]);
+                    }
+                    const int mb = cur.m0 + wm + 32 * a + 4 * lh;
+                    float* crow = C + (int64_t)mb * p.ldc + n;
+                    if (full_m) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) crow[(int64_t)((e & 3) + 8 * (e >> 2)) * p.ldc] = v[e];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int dm = (e & 3) + 8 * (e >> 2);
+                            if (mb + dm < p.M) crow[(int64_t)dm * p.ldc] = v[e];
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// C tile = epi(sum over the K slices of a split tile), fixed summation order: as gemm_fixup_kernel of gemm_f32.hip for 256 x 128 tiles
+__global__ __launch_bounds__(256) void gemm_bf3_fixup_kernel(Params p) {
+    __shared__ float4 part[3][64];
+    const int tr = blockIdx.y, q = threadIdx.y;
+    const int e = blockIdx.x * 64 + threadIdx.x, ml = e >> 5, nl = 4 * (e & 31);
+    const float* s = p.slab + (int64_t)tr * p.nsl * TILE + ml * BN + nl;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    int i = q;
+    for (; i + 12 < p.nsl; i += 16) {
+        const float4 u0 = ld4(s + (int64_t)i * TILE), u1 = ld4(s + (int64_t)(i + 4) * TILE);
+        const float4 u2 = ld4(s + (int64_t)(i + 8) * TILE), u3 = ld4(s + (int64_t)(i + 12) * TILE);
+        v.x = (((v.x + u0.x) + u1.x) + u2.x) + u3.x; v.y = (((v.y + u0.y) + u1.y) + u2.y) + u3.y;
+        v.z = (((v.z + u0.z) + u1.z) + u2.z) + u3.z; v.w = (((v.w + u0.w) + u1.w) + u2.w) + u3.w;
+    }
+    for (; i < p.nsl; i += 4) {
+        const float4 u = ld4(s + (int64_t)i * TILE);
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    if (q) part[q - 1][threadIdx.x] = v;
+    __syncthreads();
+    if (q) return;
+    const float4 g1 = part[0][threadIdx.x], g2 = part[1][threadIdx.x], g3 = part[2][threadIdx.x];
+    float o[4] = {(v.x + g1.x) + (g2.x + g3.x), (v.y + g1.y) + (g2.y + g3.y), (v.z + g1.z) + (g2.z + g3.z), (v.w + g1.w) + (g2.w + g3.w)};
+    int z, m0, n0;
+    tile_origin(p, p.nfull + tr, z, m0, n0);
+    const int m = m0 + ml, n = n0 + nl;
+    if (m >= p.M || n >= p.N) return;
+    float* c = p.C + (int64_t)z * p.sC + (int64_t)m * p.ldc + n;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (n + j >= p.N) break;
+        float x = o[j] + (p.bias ? p.bias[(int64_t)z * p.sBias + n + j] : 0.f);
+        if (p.act == 1) x = elu1(x);
+        c[j] = x;
+    }
+}
+
+struct Plan { int nfull, nsplit, nsl, kslice; };
+inline Plan make_plan(int M, int N, int K, int batch) {
+    const long nbt = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN) * batch;
+    const int ksteps = (K + BK - 1) / BK;
+    Plan pl{(int)nbt, 0, 1, ksteps * BK};
+    const int r = (int)(nbt % GRID);
+    if (r == 0 || r > GRID / 2 || ksteps < 4) return pl;
+    int s = std::min(GRID / r, ksteps / 2);
+    const int per = (ksteps + s - 1) / s;
+    s = (ksteps + per - 1) / per;
+    if (s < 2) return pl;
+    pl.nfull = (int)(nbt - r); pl.nsplit = r; pl.nsl = s; pl.kslice = per * BK;
+    return pl;
+}
+
+template <bool AKC, bool BKC, int SP>
+int launch_one(const Params& p, dim3 grid, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)gemm_bf3_kernel<AKC, BKC, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE) != hipSuccess)
+            return RESEL_ELAUNCH;
+        attr_set = true;
+    }
+    launch_timed(RESEL_PROF_GEMM, gemm_bf3_kernel<AKC, BKC, SP>, grid, dim3(NTH), (size_t)(2 * STAGE), s, p);
+    return RESEL_OK;
+}
+
+}  // namespace
+
+namespace resel {
+
+size_t gemm_bf3_workspace_bytes(int M, int N, int K, int batch) {
+    const Plan pl = make_plan(M, N, K, batch);
+    return (size_t)pl.nsplit * pl.nsl * TILE * sizeof(float);
+}
+
+// split in {6, 9}, K >= 32; argument checks are the caller's (resel_gemm_f32)
+int gemm_bf3_launch(const float* A, int64_t lda, int64_t strideA, int a_kcontig, const float* B, int64_t ldb, int64_t strideB, int b_kcontig,
+                    const float* bias, int64_t strideBias, int act, float* C, int64_t ldc, int64_t strideC, void* workspace,
+                    int M, int N, int K, int batch, int split, hipStream_t s) {
+    const Plan pl = make_plan(M, N, K, batch);
+    if (pl.nsplit && (!workspace || !aligned16(workspace))) return RESEL_EINVAL;
+    Params p{A, B, bias, C, (float*)workspace, lda, ldb, ldc, strideA, strideB, strideC, strideBias, M, N, K, act,
+             (M + BM - 1) / BM, (N + BN - 1) / BN, pl.nfull, pl.nsplit, pl.nsl, pl.kslice};
+    const int64_t total = (int64_t)pl.nfull + (int64_t)pl.nsplit * pl.nsl;
+    dim3 grid((unsigned)std::min<int64_t>(total, GRID));
+    int rc;
+#define BF3_LAUNCH(SP) \
+    do { if (a_kcontig && b_kcontig) rc = launch_one<true, true, SP>(p, grid, s); \
+         else if (a_kcontig) rc = launch_one<true, false, SP>(p, grid, s); \
+         else if (b_kcontig) rc = launch_one<false, true, SP>(p, grid, s); \
+         else rc = launch_one<false, false, SP>(p, grid, s); } while (0)
+    if (split == 9) BF3_LAUNCH(9); else BF3_LAUNCH(6);
+#undef BF3_LAUNCH
+    if (rc != RESEL_OK) return rc;
+    if (pl.nsplit) hipLaunchKernelGGL(gemm_bf3_fixup_kernel, dim3(TILE / 4 / 64, pl.nsplit), dim3(64, 4), 0, s, p);
+    return launch_status();
+}
+
+}  // namespace resel

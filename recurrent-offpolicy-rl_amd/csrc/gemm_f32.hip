@@ -37,6 +37,13 @@
 #include "resel_common.h"
 #include <algorithm>
 
+namespace resel {                      // gemm_bf3.hip: the split modes with the operands split once per block (second edition)
+size_t gemm_bf3_workspace_bytes(int M, int N, int K, int batch);
+int gemm_bf3_launch(const float* A, int64_t lda, int64_t strideA, int a_kcontig, const float* B, int64_t ldb, int64_t strideB, int b_kcontig,
+                    const float* bias, int64_t strideBias, int act, float* C, int64_t ldc, int64_t strideC, void* workspace,
+                    int M, int N, int K, int batch, int split, hipStream_t s);
+}
+
 namespace {
 using namespace resel;
 
@@ -580,7 +587,7 @@ extern "C" int resel_gemm_debug_stamps(unsigned long long* host_out) {
 extern "C" size_t resel_gemm_f32_workspace_bytes(int M, int N, int K, int batch) {
     if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return 0;
     const Plan pl = make_plan(M, N, K, batch);
-    return (size_t)pl.nsplit * pl.nsl * TILE * sizeof(float);
+    return std::max((size_t)pl.nsplit * pl.nsl * TILE * sizeof(float), gemm_bf3_workspace_bytes(M, N, K, batch));
 }
 
 extern "C" int resel_gemm_f32(const float* A, int64_t lda, int64_t strideA, int a_kcontig,
@@ -589,13 +596,18 @@ extern "C" int resel_gemm_f32(const float* A, int64_t lda, int64_t strideA, int 
                               float* C, int64_t ldc, int64_t strideC, void* workspace,
                               int M, int N, int K, int batch, int split, resel_stream_t stream) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || act < 0 || act > 1) return RESEL_EINVAL;
-    if (split != 0 && split != 6 && split != 9) return RESEL_EINVAL;
+    // 106 / 109: modes 6 / 9 on the first-edition kernel of this file (every wave splits the fragments it reads), kept for A/B runs
+    if (split != 0 && split != 6 && split != 9 && split != 106 && split != 109) return RESEL_EINVAL;
     if (K < BK) split = 0;                         // the split kernels' scheduled loads assume one whole K step per item
     if (lda % 4 || ldb % 4 || strideA % 4 || strideB % 4 || !aligned16(A) || !aligned16(B)) return RESEL_EINVAL;
     // float4 loads run along the contiguous axis: its extent must be a multiple of 4 (K for [rows][K] operands, rows otherwise)
     if ((a_kcontig ? K : M) % 4 || (b_kcontig ? K : N) % 4) return RESEL_EINVAL;
     // a thread's piece offsets inside a tile are 32-bit byte offsets: 128 rows (or 32 k) of the leading dimension must fit
     if (lda <= 0 || ldb <= 0 || ldc <= 0 || lda >= (int64_t)1 << 22 || ldb >= (int64_t)1 << 22) return RESEL_EINVAL;
+    if (split == 6 || split == 9)
+        return gemm_bf3_launch(A, lda, strideA, a_kcontig, B, ldb, strideB, b_kcontig, bias, strideBias, act, C, ldc, strideC, workspace,
+                               M, N, K, batch, split, (hipStream_t)stream);
+    if (split > 100) split -= 100;
     const Plan pl = make_plan(M, N, K, batch);
     if (pl.nsplit && (!workspace || !aligned16(workspace))) return RESEL_EINVAL;
     GemmParams p{A, B, bias, C, (float*)workspace, lda, ldb, ldc, strideA, strideB, strideC, strideBias, M, N, K, act,

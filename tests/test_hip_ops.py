@@ -689,12 +689,15 @@ def test_encode_concat_padded_block_diagonal_gemm_vs_separate_linears(ops):
     (66752, 256, 64, True, True, True, None, 1),        # two K steps per item: the persistent pipeline crosses items every other step
     (5000, 256, 16, True, True, True, None, 1),         # K shorter than one K step (every mode runs the fp32 kernel there)
     (1024, 128, 28, False, True, False, None, 1),
+    (256, 512, 8344, False, False, False, None, 1),     # weight gradient whose LAST K slice is shorter than one K step (24 of 32)
+    (1024, 256, 4172, False, False, False, None, 1),    # the same with 12 left
+    (1500, 200, 4100, True, True, True, 'elu', 1),      # ragged everything, 4 k in the last step
 ])
-@pytest.mark.parametrize('split', [0, 6, 9])
+@pytest.mark.parametrize('split', [0, 6, 9, 106])
 def test_gemm_f32_vs_fp64_product(ops, M, N, K, akc, bkc, bias, act, batch, split):
     """resel_gemm_f32 against an fp64 product: 1e-5 of the largest output magnitude in every product mode (0: fp32 MFMA, exact
-    products; 9 / 6: exact three-way bf16 operand split on the bf16 MFMA, all nine / the six leading plane products); both
-    operand layouts, ragged edges, batch strides, fused bias + ELU, deterministic K split."""
+    products; 9 / 6: exact three-way bf16 operand split on the bf16 MFMA, all nine / the six leading plane products, operands
+    split once per block into bf16 planes in LDS (gemm_bf3.hip); 106: mode 6 on the first-edition kernel); both operand layouts, ragged edges, batch strides, fused bias + ELU, deterministic K split."""
     g = torch.Generator().manual_seed(M + N + K)
     sh = (batch,) if batch > 1 else ()
     A = torch.randn(*sh, *((M, K) if akc else (K, M)), generator=g)

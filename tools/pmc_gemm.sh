@@ -15,7 +15,7 @@ import csv, glob, collections
 tot = collections.defaultdict(float); cnt = collections.defaultdict(int)
 for f in glob.glob('$OUT/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
-        if 'gemm_f32_kernel' in r['Kernel_Name']:
+        if 'gemm_' in r['Kernel_Name'] and 'fixup' not in r['Kernel_Name']:
             tot[r['Counter_Name']] += float(r['Counter_Value']); cnt[r['Counter_Name']] += 1
 for c in sorted(tot): print('   %-30s %16.0f per launch' % (c, tot[c] / cnt[c]))
 PY
