@@ -69,6 +69,9 @@ int resel_profile_collect(int kernel_id, double* total_us, int* launches);
  *   split, k > 1 = k segments; workspace: resel_selective_scan_fwd_workspace_bytes(...) for the same arguments (NULL if 0).
  */
 #define RESEL_SSCAN_CKPT 16
+/* A/B switch of the one-pass forward kernel: 3 (default) = third edition (one barrier per 16-step chunk, csrc/selective_scan.hip
+ * sscan_fwd3_kernel) where it applies (N = 8, 16, 32), 2 = second edition.  Process-global; tests and tools only. */
+int resel_selective_scan_fwd_edition(int edition);
 size_t resel_selective_scan_ckpt_bytes(int B, int L, int Di, int N);
 size_t resel_selective_scan_fwd_workspace_bytes(int B, int L, int Di, int N, int time_segments);
 int resel_selective_scan_fwd(const float* u, int64_t ld_u, const float* delta, int64_t ld_delta,

@@ -604,10 +604,12 @@ extern "C" int resel_gemm_f32(const float* A, int64_t lda, int64_t strideA, int 
     if ((a_kcontig ? K : M) % 4 || (b_kcontig ? K : N) % 4) return RESEL_EINVAL;
     // a thread's piece offsets inside a tile are 32-bit byte offsets: 128 rows (or 32 k) of the leading dimension must fit
     if (lda <= 0 || ldb <= 0 || ldc <= 0 || lda >= (int64_t)1 << 22 || ldb >= (int64_t)1 << 22) return RESEL_EINVAL;
-    if (split == 6 || split == 9)
+    // second edition (256 x 128 tiles) unless half of its tile rows would be padding: M <= 128 (narrow weight gradients) runs
+    // 1.2-1.4x faster on the first edition's 128 x 128 tiles (66 752-token weight gradients [128, 256]: 48 vs 59 us, [80, 512]: 67 vs 95)
+    if ((split == 6 || split == 9) && M > 128)
         return gemm_bf3_launch(A, lda, strideA, a_kcontig, B, ldb, strideB, b_kcontig, bias, strideBias, act, C, ldc, strideC, workspace,
                                M, N, K, batch, split, (hipStream_t)stream);
-    if (split > 100) split -= 100;
+    if (split > 100) split -= 100;                 // here: 6 / 9 = first-edition split kernels, 0 = fp32 MFMA
     const Plan pl = make_plan(M, N, K, batch);
     if (pl.nsplit && (!workspace || !aligned16(workspace))) return RESEL_EINVAL;
     GemmParams p{A, B, bias, C, (float*)workspace, lda, ldb, ldc, strideA, strideB, strideC, strideBias, M, N, K, act,

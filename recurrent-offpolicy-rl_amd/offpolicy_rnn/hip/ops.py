@@ -86,6 +86,15 @@ def profile_collect():
 SSCAN_TIME_SEGMENTS = int(os.environ.get('RESEL_SSCAN_TIME_SEGMENTS', '0'))
 
 
+def sscan_fwd_edition(edition: int):
+    """One-pass forward kernel of the selective scan: 3 (library default) = third edition, 2 = second edition (A/B runs, tests)."""
+    check(lib().resel_selective_scan_fwd_edition(int(edition)), 'selective_scan_fwd_edition')
+
+
+if os.environ.get('RESEL_SSCAN_FWD_EDITION'):
+    sscan_fwd_edition(int(os.environ['RESEL_SSCAN_FWD_EDITION']))
+
+
 class SelectiveScanFn(torch.autograd.Function):
     """Token-major selective scan with start resets.  Interface counterpart of the reference's
     `SelectiveScanFn` (mamba_ssm/ops/selective_scan_interface_new.py:19-84)."""
@@ -736,8 +745,8 @@ def gemm_f32_ok(rows, *mats):
         and all(st % 4 == 0 for st in t.stride()[:-1]) and (t.dim() < 2 or t.stride(-2) < (1 << 22)) for t in mats)
 
 
-GEMM_F32_MIN_DIM = 64        # narrower outputs (dt_proj's rank-16 input gradient, the 6-wide heads) stay with the library
-GEMM_F32_MIN_K = 32          # ... and so do reductions shorter than one K step (dt_proj forward, K = 16: 23 us library, 39 here)
+GEMM_F32_MIN_DIM = int(os.environ.get('RESEL_GEMM_F32_MIN_DIM', 64))        # narrower outputs (dt_proj's rank-16 input gradient, the 6-wide heads) stay with the library (measured equal at 12 / 16 / 32)
+GEMM_F32_MIN_K = int(os.environ.get('RESEL_GEMM_F32_MIN_K', 16))          # reductions of one partial K step run the fp32-MFMA kernel (update 26.07 -> 25.8 ms with dt_proj's K = 16 here)
 
 
 def _mine(rows, n, k, *mats):

@@ -138,6 +138,29 @@ def test_selective_scan_slow_decay_carry_is_load_bearing(ops, monkeypatch):
     assert rel > 1e-2, f'cutting the carry changed the output by only {rel:.2e}'
 
 
+@pytest.mark.parametrize('B,L,Di,N', [(3, 1043, 192, 32), (2, 333, 64, 16), (9, 50, 512, 8), (1, 16, 128, 32), (2, 17, 64, 32)])
+def test_selective_scan_forward_editions_agree(ops, monkeypatch, B, L, Di, N):
+    """The third-edition one-pass forward (8-wave workgroups over 128 channels, one barrier per 16-step chunk, staggered halves)
+    against the second edition: outputs, last state and - through the checkpoints it leaves - every gradient of the backward."""
+    ins, start, w = _slow_decay_case(B, L, Di, N, seed=B + L + N)
+    start[:, ::37] = 1
+    monkeypatch.setattr(ops, 'SSCAN_TIME_SEGMENTS', 1)
+    res = {}
+    try:
+        for ed in (2, 3):
+            ops.sscan_fwd_edition(ed)
+            dev_in = [t.clone().cuda().requires_grad_(True) for t in ins]
+            out, last = ops.selective_scan_tm(*dev_in, start.cuda(), True, return_last_state=True)
+            (out * w.cuda()).sum().backward()
+            res[ed] = (out.detach().cpu(), last.detach().cpu(), [t.grad.cpu() for t in dev_in])
+    finally:
+        ops.sscan_fwd_edition(3)
+    close(res[3][0], res[2][0], rtol=2e-6, atol_scale=1e-6, name='out')
+    close(res[3][1], res[2][1], rtol=2e-6, atol_scale=1e-6, name='last_state')
+    for a, b, nm in zip(res[3][2], res[2][2], ('du', 'ddelta', 'dA', 'dB', 'dC', 'dD', 'dz', 'dbias')):
+        close(a, b, rtol=1e-5, atol_scale=1e-6, name=nm)
+
+
 def test_selective_scan_golden_reference_vectors(ops):
     """The reference's own selective_scan_ref outputs (tests/golden/selective_scan.npz), channel-major signature."""
     gold = load_golden('selective_scan.npz')

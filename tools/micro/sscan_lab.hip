@@ -2,7 +2,7 @@
 // configs[1] size without torch, checks a few (row, channel) columns against a double-precision host recurrence and times
 // the launches with HIP events.  Lets kernel variants (-D switches) be compared in seconds on a gpurun box.
 // Build (here or on the box): hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize tools/micro/sscan_lab.hip -o tools/micro/bin/sscan_lab
-// Run: sscan_lab [B=64] [L=1043] [Di=512] [N=32] [reps=20] [bwd=1] [time segments: 0 auto, 1 off, k]
+// Run: sscan_lab [B=64] [L=1043] [Di=512] [N=32] [reps=20] [bwd=1] [time segments: 0 auto, 1 off, k] [forward edition 2 | 3]
 #include "../../recurrent-offpolicy-rl_amd/csrc/selective_scan.hip"
 #include "../../recurrent-offpolicy-rl_amd/csrc/misc.hip"          // the per-dispatch timing registry the launches refer to
 #include <cmath>
@@ -22,6 +22,7 @@ int main(int argc, char** argv) {
               N = argc > 4 ? atoi(argv[4]) : 32, reps = argc > 5 ? atoi(argv[5]) : 20, do_bwd = argc > 6 ? atoi(argv[6]) : 1;
     const int R = 16, ldx = 2 * Di, ldb = R + 2 * N;
     const int tseg = argc > 7 ? atoi(argv[7]) : 0;
+    if (argc > 8) { resel_selective_scan_fwd_edition(atoi(argv[8])); printf("forward edition %d\n", atoi(argv[8])); }
     std::mt19937 g(1);
     std::normal_distribution<float> nd(0.f, 1.f);
     std::vector<float> xz((size_t)B * L * ldx), xdbl((size_t)B * L * ldb), delta((size_t)B * L * Di), A((size_t)Di * N), Dp(Di), db(Di),
