@@ -298,6 +298,20 @@ int resel_gemm_f32(const float* A, int64_t lda, int64_t strideA, int a_kcontig,
                    float* C, int64_t ldc, int64_t strideC, void* workspace,
                    int M, int N, int K, int batch, int split, resel_stream_t stream);
 
+/* ---- mixed-precision GEMM for the bf16 attention projections (cgpt) ------------------------------------------------------
+ * C[m][n] = sum_k bf16(A(m, k)) bf16(B(n, k)) + bf16(bias[n]): operands rounded to bf16 (round to nearest even) on their way
+ * into LDS, fp32 accumulation (v_mfma_f32_32x32x16_bf16), C stored as bf16 (c_bf16 != 0) or fp32.  A / B are fp32 or bf16 in
+ * memory (x_bf16) and [rows][K] (x_kcontig = 1) or [K][rows]; lda / ldb / ldc in ELEMENTS; bias fp32 or NULL.  This is what
+ * F.linear computes under the reference's bf16 autocast (flash-attn MHA, TransformerFlashAttention.py:67-70) without the
+ * separate cast passes: forward (A = activations, B = weight [N][K]), input gradient (B = weight as [K][rows]), weight
+ * gradient (both operands [K = tokens][rows]; K slices summed in a fixed order, workspace: resel_gemm_bf16_workspace_bytes).
+ * The contiguous extent of each operand must be a multiple of 4, leading dimensions multiples of 4, bases 16-byte (fp32) or
+ * 8-byte (bf16) aligned. */
+size_t resel_gemm_bf16_workspace_bytes(int M, int N, int K);
+int resel_gemm_bf16(const void* A, int64_t lda, int a_kcontig, int a_bf16, const void* B, int64_t ldb, int b_kcontig, int b_bf16,
+                    const float* bias, void* C, int64_t ldc, int c_bf16, void* workspace, int M, int N, int K,
+                    resel_stream_t stream);
+
 /* ---- packed trajectory batch from a device-resident replay ring --------------------------------------------------
  * Device counterpart of NestedMemoryArray.sample_trajs' packing loop (reference buffers/transition_buffer/
  * nested_replay_memory.py:140-176) plus the trainer's flag surgery (algorithm/sac_full_length_rnn_ensembleQ.py:338-342).

@@ -64,6 +64,8 @@ SIGNATURES = {
     'resel_ensemble_head_bwd': (c_int, [P, P, P, P, P, P, P, L, I, L, S]),
     'resel_gemm_f32_workspace_bytes': (c_size_t, [I, I, I, I]),
     'resel_gemm_f32': (c_int, [P, L, L, I, P, L, L, I, P, L, I, P, L, L, P, I, I, I, I, I, S]),
+    'resel_gemm_bf16_workspace_bytes': (c_size_t, [I, I, I]),
+    'resel_gemm_bf16': (c_int, [P, L, I, I, P, L, I, I, P, P, L, I, P, I, I, I, S]),
     'resel_gather_trajs': (c_int, [P, I, L, P, I, I, I, I, I, I, I, I, I, P, I, P, S]),
     'resel_mamba_conv_step': (c_int, [P, L, P, L, P, L, L, L, I, P, P, P, I, I, I, I, S]),
     'resel_selective_state_update': (c_int, [P, L, P, L, P, P, L, P, P, P, P, P, L, P, I, I, I, I, S]),

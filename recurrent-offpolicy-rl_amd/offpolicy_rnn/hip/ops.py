@@ -811,6 +811,61 @@ def atb(wide, narrow, transposed=False):
     return out
 
 
+# ---------------------------------------------------------------------------------------------- bf16 projections (cgpt)
+@torch.no_grad()
+def gemm_bf16(A, B, a_kcontig=True, b_kcontig=True, bias=None, out_dtype=torch.bfloat16):
+    """C [M, N] = bf16(A) (.) bf16(B) + bf16(bias), fp32 accumulation (include/resel_hip.h `resel_gemm_bf16`).  A: [M, K]
+    (a_kcontig) or [K, M]; B: [N, K] (b_kcontig) or [K, N]; each fp32 or bf16 (rounded to bf16 on the way into LDS); bias fp32."""
+    _need_cuda('gemm_bf16', A, B)
+    assert A.dim() == 2 and B.dim() == 2 and A.stride(-1) == 1 and B.stride(-1) == 1
+    assert A.dtype in (torch.float32, torch.bfloat16) and B.dtype in (torch.float32, torch.bfloat16)
+    M, K = (A.shape[0], A.shape[1]) if a_kcontig else (A.shape[1], A.shape[0])
+    N = B.shape[0] if b_kcontig else B.shape[1]
+    assert (B.shape[1] if b_kcontig else B.shape[0]) == K
+    out = torch.empty((M, N), dtype=out_dtype, device=A.device)
+    L = lib()
+    ws = _ws(L.resel_gemm_bf16_workspace_bytes(M, N, K), A.device)
+    check(L.resel_gemm_bf16(_p(A), A.stride(0), int(a_kcontig), int(A.dtype == torch.bfloat16), _p(B), B.stride(0), int(b_kcontig),
+                            int(B.dtype == torch.bfloat16), _p(bias), _p(out), out.stride(0), int(out_dtype == torch.bfloat16), _p(ws),
+                            M, N, K, _stream()), 'gemm_bf16')
+    return out
+
+
+def gemm_bf16_ok(x, w):
+    """Operands the mixed-precision GEMM takes: packed token rows on the GPU, 8 / 16-byte aligned, extents multiples of 4."""
+    return (x.is_cuda and x.dim() == 2 and x.stride(-1) == 1 and x.dtype in (torch.float32, torch.bfloat16) and w.dtype == torch.float32
+            and x.shape[0] >= 256 and x.shape[0] % 4 == 0 and x.shape[1] % 4 == 0 and w.shape[0] % 4 == 0 and x.stride(0) % 4 == 0
+            and x.data_ptr() % 16 == 0 and w.is_contiguous() and w.data_ptr() % 16 == 0)
+
+
+class LinearBf16(torch.autograd.Function):
+    """F.linear under the reference's bf16 autocast (flash-attn MHA's Wqkv / out_proj, TransformerFlashAttention.py:67-70) as ONE
+    node on `resel_gemm_bf16`: x fp32 or bf16, fp32 master weight and bias; forward output in `out_dtype`; the input gradient comes
+    back in x's dtype, the weight / bias gradients in fp32 - the casts of the autocast graph (activation -> bf16, weight -> bf16 per
+    call, gradients back to fp32) happen inside the GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, out_dtype):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return gemm_bf16(x, weight, True, True, bias, out_dtype)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = gy if gy.stride(-1) == 1 and gy.stride(0) % 4 == 0 and gy.data_ptr() % 16 == 0 else gy.contiguous()
+        dx = gemm_bf16(gy, weight, True, False, None, x.dtype) if ctx.needs_input_grad[0] else None
+        dw = gemm_bf16(gy, x, False, False, None, torch.float32) if ctx.needs_input_grad[1] else None
+        db = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.sum(gy, 0, dtype=torch.float32)
+        return dx, dw, db, None
+
+
+def linear_bf16(x, weight, bias, out_dtype=torch.bfloat16):
+    return LinearBf16.apply(x, weight, bias, out_dtype)
+
+
 # product formation of resel_gemm_f32 (include/resel_hip.h): 0 fp32 MFMA, 9 / 6 exact three-way bf16 split on the bf16 MFMA
 GEMM_SPLIT = int(os.environ.get('RESEL_GEMM_SPLIT', 6))
 

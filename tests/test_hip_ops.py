@@ -792,3 +792,64 @@ def test_selective_scan_time_segments_equal_the_one_pass_scan(ops, monkeypatch, 
     close(o2, ref, name='out vs oracle')
     for a, b, nm in zip(g2, ref_in, ('du', 'ddelta', 'dA', 'dB', 'dC', 'dD', 'dz', 'dbias')):
         close(a, b.grad, rtol=2e-4, atol_scale=5e-5, name=nm + ' vs oracle')
+
+
+# ------------------------------------------------------------------------------------------ mixed-precision GEMM (cgpt projections)
+@pytest.mark.parametrize('M,N,K,akc,bkc,a_bf,b_bf,c_bf,bias', [
+    (1000, 768, 256, True, True, False, False, True, True),        # Wqkv forward: fp32 activations, fp32 weight -> bf16
+    (1000, 256, 256, True, True, True, False, False, True),        # out_proj forward: bf16 activations -> fp32
+    (1000, 256, 768, True, False, True, False, False, False),      # Wqkv dgrad: bf16 gradient, weight [K][rows] -> fp32
+    (1000, 256, 256, True, False, False, False, True, False),      # out_proj dgrad -> bf16
+    (768, 256, 5000, False, False, True, False, False, False),     # Wqkv wgrad: K = tokens, split over blocks
+    (256, 256, 33000, False, False, False, True, False, False),    # out_proj wgrad: bf16 activations as the [K][rows] 128-row operand
+    (300, 132, 100, True, True, False, False, True, True),         # ragged M / N, K tail
+    (4100, 260, 36, False, False, True, True, False, False),       # both bf16 [K][rows], K tail, ragged N
+    (66000, 128, 64, True, True, False, False, False, True),       # two K steps per item, more than two rounds of tiles
+])
+def test_gemm_bf16_vs_rounded_operands_in_fp64(ops, M, N, K, akc, bkc, a_bf, b_bf, c_bf, bias):
+    """resel_gemm_bf16: C = bf16(A) (.) bf16(B) + bf16(bias) with fp32 accumulation.  Reference: the same rounded operands multiplied
+    in fp64 (a bf16 x bf16 product is exact in fp32, so only the accumulation order differs): 1e-5 of the largest output for fp32
+    results, one bf16 rounding (2^-8) on top for bf16 results; bitwise reproducible."""
+    g = torch.Generator().manual_seed(M + N + K)
+    bf = torch.bfloat16
+    A = torch.randn((M, K) if akc else (K, M), generator=g)
+    B = torch.randn((N, K) if bkc else (K, N), generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g) if bias else None
+    A_in = A.to(bf) if a_bf else A
+    B_in = B.to(bf) if b_bf else B
+    Ar, Br = A.to(bf).double(), B.to(bf).double()
+    ref = (Ar if akc else Ar.t()) @ (Br.t() if bkc else Br)
+    if bias:
+        ref = ref + b.to(bf).double()
+    out = ops.gemm_bf16(A_in.cuda(), B_in.cuda(), akc, bkc, None if b is None else b.cuda(), bf if c_bf else torch.float32)
+    assert out.dtype == (bf if c_bf else torch.float32) and out.shape == (M, N)
+    close(out, ref.float(), rtol=(4e-3 if c_bf else 1e-5), atol_scale=(1e-3 if c_bf else 1e-6), name='gemm_bf16')
+    out2 = ops.gemm_bf16(A_in.cuda(), B_in.cuda(), akc, bkc, None if b is None else b.cuda(), bf if c_bf else torch.float32)
+    assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize('x_bf,out_bf', [(False, True), (True, False)])
+def test_linear_bf16_node_matches_the_autocast_graph(ops, x_bf, out_bf):
+    """The one-node form of F.linear under bf16 autocast (operands cast to bf16, fp32 master parameters) against that graph built
+    from torch ops: forward, input gradient, weight and bias gradients at bf16 tolerance."""
+    g = torch.Generator().manual_seed(7)
+    bf = torch.bfloat16
+    T, K, N = 2052, 256, 768 if not x_bf else 256
+    x = torch.randn(T, K, generator=g)
+    w, b = torch.randn(N, K, generator=g) / 16, torch.randn(N, generator=g) * 0.1
+    dy = torch.randn(T, N, generator=g)
+
+    def run(fn):
+        xs = (x.to(bf) if x_bf else x).cuda().requires_grad_(True)
+        ws, bs = w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+        y = fn(xs, ws, bs)
+        (y.float() * dy.cuda()).sum().backward()
+        return y, xs.grad, ws.grad, bs.grad
+
+    y_ref, dx_ref, dw_ref, db_ref = run(lambda xs, ws, bs: torch.nn.functional.linear(xs.to(bf), ws.to(bf), bs.to(bf)))
+    y, dx, dw, db = run(lambda xs, ws, bs: ops.linear_bf16(xs, ws, bs, bf if out_bf else torch.float32))
+    assert y.dtype == (bf if out_bf else torch.float32) and dx.dtype == (bf if x_bf else torch.float32) and dw.dtype == torch.float32
+    close(y, y_ref.float().cpu(), rtol=1e-2, atol_scale=2e-3, name='y')
+    close(dx, dx_ref.float().cpu(), rtol=1e-2, atol_scale=2e-3, name='dx')
+    close(dw, dw_ref.cpu(), rtol=1e-2, atol_scale=2e-3, name='dw')
+    close(db, db_ref.cpu(), rtol=1e-2, atol_scale=2e-3, name='db')
