@@ -262,6 +262,9 @@ __device__ __forceinline__ void mfma_lead(f32x16 (&acc)[2][2], const Frag& f) {
 }
 
 #define BF3_FENCE() __builtin_amdgcn_sched_barrier(0)
+#ifdef BF3_AB_CLOCK                    // diagnostic build: in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz per block
+__device__ unsigned long long g_bf3_clock[2 * GRID];
+#endif
 
 template <bool AKC, bool BKC, int SPLIT>
 __global__ __launch_bounds__(NTH, 2) void gemm_bf3_kernel(Params p) {
@@ -315,6 +318,9 @@ __global__ __launch_bounds__(NTH, 2) void gemm_bf3_kernel(Params p) {
         const long long t0 = __builtin_amdgcn_s_memtime();
         while ((long long)__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
     }
+#endif
+#ifdef BF3_AB_CLOCK
+    const unsigned long long ck_t0 = __builtin_amdgcn_s_memtime(), ck_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
     Frag f0, f1;
     p_open();
@@ -444,6 +450,12 @@ __global__ __launch_bounds__(NTH, 2) void gemm_bf3_kernel(Params p) {
             }
         }
     }
+#ifdef BF3_AB_CLOCK
+    if (tid == 0) {
+        g_bf3_clock[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - ck_t0;
+        g_bf3_clock[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - ck_r0;
+    }
+#endif
 }
 
 // C tile = epi(sum over the K slices of a split tile), fixed summation order: as gemm_fixup_kernel of gemm_f32.hip for 256 x 128 tiles
@@ -511,6 +523,12 @@ int launch_one(const Params& p, dim3 grid, hipStream_t s) {
 }
 
 }  // namespace
+
+#ifdef BF3_AB_CLOCK
+extern "C" int resel_bf3_debug_clock(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_bf3_clock), sizeof(unsigned long long) * 2 * GRID);
+}
+#endif
 
 namespace resel {
 

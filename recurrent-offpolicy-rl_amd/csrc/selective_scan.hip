@@ -5,8 +5,9 @@
 //   * lane  <-> channel (64 lanes = 64 consecutive channels: every global access of a wave is one or more
 //     fully used 256-byte segments);
 //   * wave  <-> group of NS states: the N = NS*NW state columns of a channel are split over the NW waves, so
-//     B_t / C_t of a step are WAVE-UNIFORM and are fetched with scalar loads (s_load_dwordx{2,4,8}) and used
-//     as SGPR operands of v_fma - no LDS, no per-lane traffic for them;
+//     B_t / C_t of a step are WAVE-UNIFORM: their rows are staged in LDS with the chunk's tiles and read with
+//     broadcast ds_read_b128 one step ahead of their use (scalar loads into SGPR operands were tried and dropped:
+//     SMEM latency is not covered by one step of look-ahead);
 //   * time is processed in chunks staged through LDS: a coalesced float4 tile load applies softplus / the
 //     delta*u product once per element, the scan phase reads one dword per lane per step, the per-wave
 //     partial sums meet again in LDS and the output tile leaves with float4 stores;
@@ -18,9 +19,10 @@
 // the checkpoint in two 8-step halves whose (state, decay) history lives in registers, and sweeps each half in
 // reverse.  Reductions over channels (dB, dC) use an in-wave multi-value butterfly (DPP) plus per-tile partial
 // slabs summed by a second kernel: no float atomics, bitwise reproducible.
-// Rates that shape both kernels (tools/micro/valu_rate.hip, MI355X): wave64 v_fma/v_mul_f32 = 4 cycles per SIMD,
-// v_pk_fma/v_pk_mul_f32 = 5.6 (two results), v_exp_f32 = 8 - the per-state arithmetic is therefore written on
-// float2 pairs, and with N = 32 states the kernels are VALU-bound well below the HBM roofline.
+// Rates that shape both kernels (tools/micro/valu_rate2.hip, MI355X, issue cycles per wave64 instruction on one SIMD):
+// v_fma/v_mul_f32 2.25 with two waves per SIMD (4.5 alone), v_pk_fma/v_pk_mul_f32 4.5 (two results), v_exp_f32 8.2 -
+// the per-state arithmetic is written on float2 pairs, and with N = 32 states the kernels are bound by vector issue
+// (and, with every CU busy, by the clock the chip holds under that load) well below the HBM roofline.
 #include "resel_common.h"
 #include <hip/hip_ext.h>
 #include <type_traits>

@@ -711,7 +711,8 @@ class LinearAct(torch.autograd.Function):
         need_db = ctx.has_bias and ctx.needs_input_grad[2]
         if y2.shape[1] % 4:                                           # narrow heads (6-wide action mean): plain torch tail
             g2 = g2 if g2.is_contiguous() else g2.contiguous()
-            gy = g2 if ctx.act is None else g2 * torch.where(y2 > 0, torch.ones_like(y2), y2 + 1.0)    # elu'(x) from the output
+            aid = ACT_IDS[ctx.act]                                     # 0: identity ('linear' / None), 1: ELU; anything else is a KeyError
+            gy = g2 if aid == 0 else g2 * torch.where(y2 > 0, torch.ones_like(y2), y2 + 1.0)          # elu'(x) from the output
             db = gy.sum(dim=0) if need_db else None
         else:
             gy, db = bias_act_bwd(g2, y2, y2.shape[0], ctx.act, need_db)
@@ -758,11 +759,12 @@ def _mine(rows, n, k, *mats):
 def mm_nt(x2, w, bias=None, act=None):
     """act(x2 [M, K] w[N, K]^T + bias): forward of an nn.Linear-shaped layer over the tokens of a pass.  Hand-written GEMM with
     the bias / ELU in its epilogue when the pass is long enough (`gemm_f32_ok`), else library GEMM (+ one in-place tail pass)."""
-    if act in (None, 'elu') and _mine(x2.shape[0], w.shape[0], w.shape[1], x2, w):
+    if act in ACT_IDS and _mine(x2.shape[0], w.shape[0], w.shape[1], x2, w):
         return gemm_f32(x2, w, True, True, bias, act)
-    if act is None or w.shape[0] % 4:
+    aid = ACT_IDS[act]                                                 # 0: identity ('linear' / None), 1: ELU; anything else is a KeyError
+    if aid == 0 or w.shape[0] % 4:
         y2 = torch.addmm(bias, x2, w.t()) if bias is not None else torch.mm(x2, w.t())
-        return y2 if act is None else torch.nn.functional.elu_(y2)
+        return y2 if aid == 0 else torch.nn.functional.elu_(y2)
     y2 = torch.mm(x2, w.t())
     return bias_act_(y2, None if bias is None else bias.reshape(1, -1).contiguous(), y2.shape[0], act)
 

@@ -20,4 +20,7 @@ else
   AK=${4:-1}; BKc=${5:-1}
   python3 $R/tools/prof_gemm.py $1 $2 $3 $AK $BKc 20 6
   for v in $VARS; do echo "ablation $v:"; RESEL_HIP_LIBRARY=$B/libresel_bf3_$v.so python3 $R/tools/prof_gemm.py $1 $2 $3 $AK $BKc 20 6; done
+  if [ -f $B/libresel_bf3_CLOCK.so ]; then   # 2 s of back-to-back launches, then the clock of the last one
+    RESEL_BF3_CLOCK=1 RESEL_HIP_LIBRARY=$B/libresel_bf3_CLOCK.so python3 $R/tools/prof_gemm.py $1 $2 $3 $AK $BKc 3000 6
+  fi
 fi

@@ -33,3 +33,14 @@ if os.environ.get('RESEL_GEMM_STAMPS'):
     for i in range(2, 26):
         d = np.diff(st[i]).tolist() + [int(st[i + 1][0] - st[i][8])]
         print(f'step {i:2d}: ' + ' '.join(f'{x:5d}' for x in d) + f' | total {int(st[i + 1][0] - st[i][0])}')
+
+if os.environ.get('RESEL_BF3_CLOCK'):            # tools/bf3_ablate.sh CLOCK build: in-kernel clock of the last launch
+    import ctypes, numpy as np
+    from offpolicy_rnn.hip._lib import lib
+    buf = np.zeros(512, dtype=np.uint64)
+    rc = ctypes.CDLL(os.environ['RESEL_HIP_LIBRARY']).resel_bf3_debug_clock(ctypes.c_void_p(buf.ctypes.data))
+    t, r = buf[0::2].astype(np.float64), buf[1::2].astype(np.float64)
+    ok = r > 0
+    clk = t[ok] / r[ok] * 0.1
+    print(f'in-kernel clock (s_memtime / s_memrealtime, {ok.sum()} blocks): median {np.median(clk):.3f} GHz, min {clk.min():.3f}, max {clk.max():.3f}; '
+          f'block lifetime median {np.median(r[ok]) * 0.01:.1f} us')
