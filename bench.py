@@ -126,12 +126,17 @@ def kernel_source_stamp():
 
 
 def load_traffic(args, Bsz):
-    """HBM bytes per launch from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile_bench.sh -> profiles/traffic.json),
-    only when that file was produced from THESE kernel sources on THIS workload (sha256 stamp, layer id, rows) - else {}."""
-    tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
-    if os.path.exists(tpath):
-        tj = json.load(open(tpath))
-        if tj.get('kernel_source_stamp') == kernel_source_stamp() and tj.get('rnn', 'smamba_s32_c16_b2_nln') == args.rnn and tj.get('rows', 64) == Bsz:
+    """HBM bytes per launch from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile_bench.sh -> profiles/traffic*.json:
+    one file per profiled workload), only from a file that was produced from THESE kernel sources on THIS workload (sha256 stamp,
+    layer id, rows) - else {}."""
+    import glob
+    stamp = kernel_source_stamp()
+    for tpath in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'traffic*.json'))):
+        try:
+            tj = json.load(open(tpath))
+        except ValueError:
+            continue
+        if tj.get('kernel_source_stamp') == stamp and tj.get('rnn', 'smamba_s32_c16_b2_nln') == args.rnn and tj.get('rows', 64) == Bsz:
             return tj.get('per_launch_bytes', {})
     return {}
 
@@ -272,7 +277,7 @@ def spawn_ranks(args, argv):
     import subprocess
     from offpolicy_rnn.parallel.data_parallel import free_port
     N = args.gpus
-    if not args.spawn_dry_run:
+    if not args.spawn_dry_run and os.environ.get('RESEL_DP_BACKEND') != 'gloo':     # gloo: ranks may share a GPU (one-GPU test boxes)
         have = torch.cuda.device_count()
         if have < N:
             print(f'bench.py: --gpus {N} but this node shows {have} GPU(s)', file=sys.stderr)
@@ -437,7 +442,7 @@ def main():
     if args.global_rows:
         assert args.global_rows % world == 0, f'--global-rows {args.global_rows} does not split over {world} ranks'
         args.rows = args.global_rows // world
-    torch.cuda.set_device(local)
+    torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
     torch.manual_seed(1234 + rank)
     np.random.seed(1234 + rank)                         # each rank samples its own rows
     alg = build_trainer(args.rnn, args.rows, args.horizon, seed=rank, algo=args.algo)

@@ -95,8 +95,8 @@ def init_from_env(backend=None):
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if (world > 1 or force_collectives()) and not dist.is_initialized():
-        if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend is None:                          # RESEL_DP_BACKEND=gloo: several ranks may then share one GPU (tests on a one-GPU box)
+            backend = os.environ.get('RESEL_DP_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         if backend == 'nccl':
             torch.cuda.set_device(local)
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')

@@ -167,3 +167,30 @@ def test_bench_line_without_a_group_reports_no_collectives():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
     assert line['rccl_ranks'] == 0 and line['backend'] is None and sum(line['collectives_per_step'].values()) == 0
+
+
+def test_bench_launcher_end_to_end_with_two_ranks_sharing_the_gpu():
+    """`python bench.py --gpus 2` end to end on a one-GPU box: the launcher starts two ranks, both run the real kernels on cuda:0 and
+    exchange gradients through `gloo` (RESEL_DP_BACKEND=gloo: RCCL refuses two ranks on one device), rank 0 reports the global
+    numbers: twice the rows, the collectives of a 2-rank job counted."""
+    import json
+    import subprocess
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'RESEL_DP_FORCE_COLLECTIVES')}
+    env['RESEL_DP_BACKEND'] = 'gloo'
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--rows', '4', '--horizon', '128'],
+                       capture_output=True, text=True, env=env, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    js = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(js) == 1
+    line = json.loads(js[0])
+    assert line['n_gpus'] == 2 and line['config']['global_rows'] == 8 and line['config']['parallelism'] == 'dp2'
+    assert line['rccl_ranks'] == 2 and line['backend'] == 'gloo' and 'spawned its own ranks' in line['launcher']
+    assert line['collectives_per_step']['all_reduce_sum'] == 2 and line['collectives_per_step']['all_reduce_max'] == 2
+    assert np.isfinite(line['value']) and line['value'] > 0
+    # strong scaling form: a fixed global batch split over the ranks
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--global-rows', '8', '--steps', '2', '--warmup', '1', '--horizon', '128'],
+                       capture_output=True, text=True, env=env, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['scaling'] == 'strong' and line['config']['global_rows'] == 8 and 'B=4/GPU' in line['config']['workload']

@@ -27,7 +27,8 @@ def pmc(name):
                            ('attn_fwd_kernel', 'attn_q_kernel<32, 0'), ('attn_dq_kernel', 'attn_q_kernel<32, 1'), ('attn_dkv_kernel', 'attn_dkv_kernel'),
                            ('linrec_real_fwd_kernel', 'linrec_real_fwd'), ('linrec_real_bwd_kernel', 'linrec_real_bwd'),
                            ('linrec_complex_fwd_kernel', 'linrec_complex_fwd'), ('linrec_complex_bwd_kernel', 'linrec_complex_bwd'),
-                           ('gemm_f32_kernel', 'gemm_f32_kernel'), ('gru_fwd_kernel', 'gru_fwd'), ('gru_bwd_kernel', 'gru_bwd')):
+                           ('gemm_f32_kernel', 'gemm_f32_kernel'), ('gemm_f32_kernel', 'gemm_bf3_kernel'), ('gru_fwd_kernel', 'gru_fwd'),
+                           ('gru_bwd_kernel', 'gru_bwd')):
             if pat in k:
                 agg[short].append(float(r['Counter_Value']))
     return {k: sum(v) / len(v) for k, v in agg.items()}
@@ -47,11 +48,11 @@ json.dump({'source': f'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over `python3 ben
 rows = list(csv.DictReader(open(os.path.join(src, f'{tag}_kernel_stats.csv'))))
 tot = sum(float(r['TotalDurationNs']) for r in rows)
 gemm = sum(float(r['TotalDurationNs']) for r in rows if r['Name'].startswith('Cijk'))
-own = sum(float(r['TotalDurationNs']) for r in rows if 'gemm_f32_kernel' in r['Name'] or 'gemm_fixup' in r['Name'])
+own = sum(float(r['TotalDurationNs']) for r in rows if any(k in r['Name'] for k in ('gemm_f32_kernel', 'gemm_bf3_kernel', 'gemm_bf16_kernel', 'gemm_fixup', 'gemm_bf3_fixup', 'gemm_bf16_fixup')))
 with open(os.path.join(dst, f'{tag}_summary.md'), 'w') as fh:
     fh.write(f'# {tag}: rocprofv3 --kernel-trace --stats over `python3 bench.py` ({n_upd} updates incl. warm-up)\n\n')
     fh.write(f'bench line: {bench["value"]:.0f} {bench["unit"]}, {bench["ms_per_step"]:.2f} ms/update; GPU kernel time {tot / n_upd / 1e6:.2f} ms/update, '
-             f'of which the hand-written GEMM (resel_gemm_f32 + its fix-up) {own / n_upd / 1e6:.2f} ms and library GEMMs (rocBLAS/hipBLASLt fp32) {gemm / n_upd / 1e6:.2f} ms\n\n| kernel | calls | ms/update | avg us |\n|---|---|---|---|\n')
+             f'of which the hand-written GEMMs (resel_gemm_f32 / resel_gemm_bf16 + their fix-ups) {own / n_upd / 1e6:.2f} ms and library GEMMs (rocBLAS/hipBLASLt fp32) {gemm / n_upd / 1e6:.2f} ms\n\n| kernel | calls | ms/update | avg us |\n|---|---|---|---|\n')
     for r in rows[:30]:
         fh.write(f"| `{r['Name'][:90]}` | {r['Calls']} | {float(r['TotalDurationNs']) / n_upd / 1e6:.3f} | {float(r['AverageNs']) / 1e3:.1f} |\n")
     fh.write('\n## HBM traffic per launch (PMC)\n\n| kernel | read MB | write MB |\n|---|---|---|\n')
