@@ -283,7 +283,7 @@ int resel_ensemble_head_bwd(const float* gq, const float* a, const float* w3, fl
  *   dgrad    dx = dy W                 A = dy (1), B = W (0)      EnsembleLinear (models/ensemble_linear_model.py:36-49)
  *   wgrad    dW = dy^T x               A = dy (0), B = x (0)      K = number of tokens: split over blocks, partial tiles summed in
  *                                                                  a fixed order (workspace: resel_gemm_f32_workspace_bytes)
- * act: 0 none, 1 ELU.  The contiguous extent of each operand (K or rows) must be a multiple of 4, pointers 16-byte aligned.
+ * act: 0 none, 1 ELU, 2 accumulate (C += product + bias: the accumulating form of an input gradient; no activation).  The contiguous extent of each operand (K or rows) must be a multiple of 4, pointers 16-byte aligned.
  * split selects how the fp32 products are formed (inputs, accumulation and outputs are fp32 in every mode):
  *   0  v_mfma_f32_32x32x2_f32 (fp32 operands, exact products);
  *   9  each operand split EXACTLY into three bf16 planes (8 + 8 + 8 significant bits), all nine plane products - each exact -

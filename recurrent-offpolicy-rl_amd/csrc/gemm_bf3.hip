@@ -436,6 +436,13 @@ __global__ __launch_bounds__(NTH, 2) void gemm_bf3_kernel(Params p) {
                     }
                     const int mb = cur.m0 + wm + 32 * a + 4 * lh;
                     float* crow = C + (int64_t)mb * p.ldc + n;
+                    if (p.act == 2) {                                // C += product (the accumulating form of an input gradient)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int dm = (e & 3) + 8 * (e >> 2);
+                            if (mb + dm < p.M) v[e] += crow[(int64_t)dm * p.ldc];
+                        }
+                    }
                     if (full_m) {
 #pragma unroll
                         for (int e = 0; e < 16; ++e) crow[(int64_t)((e & 3) + 8 * (e >> 2)) * p.ldc] = v[e];
@@ -491,6 +498,7 @@ __global__ __launch_bounds__(256) void gemm_bf3_fixup_kernel(Params p) {
         if (n + j >= p.N) break;
         float x = o[j] + (p.bias ? p.bias[(int64_t)z * p.sBias + n + j] : 0.f);
         if (p.act == 1) x = elu1(x);
+        if (p.act == 2) x += c[j];
         c[j] = x;
     }
 }

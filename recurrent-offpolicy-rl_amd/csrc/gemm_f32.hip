@@ -58,7 +58,7 @@ struct GemmParams {
     float *C, *slab;
     int64_t lda, ldb, ldc, sA, sB, sC, sBias;    // leading dimensions (floats) and per-batch strides
     int M, N, K;
-    int act;                                      // 0 none, 1 ELU
+    int act;                                      // 0 none, 1 ELU, 2 C += product
     int mt, nt;                                   // tiles along m and n
     int nfull;                                    // items [0, nfull): whole tiles; then nsplit tiles x nsl K slices of kslice
     int nsplit, nsl, kslice;
@@ -504,6 +504,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
                     }
                     const int mb = cur.m0 + wm + 32 * a + 4 * lh;
                     float* crow = C + (int64_t)mb * p.ldc + n;
+                    if (p.act == 2) {                                // C += product (the accumulating form of an input gradient)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int dm = (e & 3) + 8 * (e >> 2);
+                            if (mb + dm < p.M) v[e] += crow[(int64_t)dm * p.ldc];
+                        }
+                    }
                     if (full_m) {
 #pragma unroll
                         for (int e = 0; e < 16; ++e) crow[(int64_t)((e & 3) + 8 * (e >> 2)) * p.ldc] = v[e];
@@ -554,6 +561,7 @@ __global__ __launch_bounds__(256) void gemm_fixup_kernel(GemmParams p) {
         if (n + j >= p.N) break;
         float x = o[j] + (p.bias ? p.bias[(int64_t)z * p.sBias + n + j] : 0.f);
         if (p.act == 1) x = elu1(x);
+        if (p.act == 2) x += c[j];
         c[j] = x;
     }
 }
@@ -595,7 +603,7 @@ extern "C" int resel_gemm_f32(const float* A, int64_t lda, int64_t strideA, int 
                               const float* bias, int64_t strideBias, int act,
                               float* C, int64_t ldc, int64_t strideC, void* workspace,
                               int M, int N, int K, int batch, int split, resel_stream_t stream) {
-    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || act < 0 || act > 1) return RESEL_EINVAL;
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || act < 0 || act > 2) return RESEL_EINVAL;
     // 106 / 109: modes 6 / 9 on the first-edition kernel of this file (every wave splits the fragments it reads), kept for A/B runs
     if (split != 0 && split != 6 && split != 9 && split != 106 && split != 109) return RESEL_EINVAL;
     if (K < BK) split = 0;                         // the split kernels' scheduled loads assume one whole K step per item

@@ -43,9 +43,6 @@ class SAC:
         self.policy_args = self._make_policy_args(parameter)
         self.value_args = self._make_value_args(parameter)
         self.device = self._pick_device()
-        if self.device.type == 'cuda':
-            from ..hip.gemm_select import enable_tuned_gemms
-            self.tuned_gemms = enable_tuned_gemms()
         # The reference samples on the CPU unless --cuda_inference (sac.py:45-49).  This build has no CPU forward (every layer
         # is a HIP kernel), so on a GPU the policy always lives - and samples - on the device: the flag is implied.
         if self.device.type == 'cuda' and not parameter.cuda_inference:

@@ -198,7 +198,7 @@ class MambaInnerFn(torch.autograd.Function):
         check(lib().resel_causal_conv1d_fwd(_p(xz), 2 * Di, _p(cw), _p(conv_b), _p(maskf), _p(xc), Di, Bsz, L, Di, K, 1, _stream()),
               'causal_conv1d_fwd')
         x_dbl = mm_nt(xc, xproj_w)                                         # [M, R + 2N] = (delta_r | B | C)
-        dt = torch.mm(x_dbl[:, :R], dt_w.t())                              # [M, Di]; bias enters the scan as delta_bias
+        dt = mm_nt(x_dbl[:, :R], dt_w)                                      # [M, Di]; bias enters the scan as delta_bias
         A = -torch.exp(A_log.float())
         need_grad = any(ctx.needs_input_grad)
         ck = _ws(lib().resel_selective_scan_ckpt_bytes(Bsz, L, Di, N), x.device) if need_grad else None
@@ -242,9 +242,13 @@ class MambaInnerFn(torch.autograd.Function):
         # [Di, R] with a 66 752-long reduction: hand-written MFMA kernel (the library reaches 7 TFLOP/s on this shape)
         d_dt_w = atb(ddt, x_dbl[:, :R]) if R <= 32 and Di % 4 == 0 and ddt.stride(1) == 1 and ddt.stride(0) % 4 == 0 \
             else torch.mm(ddt.t(), x_dbl[:, :R])
-        dx_dbl[:, :R] = torch.mm(ddt, dt_w)
+        dx_dbl[:, :R] = mm_nn(ddt, dt_w)
         d_xproj_w = wgrad(dx_dbl, xc)
-        dxc.addmm_(dx_dbl, xproj_w)                                        # conv output receives scan (du) + x_proj gradients
+        # conv output receives scan (du) + x_proj gradients: the accumulating form of the input gradient
+        if _mine(dx_dbl.shape[0], xproj_w.shape[1], xproj_w.shape[0], dx_dbl, xproj_w, dxc):
+            gemm_f32(dx_dbl, xproj_w, True, False, None, GEMM_ACCUMULATE, out=dxc)
+        else:
+            dxc.addmm_(dx_dbl, xproj_w)
         dcw = torch.empty(Di, K, dtype=torch.float32, device=dev)
         dcb = torch.empty(Di, dtype=torch.float32, device=dev) if conv_b is not None else None
         ws2 = _ws(lib().resel_causal_conv1d_bwd_workspace_bytes(Bsz, L, Di, K), dev)
@@ -452,9 +456,9 @@ class GruSeqFn(torch.autograd.Function):
         ws = _ws(lib().resel_gru_workspace_bytes(Bsz, L, H), h_all.device)
         check(lib().resel_gru_seq_bwd(_p(w_hh), _p(h0), _p(h_all), _p(gates), _p(dh_all), _p(dgi), _p(dgh), _p(ws),
                                       Bsz, L, H, _stream()), 'gru_seq_bwd')
-        # dW_hh = dgh^T h_prev and db_hh = sum dgh: plain GEMM / reduction over B*L rows (library GEMM, see resel_hip.h)
+        # dW_hh = dgh^T h_prev over the B*L rows (`wgrad`: the K-split hand-written GEMM on long passes) and db_hh = sum dgh
         h_prev = torch.cat((torch.zeros(Bsz, 1, H, device=h_all.device) if h0 is None else h0.unsqueeze(1), h_all[:, :-1]), dim=1)
-        dw_hh = dgh.reshape(-1, 3 * H).t() @ h_prev.reshape(-1, H)
+        dw_hh = wgrad(dgh.reshape(-1, 3 * H), h_prev.reshape(-1, H))
         db_hh = dgh.sum(dim=(0, 1))
         return dgi, dw_hh, db_hh, None
 
@@ -638,6 +642,7 @@ def sac_target(q, subset, next_logp, log_alpha, reward, done, mask, gamma, guard
 
 # ---------------------------------------------------------------------------------------------- bias + activation tail
 ACT_IDS = {None: 0, 'linear': 0, 'elu': 1}
+GEMM_ACCUMULATE = 'accumulate'       # resel_gemm_f32 only: C += product (epilogue code 2)
 
 
 @torch.no_grad()
@@ -693,31 +698,52 @@ def ensemble_head_bwd(gq, a3, w3):
 
 class LinearAct(torch.autograd.Function):
     """act(x W^T + b) for nn.Linear weights (reference rnn_base.py:462-474: `fc` layer followed by its activation module):
-    one GEMM with the bias / activation tail (`mm_nt`); the backward needs the layer OUTPUT only."""
+    one GEMM with the bias / activation tail (`mm_nt`); the backward needs the layer OUTPUT only.  On long GPU passes an input
+    width (17- / 6-wide encoders) or an output width (6-wide TD3 action head) that is not a multiple of 4 is zero-padded inside
+    the node - exact zeros in every dot product, the padding rows / columns of the gradients are dropped - so that every
+    contraction of the update runs on the hand-written GEMM."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, act):
         x2 = x.reshape(-1, x.shape[-1])
         x2 = x2 if x2.stride(-1) == 1 else x2.contiguous()
+        long_pass = x2.is_cuda and x2.shape[0] >= GEMM_F32_MIN_ROWS
+        ctx.kpad = (-x2.shape[1]) % 4 if long_pass else 0
+        ctx.npad = (-weight.shape[0]) % 4 if long_pass else 0
+        n_out = weight.shape[0]
+        if ctx.kpad or ctx.npad:
+            x2 = torch.nn.functional.pad(x2, (0, ctx.kpad)) if ctx.kpad else x2
+            weight = torch.nn.functional.pad(weight, (0, ctx.kpad, 0, ctx.npad))
+            bias = torch.nn.functional.pad(bias, (0, ctx.npad)) if (bias is not None and ctx.npad) else bias
         y2 = mm_nt(x2, weight, bias, act)
         ctx.save_for_backward(x2, weight, y2)
         ctx.act, ctx.has_bias, ctx.xshape = act, bias is not None, x.shape
-        return y2.view(*x.shape[:-1], weight.shape[0])
+        out = y2[:, :n_out] if ctx.npad else y2
+        return out.reshape(*x.shape[:-1], n_out)
 
     @staticmethod
     def backward(ctx, g):
         x2, weight, y2 = ctx.saved_tensors
-        g2 = g.reshape(y2.shape)
+        n_out = y2.shape[1] - ctx.npad
+        g2 = g.reshape(y2.shape[0], n_out)
+        if ctx.npad:
+            g2 = torch.nn.functional.pad(g2, (0, ctx.npad))
         need_db = ctx.has_bias and ctx.needs_input_grad[2]
-        if y2.shape[1] % 4:                                           # narrow heads (6-wide action mean): plain torch tail
+        if y2.shape[1] % 4:                                           # short passes keep odd widths: plain torch tail
             g2 = g2 if g2.is_contiguous() else g2.contiguous()
             aid = ACT_IDS[ctx.act]                                     # 0: identity ('linear' / None), 1: ELU; anything else is a KeyError
             gy = g2 if aid == 0 else g2 * torch.where(y2 > 0, torch.ones_like(y2), y2 + 1.0)          # elu'(x) from the output
             db = gy.sum(dim=0) if need_db else None
         else:
             gy, db = bias_act_bwd(g2, y2, y2.shape[0], ctx.act, need_db)
-        dx = mm_nn(gy, weight).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        dx = mm_nn(gy, weight) if ctx.needs_input_grad[0] else None
         dw = wgrad(gy, x2) if ctx.needs_input_grad[1] else None
+        if ctx.kpad or ctx.npad:                      # drop the padding rows / columns again
+            k = x2.shape[1] - ctx.kpad
+            dx = None if dx is None else dx[:, :k]
+            dw = None if dw is None else dw[:n_out, :k]
+            db = None if db is None else db.reshape(-1)[:n_out]
+        dx = None if dx is None else dx.reshape(ctx.xshape)
         return dx, dw, None if db is None else db.reshape(-1), None
 
 
@@ -727,9 +753,11 @@ def linear_act(x, weight, bias, act):
 
 def linear(x, weight, bias=None):
     """x W^T + b for an fp32 nn.Linear over the tokens of a training pass: the `LinearAct` node (hand-written GEMM forward, input
-    and weight gradients) when the pass is long enough to take it, `F.linear` otherwise (rollout steps, CPU, narrow layers)."""
+    and weight gradients) when the pass is long enough to take it, `F.linear` otherwise (rollout steps, CPU, odd output widths).
+    An input width that is not a multiple of 4 (the 17-wide observation / 6-wide action encoders) is zero-padded to 16-byte rows
+    inside the node."""
     if x.is_cuda and x.dtype == torch.float32 and x.numel() // x.shape[-1] >= GEMM_F32_MIN_ROWS and weight.shape[0] >= GEMM_F32_MIN_DIM \
-            and weight.shape[1] >= GEMM_F32_MIN_K and weight.shape[1] % 4 == 0:
+            and weight.shape[1] >= GEMM_F32_MIN_K:
         return LinearAct.apply(x, weight, bias, None)
     return torch.nn.functional.linear(x, weight, bias)
 
@@ -746,8 +774,8 @@ def gemm_f32_ok(rows, *mats):
         and all(st % 4 == 0 for st in t.stride()[:-1]) and (t.dim() < 2 or t.stride(-2) < (1 << 22)) for t in mats)
 
 
-GEMM_F32_MIN_DIM = int(os.environ.get('RESEL_GEMM_F32_MIN_DIM', 64))        # narrower outputs (dt_proj's rank-16 input gradient, the 6-wide heads) stay with the library (measured equal at 12 / 16 / 32)
-GEMM_F32_MIN_K = int(os.environ.get('RESEL_GEMM_F32_MIN_K', 16))          # reductions of one partial K step run the fp32-MFMA kernel (update 26.07 -> 25.8 ms with dt_proj's K = 16 here)
+GEMM_F32_MIN_DIM = int(os.environ.get('RESEL_GEMM_F32_MIN_DIM', 4))        # narrower outputs (dt_proj's rank-16 input gradient, the 6-wide heads) stay with the library (measured equal at 12 / 16 / 32)
+GEMM_F32_MIN_K = int(os.environ.get('RESEL_GEMM_F32_MIN_K', 4))          # reductions of one partial K step run the fp32-MFMA kernel (update 26.07 -> 25.8 ms with dt_proj's K = 16 here)
 
 
 def _mine(rows, n, k, *mats):
@@ -905,7 +933,7 @@ def gemm_f32(A, B, a_kcontig=True, b_kcontig=True, bias=None, act=None, out=None
         bs = bias.stride(0) if batched else 0
     multi = batch > 1
     check(L.resel_gemm_f32(_p(A), A.stride(-2), A.stride(0) if multi else 0, int(a_kcontig), _p(B), B.stride(-2),
-                           B.stride(0) if multi else 0, int(b_kcontig), _p(bias), bs, ACT_IDS[act], _p(out), out.stride(-2),
+                           B.stride(0) if multi else 0, int(b_kcontig), _p(bias), bs, 2 if act == GEMM_ACCUMULATE else ACT_IDS[act], _p(out), out.stride(-2),
                            out.stride(0) if multi else 0, _p(ws), M, N, K, batch, GEMM_SPLIT if split is None else int(split), _stream()), 'gemm_f32')
     return out
 

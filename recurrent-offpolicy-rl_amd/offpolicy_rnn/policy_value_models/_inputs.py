@@ -42,8 +42,10 @@ def encode_concat(pairs) -> torch.Tensor:
     add exact zeros to every dot product; autograd splits the gradients back through block_diag / cat."""
     mods = [m for m, _ in pairs]
     xs = [x for _, x in pairs]
-    if not all(isinstance(m, torch.nn.Linear) and m.bias is not None for m in mods) or len(pairs) == 1:
+    if not all(isinstance(m, torch.nn.Linear) and m.bias is not None for m in mods):
         return torch.cat([m(x) for m, x in pairs], dim=-1)
+    if len(pairs) == 1:                       # one encoder alone (the actor step's action encoding): still the hand-written GEMM
+        return ops.linear(xs[0], mods[0].weight, mods[0].bias)
     w = torch.block_diag(*[m.weight for m in mods])
     b = torch.cat([m.bias for m in mods])
     pad = (-w.shape[1]) % 4                  # 17 + 17 + 6 + 1 = 41 input columns: three zero columns make the rows 16-byte multiples,

@@ -58,8 +58,8 @@ class ContextualSACValue(ContextualModel):
             # Encode state and action separately so that the first layer's backward forms just that column block of dX.
             act_fn = self.uni_model_input_mapping_activation_func
             with torch.no_grad():
-                sa_s = act_fn(self.state_input_encoder(state))
-            sa_a = act_fn(self.action_input_encoder(action))
+                sa_s = act_fn(_inputs.encode_concat([(self.state_input_encoder, state)]))
+            sa_a = act_fn(_inputs.encode_concat([(self.action_input_encoder, action)]))
             sa = torch.cat((sa_s, sa_a.detach()), dim=-1)
             part = (sa_a, sa_s.shape[-1])
         else:

@@ -739,6 +739,19 @@ def test_gemm_f32_vs_fp64_product(ops, M, N, K, akc, bkc, bias, act, batch, spli
     assert torch.equal(out, out2)                       # bitwise reproducible (no atomics)
 
 
+@pytest.mark.parametrize('M,N,K,split', [(66752, 512, 80, 6), (1000, 132, 72, 6), (5000, 256, 64, 0), (66752, 512, 80, 106)])
+def test_gemm_f32_accumulating_epilogue(ops, M, N, K, split):
+    """Epilogue code 2: C += A B (the accumulating form `dxc.addmm_(dx_dbl, x_proj.weight)` of the Mamba mixer's backward), whole
+    tiles and K-split tails alike, against the fp64 sum."""
+    g = torch.Generator().manual_seed(M + K)
+    A, B = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g) / K ** 0.5
+    C0 = torch.randn(M, N, generator=g)
+    ref = C0.double() + A.double() @ B.double()
+    out = C0.clone().cuda()
+    ops.gemm_f32(A.cuda(), B.cuda(), True, False, None, ops.GEMM_ACCUMULATE, out=out, split=split)
+    close(out, ref.float(), rtol=1e-5, atol_scale=1e-6, name='C += A B')
+
+
 def test_gemm_f32_split_modes_error_against_fp64(ops):
     """The bf16-split product modes are as accurate as the fp32 instruction: mean and maximum error against an fp64 product, on
     operands with a wide dynamic range (6 decades), K = 4096.  Mode 9 represents every product exactly (as mode 0 does): its
@@ -853,3 +866,29 @@ def test_linear_bf16_node_matches_the_autocast_graph(ops, x_bf, out_bf):
     close(dx, dx_ref.float().cpu(), rtol=1e-2, atol_scale=2e-3, name='dx')
     close(dw, dw_ref.cpu(), rtol=1e-2, atol_scale=2e-3, name='dw')
     close(db, db_ref.cpu(), rtol=1e-2, atol_scale=2e-3, name='db')
+
+
+@pytest.mark.parametrize('K,N,act', [(17, 128, None), (256, 6, None), (6, 6, 'elu'), (41, 132, 'elu'), (256, 12, None)])
+def test_linear_act_pads_odd_widths_on_long_passes(ops, K, N, act):
+    """Input / output widths that are not multiples of 4 (17-wide observation and 6-wide action encoders, the 6-wide TD3 action
+    head) are zero-padded inside the LinearAct node on long passes, so that forward, input gradient and weight gradient all run on the
+    hand-written GEMM; values and gradients equal F.linear (+ ELU)."""
+    g = torch.Generator().manual_seed(K * 7 + N)
+    T = 4500
+    x, w, b = torch.randn(3, T // 3, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g) * 0.1
+    dy = torch.randn(3, T // 3, N, generator=g)
+
+    def run(dev, fn):
+        ts = [t.clone().to(dev).requires_grad_(True) for t in (x, w, b)]
+        y = fn(*ts)
+        (y * dy.to(dev)).sum().backward()
+        return y, [t.grad for t in ts]
+
+    ref_fn = lambda x_, w_, b_: (torch.nn.functional.elu if act else (lambda t: t))(torch.nn.functional.linear(x_, w_, b_))
+    y_ref, g_ref = run('cpu', ref_fn)
+    y, gr = run('cuda', lambda x_, w_, b_: ops.linear_act(x_, w_, b_, act))
+    assert y.shape == y_ref.shape
+    close(y, y_ref, name='y')
+    for nm, a, b_ in zip(('dx', 'dw', 'db'), gr, g_ref):
+        assert a.shape == b_.shape
+        close(a, b_, rtol=2e-4, atol_scale=5e-5, name=nm)

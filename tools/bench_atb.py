@@ -3,8 +3,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'recurrent-offpolicy-rl_amd')]
 import torch
 from offpolicy_rnn.hip import ops
-from offpolicy_rnn.hip.gemm_select import enable_tuned_gemms
-enable_tuned_gemms()
 def t(fn, n=20):
     for _ in range(3): fn()
     torch.cuda.synchronize(); a = time.perf_counter()

@@ -5,8 +5,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'recurrent-offpolicy-rl_amd')]
 import torch
 from offpolicy_rnn.hip import ops
-from offpolicy_rnn.hip.gemm_select import enable_tuned_gemms
-enable_tuned_gemms()
 dev = 'cuda'
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 66752
 if len(sys.argv) > 2:

@@ -4,8 +4,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'recurrent-offpolicy-rl_amd')]
 import torch
 from offpolicy_rnn.hip import ops
-from offpolicy_rnn.hip.gemm_select import enable_tuned_gemms
-enable_tuned_gemms()
 B, L, Di, N = 64, 1043, 512, 32
 dev = 'cuda'
 u = torch.randn(B, L, Di, device=dev); dt = torch.randn(B, L, Di, device=dev) * 0.1; z = torch.randn(B, L, Di, device=dev)

@@ -3,8 +3,6 @@ ROOT='/root/repo'
 sys.path[:0]=[ROOT, os.path.join(ROOT,'recurrent-offpolicy-rl_amd')]
 import torch
 from offpolicy_rnn.hip import ops
-from offpolicy_rnn.hip.gemm_select import enable_tuned_gemms
-enable_tuned_gemms()
 T=66752
 def timeit(fn,n=20,warm=5):
     for _ in range(warm): fn()
