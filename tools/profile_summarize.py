@@ -36,8 +36,11 @@ def pmc(name):
 
 fetch, write = pmc('fetch'), pmc('write')
 traffic = {}
+# FETCH_SIZE counts wide coalesced reads (8 / 16 bytes per lane) at half their bytes on gfx950 (MI355X_MICROARCH.md 'HBM'): x 2.  The
+# linear-recurrence scans read ONE dword per lane: calibrated on their own byte count (two passes over v and f + one store of h =
+# 5 element passes = 164.1 MB at B 16, T' 2003, C 256; raw FETCH + WRITE = 164.7 MB), the raw counter is exact for them: x 1.
 for k in sorted(set(fetch) | set(write)):
-    rd, wr = fetch.get(k, 0.0) * 1024 * 2, write.get(k, 0.0) * 1024
+    rd, wr = fetch.get(k, 0.0) * 1024 * (1 if k.startswith('linrec_') else 2), write.get(k, 0.0) * 1024
     traffic[k] = {'read_bytes': rd, 'write_bytes': wr, 'total': rd + wr}
 import bench as _bench
 cfgw = bench['config']['workload']
