@@ -374,7 +374,7 @@ def rccl_one_rank_leg(args):
     env = dict(os.environ, RESEL_DP_FORCE_COLLECTIVES='1', RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1')
     env.pop('MASTER_PORT', None)
     cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--steps', '5', '--warmup', '2', '--rnn', args.rnn, '--algo', args.algo,
-           '--rows', str(args.rows), '--horizon', str(args.horizon), '--no-cpu-baseline', '--no-strict-leg', '--no-rccl-leg', '--no-suite']
+           '--rows', str(args.rows), '--horizon', str(args.horizon), '--no-cpu-baseline', '--no-strict-leg', '--no-rccl-leg', '--no-suite', '--no-graph-leg']
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
         line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
@@ -399,7 +399,7 @@ def suite_legs(args):
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
             line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
-            out[name] = {k: line.get(k) for k in ('value', 'unit', 'ms_per_step', 'steps', 'dtype', 'config', 'roofline', 'roofline_other')}
+            out[name] = {k: line.get(k) for k in ('value', 'unit', 'ms_per_step', 'steps', 'dtype', 'config', 'roofline', 'roofline_other', 'graph_update_leg')}
         except Exception as e:
             out[name] = {'failed': repr(e)[:200]}
     return out
@@ -419,6 +419,8 @@ def main():
                     help='strong scaling: a FIXED global batch of this many trajectories per update, split evenly over the --gpus ranks '
                          '(BASELINE configs[3]: 512)')
     ap.add_argument('--horizon', type=int, default=1024)
+    ap.add_argument('--graph-update', action='store_true', help='replay the whole update as one hipGraph (fixed batch shape; small per-GPU batches)')
+    ap.add_argument('--no-graph-leg', action='store_true', help='skip the extra updates that time the hipGraph replay of the update')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-strict-leg', action='store_true', help='skip the 4 extra updates that time the fp32-MFMA product mode')
     ap.add_argument('--envs', type=int, default=1, help='rollout mode: also time one graph replay over this many environments')
@@ -462,17 +464,21 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    step_fn = alg.train_one_batch
+    if args.graph_update:
+        from offpolicy_rnn.algorithm.graphed_update import GraphedUpdate
+        step_fn = GraphedUpdate(alg).step
     for _ in range(args.warmup):
-        alg.train_one_batch()
+        step_fn()
         alg.grad_num += 1
-    ops.profile_enable(True)                            # HIP event pair bound to each scan dispatch, timed region only
+    ops.profile_enable(not args.graph_update)          # per-dispatch events are not capturable                            # HIP event pair bound to each scan dispatch, timed region only
     ops.GEMM_FLOPS[0] = 0.0
     alg.grad_sync.reset_counters()
     sync()
     t0 = time.perf_counter()
     trained = 0
     for _ in range(args.steps):
-        trained += alg.train_one_batch()['real_batch_size']
+        trained += step_fn()['real_batch_size']
         alg.grad_num += 1
     sync()
     dt = time.perf_counter() - t0
@@ -482,7 +488,7 @@ def main():
     ops.profile_enable(False)
     gemm_flops = ops.GEMM_FLOPS[0]
     strict_ms = None
-    if ops.GEMM_SPLIT != 0 and not args.no_strict_leg:
+    if ops.GEMM_SPLIT != 0 and not args.no_strict_leg and not args.graph_update:
         # the same update with the GEMM products formed by the fp32 MFMA instruction (reported beside the headline, never as it)
         mode, ops.GEMM_SPLIT = ops.GEMM_SPLIT, 0
         alg.train_one_batch()
@@ -495,6 +501,25 @@ def main():
         sync()
         strict_ms = 1e3 * (time.perf_counter() - t1) / 3
         ops.GEMM_SPLIT = mode
+    graph_leg = None
+    if world == 1 and not alg.grad_sync.active and not args.graph_update and not args.no_graph_leg:
+        # the same update replayed from ONE hipGraph (algorithm/graphed_update.py), reported beside the headline: what the launch
+        # sequence costs on the host side of this box (decisive at small per-GPU batches, a few percent at 64 rows)
+        try:
+            from offpolicy_rnn.algorithm.graphed_update import GraphedUpdate
+            gu = GraphedUpdate(alg, warmup=1)
+            for _ in range(2):
+                gu.step()
+                alg.grad_num += 1
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                gu.step()
+                alg.grad_num += 1
+            sync()
+            graph_leg = {'ms_per_step': 1e3 * (time.perf_counter() - t1) / 10, 'graphs': len(gu.graphs), 'eager_fallbacks': gu.eager_fallbacks}
+        except Exception as e:                       # refused configurations (cgpt, gru, clipping ...) say why
+            graph_leg = {'not_captured': str(e)[:160]}
     stat = torch.tensor([dt, float(trained)], dtype=torch.float64, device='cuda')
     if world > 1:
         tmax = stat[:1].clone()
@@ -514,6 +539,7 @@ def main():
                                f'D=256, efc-8 critic ({baseline_config(args)})',
                    'global_rows': Bsz * world, 'parallelism': f'dp{world}'},
         # collectives the timed updates ISSUED (counted where they are called, parallel/data_parallel.py), per update
+        'graph_update': bool(args.graph_update), 'graph_update_leg': graph_leg,
         'rccl_ranks': alg.grad_sync.world if alg.grad_sync.active else 0, 'backend': alg.grad_sync.backend,
         'collectives_per_step': coll, 'collective_bytes_per_step': coll_bytes, 'parameter_broadcasts': bcast,
     }

@@ -249,6 +249,11 @@ int resel_soft_update(float* target, const float* online, float tau, int64_t n, 
 int resel_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, const int64_t* seg_end,
                      const float* seg_lr, const float* seg_wd, int nseg, float beta1, float beta2, float eps,
                      int step, const float* grad_scale, resel_stream_t stream);
+/* The same step with the step-dependent factors read from DEVICE memory: bias_corrections[0] = 1 - beta1^t,
+ * bias_corrections[1] = sqrt(1 - beta2^t).  For updates replayed from a hipGraph, where a by-value step would be frozen at capture. */
+int resel_adamw_flat_dev(float* p, const float* g, float* m, float* v, int64_t n, const int64_t* seg_end,
+                         const float* seg_lr, const float* seg_wd, int nseg, float beta1, float beta2, float eps,
+                         const float* bias_corrections, const float* grad_scale, resel_stream_t stream);
 size_t resel_sumsq_workspace_bytes(int64_t n);
 int resel_sumsq(const float* x, int64_t n, float* out, void* workspace, resel_stream_t stream);
 

@@ -185,9 +185,10 @@ __global__ void soft_update_kernel(float* __restrict__ tgt, const float* __restr
 __global__ void adamw_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                   int64_t n, const int64_t* __restrict__ seg_end, const float* __restrict__ seg_lr,
                                   const float* __restrict__ seg_wd, int nseg, float beta1, float beta2, float eps,
-                                  float bc1, float bc2_sqrt, const float* __restrict__ grad_scale) {
+                                  float bc1, float bc2_sqrt, const float* __restrict__ grad_scale, const float* __restrict__ bc_dev) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (bc_dev) { bc1 = bc_dev[0]; bc2_sqrt = bc_dev[1]; }       // captured updates: the step-dependent factors live in device memory
     int sidx = 0;
     while (sidx < nseg - 1 && i >= seg_end[sidx]) ++sidx;
     const float lr = seg_lr[sidx], wd = seg_wd[sidx];
@@ -295,7 +296,16 @@ extern "C" int resel_adamw_flat(float* p, const float* g, float* m, float* v, in
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
     hipLaunchKernelGGL(adamw_flat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
-                       seg_end, seg_lr, seg_wd, nseg, beta1, beta2, eps, bc1, bc2_sqrt, grad_scale);
+                       seg_end, seg_lr, seg_wd, nseg, beta1, beta2, eps, bc1, bc2_sqrt, grad_scale, (const float*)nullptr);
+    return launch_status();
+}
+
+extern "C" int resel_adamw_flat_dev(float* p, const float* g, float* m, float* v, int64_t n, const int64_t* seg_end,
+                                    const float* seg_lr, const float* seg_wd, int nseg, float beta1, float beta2, float eps,
+                                    const float* bias_corrections, const float* grad_scale, resel_stream_t stream) {
+    if (!p || !g || !m || !v || n <= 0 || !seg_end || !seg_lr || !seg_wd || nseg <= 0 || !bias_corrections) return RESEL_EINVAL;
+    hipLaunchKernelGGL(adamw_flat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
+                       seg_end, seg_lr, seg_wd, nseg, beta1, beta2, eps, 1.f, 1.f, grad_scale, bias_corrections);
     return launch_status();
 }
 

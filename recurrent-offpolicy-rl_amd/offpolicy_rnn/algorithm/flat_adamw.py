@@ -28,9 +28,28 @@ class FlatAdamW:
     def zero_grad(self):
         self.store.zero_grad()
 
+    # ---- captured updates (algorithm/graphed_update.py): the step-dependent factors live in device memory and are refreshed by the
+    # host before every replay; `step()` then launches the kernel that reads them and counts nothing itself
+    def enable_device_factors(self):
+        dev = self.store.flat.device
+        self._bc_host = torch.empty(2, dtype=torch.float32, pin_memory=True)
+        self._bc_dev = torch.zeros(2, dtype=torch.float32, device=dev)
+
+    def prepare_step(self):
+        """Host side of one captured step: count it and send (1 - beta1^t, sqrt(1 - beta2^t)) to the device (stream-ordered copy)."""
+        self.step_count += 1
+        t = float(self.step_count)
+        self._bc_host[0] = 1.0 - self.betas[0] ** t
+        self._bc_host[1] = (1.0 - self.betas[1] ** t) ** 0.5
+        self._bc_dev.copy_(self._bc_host, non_blocking=True)
+
     def step(self, grad_scale: torch.Tensor = None):
         """grad_scale: optional 1-element device tensor multiplied into the gradient (e.g. 1 / global valid count)."""
-        self.step_count += 1
         n = self.store.numel
+        if getattr(self, '_bc_dev', None) is not None and getattr(self, 'device_factors_active', False):
+            ops.adamw_flat_dev_(self.store.flat[:n], self.store.grad[:n], self.m, self.v, self.seg_end, self.seg_lr, self.seg_wd,
+                                self._bc_dev, self.betas[0], self.betas[1], self.eps, grad_scale)
+            return
+        self.step_count += 1
         ops.adamw_flat_(self.store.flat[:n], self.store.grad[:n], self.m, self.v, self.seg_end, self.seg_lr, self.seg_wd,
                         self.step_count, self.betas[0], self.betas[1], self.eps, grad_scale)

@@ -215,6 +215,14 @@ class SAC:
         self.sample_num += self.warmup()
         self.env_reset()
         ep_ret, ep_len = 0.0, 0
+        update = self.train_one_batch
+        if os.environ.get('RESEL_GRAPH_UPDATE') == '1':      # whole update as one hipGraph replay per batch shape (graphed_update.py)
+            from .graphed_update import GraphedUpdate
+            why = GraphedUpdate.refusal(self)
+            if why:
+                self.logger(f'RESEL_GRAPH_UPDATE: eager updates ({why})')
+            else:
+                update = GraphedUpdate(self).step
         for it in range(self.parameter.total_iteration):
             self.policy.train()
             self.policy.to(self.sample_device)
@@ -230,7 +238,7 @@ class SAC:
                     self.logger.add_tabular_data(tb_prefix='Train', EpRet=ep_ret, EpLength=ep_len)
                     ep_ret, ep_len = 0.0, 0
                 if self.sample_num % self.parameter.update_interval == 0 and self.sample_num >= self.parameter.start_train_num:
-                    self.logger.add_tabular_data(tb_prefix='train', **self.train_one_batch())
+                    self.logger.add_tabular_data(tb_prefix='train', **update())
                     self.grad_num += 1
                 self.sample_num += 1
             self.logger.log_tabular('iteration', it, tb_prefix='timestep')

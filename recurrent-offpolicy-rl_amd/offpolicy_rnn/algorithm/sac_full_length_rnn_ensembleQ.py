@@ -152,6 +152,7 @@ class SACFullLengthRNNEnsembleQ(SAC):
         self.target_policy.copy_weight_from(self.policy, tau=0.0)
         self.target_policy.eval()
         self.grad_sync = GradSync()
+        self._graph = None                             # set while a captured update is being recorded / replayed (graphed_update.py)
         self._subset_rng = None                        # REDQ subset stream: None = numpy's global stream (see _subset_stream)
         self._pinned = PinnedRing(torch.float32)       # staging blocks of the host-built batch (one event per block)
         self._needs_seq_table = any(lid.startswith('cgpt') for net in (self.values[0].uni_network, self.values[0].embedding_network,
@@ -292,6 +293,8 @@ class SACFullLengthRNNEnsembleQ(SAC):
         (8 critics, REDQ pairs: 56 rows) and a row view is returned; oversized tables fall back to a per-subset cache."""
         import itertools
         import math
+        if self._graph is not None and subset is self._graph.subset_np:   # captured update: the drawn subset sits in static buffers
+            return self._graph.subset_i64 if as_long else self._graph.subset_i32
         sub = np.ascontiguousarray(subset, dtype=np.int32)
         m, E = int(sub.size), int(max(num_ensemble, sub.max() + 1))
         tables = self.__dict__.setdefault('_subset_tables', {})
@@ -424,7 +427,13 @@ class SACFullLengthRNNEnsembleQ(SAC):
         host: Dict[str, float] = {}
         for utd_idx in range(par.utd):
             self.timer.register_point(tag='sample_trajs', level=2)
-            if getattr(self, 'device_replay', False) and self.device.type == 'cuda' \
+            if self._graph is not None:
+                # captured update (algorithm/graphed_update.py): the host half of the sampling ran before the replay, the plan sits in
+                # static buffers; here only the device half is enqueued (a memcpy node + the gather kernel)
+                dev, batch_size, table = self._graph.gather()
+                self.timer.register_end(level=2)
+                b = self._batch_views(dev, table)
+            elif getattr(self, 'device_replay', False) and self.device.type == 'cuda' \
                     and self.replay_buffer.device_supported(randomize_mask=par.randomize_mask):
                 # device-resident ring: the host decides WHICH trajectories go where, the batch array is built on the GPU
                 dev, batch_size, table = self.replay_buffer.sample_trajs_device(
@@ -538,6 +547,10 @@ class SACFullLengthRNNEnsembleQ(SAC):
             scal[k] = host.pop(k).detach()
         keys = list(scal)
         packed = torch.stack([scal[k].reshape(()).float() for k in keys])
+        if self._graph is not None:                              # captured update: a D2H node into the graph's static pinned buffer
+            return self._graph.log_node(keys, packed, host, dict(real_batch_size=batch_size, real_batch_traj_num=rows,
+                                                                  average_traj_len=self.replay_buffer.size / len(self.replay_buffer),
+                                                                  amp_scalar_pi=0, amp_scalar_q=0))
         log = DeferredLog(keys, packed, pinned=self.device.type == 'cuda')     # ONE device->host copy of all scalars
         log.set_host({k: float(v) for k, v in host.items()})
         log.set_host(dict(real_batch_size=batch_size, real_batch_traj_num=rows,

@@ -148,9 +148,10 @@ class NestedMemoryArray(MemoryArray):
         import torch
         st = self.__dict__.setdefault('_dev_state', {'buf': None})
         dirty = getattr(self, '_dirty', None)
-        if st['buf'] is None or st['buf'].device != device or st['buf'].shape != self.memory_buffer.shape or dirty is None \
-                or len(dirty) > 64:
+        if st['buf'] is None or st['buf'].device != device or st['buf'].shape != self.memory_buffer.shape:
             st['buf'] = torch.from_numpy(self.memory_buffer).to(device)
+        elif dirty is None or len(dirty) > 64:       # whole ring again, IN PLACE: captured updates hold the mirror's address
+            st['buf'].copy_(torch.from_numpy(self.memory_buffer))
         else:
             for s0, n in dirty:                      # through pinned memory: a pageable copy would stall the launch queue
                 rows = torch.from_numpy(self.memory_buffer[s0:s0 + n])
@@ -158,13 +159,9 @@ class NestedMemoryArray(MemoryArray):
         self._dirty = []
         return st['buf']
 
-    def sample_trajs_device(self, device, batch_size, max_sample_size=None, get_all=False, random_trunc_traj=False,
-                            nest_stack_trajs=True):
-        """Same sampling decisions (and numpy RNG consumption) as `sample_trajs`, but the batch array is assembled on the
-        device by `ops.gather_trajs` from the device mirror of the ring: returns (batch [rows, T', W + 3] on `device`,
-        total_size, traj_len_array)."""
-        import torch
-        from ...hip import ops
+    def plan_trajs_device(self, batch_size, max_sample_size=None, get_all=False, random_trunc_traj=False, nest_stack_trajs=True):
+        """Host half of `sample_trajs_device`: the same sampling decisions (and numpy RNG consumption) as `sample_trajs`.  Returns a dict
+        with the int32 plan `seg` [nseg, 4] = (row, first slot, length incl. skip, first transition) and the scalars the gather needs."""
         skip = self._skip_step
         if get_all:
             picked = np.arange(self.available_traj_num)
@@ -193,20 +190,43 @@ class NestedMemoryArray(MemoryArray):
         traj_len_array = np.zeros((nrow, max(len(s) for s in table)))
         for r, seq in enumerate(table):
             traj_len_array[r, :len(seq)] = seq
-        R = self.name2range
-        pairs = []
-        for dst, src in (('next_state', 'state'), ('reward', 'reward_input'), ('state', 'last_state')):
-            pairs += list(zip(range(*R[dst]), range(*R[src])))
+        seg = np.asarray(plan, dtype=np.int32)
+        return dict(seg=seg, max_len=int(seg[:, 2].max()), nrow=nrow, longest=longest, total_size=total_size, table=traj_len_array)
+
+    def _gather_pairs(self, device):
+        import torch
         st = self.__dict__.setdefault('_dev_plan', {})
         if st.get('device') != device:
             from ...utility.pinned import PinnedRing
+            R = self.name2range
+            pairs = []
+            for dst, src in (('next_state', 'state'), ('reward', 'reward_input'), ('state', 'last_state')):
+                pairs += list(zip(range(*R[dst]), range(*R[src])))
             st.update(device=device, pairs=torch.tensor(pairs, dtype=torch.int32).to(device), ring=PinnedRing(torch.int32, depth=4))
-        seg = np.asarray(plan, dtype=np.int32)
+        return st
+
+    def gather_planned(self, device, seg_dev, max_len, nrow, longest):
+        """Device half: the packed batch [rows, T', W + 3] assembled on the GPU from the device mirror of the ring and the plan."""
+        from ...hip import ops
+        R = self.name2range
+        st = self._gather_pairs(device)
+        out = ops.gather_trajs(self._mirror(device), seg_dev, max_len, self._skip_step, nrow, longest, R['mask'][0], R['start'][0],
+                               R['done'][0], R['timeout'][0] if R['timeout'][1] > R['timeout'][0] else -1, st['pairs'])
+        self._last_batch_shape = (nrow, longest)
+        return out
+
+    def sample_trajs_device(self, device, batch_size, max_sample_size=None, get_all=False, random_trunc_traj=False,
+                            nest_stack_trajs=True):
+        """Same sampling decisions (and numpy RNG consumption) as `sample_trajs`, but the batch array is assembled on the
+        device by `ops.gather_trajs` from the device mirror of the ring: returns (batch [rows, T', W + 3] on `device`,
+        total_size, traj_len_array)."""
+        import torch
+        pl = self.plan_trajs_device(batch_size, max_sample_size, get_all, random_trunc_traj, nest_stack_trajs)
+        seg = pl['seg']
+        st = self._gather_pairs(device)
         # the plan block is rewritten on every sample while earlier copies may still be queued: one event per block
         host = st['ring'].stage(seg.size, device, 1024).view(-1, 4)
         host.copy_(torch.from_numpy(seg))
         seg_dev = st['ring'].upload(host, device)
-        out = ops.gather_trajs(self._mirror(device), seg_dev, int(seg[:, 2].max()), skip, nrow, longest, R['mask'][0], R['start'][0],
-                               R['done'][0], R['timeout'][0] if R['timeout'][1] > R['timeout'][0] else -1, st['pairs'])
-        self._last_batch_shape = (nrow, longest)
-        return out, total_size, traj_len_array
+        out = self.gather_planned(device, seg_dev, pl['max_len'], pl['nrow'], pl['longest'])
+        return out, pl['total_size'], pl['table']

@@ -54,6 +54,7 @@ SIGNATURES = {
     'resel_sac_target_workspace_bytes': (c_size_t, [I]),
     'resel_soft_update': (c_int, [P, P, F, L, S]),
     'resel_adamw_flat': (c_int, [P, P, P, P, L, P, P, P, I, F, F, F, I, P, S]),
+    'resel_adamw_flat_dev': (c_int, [P, P, P, P, L, P, P, P, I, F, F, F, P, P, S]),
     'resel_sumsq_workspace_bytes': (c_size_t, [L]),
     'resel_sumsq': (c_int, [P, L, P, P, S]),
     'resel_bias_act_fwd': (c_int, [P, P, L, I, L, I, S]),

@@ -1011,6 +1011,14 @@ def adamw_flat_(p, g, m, v, seg_end, seg_lr, seg_wd, step, beta1=0.9, beta2=0.99
 
 
 @torch.no_grad()
+def adamw_flat_dev_(p, g, m, v, seg_end, seg_lr, seg_wd, bias_corrections, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=None):
+    """`adamw_flat_` with (1 - beta1^t, sqrt(1 - beta2^t)) read from the 2-element device tensor `bias_corrections` (captured updates)."""
+    _need_cuda('adamw_flat_dev', p, g, m, v, seg_end, seg_lr, seg_wd, bias_corrections)
+    check(lib().resel_adamw_flat_dev(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(seg_end), _p(seg_lr), _p(seg_wd), int(seg_end.numel()),
+                                     float(beta1), float(beta2), float(eps), _p(bias_corrections), _p(grad_scale), _stream()), 'adamw_flat_dev')
+
+
+@torch.no_grad()
 def sumsq(x, out=None):
     _need_cuda('sumsq', x)
     out = torch.empty(1, dtype=torch.float32, device=x.device) if out is None else out

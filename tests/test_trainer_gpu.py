@@ -352,3 +352,73 @@ def test_cgpt_td3_update_gpu_vs_oracle():
         got = logs[0][k][0] if isinstance(logs[0][k], tuple) else logs[0][k]
         want = v[0] if isinstance(v, tuple) else v
         assert got == pytest.approx(want, rel=5e-2, abs=5e-2), (k, got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('rnn,ragged', [('smamba_s8_c4_b1_nln', False), ('gilr', False), ('smamba_s8_c4_b1_nln', True)])
+def test_graphed_update_equals_the_eager_update(rnn, ragged, monkeypatch):
+    """The whole update replayed from ONE hipGraph (algorithm/graphed_update.py: sampling plan, REDQ subset and AdamW step factors in
+    static buffers refreshed before each replay) against the eager update: same seeds, actor noise off (the captured generator draws
+    from graph-safe Philox offsets), four updates - logged scalars and every parameter to 2e-5."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    import numpy as np
+    from test_host_logic import _push, _synth, make_parameter
+    from offpolicy_rnn import alg_init
+    from offpolicy_rnn.utility import rng
+    from offpolicy_rnn.algorithm.graphed_update import GraphedUpdate
+    monkeypatch.setattr(rng, 'randn', lambda shape, device, dtype=torch.float32: torch.zeros(tuple(shape), dtype=dtype, device=device))
+
+    def build():
+        torch.manual_seed(0)
+        np.random.seed(0)
+        alg = alg_init(make_parameter(rnn, sac_batch_size=4 * 12 - 1, cuda_inference=True, alg_name='sac_rnn_full_horizon_redQ_sep_optim'))
+        rs = np.random.RandomState(3)
+        for i in range(8):                                      # equal lengths: one batch shape; ragged: the shape changes between updates
+            n = (12, 9, 7, 12, 5, 12, 10, 8)[i] if ragged else 12
+            o, a, r = _synth(rs, n, 5, 3)
+            _push(alg.replay_buffer, o, a, r, early_done=(n != 12))
+        np.random.seed(11)
+        return alg
+
+    def state(alg):
+        return [alg.policy.store.flat.detach().clone(), alg.values[0].store.flat.detach().clone(), alg.target_values[0].store.flat.detach().clone(),
+                alg.log_sac_alpha.detach().clone()]
+
+    n_upd = 8 if ragged else 4
+    rs_new = np.random.RandomState(99)
+    fresh = [_synth(rs_new, n, 5, 3) for n in (12, 6)]         # trajectories that enter the ring in the middle of the run
+
+    def push_fresh(alg):
+        for (o, a, r), n in zip(fresh, (12, 6)):
+            _push(alg.replay_buffer, o, a, r, early_done=(n != 12))
+
+    eager = build()
+    logs_e = []
+    for i in range(n_upd):
+        if i == n_upd - 2:
+            push_fresh(eager)
+        logs_e.append(dict(eager.train_one_batch()))
+        eager.grad_num += 1
+    graphed = build()
+    # the first step() = one eager warm-up update + capture + first replay; ragged: two shapes are recorded, the others run eagerly
+    g = GraphedUpdate(graphed, warmup=1, max_graphs=2 if ragged else 4)
+    np.random.seed(11)                                          # the constructor sized its buffers with one subset draw
+    logs_g = []
+    for i in range(1, n_upd):                                   # update 0 is the warm-up inside the first step()
+        if i == n_upd - 2:
+            push_fresh(graphed)                                 # the ring mirror is refreshed outside the graph, in place
+        logs_g.append(dict(g.step()))
+        graphed.grad_num += 1
+    torch.cuda.synchronize()
+    assert g.graph is not None and (g.eager_fallbacks > 0 if ragged else (g.eager_fallbacks == 0 and 1 <= len(g.graphs) <= 4))
+    # not bit for bit: the entropy coefficient's torch AdamW runs in its `capturable` form (step count and bias corrections as
+    # fp32 device tensors instead of Python floats), and the coefficient enters every loss
+    for nm, a, b in zip(('policy', 'value', 'target value', 'log alpha'), state(graphed), state(eager)):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-5, atol=2e-7, err_msg=nm)
+    for le, lg in zip(logs_e[1:], logs_g):
+        assert set(le) == set(lg)
+        for k in le:
+            ve = le[k][0] if isinstance(le[k], tuple) else le[k]
+            vg = lg[k][0] if isinstance(lg[k], tuple) else lg[k]
+            assert abs(ve - vg) <= 2e-5 * max(1.0, abs(ve)), (k, ve, vg)
