@@ -527,6 +527,8 @@ def main():
         tot = stat[1:].clone()
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dt, trained = tmax.item(), tot.item()
+        dist.barrier()                               # every collective of every rank is behind us: tear the group down in step
+        dist.destroy_process_group()
     if rank != 0:
         return
     Bsz, Tp = args.rows, alg.replay_buffer._last_batch_shape[1]
