@@ -125,6 +125,19 @@ __device__ __forceinline__ float4 load_bc4(const float* base, int64_t tok, int64
     return make_float4(q[0], q[1], q[2], q[3]);
 }
 
+// packed multiplies whose first operand is ONE half of a register pair, broadcast to both results (op_sel): {p.x, p.x} * x and {p.y, p.y} * x
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2v pk_mul_lo(f2v p, f2v x) {         // {p.x * x.x, p.x * x.y}
+    f2v r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(r) : "v"(p), "v"(x));
+    return r;
+}
+__device__ __forceinline__ f2v pk_mul_hi(f2v p, f2v x) {         // {p.y * x.x, p.y * x.y}
+    f2v r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "v"(p), "v"(x));
+    return r;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Forward.  Ownership: workgroup = (row b, 64 channels[, time segment]), lane = channel, wave = NS-state group, time in
 // TC-step chunks staged through LDS.  What keeps the per-step overhead down (phase stamps / PMC: tools/micro/sscan_lab.hip):
@@ -155,8 +168,9 @@ __global__ __launch_bounds__(NW * 64) void sscan_fwd2_kernel(FwdParams p) {
     constexpr int BC_ITEMS = TC * N / 4;
     constexpr int PER_BC = (BC_ITEMS + NT - 1) / NT;
     static_assert(TC % 2 == 0 && (TC * 16) % NT == 0, "whole tile rows per thread pass");
-    __shared__ __attribute__((aligned(16))) float s_dl[TC][TILE_C];      // exp argument: softplus(delta + bias), +inf at a reset
-    __shared__ __attribute__((aligned(16))) float s_du[TC][TILE_C];      // softplus(delta + bias) * u
+    // per (step, channel) ONE 8-byte word {exp argument softplus(delta + bias) (+inf at a reset), that * u}: a lane's step operands
+    // arrive as a register pair whose halves feed the packed multiplies through op_sel (pk_mul_lo / pk_mul_hi: no splat moves)
+    __shared__ __attribute__((aligned(16))) float s_p[TC][TILE_C][2];
     __shared__ __attribute__((aligned(16))) float s_y[MODE == 1 ? 1 : NW][TC][TILE_C];
     __shared__ __attribute__((aligned(16))) float s_B[TC][N];
     __shared__ __attribute__((aligned(16))) float s_C[MODE == 1 ? 1 : TC][N];
@@ -206,7 +220,28 @@ __global__ __launch_bounds__(NW * 64) void sscan_fwd2_kernel(FwdParams p) {
     float pst[PER_T];
     float4 u_r[PER_T], z_r[PER_T];
 
+    const bool tile_full = d0 + TILE_C <= p.Di;     // uniform: every thread's four channels exist
     auto prefetch = [&](int c0) {
+        if (tile_full && c0 + TC <= t_end) {        // a whole chunk of a whole channel tile (uniform): no zero fill, no guards
+#pragma unroll
+            for (int i = 0; i < PER_T; ++i) {
+                const int64_t tok = tok0 + c0 + tr0 + i * (NT / 16);
+                pu[i] = ld4(p.u + tok * p.ld_u + d0 + tc4);
+                pd[i] = ld4(p.delta + tok * p.ld_delta + d0 + tc4);
+                pz[i] = (MODE != 1 && p.z) ? ld4(p.z + tok * p.ld_z + d0 + tc4) : zero4;
+                pst[i] = p.start ? p.start[tok] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < PER_BC; ++i) {
+                const int it = tid + i * NT;
+                const int t = c0 + it / (N / 4), c = (it % (N / 4)) * 4;
+                if (PER_BC * NT == BC_ITEMS || it < BC_ITEMS) {
+                    pB[i] = load_bc4(p.Bm, tok0 + t, p.ld_b, c, p.bc_vec);
+                    if (MODE != 1) pC[i] = load_bc4(p.Cm, tok0 + t, p.ld_c, c, p.bc_vec);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < PER_T; ++i) {
             const int t = c0 + tr0 + i * (NT / 16);
@@ -283,8 +318,8 @@ __global__ __launch_bounds__(NW * 64) void sscan_fwd2_kernel(FwdParams p) {
             }
             u_r[i] = uv;
             z_r[i] = pz[i];
-            st4(&s_dl[r][tc4], dv);
-            st4(&s_du[r][tc4], du4);
+            st4(&s_p[r][tc4][0], make_float4(dv.x, du4.x, dv.y, du4.y));
+            st4(&s_p[r][tc4 + 2][0], make_float4(dv.z, du4.z, dv.w, du4.w));
         }
 #pragma unroll
         for (int i = 0; i < PER_BC; ++i) {
@@ -300,9 +335,9 @@ __global__ __launch_bounds__(NW * 64) void sscan_fwd2_kernel(FwdParams p) {
         prefetch(c0 + TC);                           // in flight during the whole scan phase (past the end: every load is guarded off)
 
         // ---- scan
-        float dlr[TC], dur[TC];
+        f2v Pr[TC];
 #pragma unroll
-        for (int t = 0; t < TC; ++t) { dlr[t] = s_dl[t][lane]; dur[t] = s_du[t][lane]; }
+        for (int t = 0; t < TC; ++t) Pr[t] = *reinterpret_cast<const f2v*>(&s_p[t][lane][0]);
         const bool ck_on = p.ckpt != nullptr;
         f2 Bq[2][NP], Cq[2][NP];                      // operand rows one step ahead of their use (two register sets)
         lds_coef2<NS>(&s_B[0][w * NS], Bq[0]);
@@ -313,19 +348,19 @@ __global__ __launch_bounds__(NW * 64) void sscan_fwd2_kernel(FwdParams p) {
                 lds_coef2<NS>(&s_B[t + 1][w * NS], Bq[(t + 1) & 1]);
                 if (MODE != 1) lds_coef2<NS>(&s_C[t + 1][w * NS], Cq[(t + 1) & 1]);
             }
-            const f2 dl2 = {dlr[t], dlr[t]}, du2 = {dur[t], dur[t]};
+            const f2v Pt = Pr[t];
             f2 yacc = {0.f, 0.f};
 #pragma unroll
             for (int k = 0; k < NP; ++k) {
-                const f2 arg = dl2 * A2p[k];
+                const f2v arg = pk_mul_lo(Pt, A2p[k]);
                 f2 dA;
                 dA.x = fast_exp2(arg.x);
                 dA.y = fast_exp2(arg.y);
-                hp[k] = __builtin_elementwise_fma(dA, hp[k], du2 * Bq[t & 1][k]);
-                if (MODE != 1) yacc = __builtin_elementwise_fma(Cq[t & 1][k], hp[k], yacc);
+                hp[k] = __builtin_elementwise_fma(dA, hp[k], (f2)pk_mul_hi(Pt, Bq[t & 1][k]));
+                if (MODE != 1) yacc = (k == 0) ? Cq[t & 1][k] * hp[k] : __builtin_elementwise_fma(Cq[t & 1][k], hp[k], yacc);
             }
             if (MODE == 1) {
-                sdl += dlr[t];
+                sdl += Pt.x;
             } else {
                 s_y[w][t][lane] = yacc.x + yacc.y;
                 if ((t + 1) % CKS == 0 && ck_on) {                           // c0 is a multiple of TC, TC of CKS
@@ -426,18 +461,6 @@ __global__ __launch_bounds__(NW * 64) void sscan_fwd2_kernel(FwdParams p) {
 //   * parks what the output tile needs besides the partial sums - silu(z), D * u - in LDS when the chunk is staged (the staging
 //     thread's own slots: thread-private, no hazard) and sends checkpoints (every 16 steps = a chunk end) straight from the state
 //     registers as 256-byte rows.
-typedef float f2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f2v pk_mul_lo(f2v p, f2v x) {         // {p.x * x.x, p.x * x.y}
-    f2v r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(r) : "v"(p), "v"(x));
-    return r;
-}
-__device__ __forceinline__ f2v pk_mul_hi(f2v p, f2v x) {         // {p.y * x.x, p.y * x.y}
-    f2v r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "v"(p), "v"(x));
-    return r;
-}
-
 constexpr int F3_CW = 128;            // channels per workgroup of the third edition
 
 template <int NS, int NW>
