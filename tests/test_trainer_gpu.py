@@ -355,8 +355,9 @@ def test_cgpt_td3_update_gpu_vs_oracle():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('rnn,ragged', [('smamba_s8_c4_b1_nln', False), ('gilr', False), ('smamba_s8_c4_b1_nln', True)])
-def test_graphed_update_equals_the_eager_update(rnn, ragged, monkeypatch):
+@pytest.mark.parametrize('rnn,ragged,algo', [('smamba_s8_c4_b1_nln', False, 'sac'), ('gilr', False, 'sac'), ('smamba_s8_c4_b1_nln', True, 'sac'),
+                                              ('lru', False, 'td3')])
+def test_graphed_update_equals_the_eager_update(rnn, ragged, algo, monkeypatch):
     """The whole update replayed from ONE hipGraph (algorithm/graphed_update.py: sampling plan, REDQ subset and AdamW step factors in
     static buffers refreshed before each replay) against the eager update: same seeds, actor noise off (the captured generator draws
     from graph-safe Philox offsets), four updates - logged scalars and every parameter to 2e-5."""
@@ -372,7 +373,7 @@ def test_graphed_update_equals_the_eager_update(rnn, ragged, monkeypatch):
     def build():
         torch.manual_seed(0)
         np.random.seed(0)
-        alg = alg_init(make_parameter(rnn, sac_batch_size=4 * 12 - 1, cuda_inference=True, alg_name='sac_rnn_full_horizon_redQ_sep_optim'))
+        alg = alg_init(make_parameter(rnn, algo=algo, sac_batch_size=4 * 12 - 1, cuda_inference=True))
         rs = np.random.RandomState(3)
         for i in range(8):                                      # equal lengths: one batch shape; ragged: the shape changes between updates
             n = (12, 9, 7, 12, 5, 12, 10, 8)[i] if ragged else 12
