@@ -103,6 +103,7 @@ struct AttnParams {
     const float* delta;         // [H, T]
     bf16_t* dqkv;
     int T, S, H;
+    int nqb;                    // query blocks per sequence in the attn_q_kernel grid
     float scale;
     uint32_t thr;               // dropout: keep iff random byte < thr (256 = keep all)
     float rp;                   // 1 / (1 - p)
@@ -166,33 +167,102 @@ __device__ __forceinline__ void store_kv(const KVRegs<HD>& r, int tid, bf16_t (*
     }
 }
 
-// ------------------------------------------------------------------------------------------------- forward
+// ------------------------------------------------------------------------------------------------- forward / dQ
+// Swizzled row-major LDS image of a [rows][HD] bf16 tile.  ONE image serves both operand forms (guide T10):
+//   * row reads  (ds_read_b128: lane (r, hh) takes row r, 16-byte chunk 2 ks + hh) - the A operand of S^T = K Q^T, dP^T = V dO^T;
+//   * transposed reads (ds_read_b64_tr_b16: a 16-lane group takes a 4-row x 16-column block and each lane receives a COLUMN)
+//     - the A operand of O^T = V^T P^T and dQ^T = K^T dS^T in the accumulator's k-order 16 s + 8 (j >> 2) + 4 h + (j & 3).
+// chunk ch of row `row` lives at chunk position ch ^ swz(row); with swz below both read forms are bank-conflict free
+// (64-byte rows: 4 rows span the 64 banks, the 16-lane groups of ds_read_b128 hold 4 rows of each residue mod 4 whose
+// (row >> 2) & 3 differ; 128-byte rows: 2 rows span the banks and the row bits 1..3 separate the 8 rows of a group).
+#define LDS_AS __attribute__((address_space(3)))
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+template <int HD>
+struct Img {
+    static constexpr int ROWB = HD * 2;
+    static __device__ __forceinline__ int swz(int row) {
+        return HD == 32 ? ((row >> 2) & 3) : ((((row >> 1) & 1) << 2) | ((row >> 2) & 3));
+    }
+    static __device__ __forceinline__ int off(int row, int ch) { return row * ROWB + ((ch ^ swz(row)) << 4); }
+    // lane-constant part of the row-read address of k-step ks (tile rows start at a multiple of 32: swz does not see them)
+    static __device__ __forceinline__ int row_off(int r, int hh, int ks) { return off(r, 2 * ks + hh); }
+    // lane-constant part of the transposed-read address: k-step s2, first / second block of the step (sec), column tile t
+    static __device__ __forceinline__ int tr_off(int lane, int s2, int sec, int t) {
+        const int li = lane & 15, dh = (lane >> 4) & 1, hh = lane >> 5;
+        const int row = 16 * s2 + 8 * sec + 4 * hh + (li >> 2);
+        return off(row, 4 * t + 2 * dh + ((li & 3) >> 1)) + 8 * (li & 1);
+    }
+};
+__device__ __forceinline__ bf16x8 lds_row(LDS_AS const char* a) { return *reinterpret_cast<LDS_AS const bf16x8*>(a); }
+__device__ __forceinline__ bf16x8 lds_tr(LDS_AS const char* lo, LDS_AS const char* hi) {      // EXEC must be all ones
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)lo);
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)hi);
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+// max / sum over the two 32-lane halves of a wave in the VALU (v_permlane32_swap; no LDS round trip)
+__device__ __forceinline__ void halves(float x, float& a, float& b) {      // a = lower half's value, b = upper half's, in all lanes
+    // inline asm: with both operands the same value, hipcc (ROCm 7.2) folds the two results of
+    // __builtin_amdgcn_permlane32_swap into one register (a + b became 2 a)
+    a = x;
+    b = x;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float half_max(float x) { float a, b; halves(x, a, b); return fmaxf(a, b); }
+__device__ __forceinline__ float half_sum(float x) { float a, b; halves(x, a, b); return a + b; }
+
+template <int V> struct IntC { static constexpr int value = V; };
+__device__ __forceinline__ float sgpr(float x) {                 // a wave-uniform value, held in a scalar register
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));
+}
+
 // MODE 0: forward (O, lse).  MODE 1: dQ (needs dout, lse, delta).
+// Workgroup = 128 queries x 4 * KSPL waves: wave w works on query tile w & 3 (32 queries, one per lane column) and, with KSPL = 2,
+// on every second 32-key tile of a staged key block - the two waves of a query tile keep private running statistics /
+// accumulators and are merged through LDS at the end (halves the serial tile chain of the late query blocks, which is what
+// bounds a launch of few long sequences).  Key blocks (KTB keys of K and V) are double-buffered in LDS: one barrier per block,
+// the global loads of block i + 2 are in flight during block i + 1.
 // The softmax work per score element is what bounds these kernels at hd = 32 (4 MFMAs per 32x32 tile), so it is kept
-// minimal: the ALiBi term is one add of a per-lane constant and a per-tile offset folded into the scale FMA, the causal /
-// length mask is evaluated only on tiles that cross the diagonal or the sequence end (wave-uniform branch), and the
-// accumulator is rescaled only when some lane's running maximum actually moved.
-template <int HD, int MODE, bool DROP>
-__global__ __launch_bounds__(256) void attn_q_kernel(AttnParams p) {
-    constexpr int KS = HD / 16, ND = HD / 32;
-    __shared__ __attribute__((aligned(16))) bf16_t k_lds[KTB][HD + PADE];
-    __shared__ __attribute__((aligned(16))) bf16_t v_lds[MODE == 1 ? KTB : 1][HD + PADE];         // row-major V (dQ only)
-    __shared__ __attribute__((aligned(16))) bf16_t tr_lds[HD][KTB + PADE];                         // V^T (fwd) or K^T (dQ)
-    const int s = blockIdx.y, h = blockIdx.z;
+// minimal: the ALiBi term is one add of a per-lane constant and a per-tile offset folded into the accumulator's initial
+// value, the causal / length mask is evaluated only on tiles that cross the diagonal or the sequence end (wave-uniform
+// branch), the accumulator is rescaled only when some lane's running maximum actually moved, and the forward takes two
+// tiles per step (one maximum exchange / rescale test / loop turn per 64 keys, two independent MFMA chains in flight).
+template <int HD, int MODE, bool DROP, int KSPL>
+__global__ __launch_bounds__(256 * KSPL, KSPL == 2 && HD == 32 ? 4 : 1) void attn_q_kernel(AttnParams p) {
+    constexpr int KS = HD / 16, ND = HD / 32, NTHR = 256 * KSPL;
+    constexpr int ROWB = HD * 2, IMG = KTB * ROWB;
+    constexpr int NI = KTB * HD / 8 / NTHR;                      // 16-byte pieces of K (and of V) per thread and key block
+    constexpr int NTS = MODE == 0 ? 2 : 1;                       // tiles per step
+    static_assert(NI >= 1 && KTB / KT == 4, "staging split");
+    constexpr int COMB = 4 * 64 * (16 * ND + 2) * 4;             // merge buffer of the key-split pairs (aliases the images)
+    static_assert(KSPL == 1 || COMB <= 4 * IMG, "merge buffer");
+    __shared__ __attribute__((aligned(16))) char smem[4 * IMG];  // [buffer][K image | V image]
+    LDS_AS char* const lds = (LDS_AS char*)smem;
+
+    // 1-D grid, XCD-aware: consecutive workgroup ids go round the 8 XCDs, so the query blocks of one (sequence, head) - which all
+    // read the same K / V rows - take consecutive slots of ONE XCD (one L2), latest (= longest, causal) block first
+    const int nqb = p.nqb;
+    const int jb = blockIdx.x >> 3;
+    const int pair = (jb / nqb) * 8 + (blockIdx.x & 7);
+    if (pair >= p.S * p.H) return;
+    const int h = pair % p.H, s = pair / p.H;                    // heads fastest: the sequences of a ragged batch spread over all XCDs
     const int t0 = p.cu[s], len = p.cu[s + 1] - t0;
-    const int qb0 = blockIdx.x * 128;
+    const int qb0 = (nqb - 1 - jb % nqb) * 128;
     if (qb0 >= len) return;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qt = w & 3, kh = w >> 2;
     const int r = lane & 31, hh = lane >> 5;
-    const int q = qb0 + w * 32 + r;
+    const int q = qb0 + qt * 32 + r;
     const bool q_ok = q < len;
     const float c1 = p.scale * RESEL_LOG2E;
     const float slope2 = (p.slopes ? p.slopes[h] : 0.f) * RESEL_LOG2E;
-    bf16x8 qf[KS], dof[KS];
+    bf16x8 qf[KS], dof[MODE == 1 ? KS : 1];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         qf[ks] = zero8();
-        dof[ks] = zero8();
+        if (MODE == 1) dof[ks] = zero8();
         if (q_ok) {
             qf[ks] = *reinterpret_cast<const bf16x8*>(p.qkv + (((int64_t)(t0 + q) * 3 + 0) * p.H + h) * HD + 16 * ks + 8 * hh);
             if (MODE == 1) dof[ks] = *reinterpret_cast<const bf16x8*>(p.dout + ((int64_t)(t0 + q) * p.H + h) * HD + 16 * ks + 8 * hh);
@@ -212,9 +282,11 @@ __global__ __launch_bounds__(256) void attn_q_kernel(AttnParams p) {
     // pass, -lse; exp2(acc * c1 [- m]) then needs one multiply-add per score and no separate bias / lse arithmetic (the
     // constants replace the zero fill, instruction for instruction).  dP starts from -delta the same way.
     const float inv_c1 = 1.f / c1;
-    float crow[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) crow[i] = slope2 * inv_c1 * (float)acc_row(i, hh);
+    const float sl = slope2 * inv_c1;
+    // ... through ONE v_mfma_f32_32x32x2_f32 per tile (k = 2, fp32 operands: exact): A[key row][0] = slope * row, B[0][q] = 1 and
+    // A[key row][1] = 1, B[1][q] = -slope (q - k0) [- lse]; lane (r, hh) holds A[r][hh] / B[hh][r].  16 VALU adds per tile become
+    // one matrix instruction on a pipe that is ~15 % busy here, and one VALU operation for the B value.
+    const float bias_a = hh == 0 ? sl * (float)r : 1.f;
     const float lse_c = MODE == 1 ? lse2 * inv_c1 : 0.f;
     constexpr float RESCALE_THR = 5.f;              // forward: rescale the running sums only when a maximum grows by > 2^5
 
@@ -227,91 +299,260 @@ __global__ __launch_bounds__(256) void attn_q_kernel(AttnParams p) {
     }
     const int q_hi = min(len, qb0 + 128) - 1;                    // last query of this block
     const int nkeys = q_hi + 1;                                  // causal: keys <= q_hi
-    const int wq_lo = qb0 + w * 32, wq_hi = wq_lo + 31;          // this wave's queries
-    KVRegs<HD> kv;
-    load_kv<HD>(p, t0, len, 0, h, tid, kv);
-    for (int kb = 0; kb < nkeys; kb += KTB) {
-        __syncthreads();
-        store_kv<HD, MODE == 1, MODE == 1, MODE == 0>(kv, tid, k_lds, v_lds, tr_lds);
-        __syncthreads();
-        if (kb + KTB < nkeys) load_kv<HD>(p, t0, len, kb + KTB, h, tid, kv);   // in flight while this stage is consumed
-      for (int sub = 0; sub < KTB / KT; ++sub) {
-        const int k0 = kb + sub * KT, ko = sub * KT;
-        if (k0 > wq_hi || k0 >= nkeys) break;                    // the rest lies in this wave's future (uniform per wave)
-        const bool masked = (k0 + KT - 1 > wq_lo) || (wq_hi >= len);          // tile crosses the diagonal / the sequence end
-        const float base = -slope2 * inv_c1 * (float)(q - k0) - lse_c;
-        f32x16 st;
+    const int nkb = (nkeys + KTB - 1) / KTB;
+    const int wq_lo = qb0 + qt * 32;                             // this wave's queries; a wave past the sequence end only stages
+    const int wq_hi = wq_lo < len ? wq_lo + 31 : -1;
+
+    // lane-constant LDS offsets of the operand reads (the tile's first row and the image select are added per tile)
+    int roff[KS], toff[2][2][ND];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) st[i] = crow[i] + base;
+    for (int ks = 0; ks < KS; ++ks) roff[ks] = Img<HD>::row_off(r, hh, ks);
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-            st = mfma(*reinterpret_cast<const bf16x8*>(&k_lds[ko + r][16 * ks + 8 * hh]), qf[ks], st);
-        if (masked) {
+    for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) st[i] = (q_ok && (k0 + acc_row(i, hh)) <= q) ? st[i] : NEG_BIG;      // (key <= q < len)
-        }
-        uint32_t dw[4] = {0, 0, 0, 0};
-        if (DROP) {
-            const uint32_t kbase = (uint32_t)(k0 >> 2) * DROP_CK;
+        for (int sec = 0; sec < 2; ++sec)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) dw[g] = mix32(dq_word ^ (kbase + dk_off[g]));
-        }
-        f32x16 pt;
-        if (MODE == 0) {
-            float mloc = fmaxf(fmaxf(st[0], st[1]), st[2]);
+            for (int t = 0; t < ND; ++t) toff[s2][sec][t] = Img<HD>::tr_off(lane, s2, sec, t);
+
+    // staging: thread -> NI (key row, chunk) pieces of K and of V
+    bf16x8 kreg[NI], vreg[NI];
+    // staging: thread -> NI (key row, chunk) pieces of K and of V; per key block only the uniform bases move (SGPRs), the lane
+    // parts are two constants: byte offset from the block's first K row and byte offset into the LDS image
+    uint32_t goff[NI], loff[NI];
 #pragma unroll
-            for (int i = 3; i < 15; i += 2) mloc = fmaxf(fmaxf(mloc, st[i]), st[i + 1]);
-            mloc = fmaxf(mloc, st[15]);
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64)) * c1;
-            if (__any(mloc > m + RESCALE_THR)) {                 // some lane's maximum grew past the threshold: rescale the running sums
-                const float mnew = fmaxf(m, mloc);
-                const float alpha = fast_exp2(m - mnew);
-                l *= alpha;
+    for (int n = 0; n < NI; ++n) {
+        const int i = tid + n * NTHR;
+        goff[n] = (uint32_t)((i / (HD / 8)) * 3 * p.H * HD + (i % (HD / 8)) * 8) * 2u;
+        loff[n] = (uint32_t)Img<HD>::off(i / (HD / 8), i % (HD / 8));
+    }
+    auto load_kv = [&](int kb) {
+        const char* const kbase = reinterpret_cast<const char*>(p.qkv + (((int64_t)(t0 + kb) * 3 + 1) * p.H + h) * HD);
+        const char* const vbase = kbase + (int64_t)p.H * HD * 2;
+        const int nrow = len - kb;
 #pragma unroll
-                for (int t = 0; t < ND; ++t)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[t][i] *= alpha;
-                m = mnew;
+        for (int n = 0; n < NI; ++n) {
+            kreg[n] = zero8();
+            vreg[n] = zero8();
+            if ((tid + n * NTHR) / (HD / 8) < nrow) {
+                kreg[n] = *reinterpret_cast<const bf16x8*>(kbase + goff[n]);
+                vreg[n] = *reinterpret_cast<const bf16x8*>(vbase + goff[n]);
             }
-            const float negm = -m;
-            float psum = 0.f;
+        }
+    };
+    auto store_kv = [&](int buf) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {                       // masked scores (-1e30) give exp2(-huge) = 0 by themselves
-                pt[i] = fast_exp2(__builtin_fmaf(st[i], c1, negm));
-                psum += pt[i];
+        for (int n = 0; n < NI; ++n) {
+            LDS_AS char* dst = lds + buf * 2 * IMG + loff[n];
+            *reinterpret_cast<LDS_AS bf16x8*>(dst) = kreg[n];
+            *reinterpret_cast<LDS_AS bf16x8*>(dst + IMG) = vreg[n];
+        }
+    };
+
+    // the per-query operands have landed before the key loop starts: vmcnt is an in-order counter, so a first use of them
+    // inside the loop would also wait for the K / V prefetch issued just before it
+    __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0)
+    load_kv(0);
+    store_kv(0);
+    if (nkb > 1) load_kv(KTB);
+    __syncthreads();
+
+    for (int ib = 0; ib < nkb; ++ib) {
+        const int kb = ib * KTB;
+        LDS_AS const char* const kimg = lds + (ib & 1) * 2 * IMG;
+        LDS_AS const char* const vimg = kimg + IMG;
+
+        // One instantiation serves every step: the accumulators then live in the same registers on every path (two code paths
+        // - a one-tile and a two-tile step - made hipcc copy the 16 accumulator registers behind the last MFMA of each step, a
+        // full MFMA-pipeline drain per step).  An odd tile count (diagonal key block only) runs the second tile fully masked.
+        auto step = [&](auto NTc, int sub_a, int sub_b, bool b_on) {
+            constexpr int NT = decltype(NTc)::value;
+            const int sub[2] = {sub_a, sub_b};
+            f32x16 st[NT];
+            uint32_t dw[NT][4];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int ko = sub[n] * KT, k0 = kb + ko;
+                const float bias_b = hh == 0 ? 1.f : -sl * (float)(q - k0) - lse_c;
+                st[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bias_a, bias_b, zero16(), 0, 0, 0);
+                if (n == 0 || b_on) {
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+#if defined(ATTN_AB_NOQK)
+                        st[n][ks] += (float)qf[ks][0];
+#elif defined(ATTN_AB_NOKROW)
+                        st[n] = mfma(qf[KS - 1 - ks], qf[ks], st[n]);
+#else
+                        st[n] = mfma(lds_row(kimg + ko * ROWB + roff[ks]), qf[ks], st[n]);
+#endif
+                    }
+                }
             }
-            l += psum;
-            if (DROP) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) pt[i] = ((dw[i >> 2] >> (8 * (i & 3))) & 0xffu) < p.thr ? pt[i] : 0.f;
+            for (int n = 0; n < NT; ++n) {
+                const int k0 = kb + sub[n] * KT;
+                if ((k0 + KT - 1 > wq_lo) || (wq_hi >= len)) {   // tile crosses the diagonal / the sequence end (wave-uniform)
+                    int qm = q_ok && (n == 0 || b_on) ? q - k0 : -1;                 // opaque to the optimiser: it hoists the 16 compares of this rare
+                    asm volatile("" : "+v"(qm));                 // branch into every turn of the tile loop otherwise
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) st[n][i] = acc_row(i, hh) <= qm ? st[n][i] : NEG_BIG;                      // (key <= q < len)
+                }
+                if (DROP) {
+                    const uint32_t kbase = (uint32_t)(k0 >> 2) * DROP_CK;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) dw[n][g] = mix32(dq_word ^ (kbase + dk_off[g]));
+                }
+            }
+            f32x16 pt[NT];
+            if (MODE == 0) {
+                float mloc = fmaxf(fmaxf(st[0][0], st[0][1]), st[0][2]);
+#ifndef ATTN_AB_NOMAX
+#pragma unroll
+                for (int i = 3; i < 15; i += 2) mloc = fmaxf(fmaxf(mloc, st[0][i]), st[0][i + 1]);
+                mloc = fmaxf(mloc, st[0][15]);
+                if (NT == 2) {
+                    float m1 = fmaxf(fmaxf(st[NT - 1][0], st[NT - 1][1]), st[NT - 1][2]);
+#pragma unroll
+                    for (int i = 3; i < 15; i += 2) m1 = fmaxf(fmaxf(m1, st[NT - 1][i]), st[NT - 1][i + 1]);
+                    mloc = fmaxf(fmaxf(mloc, m1), st[NT - 1][15]);
+                }
+#endif
+#ifdef ATTN_AB_NOMAX
+                mloc = st[0][0] * c1;
+#else
+                mloc = half_max(mloc) * c1;
+#endif
+#ifdef ATTN_AB_NORESCALE
+                if (__any(mloc > m + 1e30f)) {
+#else
+                if (__any(mloc > m + RESCALE_THR)) {
+#endif             // some lane's maximum grew past the threshold: rescale the running sums
+                    const float mnew = fmaxf(m, mloc);
+                    const float alpha = fast_exp2(m - mnew);
+                    l *= alpha;
+#pragma unroll
+                    for (int t = 0; t < ND; ++t)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) acc[t][i] *= alpha;
+                    m = mnew;
+                }
+                const float negm = -m;
+                float ps[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {               // masked scores (-1e30) give exp2(-huge) = 0 by themselves
+#ifdef ATTN_AB_NOEXP
+                        pt[n][i] = __builtin_fmaf(st[n][i], c1, negm);
+#else
+                        pt[n][i] = fast_exp2(__builtin_fmaf(st[n][i], c1, negm));
+#endif
+#ifndef ATTN_AB_NOSUM
+                        ps[i & 3] += pt[n][i];
+#endif
+                    }
+                l += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+                if (DROP) {
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) pt[n][i] = ((dw[n][i >> 2] >> (8 * (i & 3))) & 0xffu) < p.thr ? pt[n][i] : 0.f;
+                }
+            } else {
+                // dP^T = V dO^T ; dS^T = P^T (dP^T - delta)   (the 1/sqrt(d) factor of dS is applied once, to dQ, in the epilogue)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const int ko = sub[n] * KT;
+                    f32x16 dp;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) dp[i] = DROP ? 0.f : -dlt;
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) dp = mfma(lds_row(vimg + ko * ROWB + roff[ks]), dof[ks], dp);
+                    if (DROP) {                                  // dP = mask / (1 - p) * (dO V^T), then - delta
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) dp[i] = (((dw[n][i >> 2] >> (8 * (i & 3))) & 0xffu) < p.thr ? dp[i] * p.rp : 0.f) - dlt;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) pt[n][i] = fast_exp2(st[n][i] * c1) * dp[i];
+                }
+            }
+            LDS_AS const char* const timg = MODE == 0 ? vimg : kimg;       // V^T (forward) / K^T (dQ) through transposed reads
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int ko = sub[n] * KT;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const bf16x8 bfr = acc_to_frag(pt[n], s2);
+#pragma unroll
+                    for (int t = 0; t < ND; ++t) {
+#if defined(ATTN_AB_NOPV)
+                        acc[t][4 * s2 + n] += pt[n][8 * s2] + (float)bfr[0];
+#elif defined(ATTN_AB_NOTR)
+                        acc[t] = mfma(qf[s2 % KS], bfr, acc[t]);
+#else
+                        acc[t] = mfma(lds_tr(timg + ko * ROWB + toff[s2][0][t], timg + ko * ROWB + toff[s2][1][t]), bfr, acc[t]);
+#endif
+                    }
+                }
+            }
+        };
+        auto valid = [&](int sub) { const int k0 = kb + sub * KT; return k0 <= wq_hi && k0 < nkeys; };      // wave-uniform
+        if (NTS == 2) {
+            // KSPL = 2: one step on the tiles {kh, kh + 2}; KSPL = 1: steps {0, 1}, {2, 3}
+#pragma unroll 1
+            for (int g = 0; g < 2 / KSPL; ++g) {
+                const int a = KSPL == 2 ? kh : 2 * g, b = KSPL == 2 ? kh + 2 : 2 * g + 1;
+                if (valid(a)) step(IntC<2>{}, a, b, valid(b));
             }
         } else {
-            // dP^T = V dO^T ; dS^T = P^T (dP^T - delta)   (the 1/sqrt(d) factor of dS is applied once, to dQ, in the epilogue)
-            f32x16 dp;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) dp[i] = DROP ? 0.f : -dlt;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-                dp = mfma(*reinterpret_cast<const bf16x8*>(&v_lds[ko + r][16 * ks + 8 * hh]), dof[ks], dp);
-            if (DROP) {                                          // dP = mask / (1 - p) * (dO V^T), then - delta
-#pragma unroll
-                for (int i = 0; i < 16; ++i) dp[i] = (((dw[i >> 2] >> (8 * (i & 3))) & 0xffu) < p.thr ? dp[i] * p.rp : 0.f) - dlt;
+#pragma unroll 1
+            for (int g = 0; g < 4 / KSPL; ++g) {
+                const int a = KSPL == 2 ? kh + 2 * g : g;
+                if (valid(a)) step(IntC<1>{}, a, a, true);
             }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) pt[i] = fast_exp2(st[i] * c1) * dp[i];
         }
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            const bf16x8 bfr = acc_to_frag(pt, s2);
-#pragma unroll
-            for (int t = 0; t < ND; ++t) acc[t] = mfma(tr_frag(&tr_lds[32 * t + r][ko], s2, hh), bfr, acc[t]);
+#ifndef ATTN_AB_NOSTAGE
+        if (ib + 1 < nkb) {
+            store_kv((ib + 1) & 1);                              // block i + 1 (loaded an iteration ago) -> the other buffer
+            if (ib + 2 < nkb) load_kv(kb + 2 * KTB);
         }
-      }
+        __syncthreads();
+#endif
+    }
+
+    // merge the key-split pair: the kh = 1 wave hands its statistics / accumulator to its kh = 0 partner through LDS
+    if (KSPL == 2) {
+        LDS_AS float* const cb = (LDS_AS float*)lds + (qt * (16 * ND + 2)) * 64 + lane;
+        if (kh == 1) {
+#pragma unroll
+            for (int t = 0; t < ND; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) cb[(16 * t + i) * 64] = acc[t][i];
+            cb[16 * ND * 64] = m;
+            cb[(16 * ND + 1) * 64] = l;
+        }
+        __syncthreads();
+        if (kh == 1) return;
+        if (MODE == 0) {
+            const float m1 = cb[16 * ND * 64], l1 = cb[(16 * ND + 1) * 64];
+            const float mn = fmaxf(m, m1);
+            const float a0 = fast_exp2(m - mn), a1 = fast_exp2(m1 - mn);
+            l = l * a0 + l1 * a1;
+#pragma unroll
+            for (int t = 0; t < ND; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[t][i] = acc[t][i] * a0 + cb[(16 * t + i) * 64] * a1;
+            m = mn;
+        } else {
+#pragma unroll
+            for (int t = 0; t < ND; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[t][i] += cb[(16 * t + i) * 64];
+        }
     }
     // epilogue: acc[t][reg] = X^T[d = 32t + row(reg)][q]
     float inv = MODE == 1 ? p.scale : 1.f;
     if (MODE == 0) {
-        const float ltot = l + __shfl_xor(l, 32, 64);
+        const float ltot = half_sum(l);
         inv = ltot > 0.f ? (DROP ? p.rp : 1.f) / ltot : 0.f;
         if (q_ok && hh == 0) p.lse[(int64_t)h * p.T + t0 + q] = m + __log2f(fmaxf(ltot, 1e-37f));
     }
@@ -346,23 +587,40 @@ __global__ void attn_delta_kernel(const bf16_t* __restrict__ out, const bf16_t* 
 }
 
 // ------------------------------------------------------------------------------------------------- dK / dV
+// Workgroup = 128 keys x 4 waves: wave w owns the keys [k0 + 32 w, +32) - K and V fragments of its keys stay in registers as B
+// operands for the whole launch, dK^T / dV^T of its keys in its accumulators (no cross-wave reduction).  The query side
+// streams through LDS in blocks of 128 queries, double-buffered (one barrier per block), from the diagonal block to the end of
+// the sequence: Q and dO as swizzled row-major images (row reads feed S = Q K^T and dP = dO V^T, transposed reads of the SAME
+// images feed dV^T = dO^T P and dK^T = Q^T dS), plus one fp32 value pair per query: -(slope q + lse) / c1 (ALiBi row part and
+// log-sum-exp folded into the score accumulator's initial value) and -delta (initial value of dP).
 template <int HD, bool DROP>
 __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnParams p) {
-    constexpr int KS = HD / 16, ND = HD / 32;
-    __shared__ __attribute__((aligned(16))) bf16_t qT[4][HD][KT + PADE];       // per-wave transposed Q tile  [d][q]
-    __shared__ __attribute__((aligned(16))) bf16_t doT[4][HD][KT + PADE];      // per-wave transposed dO tile [d][q]
-    __shared__ float s_red[4][2 * ND][16][64];
-    __shared__ float s_lse[4][KT], s_dlt[4][KT];               // per-wave lse / delta of the query tile (one coalesced load)
-    const int s = blockIdx.y, h = blockIdx.z;
+    constexpr int KS = HD / 16, ND = HD / 32, NTHR = 256;
+    constexpr int ROWB = HD * 2, IMG = KTB * ROWB;
+    constexpr int NI = KTB * HD / 8 / NTHR;                      // 16-byte pieces of Q (and of dO) per thread and query block
+    constexpr int BUF = 2 * IMG + 2 * KTB * 4;                   // Q image | dO image | comb[128] | -delta[128]
+    __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+    LDS_AS char* const lds = (LDS_AS char*)smem;
+
+    // 1-D grid, XCD-aware as in attn_q_kernel; key block 0 sees every query block (longest): ascending order = longest first
+    const int nkb = p.nqb;
+    const int jb = blockIdx.x >> 3;
+    const int pair = (jb / nkb) * 8 + (blockIdx.x & 7);
+    if (pair >= p.S * p.H) return;
+    const int h = pair % p.H, s = pair / p.H;
     const int t0 = p.cu[s], len = p.cu[s + 1] - t0;
-    const int k0 = blockIdx.x * KT;
-    if (k0 >= len) return;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int kb0 = (jb % nkb) * KTB;
+    if (kb0 >= len) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
+    const int k0 = kb0 + w * KT;                                 // this wave's keys
     const int key = k0 + r;
     const bool k_ok = key < len;
+    const bool w_on = k0 < len;                                  // a wave past the sequence end only stages
     const float c1 = p.scale * RESEL_LOG2E;
     const float slope2 = (p.slopes ? p.slopes[h] : 0.f) * RESEL_LOG2E;
+    const float inv_c1 = 1.f / c1;
     bf16x8 kf[KS], vf[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -376,12 +634,7 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnParams p) {
     f32x16 dkt[ND], dvt[ND];
 #pragma unroll
     for (int t = 0; t < ND; ++t) { dkt[t] = zero16(); dvt[t] = zero16(); }
-    // as in attn_q_kernel the accumulators start from the row constants (raw units): ALiBi -slope (q - key) = -slope row(i) -
-    // slope (q0 - key), -lse of the query row (staged per tile as -lse / c1) for the scores and -delta for dP
-    const float inv_c1 = 1.f / c1;
-    float crow[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) crow[i] = -slope2 * inv_c1 * (float)acc_row(i, hh);
+    const float lane_c = slope2 * inv_c1 * (float)key;           // ALiBi -slope (q - key): the key part (the query part is staged)
     // dropout: the word of (query row, this lane's key quad) serves the four lanes of a quad, one byte each; a lane
     // hashes the rows with (row & 3) == (lane & 3) and the quad exchanges them by DPP
     uint32_t dk_word = 0, dq_off[4] = {0, 0, 0, 0};
@@ -391,126 +644,163 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnParams p) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) dq_off[g] = (uint32_t)((r & 3) + 8 * g + 4 * hh) * DROP_CQ;
     }
-    const int nqt = (len + KT - 1) / KT;
-    const int qt_first = k0 / KT;                                // first query tile that can see these keys
-    const int niter = (nqt - qt_first + 3) / 4;
-    for (int it = 0; it < niter; ++it) {
-        const int qt = qt_first + it * 4 + w;
-        const bool active = qt < nqt;
-        const int q0 = qt * KT;
-        const int qa = q0 + r;                                   // the query this lane loads as an A-operand row
-        bf16x8 qa_f[KS], doa_f[KS];
+    int roff[KS], toff[2][ND];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            qa_f[ks] = zero8();
-            doa_f[ks] = zero8();
-            if (active && qa < len) {
-                qa_f[ks] = *reinterpret_cast<const bf16x8*>(p.qkv + (((int64_t)(t0 + qa) * 3 + 0) * p.H + h) * HD + 16 * ks + 8 * hh);
-                doa_f[ks] = *reinterpret_cast<const bf16x8*>(p.dout + ((int64_t)(t0 + qa) * p.H + h) * HD + 16 * ks + 8 * hh);
+    for (int ks = 0; ks < KS; ++ks) roff[ks] = Img<HD>::row_off(r, hh, ks);
+#pragma unroll
+    for (int sec = 0; sec < 2; ++sec)
+#pragma unroll
+        for (int t = 0; t < ND; ++t) toff[sec][t] = Img<HD>::tr_off(lane, 0, sec, t);     // k-step s2: + 16 s2 rows (swz does not see them)
+
+    // staging: thread -> NI (query row, chunk) pieces of Q and of dO, and one of the 256 per-query floats
+    bf16x8 qreg[NI], oreg[NI];
+    float freg;
+    uint32_t gq[NI], go[NI], loff[NI];
+#pragma unroll
+    for (int n = 0; n < NI; ++n) {
+        const int i = tid + n * NTHR;
+        gq[n] = (uint32_t)((i / (HD / 8)) * 3 * p.H * HD + (i % (HD / 8)) * 8) * 2u;
+        go[n] = (uint32_t)((i / (HD / 8)) * p.H * HD + (i % (HD / 8)) * 8) * 2u;
+        loff[n] = (uint32_t)Img<HD>::off(i / (HD / 8), i % (HD / 8));
+    }
+    const int frow = tid & (KTB - 1);
+    auto load_q = [&](int qb) {
+        const char* const qbase = reinterpret_cast<const char*>(p.qkv + ((int64_t)(t0 + qb) * 3 * p.H + h) * HD);
+        const char* const obase = reinterpret_cast<const char*>(p.dout + ((int64_t)(t0 + qb) * p.H + h) * HD);
+        const int nrow = len - qb;
+#pragma unroll
+        for (int n = 0; n < NI; ++n) {
+            qreg[n] = zero8();
+            oreg[n] = zero8();
+            if ((tid + n * NTHR) / (HD / 8) < nrow) {
+                qreg[n] = *reinterpret_cast<const bf16x8*>(qbase + gq[n]);
+                oreg[n] = *reinterpret_cast<const bf16x8*>(obase + go[n]);
             }
         }
-        float l2q = 0.f, dlq = 0.f;
-        if (active && hh == 0 && qa < len) {
-            l2q = p.lse[(int64_t)h * p.T + t0 + qa];
-            dlq = p.delta[(int64_t)h * p.T + t0 + qa];
+        freg = 0.f;
+        if (frow < nrow) {
+            const int64_t at = (int64_t)h * p.T + t0 + qb + frow;
+            freg = tid < KTB ? -(slope2 * (float)(qb + frow) + p.lse[at]) * inv_c1 : -p.delta[at];
         }
-        __syncthreads();                                         // previous iteration's transposed tiles fully consumed
-        if (hh == 0) { s_lse[w][r] = -l2q * inv_c1; s_dlt[w][r] = -dlq; }
+    };
+    auto store_q = [&](int buf) {
+        LDS_AS char* const base = lds + buf * BUF;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                qT[w][16 * ks + 8 * hh + e][r] = qa_f[ks][e];
-                doT[w][16 * ks + 8 * hh + e][r] = doa_f[ks][e];
-            }
-        __syncthreads();
-        if (!active) continue;
-        const float offk = -slope2 * inv_c1 * (float)(q0 - key);
-        f32x16 sacc, dp;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = acc_row(i, hh);
-            sacc[i] = crow[i] + offk + s_lse[w][row];
-            dp[i] = DROP ? 0.f : s_dlt[w][row];
+        for (int n = 0; n < NI; ++n) {
+            *reinterpret_cast<LDS_AS bf16x8*>(base + loff[n]) = qreg[n];
+            *reinterpret_cast<LDS_AS bf16x8*>(base + IMG + loff[n]) = oreg[n];
         }
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            sacc = mfma(qa_f[ks], kf[ks], sacc);                 // S[q][key] (+ ALiBi - lse, raw units)
-            dp = mfma(doa_f[ks], vf[ks], dp);                    // dP[q][key] - delta
-        }
-        f32x16 pm, ds;
-        bool keep[16];
-        if (DROP) {
-            const uint32_t qbase = (uint32_t)(t0 + q0) * DROP_CQ;
-            uint32_t mine[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) mine[g] = mix32((qbase + dq_off[g]) ^ dk_word);
+        *reinterpret_cast<LDS_AS float*>(base + 2 * IMG + tid * 4) = freg;
+    };
+
+    const int nblk = (len - kb0 + KTB - 1) / KTB;                // query blocks from the diagonal one to the end of the sequence
+    __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0): K / V fragments landed (see attn_q_kernel)
+    load_q(kb0);
+    store_q(0);
+    if (nblk > 1) load_q(kb0 + KTB);
+    __syncthreads();
+
+    for (int ib = 0; ib < nblk; ++ib) {
+        const int qb = kb0 + ib * KTB;
+        LDS_AS const char* const qimg = lds + (ib & 1) * BUF;
+        LDS_AS const char* const oimg = qimg + IMG;
+        LDS_AS const float* const comb = reinterpret_cast<LDS_AS const float*>(qimg + 2 * IMG);
+        LDS_AS const float* const sdl = comb + KTB;
+#pragma unroll 1
+        for (int sub = 0; sub < KTB / KT; ++sub) {
+            const int ro = sub * KT, q0 = qb + ro;
+            if (!w_on || q0 + KT - 1 < k0 || q0 >= len) continue;        // wave-uniform: tile before the diagonal / past the end
+            f32x16 sacc, dp;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                keep[4 * g + 0] = ((quad_bcast<0>(mine[g]) >> dsh) & 0xffu) < p.thr;
-                keep[4 * g + 1] = ((quad_bcast<1>(mine[g]) >> dsh) & 0xffu) < p.thr;
-                keep[4 * g + 2] = ((quad_bcast<2>(mine[g]) >> dsh) & 0xffu) < p.thr;
-                keep[4 * g + 3] = ((quad_bcast<3>(mine[g]) >> dsh) & 0xffu) < p.thr;
+                const f32x4 cv = *reinterpret_cast<LDS_AS const f32x4*>(comb + ro + 8 * g + 4 * hh);
+                const f32x4 dv = *reinterpret_cast<LDS_AS const f32x4*>(sdl + ro + 8 * g + 4 * hh);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    sacc[4 * g + e] = cv[e] + lane_c;
+                    dp[4 * g + e] = DROP ? 0.f : dv[e];
+                }
             }
 #pragma unroll
-            for (int i = 0; i < 16; ++i) dp[i] = (keep[i] ? dp[i] * p.rp : 0.f) + s_dlt[w][acc_row(i, hh)];
-        }
-        const bool masked = (q0 < k0 + KT - 1) || (q0 + KT > len) || (k0 + KT > len);      // diagonal tile or ragged end (wave-uniform)
-        if (masked) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int qq = q0 + acc_row(i, hh);
-                const bool ok = k_ok && qq < len && key <= qq;
-                const float e = ok ? fast_exp2(sacc[i] * c1) : 0.f;
-                pm[i] = e;
-                ds[i] = e * dp[i];
+            for (int ks = 0; ks < KS; ++ks) {
+                sacc = mfma(lds_row(qimg + ro * ROWB + roff[ks]), kf[ks], sacc);          // S[q][key] (+ ALiBi - lse, raw units)
+                dp = mfma(lds_row(oimg + ro * ROWB + roff[ks]), vf[ks], dp);              // dP[q][key] - delta
             }
-        } else {
+            f32x16 pm, ds;
+            bool keep[16];
+            if (DROP) {
+                const uint32_t qbase = (uint32_t)(t0 + q0) * DROP_CQ;
+                uint32_t mine[4];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float e = fast_exp2(sacc[i] * c1);
-                pm[i] = e;
-                ds[i] = e * dp[i];
+                for (int g = 0; g < 4; ++g) mine[g] = mix32((qbase + dq_off[g]) ^ dk_word);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    keep[4 * g + 0] = ((quad_bcast<0>(mine[g]) >> dsh) & 0xffu) < p.thr;
+                    keep[4 * g + 1] = ((quad_bcast<1>(mine[g]) >> dsh) & 0xffu) < p.thr;
+                    keep[4 * g + 2] = ((quad_bcast<2>(mine[g]) >> dsh) & 0xffu) < p.thr;
+                    keep[4 * g + 3] = ((quad_bcast<3>(mine[g]) >> dsh) & 0xffu) < p.thr;
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 dv = *reinterpret_cast<LDS_AS const f32x4*>(sdl + ro + 8 * g + 4 * hh);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dp[4 * g + e] = (keep[4 * g + e] ? dp[4 * g + e] * p.rp : 0.f) + dv[e];
+                }
+            }
+            if ((q0 < k0 + KT - 1) || (q0 + KT > len) || (k0 + KT > len)) {              // diagonal tile or ragged end (wave-uniform)
+                int km = k_ok ? key - q0 : 1 << 20;              // opaque to the optimiser (see attn_q_kernel)
+                int qn = len - q0;
+                asm volatile("" : "+v"(km), "+s"(qn));
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int row = acc_row(i, hh);
+                    const float e = (row >= km && row < qn) ? fast_exp2(sacc[i] * c1) : 0.f;      // key <= q < len
+                    pm[i] = e;
+                    ds[i] = e * dp[i];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float e = fast_exp2(sacc[i] * c1);
+                    pm[i] = e;
+                    ds[i] = e * dp[i];
+                }
+            }
+            if (DROP) {                                          // dV sees the dropped, rescaled probabilities
+#pragma unroll
+                for (int i = 0; i < 16; ++i) pm[i] = keep[i] ? pm[i] * p.rp : 0.f;
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pb = acc_to_frag(pm, s2), dsb = acc_to_frag(ds, s2);
+                const int so = (ro + 16 * s2) * ROWB;
+#pragma unroll
+                for (int t = 0; t < ND; ++t) {
+                    dvt[t] = mfma(lds_tr(oimg + so + toff[0][t], oimg + so + toff[1][t]), pb, dvt[t]);     // dV^T[d][key] += dO^T[d][q] P[q][key]
+                    dkt[t] = mfma(lds_tr(qimg + so + toff[0][t], qimg + so + toff[1][t]), dsb, dkt[t]);    // dK^T[d][key] += Q^T[d][q] dS[q][key]
+                }
             }
         }
-        if (DROP) {                                              // dV sees the dropped, rescaled probabilities
-#pragma unroll
-            for (int i = 0; i < 16; ++i) pm[i] = keep[i] ? pm[i] * p.rp : 0.f;
+        if (ib + 1 < nblk) {
+            store_q((ib + 1) & 1);
+            if (ib + 2 < nblk) load_q(qb + 2 * KTB);
         }
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            const bf16x8 pb = acc_to_frag(pm, s2), dsb = acc_to_frag(ds, s2);
-#pragma unroll
-            for (int t = 0; t < ND; ++t) {
-                dvt[t] = mfma(tr_frag(&doT[w][32 * t + r][0], s2, hh), pb, dvt[t]);     // dV^T[d][key] += dO^T[d][q] P[q][key]
-                dkt[t] = mfma(tr_frag(&qT[w][32 * t + r][0], s2, hh), dsb, dkt[t]);     // dK^T[d][key] += Q^T[d][q] dS[q][key]
-            }
-        }
+        __syncthreads();
     }
-    // sum the four waves' partial accumulators, then store dK / dV rows
-    __syncthreads();
+    // epilogue: dkt / dvt [t][reg] = X^T[d = 32 t + row(reg)][key]
+    if (k_ok) {
 #pragma unroll
-    for (int t = 0; t < ND; ++t)
+        for (int which = 1; which <= 2; ++which) {
+            bf16_t* dst = p.dqkv + (((int64_t)(t0 + key) * 3 + which) * p.H + h) * HD;
+            const float sc = which == 1 ? p.scale : 1.f;         // dK carries the 1/sqrt(d) of dS
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            s_red[w][t][i][lane] = dkt[t][i];
-            s_red[w][ND + t][i][lane] = dvt[t][i];
-        }
-    __syncthreads();
-    for (int pair = w; pair < 2 * ND; pair += 4) {
-        const int which = pair < ND ? 1 : 2, t = pair < ND ? pair : pair - ND;
-        if (!k_ok) continue;
-        bf16_t* dst = p.dqkv + (((int64_t)(t0 + key) * 3 + which) * p.H + h) * HD + 32 * t;
+            for (int t = 0; t < ND; ++t)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int i = 4 * g + e;
-                v[e] = ((s_red[0][pair][i][lane] + s_red[1][pair][i][lane]) + (s_red[2][pair][i][lane] + s_red[3][pair][i][lane])) *
-                       (which == 1 ? p.scale : 1.f);                  // dK carries the 1/sqrt(d) of dS
-            }
-            *reinterpret_cast<bf16x4*>(dst + 8 * g + 4 * hh) = __builtin_convertvector(v, bf16x4);
+                for (int g = 0; g < 4; ++g) {
+                    const f32x16& x = which == 1 ? dkt[t] : dvt[t];
+                    const f32x4 v = {x[4 * g] * sc, x[4 * g + 1] * sc, x[4 * g + 2] * sc, x[4 * g + 3] * sc};
+                    *reinterpret_cast<bf16x4*>(dst + 32 * t + 8 * g + 4 * hh) = __builtin_convertvector(v, bf16x4);
+                }
         }
     }
 }
@@ -527,13 +817,14 @@ inline void set_dropout(AttnParams& p, float p_drop, uint64_t seed, uint64_t off
 
 template <int HD, bool DROP>
 void launch_fwd(const AttnParams& p, dim3 grid, hipStream_t s) {
-    launch_timed(RESEL_PROF_ATTN_FWD, attn_q_kernel<HD, 0, DROP>, grid, dim3(256), 0, s, p);
+    constexpr int KSPL = HD == 32 ? 2 : 1;
+    launch_timed(RESEL_PROF_ATTN_FWD, attn_q_kernel<HD, 0, DROP, KSPL>, grid, dim3(256 * KSPL), 0, s, p);
 }
 template <int HD, bool DROP>
 void launch_bwd(const AttnParams& p, const bf16_t* out, dim3 gq, dim3 gk, hipStream_t s) {
     const int n = p.T * p.H;
     hipLaunchKernelGGL(attn_delta_kernel<HD>, dim3((n + 255) / 256), dim3(256), 0, s, out, p.dout, const_cast<float*>(p.delta), p.T, p.H);
-    launch_timed(RESEL_PROF_ATTN_DQ, attn_q_kernel<HD, 1, DROP>, gq, dim3(256), 0, s, p);
+    launch_timed(RESEL_PROF_ATTN_DQ, attn_q_kernel<HD, 1, DROP, 1>, gq, dim3(256), 0, s, p);
     launch_timed(RESEL_PROF_ATTN_DKV, attn_dkv_kernel<HD, DROP>, gk, dim3(256), 0, s, p);
 }
 
@@ -543,9 +834,10 @@ extern "C" int resel_attn_varlen_fwd(const uint16_t* qkv, const int32_t* cu_seql
                                      int T, int S, int H, int hd, int max_seqlen, float scale,
                                      float p_drop, uint64_t seed, uint64_t offset, resel_stream_t stream) {
     if (!qkv || !cu_seqlens || !out || !lse || !attn_ok(T, S, H, hd, max_seqlen, p_drop) || !aligned16(qkv) || !aligned16(out)) return RESEL_EINVAL;
-    AttnParams p{(const bf16_t*)qkv, cu_seqlens, slopes, (bf16_t*)out, lse, nullptr, nullptr, nullptr, T, S, H, scale, 256u, 1.f, 0, 0};
+    AttnParams p{(const bf16_t*)qkv, cu_seqlens, slopes, (bf16_t*)out, lse, nullptr, nullptr, nullptr, T, S, H, 0, scale, 256u, 1.f, 0, 0};
     set_dropout(p, p_drop, seed, offset);
-    dim3 grid((max_seqlen + 127) / 128, S, H);
+    p.nqb = (max_seqlen + 127) / 128;
+    dim3 grid((S * H + 7) / 8 * 8 * p.nqb);
     hipStream_t s = (hipStream_t)stream;
     const bool drop = p_drop > 0.f;
     if (hd == 32) { if (drop) launch_fwd<32, true>(p, grid, s); else launch_fwd<32, false>(p, grid, s); }
@@ -565,11 +857,12 @@ extern "C" int resel_attn_varlen_bwd(const uint16_t* qkv, const int32_t* cu_seql
     if (!qkv || !cu_seqlens || !out || !lse || !dout || !dqkv || !workspace || !attn_ok(T, S, H, hd, max_seqlen, p_drop)) return RESEL_EINVAL;
     if (!aligned16(qkv) || !aligned16(out) || !aligned16(dout) || !aligned16(dqkv)) return RESEL_EINVAL;
     float* delta = (float*)workspace;
-    AttnParams p{(const bf16_t*)qkv, cu_seqlens, slopes, nullptr, const_cast<float*>(lse), (const bf16_t*)dout, delta, (bf16_t*)dqkv, T, S, H, scale,
+    AttnParams p{(const bf16_t*)qkv, cu_seqlens, slopes, nullptr, const_cast<float*>(lse), (const bf16_t*)dout, delta, (bf16_t*)dqkv, T, S, H, 0, scale,
                  256u, 1.f, 0, 0};
     set_dropout(p, p_drop, seed, offset);
     hipStream_t s = (hipStream_t)stream;
-    dim3 gq((max_seqlen + 127) / 128, S, H), gk((max_seqlen + KT - 1) / KT, S, H);
+    p.nqb = (max_seqlen + 127) / 128;
+    dim3 gq((S * H + 7) / 8 * 8 * p.nqb), gk((S * H + 7) / 8 * 8 * p.nqb);
     const bool drop = p_drop > 0.f;
     if (hd == 32) { if (drop) launch_bwd<32, true>(p, (const bf16_t*)out, gq, gk, s); else launch_bwd<32, false>(p, (const bf16_t*)out, gq, gk, s); }
     else          { if (drop) launch_bwd<64, true>(p, (const bf16_t*)out, gq, gk, s); else launch_bwd<64, false>(p, (const bf16_t*)out, gq, gk, s); }

@@ -21,3 +21,14 @@ for _ in range(20):
         ops.attn_varlen(qkv, cu, max(lens), slopes)
 b.record(); torch.cuda.synchronize()
 print(f'fwd {a.elapsed_time(b) / 20 * 1e3:.1f} us')
+# per-kernel averages (HIP events around each dispatch), without and with attention-probability dropout
+for p_drop in (0.0, 0.1):
+    ops.profile_enable(True); ops.profile_collect()
+    for _ in range(10):
+        out = ops.attn_varlen(qkv, cu, max(lens), slopes, p_drop=p_drop, seed=7)
+        out.backward(torch.ones_like(out))
+    torch.cuda.synchronize()
+    prof = ops.profile_collect(); ops.profile_enable(False)
+    flops = 2.0 * 1026 ** 2 * rows * H * hd          # one product over the causal half, x2 products
+    print(f'p_drop {p_drop}: ' + '  '.join(f'{k[5:-7]} {v[1]:.1f} us ({flops * m / v[1] * 1e-6:.0f} TF/s)'
+                                        for (k, v), m in zip(sorted(prof.items(), key=lambda kv: ('fwd', 'dq', 'dkv').index(kv[0][5:-7])), (1, 1.5, 2))))
