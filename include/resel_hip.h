@@ -182,16 +182,20 @@ int resel_gru_seq_bwd(const float* w_hh, const float* h0, const float* h_all, co
  * qkv: [T, 3, H, hd] bf16 packed tokens (q | k | v); cu_seqlens: int32 [S + 1] device; slopes: [H] fp32 or NULL;
  * out: [T, H, hd] bf16; lse: [H, T] fp32 (base-2 log-sum-exp, saved for the backward).  hd in {32, 64}; max_seqlen bounds
  * the grid.  Backward: dqkv [T, 3, H, hd] bf16 (fully overwritten); workspace resel_attn_varlen_bwd_workspace_bytes().
+ * Forward workspace (resel_attn_varlen_fwd_workspace_bytes(), may be NULL): holds the device-built work list - the real
+ * (sequence, 128-token block) items of the ragged batch, longest first - that the kernels' workgroups take their work from;
+ * without it they run in (sequence, block) order, which is slower on ragged batches.  Results do not depend on it.
  * Attention-probability dropout (MHA(dropout=p), TransformerFlashAttention.py:67-70, active in .train() passes): p_drop in
  * [0, 1); the keep mask is a counter function of (seed, offset, head, packed query token, key position) - no state, the
  * backward regenerates it from the same (seed, offset).  8-bit keep threshold floor((1 - p) * 255) + 1 and the 1 / (1 - p)
  * rescale as in flash-attn; the counter function itself is this library's (oracle/kernels.py `attn_dropout_keep`).
  * p_drop == 0 runs the dropout-free kernels.
  */
+size_t resel_attn_varlen_fwd_workspace_bytes(int S, int max_seqlen);
 int resel_attn_varlen_fwd(const uint16_t* qkv, const int32_t* cu_seqlens, const float* slopes, uint16_t* out, float* lse,
-                          int T, int S, int H, int hd, int max_seqlen, float scale,
+                          void* workspace, int T, int S, int H, int hd, int max_seqlen, float scale,
                           float p_drop, uint64_t seed, uint64_t offset, resel_stream_t stream);
-size_t resel_attn_varlen_bwd_workspace_bytes(int T, int H, int hd);
+size_t resel_attn_varlen_bwd_workspace_bytes(int T, int S, int H, int hd, int max_seqlen);
 int resel_attn_varlen_bwd(const uint16_t* qkv, const int32_t* cu_seqlens, const float* slopes, const uint16_t* out,
                           const float* lse, const uint16_t* dout, uint16_t* dqkv, void* workspace,
                           int T, int S, int H, int hd, int max_seqlen, float scale,

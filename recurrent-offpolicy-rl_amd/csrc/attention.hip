@@ -100,10 +100,12 @@ struct AttnParams {
     bf16_t* out;
     float* lse;                 // [H, T] base-2 log-sum-exp of the scaled + biased scores
     const bf16_t* dout;
-    const float* delta;         // [H, T]
+    const float* delta;         // [H, T]  MINUS delta = -sum_d dO O (backward pre-pass)
+    const float* comb;          // [H, T]  -(slope_h q + lse) / (scale log2 e): the score accumulator's per-query start value (dK/dV kernel)
     bf16_t* dqkv;
     int T, S, H;
-    int nqb;                    // query blocks per sequence in the attn_q_kernel grid
+    int nqb;                    // 128-token blocks of the longest sequence (grid bound)
+    const uint32_t* wl;         // work list (attn_worklist): [0] = items, then (sequence << 16 | level), longest first; NULL: static order
     float scale;
     uint32_t thr;               // dropout: keep iff random byte < thr (256 = keep all)
     float rp;                   // 1 / (1 - p)
@@ -167,6 +169,62 @@ __device__ __forceinline__ void store_kv(const KVRegs<HD>& r, int tid, bf16_t (*
     }
 }
 
+// ------------------------------------------------------------------------------------------------- work list
+// Causal attention over a ragged batch is a set of very unequal workgroups: the block of 128 queries (keys, in the dK/dV kernel)
+// number b of a sequence streams b + 1 (blocks - b) blocks of the other side.  A grid in (sequence, block) order runs short and
+// long ones as they come and idles most of the chip behind the last long ones; empty blocks of short sequences in front of real
+// ones cost dispatch slots.  The work list holds exactly the real (sequence, block) items, LONGEST FIRST within chunks of
+// WL_CHUNK consecutive sequences (level k = blocks streamed: every sequence with >= k blocks has one item per level), so the
+// dispatcher - which hands workgroups out in id order to whichever CU has room - does longest-processing-time-first scheduling.
+// Chunks, not the whole batch: the blocks of one (sequence, head) re-read the same K / V rows, and with every sequence's long
+// blocks in flight at once those rows fall out of the L2 between uses (128 sequences of 1026: dQ 20 % slower than in sequence
+// order).  Built on the device from cu_seqlens by one wave (ballot ranks: the order is deterministic).
+constexpr int WL_MAX_LEVELS = 1024;
+constexpr int WL_CHUNK = 32;
+__global__ __launch_bounds__(64) void attn_worklist_kernel(const int32_t* __restrict__ cu, int S, int nlev, uint32_t* __restrict__ wl) {
+    const int lane = threadIdx.x;
+    uint32_t run = 0;
+    for (int c0 = 0; c0 < S; c0 += WL_CHUNK) {
+        const int s = c0 + lane;
+        const int nb = (lane < WL_CHUNK && s < S) ? min((cu[s + 1] - cu[s] + KTB - 1) / KTB, nlev) : 0;
+        int kmax = nb;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) kmax = max(kmax, __shfl_xor(kmax, d, 64));
+        for (int k = kmax; k >= 1; --k) {
+            const uint64_t m = __ballot(nb >= k);
+            if (nb >= k) wl[1 + run + __popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)s << 16) | (uint32_t)k;
+            run += (uint32_t)__popcll(m);
+        }
+    }
+    if (lane == 0) wl[0] = run;
+}
+inline bool worklist_ok(int S, int max_seqlen) { return S < 65536 && (max_seqlen + KTB - 1) / KTB <= WL_MAX_LEVELS; }
+inline size_t worklist_bytes(int S, int max_seqlen) {
+    return worklist_ok(S, max_seqlen) ? ((size_t)S * ((max_seqlen + KTB - 1) / KTB) + 1) * sizeof(uint32_t) : 0;
+}
+
+// workgroup id -> (sequence, head, level).  XCD-aware: consecutive ids go round the 8 XCDs, so head h runs on XCD h % 8 for every
+// sequence - the blocks of one (sequence, head), which all read the same K / V (Q / dO) rows, share one L2.  With a work list the
+// items follow in its order; without, (sequence, block) order with each sequence's longest block first.  false: nothing to do.
+__device__ __forceinline__ bool attn_block(const AttnParams& p, int& s, int& h, int& level) {
+    const int hg = (p.H + 7) >> 3;
+    const int j = blockIdx.x >> 3;
+    h = (j % hg) * 8 + (blockIdx.x & 7);
+    if (h >= p.H) return false;
+    const int item = j / hg;
+    if (p.wl != nullptr) {
+        if ((uint32_t)item >= p.wl[0]) return false;
+        const uint32_t e = p.wl[1 + item];
+        s = (int)(e >> 16);
+        level = (int)(e & 0xffffu);
+    } else {
+        s = item / p.nqb;
+        level = p.nqb - item % p.nqb;
+        if ((level - 1) * KTB >= p.cu[s + 1] - p.cu[s]) return false;
+    }
+    return true;
+}
+
 // ------------------------------------------------------------------------------------------------- forward / dQ
 // Swizzled row-major LDS image of a [rows][HD] bf16 tile.  ONE image serves both operand forms (guide T10):
 //   * row reads  (ds_read_b128: lane (r, hh) takes row r, 16-byte chunk 2 ks + hh) - the A operand of S^T = K Q^T, dP^T = V dO^T;
@@ -213,6 +271,26 @@ __device__ __forceinline__ float half_max(float x) { float a, b; halves(x, a, b)
 __device__ __forceinline__ float half_sum(float x) { float a, b; halves(x, a, b); return a + b; }
 
 template <int V> struct IntC { static constexpr int value = V; };
+// Asynchronous global -> LDS copies (global_load_lds_dwordx4 / _dword): the LDS address is the wave-uniform base (M0) + lane * size.
+// Inline assembly on purpose: hipcc guards every LDS read that may alias a builtin copy's destination with s_waitcnt vmcnt(0);
+// written this way the copies are invisible to its counters and the kernel retires them itself with vm_wait<N>().
+__device__ __forceinline__ void glds16(const char* g, LDS_AS char* lds_wave_base) {
+    const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(l) : "memory");
+}
+__device__ __forceinline__ void glds4(const float* g, LDS_AS char* lds_wave_base) {
+    const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(l) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void vm_wait() {                      // s_waitcnt vmcnt(N) only (expcnt / lgkmcnt left alone)
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 __device__ __forceinline__ float sgpr(float x) {                 // a wave-uniform value, held in a scalar register
     return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));
 }
@@ -229,27 +307,34 @@ __device__ __forceinline__ float sgpr(float x) {                 // a wave-unifo
 // branch), the accumulator is rescaled only when some lane's running maximum actually moved, and the forward takes two
 // tiles per step (one maximum exchange / rescale test / loop turn per 64 keys, two independent MFMA chains in flight).
 template <int HD, int MODE, bool DROP, int KSPL>
+#ifdef ATTN_AB_OCC5
+__global__ __launch_bounds__(256 * KSPL, HD == 32 && MODE == 0 && !DROP ? 5 : 1) void attn_q_kernel(AttnParams p) {
+#else
 __global__ __launch_bounds__(256 * KSPL, KSPL == 2 && HD == 32 ? 4 : 1) void attn_q_kernel(AttnParams p) {
+#endif
     constexpr int KS = HD / 16, ND = HD / 32, NTHR = 256 * KSPL;
     constexpr int ROWB = HD * 2, IMG = KTB * ROWB;
     constexpr int NI = KTB * HD / 8 / NTHR;                      // 16-byte pieces of K (and of V) per thread and key block
+#ifdef ATTN_AB_NT1
+    constexpr int NTS = 1;
+#else
     constexpr int NTS = MODE == 0 ? 2 : 1;                       // tiles per step
+#endif
     static_assert(NI >= 1 && KTB / KT == 4, "staging split");
     constexpr int COMB = 4 * 64 * (16 * ND + 2) * 4;             // merge buffer of the key-split pairs (aliases the images)
-    static_assert(KSPL == 1 || COMB <= 4 * IMG, "merge buffer");
-    __shared__ __attribute__((aligned(16))) char smem[4 * IMG];  // [buffer][K image | V image]
+    static_assert(KSPL == 1 || COMB <= 4 * IMG, "merge buffer");     // NBUF * 2 * IMG >= 4 * IMG
+#ifdef ATTN_AB_NBUF3
+    constexpr int NBUF = 3;                                      // one barrier per key block, but 48 KB: 3 workgroups per CU - measured slower
+#else
+    constexpr int NBUF = 2;
+#endif
+    __shared__ __attribute__((aligned(16))) char smem[NBUF * 2 * IMG];   // [buffer][K image | V image]
     LDS_AS char* const lds = (LDS_AS char*)smem;
 
-    // 1-D grid, XCD-aware: consecutive workgroup ids go round the 8 XCDs, so the query blocks of one (sequence, head) - which all
-    // read the same K / V rows - take consecutive slots of ONE XCD (one L2), latest (= longest, causal) block first
-    const int nqb = p.nqb;
-    const int jb = blockIdx.x >> 3;
-    const int pair = (jb / nqb) * 8 + (blockIdx.x & 7);
-    if (pair >= p.S * p.H) return;
-    const int h = pair % p.H, s = pair / p.H;                    // heads fastest: the sequences of a ragged batch spread over all XCDs
+    int s, h, level;
+    if (!attn_block(p, s, h, level)) return;
     const int t0 = p.cu[s], len = p.cu[s + 1] - t0;
-    const int qb0 = (nqb - 1 - jb % nqb) * 128;
-    if (qb0 >= len) return;
+    const int qb0 = (level - 1) * 128;                           // level = key blocks this query block streams
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qt = w & 3, kh = w >> 2;
@@ -272,7 +357,7 @@ __global__ __launch_bounds__(256 * KSPL, KSPL == 2 && HD == 32 ? 4 : 1) void att
     float lse2 = 0.f, dlt = 0.f;
     if (MODE == 1 && q_ok) {
         lse2 = p.lse[(int64_t)h * p.T + t0 + q];
-        dlt = p.delta[(int64_t)h * p.T + t0 + q];
+        dlt = -p.delta[(int64_t)h * p.T + t0 + q];
     }
     f32x16 acc[ND];
 #pragma unroll
@@ -315,50 +400,45 @@ __global__ __launch_bounds__(256 * KSPL, KSPL == 2 && HD == 32 ? 4 : 1) void att
             for (int t = 0; t < ND; ++t) toff[s2][sec][t] = Img<HD>::tr_off(lane, s2, sec, t);
 
     // staging: thread -> NI (key row, chunk) pieces of K and of V
-    bf16x8 kreg[NI], vreg[NI];
-    // staging: thread -> NI (key row, chunk) pieces of K and of V; per key block only the uniform bases move (SGPRs), the lane
-    // parts are two constants: byte offset from the block's first K row and byte offset into the LDS image
-    uint32_t goff[NI], loff[NI];
+    // staging by LDS-DMA (global_load_lds: no register in between, no LDS store instruction).  A wave-instruction fills 64
+    // consecutive 16-byte slots of an image, so the swizzle is applied on the SOURCE side: slot (row, chunk') is fed from
+    // chunk' ^ swz(row) of that row.  Keys past the sequence end re-read its last row (finite data; their scores are masked).
+    int srow[NI];
+    uint32_t sch[NI];
 #pragma unroll
     for (int n = 0; n < NI; ++n) {
-        const int i = tid + n * NTHR;
-        goff[n] = (uint32_t)((i / (HD / 8)) * 3 * p.H * HD + (i % (HD / 8)) * 8) * 2u;
-        loff[n] = (uint32_t)Img<HD>::off(i / (HD / 8), i % (HD / 8));
+        const int slot = (n * (NTHR / 64) + w) * 64 + lane;
+        srow[n] = slot / (HD / 8);
+        sch[n] = (uint32_t)((slot % (HD / 8)) ^ Img<HD>::swz(srow[n])) * 16u;
     }
-    auto load_kv = [&](int kb) {
+    auto issue_kv = [&](int kb, int buf) {
         const char* const kbase = reinterpret_cast<const char*>(p.qkv + (((int64_t)(t0 + kb) * 3 + 1) * p.H + h) * HD);
         const char* const vbase = kbase + (int64_t)p.H * HD * 2;
-        const int nrow = len - kb;
+        const int last = len - kb - 1;
+        LDS_AS char* const base = lds + buf * 2 * IMG;
 #pragma unroll
         for (int n = 0; n < NI; ++n) {
-            kreg[n] = zero8();
-            vreg[n] = zero8();
-            if ((tid + n * NTHR) / (HD / 8) < nrow) {
-                kreg[n] = *reinterpret_cast<const bf16x8*>(kbase + goff[n]);
-                vreg[n] = *reinterpret_cast<const bf16x8*>(vbase + goff[n]);
-            }
+            const int64_t go = (int64_t)min(srow[n], last) * (3 * p.H * HD * 2) + sch[n];
+            glds16(kbase + go, base + (n * (NTHR / 64) + w) * 1024);
+            glds16(vbase + go, base + IMG + (n * (NTHR / 64) + w) * 1024);
         }
     };
-    auto store_kv = [&](int buf) {
-#pragma unroll
-        for (int n = 0; n < NI; ++n) {
-            LDS_AS char* dst = lds + buf * 2 * IMG + loff[n];
-            *reinterpret_cast<LDS_AS bf16x8*>(dst) = kreg[n];
-            *reinterpret_cast<LDS_AS bf16x8*>(dst + IMG) = vreg[n];
-        }
-    };
+    constexpr int NVM = 2 * NI;                                  // vector-memory operations per thread and key block
 
-    // the per-query operands have landed before the key loop starts: vmcnt is an in-order counter, so a first use of them
-    // inside the loop would also wait for the K / V prefetch issued just before it
+    // the per-query operands have landed before the key loop starts (the compiler would otherwise place its wait at their first
+    // use inside the loop, where vmcnt - an in-order counter - also covers the copies in flight)
     __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0)
-    load_kv(0);
-    store_kv(0);
-    if (nkb > 1) load_kv(KTB);
-    __syncthreads();
+    issue_kv(0, 0);
+    if (nkb > 1) issue_kv(KTB, 1);
 
     for (int ib = 0; ib < nkb; ++ib) {
         const int kb = ib * KTB;
-        LDS_AS const char* const kimg = lds + (ib & 1) * 2 * IMG;
+        // block ib has landed (the copies of block ib + 1 may stay in flight: vmcnt retires in order); with three buffers the
+        // barrier also says that every wave is done with block ib - 1, whose buffer the copies of block ib + 2 overwrite
+        if (ib + 1 < nkb) vm_wait<NVM>(); else vm_wait<0>();
+        __syncthreads();
+        if (NBUF == 3 && ib + 2 < nkb) issue_kv(kb + 2 * KTB, (ib + 2) % 3);
+        LDS_AS const char* const kimg = lds + (ib % NBUF) * 2 * IMG;
         LDS_AS const char* const vimg = kimg + IMG;
 
         // One instantiation serves every step: the accumulators then live in the same registers on every path (two code paths
@@ -510,18 +590,16 @@ __global__ __launch_bounds__(256 * KSPL, KSPL == 2 && HD == 32 ? 4 : 1) void att
                 if (valid(a)) step(IntC<1>{}, a, a, true);
             }
         }
-#ifndef ATTN_AB_NOSTAGE
-        if (ib + 1 < nkb) {
-            store_kv((ib + 1) & 1);                              // block i + 1 (loaded an iteration ago) -> the other buffer
-            if (ib + 2 < nkb) load_kv(kb + 2 * KTB);
+        if (NBUF == 2) {                                         // two buffers (hd 64: LDS): a second barrier frees this block's buffer
+            __syncthreads();
+            if (ib + 2 < nkb) issue_kv(kb + 2 * KTB, ib & 1);
         }
-        __syncthreads();
-#endif
     }
 
     // merge the key-split pair: the kh = 1 wave hands its statistics / accumulator to its kh = 0 partner through LDS
     if (KSPL == 2) {
         LDS_AS float* const cb = (LDS_AS float*)lds + (qt * (16 * ND + 2)) * 64 + lane;
+        __syncthreads();                                         // every wave is done with the last key block's images
         if (kh == 1) {
 #pragma unroll
             for (int t = 0; t < ND; ++t)
@@ -569,21 +647,30 @@ __global__ __launch_bounds__(256 * KSPL, KSPL == 2 && HD == 32 ? 4 : 1) void att
     }
 }
 
-// delta[h, tok] = sum_d dO * O
+// Backward pre-pass, per (sequence, token, head): ndelta[h, tok] = -sum_d dO * O and comb[h, tok] = -(slope_h q + lse) / c1 with
+// q the token's position in its sequence - the per-query start values of the dP / score accumulators of the dK/dV kernel
+// (which copies them global -> LDS without touching a register).
 template <int HD>
-__global__ void attn_delta_kernel(const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout, float* __restrict__ delta, int T, int H) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;         // over T * H
-    if (i >= T * H) return;
-    const int tok = i / H, h = i % H;
+__global__ void attn_delta_kernel(const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                  const int32_t* __restrict__ cu, const float* __restrict__ slopes, float* __restrict__ ndelta,
+                                  float* __restrict__ comb, int T, int H, float inv_c1) {
+    const int s = blockIdx.y;
+    const int t0 = cu[s], len = cu[s + 1] - t0;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;         // over len * H
+    if (j >= len * H) return;
+    const int q = j / H, h = j % H;
+    const int64_t i = (int64_t)(t0 + q) * H + h;
     float acc = 0.f;
 #pragma unroll
     for (int c = 0; c < HD; c += 8) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(out + (int64_t)i * HD + c);
-        const bf16x8 b = *reinterpret_cast<const bf16x8*>(dout + (int64_t)i * HD + c);
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(out + i * HD + c);
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(dout + i * HD + c);
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc += (float)a[e] * (float)b[e];
     }
-    delta[(int64_t)h * T + tok] = acc;
+    const int64_t at = (int64_t)h * T + t0 + q;
+    ndelta[at] = -acc;
+    comb[at] = -((slopes ? slopes[h] : 0.f) * RESEL_LOG2E * (float)q + lse[at]) * inv_c1;
 }
 
 // ------------------------------------------------------------------------------------------------- dK / dV
@@ -599,18 +686,13 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnParams p) {
     constexpr int ROWB = HD * 2, IMG = KTB * ROWB;
     constexpr int NI = KTB * HD / 8 / NTHR;                      // 16-byte pieces of Q (and of dO) per thread and query block
     constexpr int BUF = 2 * IMG + 2 * KTB * 4;                   // Q image | dO image | comb[128] | -delta[128]
-    __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+    __shared__ __attribute__((aligned(16))) char smem[3 * BUF];  // three buffers: one barrier per query block
     LDS_AS char* const lds = (LDS_AS char*)smem;
 
-    // 1-D grid, XCD-aware as in attn_q_kernel; key block 0 sees every query block (longest): ascending order = longest first
-    const int nkb = p.nqb;
-    const int jb = blockIdx.x >> 3;
-    const int pair = (jb / nkb) * 8 + (blockIdx.x & 7);
-    if (pair >= p.S * p.H) return;
-    const int h = pair % p.H, s = pair / p.H;
+    int s, h, level;
+    if (!attn_block(p, s, h, level)) return;
     const int t0 = p.cu[s], len = p.cu[s + 1] - t0;
-    const int kb0 = (jb % nkb) * KTB;
-    if (kb0 >= len) return;
+    const int kb0 = ((len + KTB - 1) / KTB - level) * KTB;       // level = query blocks this key block streams (diagonal .. end)
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
@@ -652,57 +734,50 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnParams p) {
 #pragma unroll
         for (int t = 0; t < ND; ++t) toff[sec][t] = Img<HD>::tr_off(lane, 0, sec, t);     // k-step s2: + 16 s2 rows (swz does not see them)
 
-    // staging: thread -> NI (query row, chunk) pieces of Q and of dO, and one of the 256 per-query floats
-    bf16x8 qreg[NI], oreg[NI];
-    float freg;
-    uint32_t gq[NI], go[NI], loff[NI];
+    // staging by LDS-DMA (global_load_lds: no register in between, no LDS store instruction).  A wave-instruction fills 64
+    // consecutive 16-byte slots of an image, so the swizzle is applied on the SOURCE side: slot (row, chunk') is fed from
+    // chunk' ^ swz(row) of that row.  Rows past the sequence end re-read its last row (finite data; their scores are masked).
+    // Per query block and thread: NI slots of Q, NI of dO (16 bytes) and one of the 256 per-query floats (4 bytes).
+    int srow[NI];
+    uint32_t sq[NI], so[NI];                                     // byte offset of the slot's chunk within its row
 #pragma unroll
     for (int n = 0; n < NI; ++n) {
-        const int i = tid + n * NTHR;
-        gq[n] = (uint32_t)((i / (HD / 8)) * 3 * p.H * HD + (i % (HD / 8)) * 8) * 2u;
-        go[n] = (uint32_t)((i / (HD / 8)) * p.H * HD + (i % (HD / 8)) * 8) * 2u;
-        loff[n] = (uint32_t)Img<HD>::off(i / (HD / 8), i % (HD / 8));
+        const int slot = (n * 4 + w) * 64 + lane;
+        srow[n] = slot / (HD / 8);
+        const uint32_t ch = (uint32_t)((slot % (HD / 8)) ^ Img<HD>::swz(srow[n]));
+        sq[n] = ch * 16u;
+        so[n] = ch * 16u;
     }
+    const float* const fsrc = (tid < KTB ? p.comb : p.delta) + (int64_t)h * p.T + t0;
     const int frow = tid & (KTB - 1);
-    auto load_q = [&](int qb) {
+    auto issue_q = [&](int qb, int buf) {
         const char* const qbase = reinterpret_cast<const char*>(p.qkv + ((int64_t)(t0 + qb) * 3 * p.H + h) * HD);
         const char* const obase = reinterpret_cast<const char*>(p.dout + ((int64_t)(t0 + qb) * p.H + h) * HD);
-        const int nrow = len - qb;
-#pragma unroll
-        for (int n = 0; n < NI; ++n) {
-            qreg[n] = zero8();
-            oreg[n] = zero8();
-            if ((tid + n * NTHR) / (HD / 8) < nrow) {
-                qreg[n] = *reinterpret_cast<const bf16x8*>(qbase + gq[n]);
-                oreg[n] = *reinterpret_cast<const bf16x8*>(obase + go[n]);
-            }
-        }
-        freg = 0.f;
-        if (frow < nrow) {
-            const int64_t at = (int64_t)h * p.T + t0 + qb + frow;
-            freg = tid < KTB ? -(slope2 * (float)(qb + frow) + p.lse[at]) * inv_c1 : -p.delta[at];
-        }
-    };
-    auto store_q = [&](int buf) {
+        const int last = len - qb - 1;
         LDS_AS char* const base = lds + buf * BUF;
 #pragma unroll
         for (int n = 0; n < NI; ++n) {
-            *reinterpret_cast<LDS_AS bf16x8*>(base + loff[n]) = qreg[n];
-            *reinterpret_cast<LDS_AS bf16x8*>(base + IMG + loff[n]) = oreg[n];
+            const int row = min(srow[n], last);
+            glds16(qbase + (int64_t)row * (3 * p.H * HD * 2) + sq[n], base + (n * 4 + w) * 1024);
+            glds16(obase + (int64_t)row * (p.H * HD * 2) + so[n], base + IMG + (n * 4 + w) * 1024);
         }
-        *reinterpret_cast<LDS_AS float*>(base + 2 * IMG + tid * 4) = freg;
+        glds4(fsrc + qb + min(frow, last), base + 2 * IMG + w * 256);
     };
+    constexpr int NVM = 2 * NI + 1;                              // vector-memory operations per thread and query block
 
     const int nblk = (len - kb0 + KTB - 1) / KTB;                // query blocks from the diagonal one to the end of the sequence
     __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0): K / V fragments landed (see attn_q_kernel)
-    load_q(kb0);
-    store_q(0);
-    if (nblk > 1) load_q(kb0 + KTB);
-    __syncthreads();
+    issue_q(kb0, 0);
+    if (nblk > 1) issue_q(kb0 + KTB, 1);
 
     for (int ib = 0; ib < nblk; ++ib) {
         const int qb = kb0 + ib * KTB;
-        LDS_AS const char* const qimg = lds + (ib & 1) * BUF;
+        // block ib has landed (the copies of block ib + 1 may stay in flight: vmcnt retires in order); the barrier also says that
+        // every wave is done with block ib - 1, whose buffer the copies of block ib + 2 now overwrite
+        if (ib + 1 < nblk) vm_wait<NVM>(); else vm_wait<0>();
+        __syncthreads();
+        if (ib + 2 < nblk) issue_q(qb + 2 * KTB, (ib + 2) % 3);
+        LDS_AS const char* const qimg = lds + (ib % 3) * BUF;
         LDS_AS const char* const oimg = qimg + IMG;
         LDS_AS const float* const comb = reinterpret_cast<LDS_AS const float*>(qimg + 2 * IMG);
         LDS_AS const float* const sdl = comb + KTB;
@@ -781,11 +856,6 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnParams p) {
                 }
             }
         }
-        if (ib + 1 < nblk) {
-            store_q((ib + 1) & 1);
-            if (ib + 2 < nblk) load_q(qb + 2 * KTB);
-        }
-        __syncthreads();
     }
     // epilogue: dkt / dvt [t][reg] = X^T[d = 32 t + row(reg)][key]
     if (k_ok) {
@@ -817,13 +887,17 @@ inline void set_dropout(AttnParams& p, float p_drop, uint64_t seed, uint64_t off
 
 template <int HD, bool DROP>
 void launch_fwd(const AttnParams& p, dim3 grid, hipStream_t s) {
+#ifdef ATTN_AB_KSPL2
     constexpr int KSPL = HD == 32 ? 2 : 1;
+#else
+    constexpr int KSPL = 1;                                      // key-split pairs (2): measured slower at every batch size tried (r03 profile notes)
+#endif
     launch_timed(RESEL_PROF_ATTN_FWD, attn_q_kernel<HD, 0, DROP, KSPL>, grid, dim3(256 * KSPL), 0, s, p);
 }
 template <int HD, bool DROP>
 void launch_bwd(const AttnParams& p, const bf16_t* out, dim3 gq, dim3 gk, hipStream_t s) {
-    const int n = p.T * p.H;
-    hipLaunchKernelGGL(attn_delta_kernel<HD>, dim3((n + 255) / 256), dim3(256), 0, s, out, p.dout, const_cast<float*>(p.delta), p.T, p.H);
+    hipLaunchKernelGGL(attn_delta_kernel<HD>, dim3((p.nqb * 128 * p.H + 255) / 256, p.S), dim3(256), 0, s, out, p.dout, p.lse, p.cu, p.slopes,
+                       const_cast<float*>(p.delta), const_cast<float*>(p.comb), p.T, p.H, 1.f / (p.scale * RESEL_LOG2E));
     launch_timed(RESEL_PROF_ATTN_DQ, attn_q_kernel<HD, 1, DROP, 1>, gq, dim3(256), 0, s, p);
     launch_timed(RESEL_PROF_ATTN_DKV, attn_dkv_kernel<HD, DROP>, gk, dim3(256), 0, s, p);
 }
@@ -831,23 +905,29 @@ void launch_bwd(const AttnParams& p, const bf16_t* out, dim3 gq, dim3 gk, hipStr
 }  // namespace
 
 extern "C" int resel_attn_varlen_fwd(const uint16_t* qkv, const int32_t* cu_seqlens, const float* slopes, uint16_t* out, float* lse,
-                                     int T, int S, int H, int hd, int max_seqlen, float scale,
+                                     void* workspace, int T, int S, int H, int hd, int max_seqlen, float scale,
                                      float p_drop, uint64_t seed, uint64_t offset, resel_stream_t stream) {
     if (!qkv || !cu_seqlens || !out || !lse || !attn_ok(T, S, H, hd, max_seqlen, p_drop) || !aligned16(qkv) || !aligned16(out)) return RESEL_EINVAL;
-    AttnParams p{(const bf16_t*)qkv, cu_seqlens, slopes, (bf16_t*)out, lse, nullptr, nullptr, nullptr, T, S, H, 0, scale, 256u, 1.f, 0, 0};
+    AttnParams p{(const bf16_t*)qkv, cu_seqlens, slopes, (bf16_t*)out, lse, nullptr, nullptr, nullptr, nullptr, T, S, H, 0, nullptr, scale, 256u, 1.f, 0, 0};
     set_dropout(p, p_drop, seed, offset);
     p.nqb = (max_seqlen + 127) / 128;
-    dim3 grid((S * H + 7) / 8 * 8 * p.nqb);
+    dim3 grid((H + 7) / 8 * 8 * S * p.nqb);
     hipStream_t s = (hipStream_t)stream;
+    if (workspace && worklist_ok(S, max_seqlen)) {
+        hipLaunchKernelGGL(attn_worklist_kernel, dim3(1), dim3(64), 0, s, cu_seqlens, S, p.nqb, (uint32_t*)workspace);
+        p.wl = (const uint32_t*)workspace;
+    }
     const bool drop = p_drop > 0.f;
     if (hd == 32) { if (drop) launch_fwd<32, true>(p, grid, s); else launch_fwd<32, false>(p, grid, s); }
     else          { if (drop) launch_fwd<64, true>(p, grid, s); else launch_fwd<64, false>(p, grid, s); }
     return launch_status();
 }
 
-extern "C" size_t resel_attn_varlen_bwd_workspace_bytes(int T, int H, int hd) {
+extern "C" size_t resel_attn_varlen_fwd_workspace_bytes(int S, int max_seqlen) { return worklist_bytes(S, max_seqlen); }
+
+extern "C" size_t resel_attn_varlen_bwd_workspace_bytes(int T, int S, int H, int hd, int max_seqlen) {
     (void)hd;
-    return (size_t)T * H * sizeof(float);
+    return (size_t)2 * T * H * sizeof(float) + worklist_bytes(S, max_seqlen);          // -delta | comb | work list
 }
 
 extern "C" int resel_attn_varlen_bwd(const uint16_t* qkv, const int32_t* cu_seqlens, const float* slopes, const uint16_t* out,
@@ -857,12 +937,17 @@ extern "C" int resel_attn_varlen_bwd(const uint16_t* qkv, const int32_t* cu_seql
     if (!qkv || !cu_seqlens || !out || !lse || !dout || !dqkv || !workspace || !attn_ok(T, S, H, hd, max_seqlen, p_drop)) return RESEL_EINVAL;
     if (!aligned16(qkv) || !aligned16(out) || !aligned16(dout) || !aligned16(dqkv)) return RESEL_EINVAL;
     float* delta = (float*)workspace;
-    AttnParams p{(const bf16_t*)qkv, cu_seqlens, slopes, nullptr, const_cast<float*>(lse), (const bf16_t*)dout, delta, (bf16_t*)dqkv, T, S, H, 0, scale,
+    AttnParams p{(const bf16_t*)qkv, cu_seqlens, slopes, nullptr, const_cast<float*>(lse), (const bf16_t*)dout, delta, delta + (size_t)T * H, (bf16_t*)dqkv, T, S, H, 0, nullptr, scale,
                  256u, 1.f, 0, 0};
     set_dropout(p, p_drop, seed, offset);
     hipStream_t s = (hipStream_t)stream;
     p.nqb = (max_seqlen + 127) / 128;
-    dim3 gq((S * H + 7) / 8 * 8 * p.nqb), gk((S * H + 7) / 8 * 8 * p.nqb);
+    dim3 gq((H + 7) / 8 * 8 * S * p.nqb), gk((H + 7) / 8 * 8 * S * p.nqb);
+    if (worklist_ok(S, max_seqlen)) {
+        uint32_t* wl = (uint32_t*)(delta + (size_t)2 * T * H);
+        hipLaunchKernelGGL(attn_worklist_kernel, dim3(1), dim3(64), 0, s, cu_seqlens, S, p.nqb, wl);
+        p.wl = wl;
+    }
     const bool drop = p_drop > 0.f;
     if (hd == 32) { if (drop) launch_bwd<32, true>(p, (const bf16_t*)out, gq, gk, s); else launch_bwd<32, false>(p, (const bf16_t*)out, gq, gk, s); }
     else          { if (drop) launch_bwd<64, true>(p, (const bf16_t*)out, gq, gk, s); else launch_bwd<64, false>(p, (const bf16_t*)out, gq, gk, s); }

@@ -41,8 +41,9 @@ SIGNATURES = {
     'resel_gru_workspace_bytes': (c_size_t, [I, I, I]),
     'resel_gru_seq_fwd': (c_int, [P, P, P, P, P, P, P, I, I, I, S]),
     'resel_gru_seq_bwd': (c_int, [P, P, P, P, P, P, P, P, I, I, I, S]),
-    'resel_attn_varlen_fwd': (c_int, [P, P, P, P, P, I, I, I, I, I, F, F, U, U, S]),
-    'resel_attn_varlen_bwd_workspace_bytes': (c_size_t, [I, I, I]),
+    'resel_attn_varlen_fwd_workspace_bytes': (c_size_t, [I, I]),
+    'resel_attn_varlen_fwd': (c_int, [P, P, P, P, P, P, I, I, I, I, I, F, F, U, U, S]),
+    'resel_attn_varlen_bwd_workspace_bytes': (c_size_t, [I, I, I, I, I]),
     'resel_attn_varlen_bwd': (c_int, [P, P, P, P, P, P, P, P, I, I, I, I, I, F, F, U, U, S]),
     'resel_dropout': (c_int, [P, P, L, F, U, U, S]),
     'resel_gelu_dropout_fwd': (c_int, [P, P, L, F, U, U, S]),

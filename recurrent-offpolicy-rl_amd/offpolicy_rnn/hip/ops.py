@@ -481,7 +481,8 @@ class AttnVarlenFn(torch.autograd.Function):
         slopes = None if slopes is None else slopes.float().contiguous()
         out = torch.empty(T, H, hd, dtype=torch.bfloat16, device=qkv.device)
         lse = torch.empty(H, T, dtype=torch.float32, device=qkv.device)
-        check(lib().resel_attn_varlen_fwd(_p(qkv), _p(cu), _p(slopes), _p(out), _p(lse), T, S, H, hd, int(max_seqlen), float(scale),
+        ws = _ws(lib().resel_attn_varlen_fwd_workspace_bytes(S, int(max_seqlen)), qkv.device)
+        check(lib().resel_attn_varlen_fwd(_p(qkv), _p(cu), _p(slopes), _p(out), _p(lse), _p(ws), T, S, H, hd, int(max_seqlen), float(scale),
                                           float(p_drop), int(seed), int(offset), _stream()), 'attn_varlen_fwd')
         ctx.save_for_backward(qkv, cu, slopes, out, lse)
         ctx.max_seqlen, ctx.scale, ctx.drop = int(max_seqlen), float(scale), (float(p_drop), int(seed), int(offset))
@@ -493,7 +494,7 @@ class AttnVarlenFn(torch.autograd.Function):
         T, _, H, hd = qkv.shape
         dout = dout.to(torch.bfloat16).contiguous()
         dqkv = torch.empty_like(qkv)
-        ws = _ws(lib().resel_attn_varlen_bwd_workspace_bytes(T, H, hd), qkv.device)
+        ws = _ws(lib().resel_attn_varlen_bwd_workspace_bytes(T, cu.numel() - 1, H, hd, ctx.max_seqlen), qkv.device)
         check(lib().resel_attn_varlen_bwd(_p(qkv), _p(cu), _p(slopes), _p(out), _p(lse), _p(dout), _p(dqkv), _p(ws), T, cu.numel() - 1, H, hd,
                                           ctx.max_seqlen, ctx.scale, *ctx.drop, _stream()), 'attn_varlen_bwd')
         return dqkv, None, None, None, None, None, None, None

@@ -429,6 +429,47 @@ def test_attn_varlen_alibi_fwd_bwd(ops, H, hd, lens):
     close(x.grad.float(), ref_in.grad, rtol=2e-2, atol_scale=2e-2, name='dqkv')
 
 
+def test_attn_ragged_batch_work_list(ops):
+    """70 sequences (more than one work-list chunk) of lengths 1 .. 300, several exactly on / next to the 128-token block edges:
+    every (sequence, block) item of the device-built work list is run once, and the result is the oracle's."""
+    H, hd = 4, 32
+    g = torch.Generator().manual_seed(11)
+    lens = [1, 128, 129, 127, 256, 257, 300, 2, 64, 255] + [int(x) for x in torch.randint(1, 301, (60,), generator=g)]
+    T = sum(lens)
+    qkv = (torch.randn(T, 3, H, hd, generator=g) * 0.8).to(torch.bfloat16)
+    dout = torch.randn(T, H, hd, generator=g).to(torch.bfloat16)
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32)
+    slopes = K.alibi_slopes(H)
+    ref_in = qkv.float().requires_grad_(True)
+    ref = K.attention_alibi_varlen_ref(ref_in[:, 0], ref_in[:, 1], ref_in[:, 2], cu, slopes)
+    (ref * dout.float()).sum().backward()
+    x = qkv.cuda().requires_grad_(True)
+    out = ops.attn_varlen(x, cu.cuda(), max(lens), slopes.cuda())
+    (out.float() * dout.cuda().float()).sum().backward()
+    close(out.float(), ref, rtol=1e-2, atol_scale=1e-2, name='out')
+    close(x.grad.float(), ref_in.grad, rtol=2e-2, atol_scale=2e-2, name='dqkv')
+
+
+def test_attn_forward_without_work_list_is_bitwise_the_same(ops):
+    """workspace == NULL: the kernels fall back to (sequence, block) order - scheduling only, the same bits."""
+    from offpolicy_rnn.hip._lib import lib
+    from offpolicy_rnn.hip.ops import _p, _stream, check
+    H, hd, lens = 8, 32, [1, 130, 37, 300, 64]
+    g = torch.Generator().manual_seed(3)
+    T, S = sum(lens), len(lens)
+    qkv = (torch.randn(T, 3, H, hd, generator=g) * 0.8).to(torch.bfloat16).cuda()
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32).cuda()
+    slopes = K.alibi_slopes(H).cuda()
+    with torch.no_grad():
+        a = ops.attn_varlen(qkv, cu, max(lens), slopes)
+    out = torch.empty(T, H, hd, dtype=torch.bfloat16, device='cuda')
+    lse = torch.empty(H, T, dtype=torch.float32, device='cuda')
+    check(lib().resel_attn_varlen_fwd(_p(qkv), _p(cu), _p(slopes), _p(out), _p(lse), None, T, S, H, hd, max(lens), hd ** -0.5,
+                                      0.0, 0, 0, _stream()), 'attn_varlen_fwd')
+    torch.cuda.synchronize()
+    assert torch.equal(a.view(torch.int16), out.view(torch.int16))
+
+
 def test_attn_layout_with_integer_data(ops):
     """Exact small-integer operands (products and sums exact in bf16/fp32) catch any fragment-layout transposition."""
     H, hd, L = 2, 32, 70

@@ -8,7 +8,7 @@ VARS="${ATTN_VARS:-NOMAX NORESCALE NOEXP NOSUM}"
 if [ "$1" = build ]; then
   mkdir -p $B/ab
   for v in $VARS; do
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form -I$R/include -DATTN_AB_$v -c $C/attention.hip -o $B/ab/attn_$v.o &
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form -I$R/include $(for f in ${v//_/ }; do echo -n "-DATTN_AB_$f "; done) -c $C/attention.hip -o $B/ab/attn_$v.o &
   done
   wait
   for v in $VARS; do

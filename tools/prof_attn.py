@@ -5,7 +5,8 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, 'recurrent-offpolicy-rl_amd')]
 import torch
 from offpolicy_rnn.hip import ops
 rows, H, hd = 32, 8, 32
-lens = [1, 1026] * rows
+lens = {'alt': [1, 1026] * rows, 'short_first': [1] * rows + [1026] * rows, 'long_first': [1026] * rows + [1] * rows,
+        'mixed': [1 + (i * 389) % 1026 for i in range(2 * rows)]}[os.environ.get('PROF_LENS', 'alt')]
 cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device='cuda')
 T = sum(lens)
 qkv = (torch.randn(T, 3, H, hd, device='cuda') * 0.5).to(torch.bfloat16).requires_grad_(True)
