@@ -5,11 +5,19 @@
 // statistics are per LANE (MFMA C/D layout: column = lane & 31, 16 rows in registers, row = (r&3) + 8(r>>2) + 4(lane>>5)):
 //   forward / dQ kernel : S^T[key][q] = K Q^T      -> column = query: running max / sum / lse / delta are one value per lane,
 //                         and the probability tile feeds the next product (O^T = V^T P^T, dQ^T = K^T dS^T) straight from
-//                         registers as the B operand (rows = summed index; k-order 16s + 8(j>>2) + 4h + (j&3)), while the
-//                         A operand (V^T / K^T) is read from a transposed LDS tile in that same k-order with two ds_read_b64;
+//                         registers as the B operand (rows = summed index; k-order 16s + 8(j>>2) + 4h + (j&3));
 //   dK/dV kernel        : S[q][key] = Q K^T        -> column = key: dV^T = dO^T P and dK^T = Q^T dS sum over the row index q.
+// Second edition (round 3).  What streams through LDS (K / V in the forward and dQ kernel, Q / dO in the dK/dV kernel) is kept
+// as ONE swizzled row-major image per tensor: the products that want rows read it with ds_read_b128, the ones that want the
+// transpose (V^T, K^T, dO^T, Q^T in the accumulator's k-order) read the SAME image with ds_read_b64_tr_b16 - no transposed
+// copy, no 2-byte LDS stores, zero bank conflicts on either form (struct Img).  The images are filled by LDS-DMA
+// (global_load_lds_dwordx4: no staging register, no LDS store instruction), double-buffered; the workgroups take their
+// (sequence, block) from a device-built longest-first work list (attn_worklist_kernel), which is what a ragged causal batch
+// needs to keep 256 CUs busy.  Measured at 32 sequences x 1026 tokens (+ 32 of one token) x 8 heads x 32: forward 87 -> 64 us
+// (269 TFLOP/s of causal-half flops), dQ 87 -> 64 us, dK/dV 200 -> 77 us; profiles/r03_attention.md has the steps and the
+// things that did not help (key-split wave pairs, a third LDS buffer, 5 waves per SIMD with spills, fp32-MFMA bias start).
 // Arithmetic intensity is low for hd = 32 (4 MFMAs per 32x32 tile against ~16 exp2 per lane), so these kernels are
-// VALU/exp-bound rather than MFMA-bound; the whole attention share of a cgpt update is ~1 TFLOP.
+// VALU-issue-bound rather than MFMA-bound (PMC: VALU 58 % busy, MFMA 21 %); the whole attention share of a cgpt update is ~1 TFLOP.
 // Semantics restated from flash-attn's MHA(causal, alibi) - see oracle/kernels.py attention_alibi_varlen_ref: PARITY UNPINNED.
 //
 // Attention-probability dropout (MHA(dropout=p), reference TransformerFlashAttention.py:67-70): the keep mask is a pure
