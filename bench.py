@@ -487,10 +487,11 @@ def main():
     prof = ops.profile_collect()
     ops.profile_enable(False)
     gemm_flops = ops.GEMM_FLOPS[0]
-    strict_ms = None
-    if ops.GEMM_SPLIT != 0 and not args.no_strict_leg and not args.graph_update:
-        # the same update with the GEMM products formed by the fp32 MFMA instruction (reported beside the headline, never as it)
-        mode, ops.GEMM_SPLIT = ops.GEMM_SPLIT, 0
+    strict_ms = high_ms = None
+    gemm_mode = ops.gemm_split()                         # product mode of the timed region
+
+    def leg_with_products(split):
+        keep, ops.GEMM_SPLIT = ops.GEMM_SPLIT, split
         alg.train_one_batch()
         alg.grad_num += 1
         sync()
@@ -499,8 +500,15 @@ def main():
             alg.train_one_batch()
             alg.grad_num += 1
         sync()
-        strict_ms = 1e3 * (time.perf_counter() - t1) / 3
-        ops.GEMM_SPLIT = mode
+        ops.GEMM_SPLIT = keep
+        return 1e3 * (time.perf_counter() - t1) / 3
+    if gemm_mode != 0 and not args.no_strict_leg and not args.graph_update:
+        # the same update with the GEMM products formed by the fp32 MFMA instruction (reported beside the headline, never as it)
+        strict_ms = leg_with_products(0)
+    if gemm_mode != 3 and not args.no_strict_leg and not args.graph_update:
+        # ... and with two bf16 planes per operand ("bf16x3" = torch.set_float32_matmul_precision('high'), SURVEY 8(d)'s 'TF32-class'
+        # option): NOT the reference's precision setting, so never the headline either
+        high_ms = leg_with_products(3)
     graph_leg = None
     if world == 1 and not alg.grad_sync.active and not args.graph_update and not args.no_graph_leg:
         # the same update replayed from ONE hipGraph (algorithm/graphed_update.py), reported beside the headline: what the launch
@@ -536,7 +544,7 @@ def main():
     out = {
         'metric': 'env-steps/sec trained', 'value': trained / dt, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'strong' if args.global_rows else 'weak', 'vs_baseline': None,
-        'dtype': 'f32', 'dtype_note': ('inputs, accumulators and outputs of every kernel are fp32; GEMM products: ' + {0: 'fp32 MFMA instruction', 6: 'exact 3-way bf16 split of both fp32 operands, 6 leading plane products on the bf16 MFMA (as accurate vs fp64 as the fp32 instruction: DESIGN.md 4)', 9: 'exact 3-way bf16 split of both fp32 operands, all 9 plane products on the bf16 MFMA'}[ops.GEMM_SPLIT]), 'data': 'synthetic',
+        'dtype': 'f32', 'dtype_note': ('inputs, accumulators and outputs of every kernel are fp32; GEMM products: ' + {0: 'fp32 MFMA instruction', 6: 'exact 3-way bf16 split of both fp32 operands, 6 leading plane products on the bf16 MFMA (as accurate vs fp64 as the fp32 instruction: DESIGN.md 4)', 9: 'exact 3-way bf16 split of both fp32 operands, all 9 plane products on the bf16 MFMA', 3: 'two bf16 planes per fp32 operand, 3 leading plane products on the bf16 MFMA (bf16x3: float32 matmul precision "high", NOT fp32-accurate)'}[gemm_mode]), 'data': 'synthetic',
         'config': {'workload': f'{args.rnn} {args.algo.upper()}-REDQ full-trajectory update, B={Bsz}/GPU, T={args.horizon} (row length {Tp}), obs={OBS}, act={ACT}, '
                                f'D=256, efc-8 critic ({baseline_config(args)})',
                    'global_rows': Bsz * world, 'parallelism': f'dp{world}'},
@@ -550,7 +558,7 @@ def main():
     if 'gemm_f32_kernel' in kern:
         g = kern['gemm_f32_kernel']
         t = g['launches'] * g['avg_us'] * 1e-6
-        mode = ops.GEMM_SPLIT
+        mode = gemm_mode
         # `achieved` = ALGORITHMIC flops (2 x tokens x in x out = 2 M N K, summed over the calls) over the event-timed
         # kernel time.  `peak`: an fp32-accurate product costs `mode` bf16 MFMA products here, so the most this formulation can
         # reach is the dense bf16 MFMA peak / mode (mode 0: the f32-input MFMA peak itself).  The fractions of the raw instruction
@@ -565,8 +573,10 @@ def main():
              'algorithmic_flops': gemm_flops / g['launches'], 'fp32_equivalent_tflops': ach,
              'mfma': 'v_mfma_f32_32x32x16_bf16' if mode else 'v_mfma_f32_32x32x2_f32',
              'products': {0: 'fp32 operands', 6: 'exact 3-way bf16 operand split, 6 leading plane products, fp32 accumulate',
-                          9: 'exact 3-way bf16 operand split, all 9 plane products, fp32 accumulate'}[mode],
+                          9: 'exact 3-way bf16 operand split, all 9 plane products, fp32 accumulate',
+                          3: 'two bf16 planes per operand, 3 leading plane products, fp32 accumulate (bf16x3)'}[mode],
              'ms_per_step_with_fp32_mfma_products': strict_ms,
+             'ms_per_step_with_matmul_precision_high_bf16x3': high_ms,
              'note': 'all fc / efc-E / projection GEMMs of the update (inputs, accumulation and outputs fp32): DESIGN.md 4 "The GEMMs", profiles/r02_gemm.md'}
         ranked.append((t * 1e6, o))
     ranked.sort(key=lambda x: -x[0])

@@ -298,6 +298,9 @@ int resel_ensemble_head_bwd(const float* gq, const float* a, const float* w3, fl
  *   9  each operand split EXACTLY into three bf16 planes (8 + 8 + 8 significant bits), all nine plane products - each exact -
  *      accumulated in fp32 by v_mfma_f32_32x32x16_bf16: the product a b is represented exactly, as in mode 0;
  *   6  as 9 without the three smallest terms (each <= 2^-24 |a b|, the size of one fp32 rounding of the product);
+ *   3  "bf16x3": two planes per operand (16 significant bits) and the three leading plane products; every dropped term is
+ *      <= 2^-16 |a b|.  The class torch names float32 matmul precision 'high' (TF32 / bf16x3) - NOT the reference's default
+ *      ('highest' = modes 0 / 6 / 9); half the matrix instructions of mode 6.  Shapes with M <= 128 run mode 6;
  *   106 / 109  modes 6 / 9 on the first-edition kernel (every wave splits the fragments it reads; kept for A/B measurements).
  * Modes 6 / 9 split each operand element once per block on its way into LDS (csrc/gemm_bf3.hip, 256 x 128 tiles). */
 size_t resel_gemm_f32_workspace_bytes(int M, int N, int K, int batch);

@@ -5,7 +5,9 @@
 // Product formation (resel_gemm_f32 modes 6 / 9, gemm_f32.hip 'SPLIT'): every fp32 operand element x is written exactly as
 // x1 + x2 + x3, three bf16 values obtained by truncation; a bf16 x bf16 product is exact in fp32 and v_mfma_f32_32x32x16_bf16
 // accumulates the plane products in fp32.  Mode 9 keeps all nine plane products, mode 6 drops a2 b3, a3 b2, a3 b3 (each at
-// most 2^-24 |a b|).  The first edition kept fp32 tiles in LDS and every wave split the fragments it read: with 2 x 2 waves
+// most 2^-24 |a b|).  Mode 3 ("bf16x3", what torch.set_float32_matmul_precision('high') names) keeps two planes per operand -
+// 16 significant bits - and the products a1 b1 + a1 b2 + a2 b1: every dropped term is at most 2^-16 |a b|; half the matrix
+// instructions and two thirds of the split / LDS work of mode 6.  The first edition kept fp32 tiles in LDS and every wave split the fragments it read: with 2 x 2 waves
 // per block each element was split twice, 352 vector instructions per wave and K step beside 48 matrix instructions - the
 // vector pipe, not the matrix pipe, set the pace (PMC: matrix pipe 50 % busy, profiles/r02_gemm.md).  Here
 //   * the thread that LOADS an element splits it (22 vector instructions per four elements, once) and stores the three planes
@@ -78,33 +80,51 @@ __device__ __forceinline__ int plane_off(int row, int c) {
     return ((row ^ (q & 1)) << 6) + ((c ^ (q & 3)) << 4);
 }
 
-// ---- four fp32 values -> three planes of four bf16 (8 bytes each)
+// ---- four fp32 values -> three planes of four bf16 (8 bytes each).  NP = 2 (mode 3): the second plane is the residual ROUNDED to
+// nearest even (v_cvt_pk_bf16_f32) instead of truncated - the dropped part is then unbiased and at most 2^-17 |x|
+__device__ __forceinline__ uint32_t rne_pair(float lo, float hi) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
 struct P3 { uint2 p1, p2, p3; };
+template <int NP>
 __device__ __forceinline__ P3 split4(const float4& v) {
 #ifdef BF3_AB_NOSPLIT                  // ablation (wrong results): no vector work for the split
     return P3{make_uint2(__float_as_uint(v.x), __float_as_uint(v.y)), make_uint2(__float_as_uint(v.z), __float_as_uint(v.w)),
               make_uint2(__float_as_uint(v.x), __float_as_uint(v.w))};
 #endif
     const float x[4] = {v.x, v.y, v.z, v.w};
-    uint32_t w1[2], w2[2], w3[2];
+    uint32_t w1[2], w2[2], w3[2] = {0u, 0u};
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const uint32_t u0 = __float_as_uint(x[2 * q]), u1 = __float_as_uint(x[2 * q + 1]);
         w1[q] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);        // {hi16(x[2q+1]), hi16(x[2q])}: element 2q in the low half
         const float r0 = x[2 * q] - __uint_as_float(u0 & 0xffff0000u), r1 = x[2 * q + 1] - __uint_as_float(u1 & 0xffff0000u);
-        const uint32_t v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
-        w2[q] = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
-        const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
-        w3[q] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+        if (NP == 2) {
+            w2[q] = rne_pair(r0, r1);
+        } else {
+            const uint32_t v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+            w2[q] = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+            const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
+            w3[q] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+        }
     }
     return P3{make_uint2(w1[0], w1[1]), make_uint2(w2[0], w2[1]), make_uint2(w3[0], w3[1])};
 }
 struct P3h { uint32_t p1, p2, p3; };                 // two values -> three planes of two bf16
+template <int NP>
 __device__ __forceinline__ P3h split2(float x0, float x1) {
     const uint32_t u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
     P3h o;
     o.p1 = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
     const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u), r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
+    if (NP == 2) {
+        o.p2 = rne_pair(r0, r1);
+        o.p3 = 0u;
+        return o;
+    }
     const uint32_t v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
     o.p2 = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
     const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
@@ -189,34 +209,34 @@ struct Src {
         base += step;
     }
     // split the staged values and store the planes of this thread's pieces into the plane set at `pl` (plane stride PL bytes)
-    template <int PL>
+    template <int PL, int NP>
     __device__ __forceinline__ void store(char* pl) const {
         if (KC) {
 #pragma unroll
             for (int i = 0; i < NPC; ++i) {
-                const P3 s = split4(r[i]);
+                const P3 s = split4<NP>(r[i]);
                 *reinterpret_cast<uint2*>(pl + loff[i]) = s.p1;
                 *reinterpret_cast<uint2*>(pl + PL + loff[i]) = s.p2;
-                *reinterpret_cast<uint2*>(pl + 2 * PL + loff[i]) = s.p3;
+                if (NP == 3) *reinterpret_cast<uint2*>(pl + 2 * PL + loff[i]) = s.p3;
             }
         } else if (ROWS == 256) {
             const float c[4][4] = {{r[0].x, r[1].x, r[2].x, r[3].x}, {r[0].y, r[1].y, r[2].y, r[3].y},
                                    {r[0].z, r[1].z, r[2].z, r[3].z}, {r[0].w, r[1].w, r[2].w, r[3].w}};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const P3 s = split4(make_float4(c[j][0], c[j][1], c[j][2], c[j][3]));
+                const P3 s = split4<NP>(make_float4(c[j][0], c[j][1], c[j][2], c[j][3]));
                 *reinterpret_cast<uint2*>(pl + loff[j]) = s.p1;
                 *reinterpret_cast<uint2*>(pl + PL + loff[j]) = s.p2;
-                *reinterpret_cast<uint2*>(pl + 2 * PL + loff[j]) = s.p3;
+                if (NP == 3) *reinterpret_cast<uint2*>(pl + 2 * PL + loff[j]) = s.p3;
             }
         } else {
             const float c[4][2] = {{r[0].x, r[1].x}, {r[0].y, r[1].y}, {r[0].z, r[1].z}, {r[0].w, r[1].w}};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const P3h s = split2(c[j][0], c[j][1]);
+                const P3h s = split2<NP>(c[j][0], c[j][1]);
                 *reinterpret_cast<uint32_t*>(pl + loff[j]) = s.p1;
                 *reinterpret_cast<uint32_t*>(pl + PL + loff[j]) = s.p2;
-                *reinterpret_cast<uint32_t*>(pl + 2 * PL + loff[j]) = s.p3;
+                if (NP == 3) *reinterpret_cast<uint32_t*>(pl + 2 * PL + loff[j]) = s.p3;
             }
         }
     }
@@ -226,15 +246,17 @@ struct Frag { bf16x8 a[3][2], b[3][2]; };            // [plane][32-row tile] of 
 
 __device__ __forceinline__ bf16x8 lds16(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
 // fa / fb: this lane's fragment address of slab `s` in plane 0, tile 0 of the stage (byte pointers into LDS)
+template <int NP>
 __device__ __forceinline__ void read_a(Frag& f, const char* fa) {
 #pragma unroll
-    for (int pi = 0; pi < 3; ++pi)
+    for (int pi = 0; pi < NP; ++pi)
 #pragma unroll
         for (int t = 0; t < 2; ++t) f.a[pi][t] = lds16(fa + pi * PLA + t * 32 * ROWB);
 }
+template <int NP>
 __device__ __forceinline__ void read_b(Frag& f, const char* fb) {
 #pragma unroll
-    for (int pi = 0; pi < 3; ++pi)
+    for (int pi = 0; pi < NP; ++pi)
 #pragma unroll
         for (int t = 0; t < 2; ++t) f.b[pi][t] = lds16(fb + pi * PLB + t * 32 * ROWB);
 }
@@ -254,6 +276,7 @@ __device__ __forceinline__ void mfma_term(f32x16 (&acc)[2][2], const Frag& f) {
 // the small terms are added first
 template <int SPLIT>
 __device__ __forceinline__ void mfma_small(f32x16 (&acc)[2][2], const Frag& f) {
+    if (SPLIT == 3) return;                         // two planes per operand: a1 b1 + a1 b2 + a2 b1 only (mfma_lead)
     if (SPLIT == 9) { mfma_term<2, 2>(acc, f); mfma_term<2, 1>(acc, f); mfma_term<1, 2>(acc, f); }
     mfma_term<2, 0>(acc, f); mfma_term<0, 2>(acc, f); mfma_term<1, 1>(acc, f);
 }
@@ -269,6 +292,7 @@ __device__ unsigned long long g_bf3_clock[2 * GRID];
 template <bool AKC, bool BKC, int SPLIT>
 __global__ __launch_bounds__(NTH, 2) void gemm_bf3_kernel(Params p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];           // 2 stages
+    constexpr int NP = SPLIT == 3 ? 2 : 3;                               // planes per operand element
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
     const int li = lane & 31, lh = lane >> 5;
@@ -299,8 +323,8 @@ __global__ __launch_bounds__(NTH, 2) void gemm_bf3_kernel(Params p) {
         }
     };
     auto stage_store = [&](int st) {
-        sa.template store<PLA>(lds + st * STAGE);
-        sb.template store<PLB>(lds + st * STAGE + 3 * PLA);
+        sa.template store<PLA, NP>(lds + st * STAGE);
+        sb.template store<PLB, NP>(lds + st * STAGE + 3 * PLA);
     };
     // fragment addresses: slab s of the lane = chunk 2 s + lh of row li of the wave's tile rows
     const char* fa[2];
@@ -328,7 +352,7 @@ __global__ __launch_bounds__(NTH, 2) void gemm_bf3_kernel(Params p) {
     stage_store(0);
     produce();
     __syncthreads();
-    read_a(f0, fa[0]); read_b(f0, fb[0]);
+    read_a<NP>(f0, fa[0]); read_b<NP>(f0, fb[0]);
     int cur_st = 0;
     for (int c_item = blockIdx.x; c_item < total; c_item += G) {
         const Item cur = decode(p, c_item);
@@ -356,14 +380,23 @@ __global__ __launch_bounds__(NTH, 2) void gemm_bf3_kernel(Params p) {
             BF3_FENCE();
             // ---- region A: 36 (54) matrix instructions; in their shadow slab 1's fragment reads, the split + LDS stores of step
             // s + 1's tile and the global loads of step s + 2 into the registers the split has just released
-            read_a(f1, fa[1] + so); read_b(f1, fb[1] + so);
+            read_a<NP>(f1, fa[1] + so); read_b<NP>(f1, fb[1] + so);
             mfma_small<SPLIT>(acc, f0);
             stage_store(cur_st ^ 1);
             mfma_lead(acc, f0);
             sa.load_sched(fast);
             sb.load_sched(fast);
             mfma_small<SPLIT>(acc, f1);
-            {
+            if (SPLIT == 3) {                       // 12 matrix instructions carry 8 fragment reads, the two-plane split, 12 LDS writes, the loads
+#pragma unroll
+                for (int i = 0; i < 12; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (i < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                    if (i >= 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+            } else {
                 constexpr int NMA = SPLIT == 9 ? 60 : 36;
 #pragma unroll
                 for (int i = 0; i < NMA; ++i) {
@@ -382,12 +415,12 @@ __global__ __launch_bounds__(NTH, 2) void gemm_bf3_kernel(Params p) {
 #endif
             BF3_FENCE();
             // ---- region B: the leading terms of slab 1 with the fragment reads of step s + 1's slab 0
-            read_a(f0, fa[0] + sn); read_b(f0, fb[0] + sn);
+            read_a<NP>(f0, fa[0] + sn); read_b<NP>(f0, fb[0] + sn);
             mfma_lead(acc, f1);
 #pragma unroll
             for (int i = 0; i < 12; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (i < 4 * NP) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
             BF3_FENCE();
             if (fast) {
@@ -545,7 +578,7 @@ size_t gemm_bf3_workspace_bytes(int M, int N, int K, int batch) {
     return (size_t)pl.nsplit * pl.nsl * TILE * sizeof(float);
 }
 
-// split in {6, 9}, K >= 32; argument checks are the caller's (resel_gemm_f32)
+// split in {3, 6, 9}, K >= 32; argument checks are the caller's (resel_gemm_f32)
 int gemm_bf3_launch(const float* A, int64_t lda, int64_t strideA, int a_kcontig, const float* B, int64_t ldb, int64_t strideB, int b_kcontig,
                     const float* bias, int64_t strideBias, int act, float* C, int64_t ldc, int64_t strideC, void* workspace,
                     int M, int N, int K, int batch, int split, hipStream_t s) {
@@ -561,7 +594,7 @@ int gemm_bf3_launch(const float* A, int64_t lda, int64_t strideA, int a_kcontig,
          else if (a_kcontig) rc = launch_one<true, false, SP>(p, grid, s); \
          else if (b_kcontig) rc = launch_one<false, true, SP>(p, grid, s); \
          else rc = launch_one<false, false, SP>(p, grid, s); } while (0)
-    if (split == 9) BF3_LAUNCH(9); else BF3_LAUNCH(6);
+    if (split == 9) BF3_LAUNCH(9); else if (split == 3) BF3_LAUNCH(3); else BF3_LAUNCH(6);
 #undef BF3_LAUNCH
     if (rc != RESEL_OK) return rc;
     if (pl.nsplit) hipLaunchKernelGGL(gemm_bf3_fixup_kernel, dim3(TILE / 4 / 64, pl.nsplit), dim3(64, 4), 0, s, p);

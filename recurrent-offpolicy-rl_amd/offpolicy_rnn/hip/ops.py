@@ -897,8 +897,17 @@ def linear_bf16(x, weight, bias, out_dtype=torch.bfloat16):
     return LinearBf16.apply(x, weight, bias, out_dtype)
 
 
-# product formation of resel_gemm_f32 (include/resel_hip.h): 0 fp32 MFMA, 9 / 6 exact three-way bf16 split on the bf16 MFMA
-GEMM_SPLIT = int(os.environ.get('RESEL_GEMM_SPLIT', 6))
+# product formation of resel_gemm_f32 (include/resel_hip.h): 0 fp32 MFMA, 9 / 6 exact three-way bf16 split on the bf16 MFMA (fp32-accurate),
+# 3 two planes per operand ("bf16x3").  None (no RESEL_GEMM_SPLIT): follow torch.get_float32_matmul_precision() the way torch's own
+# GEMMs do - 'highest' (torch's default, the reference's setting) = 6, 'high' / 'medium' = 3.
+GEMM_SPLIT = int(os.environ['RESEL_GEMM_SPLIT']) if os.environ.get('RESEL_GEMM_SPLIT') else None
+
+
+def gemm_split():
+    if GEMM_SPLIT is not None:
+        return GEMM_SPLIT
+    return 6 if torch.get_float32_matmul_precision() == 'highest' else 3
+
 
 
 _GEMM_WS_BYTES = {}           # (M, N, K, batch) -> workspace bytes of resel_gemm_f32 (a pure function of the shape)
@@ -935,7 +944,7 @@ def gemm_f32(A, B, a_kcontig=True, b_kcontig=True, bias=None, act=None, out=None
     multi = batch > 1
     check(L.resel_gemm_f32(_p(A), A.stride(-2), A.stride(0) if multi else 0, int(a_kcontig), _p(B), B.stride(-2),
                            B.stride(0) if multi else 0, int(b_kcontig), _p(bias), bs, 2 if act == GEMM_ACCUMULATE else ACT_IDS[act], _p(out), out.stride(-2),
-                           out.stride(0) if multi else 0, _p(ws), M, N, K, batch, GEMM_SPLIT if split is None else int(split), _stream()), 'gemm_f32')
+                           out.stride(0) if multi else 0, _p(ws), M, N, K, batch, gemm_split() if split is None else int(split), _stream()), 'gemm_f32')
     return out
 
 

@@ -814,6 +814,50 @@ def test_gemm_f32_split_modes_error_against_fp64(ops):
     assert err[6][1] < 1e-6
 
 
+@pytest.mark.parametrize('M,N,K,akc,bkc,bias,act,batch', [
+    (300, 256, 384, True, True, True, 'elu', 1), (513, 384, 256, True, False, False, None, 1), (20000, 256, 256, False, False, False, None, 1),
+    (16640, 512, 136, True, True, True, 'elu', 1), (600, 260, 99, False, False, False, None, 1), (260, 256, 256, True, False, True, 'elu', 8),
+    (1500, 200, 4100, True, True, True, 'elu', 1)])
+def test_gemm_f32_two_plane_mode(ops, M, N, K, akc, bkc, bias, act, batch):
+    """Mode 3 ("bf16x3": two bf16 planes per operand, three plane products - torch's float32 matmul precision 'high'): every dropped
+    term is <= 2^-16 |a b|, so the error against fp64 is bounded by 3 x 2^-16 sum |a b| (measured ~ 2^-18 of the output scale);
+    same layouts / tails / fix-up as the fp32-accurate modes, bitwise reproducible."""
+    g = torch.Generator().manual_seed(M + N + K)
+    sh = (batch,) if batch > 1 else ()
+    A = torch.randn(*sh, *((M, K) if akc else (K, M)), generator=g)
+    B = torch.randn(*sh, *((N, K) if bkc else (K, N)), generator=g) / K ** 0.5
+    b = torch.randn(*sh, N, generator=g) if bias else None
+    Ad = A.double() if akc else A.double().transpose(-1, -2)
+    Bd = B.double().transpose(-1, -2) if bkc else B.double()
+    ref = Ad @ Bd
+    bound = 3 * 2.0 ** -16 * (Ad.abs() @ Bd.abs()) + 1e-6
+    if bias:
+        ref = ref + b.double().unsqueeze(-2)
+    out = ops.gemm_f32(A.cuda(), B.cuda(), akc, bkc, None if b is None else b.cuda(), None, split=3)
+    assert ((out.double().cpu() - ref).abs() <= bound).all()
+    if act == 'elu':
+        out_a = ops.gemm_f32(A.cuda(), B.cuda(), akc, bkc, None if b is None else b.cuda(), act, split=3)
+        close(out_a, torch.nn.functional.elu(ref).float(), rtol=1e-4, atol_scale=1e-5, name='gemm_f32 mode 3 + elu')
+    out2 = ops.gemm_f32(A.cuda(), B.cuda(), akc, bkc, None if b is None else b.cuda(), None, split=3)
+    assert torch.equal(out, out2)
+
+
+def test_gemm_f32_follows_torch_matmul_precision(ops, monkeypatch):
+    """No RESEL_GEMM_SPLIT: 'highest' (torch's default and the reference's setting) = the fp32-accurate mode 6, 'high' = mode 3."""
+    monkeypatch.setattr(ops, 'GEMM_SPLIT', None)
+    g = torch.Generator().manual_seed(1)
+    A, B = torch.randn(1024, 512, generator=g).cuda(), torch.randn(256, 512, generator=g).cuda()
+    keep = torch.get_float32_matmul_precision()
+    try:
+        torch.set_float32_matmul_precision('highest')
+        assert ops.gemm_split() == 6 and torch.equal(ops.gemm_f32(A, B), ops.gemm_f32(A, B, split=6))
+        torch.set_float32_matmul_precision('high')
+        assert ops.gemm_split() == 3 and torch.equal(ops.gemm_f32(A, B), ops.gemm_f32(A, B, split=3))
+        assert not torch.equal(ops.gemm_f32(A, B, split=3), ops.gemm_f32(A, B, split=6))
+    finally:
+        torch.set_float32_matmul_precision(keep)
+
+
 # ------------------------------------------------------------------------------------------ time-parallel selective scan
 @pytest.mark.parametrize('B,L,Di,N,segs', [(2, 333, 128, 32, 4), (1, 200, 64, 16, 3), (3, 1043, 64, 32, 0), (2, 97, 64, 8, 2)])
 def test_selective_scan_time_segments_equal_the_one_pass_scan(ops, monkeypatch, B, L, Di, N, segs):
