@@ -1,4 +1,5 @@
-"""Error pattern of the attention kernels on small cases (debug aid).  GPU box."""
+"""Error pattern of the attention kernels against the oracle on small cases (debug aid, not collected by pytest; lives under tests/ because
+only tests may import oracle/).  GPU box: python3 tests/attn_debug.py"""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'recurrent-offpolicy-rl_amd')]
