@@ -268,6 +268,17 @@ __device__ __forceinline__ void mfma_term(f32x16 (&acc)[2][2], const Frag& f) {
         for (int b = 0; b < 2; ++b) {
 #ifdef BF3_AB_NOMFMA                   // ablation (wrong results): operands consumed, no matrix instruction
             asm volatile("" :: "v"(f.a[P][a]), "v"(f.b[Q][b]));
+#elif defined(BF3_AB_M16)              // ablation (wrong results): the same matrix-pipe time as TWO v_mfma_f32_16x16x32_bf16 on accumulator quarters
+            {
+                typedef float f32x4v __attribute__((ext_vector_type(4)));
+                constexpr int h = ((P + Q) & 1) * 2;
+                f32x4v q0 = __builtin_shufflevector(acc[a][b], acc[a][b], 4 * h, 4 * h + 1, 4 * h + 2, 4 * h + 3);
+                f32x4v q1 = __builtin_shufflevector(acc[a][b], acc[a][b], 4 * h + 4, 4 * h + 5, 4 * h + 6, 4 * h + 7);
+                q0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[P][a], f.b[Q][b], q0, 0, 0, 0);
+                q1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[P][a], f.b[Q][b], q1, 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { acc[a][b][4 * h + e] = q0[e]; acc[a][b][4 * h + 4 + e] = q1[e]; }
+            }
 #else
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[P][a], f.b[Q][b], acc[a][b], 0, 0, 0);
 #endif
