@@ -605,7 +605,7 @@ extern "C" int resel_gemm_f32(const float* A, int64_t lda, int64_t strideA, int 
                               int M, int N, int K, int batch, int split, resel_stream_t stream) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || act < 0 || act > 2) return RESEL_EINVAL;
     // 106 / 109: modes 6 / 9 on the first-edition kernel of this file (every wave splits the fragments it reads), kept for A/B runs
-    if (split != 0 && split != 3 && split != 6 && split != 9 && split != 106 && split != 109 && split != 203 && split != 206 && split != 209) return RESEL_EINVAL;
+    if (split != 0 && split != 3 && split != 6 && split != 9 && split != 106 && split != 109) return RESEL_EINVAL;
     if (K < BK) split = 0;                         // the split kernels' scheduled loads assume one whole K step per item
     if (lda % 4 || ldb % 4 || strideA % 4 || strideB % 4 || !aligned16(A) || !aligned16(B)) return RESEL_EINVAL;
     // float4 loads run along the contiguous axis: its extent must be a multiple of 4 (K for [rows][K] operands, rows otherwise)
@@ -614,8 +614,7 @@ extern "C" int resel_gemm_f32(const float* A, int64_t lda, int64_t strideA, int 
     if (lda <= 0 || ldb <= 0 || ldc <= 0 || lda >= (int64_t)1 << 22 || ldb >= (int64_t)1 << 22) return RESEL_EINVAL;
     // second edition (256 x 128 tiles) unless half of its tile rows would be padding: M <= 128 (narrow weight gradients) runs
     // 1.2-1.4x faster on the first edition's 128 x 128 tiles (66 752-token weight gradients [128, 256]: 48 vs 59 us, [80, 512]: 67 vs 95)
-    if (split >= 200 && (M <= 128 || K < 3 * BK)) split -= 200;     // the 16x16x32 edition keeps three K steps in flight
-    if ((split == 3 || split == 6 || split == 9 || split >= 200) && M > 128)
+    if ((split == 3 || split == 6 || split == 9) && M > 128)
         return gemm_bf3_launch(A, lda, strideA, a_kcontig, B, ldb, strideB, b_kcontig, bias, strideBias, act, C, ldc, strideC, workspace,
                                M, N, K, batch, split, (hipStream_t)stream);
     if (split > 100) split -= 100;                 // here: 6 / 9 = first-edition split kernels, 0 = fp32 MFMA
