@@ -470,6 +470,41 @@ def test_attn_forward_without_work_list_is_bitwise_the_same(ops):
     assert torch.equal(a.view(torch.int16), out.view(torch.int16))
 
 
+def test_attn_more_heads_than_xcds_and_grid_bound_above_the_longest_sequence(ops):
+    """H = 12 (two head groups per XCD slot of the work-item mapping) and max_seqlen well above the longest sequence (work-list levels
+    beyond every sequence are simply empty)."""
+    H, hd, lens = 12, 32, [3, 200, 129, 64, 1]
+    g = torch.Generator().manual_seed(21)
+    T = sum(lens)
+    qkv = (torch.randn(T, 3, H, hd, generator=g) * 0.8).to(torch.bfloat16)
+    dout = torch.randn(T, H, hd, generator=g).to(torch.bfloat16)
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32)
+    slopes = K.alibi_slopes(H)
+    ref_in = qkv.float().requires_grad_(True)
+    ref = K.attention_alibi_varlen_ref(ref_in[:, 0], ref_in[:, 1], ref_in[:, 2], cu, slopes)
+    (ref * dout.float()).sum().backward()
+    x = qkv.cuda().requires_grad_(True)
+    out = ops.attn_varlen(x, cu.cuda(), 1000, slopes.cuda())
+    (out.float() * dout.cuda().float()).sum().backward()
+    close(out.float(), ref, rtol=1e-2, atol_scale=1e-2, name='out')
+    close(x.grad.float(), ref_in.grad, rtol=2e-2, atol_scale=2e-2, name='dqkv')
+
+
+def test_attn_more_sequences_than_the_work_list_can_index(ops):
+    """S >= 65 536 sequences: no work list is built (16-bit sequence field), the kernels run in (sequence, block) order.  With one
+    token per sequence the softmax is over a single key: out == v and dv == dout exactly; dq, dk = 0 up to the fp32 summation order of
+    dP - delta (two sums of the same 32 products)."""
+    S, H, hd = 70000, 2, 32
+    g = torch.Generator().manual_seed(2)
+    qkv = torch.randn(S, 3, H, hd, generator=g).to(torch.bfloat16).cuda().requires_grad_(True)
+    cu = torch.arange(S + 1, dtype=torch.int32, device='cuda')
+    out = ops.attn_varlen(qkv, cu, 1, None)
+    assert torch.equal(out, qkv.detach()[:, 2])
+    dout = torch.randn(S, H, hd, generator=g).to(torch.bfloat16).cuda()
+    out.backward(dout)
+    assert torch.equal(qkv.grad[:, 2], dout) and qkv.grad[:, :2].float().abs().max() < 1e-4
+
+
 def test_attn_layout_with_integer_data(ops):
     """Exact small-integer operands (products and sums exact in bf16/fp32) catch any fragment-layout transposition."""
     H, hd, L = 2, 32, 70
