@@ -21,6 +21,13 @@
 namespace {
 using namespace resel;
 
+// gate non-linearities on v_exp_f32 / v_rcp_f32 (1 ulp each: 2e-7 on a gate, parity bar 1e-4).  They sit on the serial chain of
+// every step - 64 threads, everyone else waiting at a barrier - where libm's expf / tanhf cost ~0.25 us of a 3.4 us step.
+__device__ __forceinline__ float gru_tanh(float x) {
+    const float e = fast_exp(-2.0f * fabsf(x));                 // tanh|x| = (1 - e) / (1 + e)
+    return copysignf((1.0f - e) * fast_rcp(1.0f + e), x);
+}
+
 constexpr int US = 16;    // hidden units per block
 constexpr int RG = 4;     // batch rows per block
 constexpr int KQMAX = 16; // reduction-axis pieces: H = KC * KQ with KQ <= 16; a block has 16 * KQ threads
@@ -116,10 +123,10 @@ __global__ __launch_bounds__(256) void gru_fwd_step_kernel(GruFwd p) {
         float ar = 0.f, az = 0.f, an = 0.f;
         for (int q = 0; q < KQ; ++q) { ar += s_p[q][ro * 3][j]; az += s_p[q][ro * 3 + 1][j]; an += s_p[q][ro * 3 + 2][j]; }
         const int64_t tok = (int64_t)(b0 + ro) * p.L + p.t;
-        const float rg = 1.f / (1.f + expf(-(gir + ar + br)));
-        const float zg = 1.f / (1.f + expf(-(giz + az + bz)));
+        const float rg = sigmoidf_(gir + ar + br);
+        const float zg = sigmoidf_(giz + az + bz);
         const float hn = an + bn;
-        const float ng = tanhf(gin + rg * hn);
+        const float ng = gru_tanh(gin + rg * hn);
         const float hp = s_h[ro][uo];
         p.h_all[tok * H + uo] = (1.f - zg) * ng + zg * hp;
         if (p.gates) {
@@ -234,10 +241,10 @@ __global__ __launch_bounds__(256) void gru_fwd_persistent_kernel(GruFwd p, u64* 
                 float ar = 0.f, az = 0.f, an = 0.f;
                 for (int q = 0; q < KQ; ++q) { ar += s_p[q][ro * 3][j]; az += s_p[q][ro * 3 + 1][j]; an += s_p[q][ro * 3 + 2][j]; }
                 const int64_t tok = (int64_t)(b0 + ro) * p.L + t;
-                const float rgt = 1.f / (1.f + expf(-(gir + ar + br)));
-                const float zg = 1.f / (1.f + expf(-(giz + az + bz)));
+                const float rgt = sigmoidf_(gir + ar + br);
+                const float zg = sigmoidf_(giz + az + bz);
                 const float hn = an + bn;
-                const float ng = tanhf(gin + rgt * hn);
+                const float ng = gru_tanh(gin + rgt * hn);
                 const float hp = s_h[ro][uo];
                 hnew = (1.f - zg) * ng + zg * hp;
                 p.h_all[tok * H + uo] = hnew;
