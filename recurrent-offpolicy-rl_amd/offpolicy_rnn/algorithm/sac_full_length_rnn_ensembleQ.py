@@ -16,7 +16,7 @@ What is organised differently for the MI355X:
     that the reference computes and throws away;
   * every scalar of the log dict is gathered on the device and fetched with one transfer at the end.
 """
-from typing import Dict, List
+from typing import Dict
 
 import os
 

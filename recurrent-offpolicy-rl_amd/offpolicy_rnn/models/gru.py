@@ -6,7 +6,6 @@ mask handling (:453-454).  This module keeps the parameter names of nn.GRU (`wei
 one GEMM over all B*T' tokens, the recurrence runs in `ops.gru_seq`."""
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from ..hip import ops
 

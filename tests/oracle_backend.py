@@ -3,8 +3,6 @@
 
 This is test infrastructure: the product never imports it, and on a GPU box the real HIP kernels run instead
 (tests/test_hip_ops.py, tests/test_trainer_gpu.py).  Installed by the `oracle_ops` fixture in conftest.py."""
-import math
-
 import torch
 
 from oracle import kernels as K

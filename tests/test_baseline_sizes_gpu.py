@@ -6,7 +6,6 @@ bar (1e-4, relative to the largest reference magnitude of the compared tensor; t
   configs[1] / [3]: smamba_s32_c16_b2_nln, T' = 1043 (T = 1024 + skip 18 + 1), d_inner 512, N 32, conv K 16;
   configs[4]: gilr and lru, T' = 2003 (T = 2000 full episode), B = 16.
 Flags as the trainer builds them: the pre-step slots of a row are `start`, validity covers the trajectory, one mid-row reset."""
-import numpy as np
 import pytest
 import torch
 
