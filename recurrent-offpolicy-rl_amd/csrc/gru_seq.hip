@@ -234,6 +234,9 @@ __global__ __launch_bounds__(256) void gru_fwd_persistent_kernel(GruFwd p, u64* 
             s_p[kq][r * 3 + 1][j] = a[1];
             s_p[kq][r * 3 + 2][j] = a[2];
         }
+        // h_{t-1} of the owned unit is fetched on THIS side of the barrier: behind it nothing reads s_h any more, so the next step's
+        // poll may overwrite it while slower waves still finish this step - one barrier per step less
+        const float hp = tid < RG * US ? s_h[ro][uo] : 0.f;
         __syncthreads();
         if (tid < RG * US) {
             float hnew = 0.f;
@@ -245,7 +248,6 @@ __global__ __launch_bounds__(256) void gru_fwd_persistent_kernel(GruFwd p, u64* 
                 const float zg = sigmoidf_(giz + az + bz);
                 const float hn = an + bn;
                 const float ng = gru_tanh(gin + rgt * hn);
-                const float hp = s_h[ro][uo];
                 hnew = (1.f - zg) * ng + zg * hp;
                 p.h_all[tok * H + uo] = hnew;
                 if (p.gates) {
@@ -257,7 +259,10 @@ __global__ __launch_bounds__(256) void gru_fwd_persistent_kernel(GruFwd p, u64* 
             __hip_atomic_store(xg + (size_t)(t & 1) * RG * H + (size_t)ro * H + uo, ((u64)(unsigned)(t + 1) << 32) | __float_as_uint(hnew),
                                RESEL_RLX_AGENT);
         }
-        __syncthreads();                             // s_h / s_p are rewritten by the next step
+        // A third barrier is not needed for correctness any more (nothing behind the second one reads s_h; s_p is rewritten behind the
+        // next step's first barrier) but the forward is FASTER with it: 2.71 against 3.00 us per step on the same box - the waves stay in
+        // step for the next poll.  (The backward is faster without: 3.35 against 3.44.)
+        __syncthreads();
     }
 }
 
@@ -439,17 +444,18 @@ __global__ __launch_bounds__(256) void gru_bwd_persistent_kernel(GruBwd p, u64* 
             }
             s_p[kq][r][j] = acc;
         }
+        const float dz_own = tid < RG * US ? s_dz[tid >> 4][j] : 0.f;     // read on this side of the barrier (as h_{t-1} in the forward)
         __syncthreads();
         if (tid < RG * US) {
             const int r = tid >> 4;
-            float acc = s_dz[r][j];
+            float acc = dz_own;
             for (int q = 0; q < KQ; ++q) acc += s_p[q][r][j];
             if (b0 + r >= p.B) acc = 0.f;
             if (t == 0) { if (b0 + r < p.B) p.carry_out[(int64_t)(b0 + r) * H + s * US + j] = acc; }     // d h_0 (unused by the caller)
             else __hip_atomic_store(xg + (size_t)(k & 1) * RG * H + (size_t)r * H + s * US + j,
                                     ((u64)(unsigned)(k + 1) << 32) | __float_as_uint(acc), RESEL_RLX_AGENT);
         }
-        __syncthreads();
+        // no third barrier: s_g / s_dz are rewritten before, s_p behind the next step's first barrier - neither is read above (3.44 -> 3.35 us per step)
     }
 }
 
