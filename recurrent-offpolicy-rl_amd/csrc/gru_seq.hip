@@ -192,6 +192,12 @@ __global__ __launch_bounds__(256) void gru_fwd_persistent_kernel(GruFwd p, u64* 
             // case instead of one per granule (the polls were the longest part of a step)
             constexpr int NPOLL = (RG * KC + 15) / 16;           // = RG * H / NT  (H = KC * KQ, NT = 16 * KQ)
             u64 xv[NPOLL];
+            // The first poll is held back by ~770 cycles where a step is long enough (H >= 256): h_{t-1} of the other slices becomes
+            // visible 0.4-0.5 us after this workgroup's own publish, and a poll that arrives in L2 before the data costs a whole second
+            // round trip.  B = 64, H = 256, same box, us per step: no delay 2.70; s_sleep 2 / 4 / 8 / 12 / 16 / 20 / 24 / 32: 2.61 / 2.62 /
+            // 2.65 / 2.20 / 2.24 / 2.35 / 2.46 / 2.67.  B = 32: 2.58 -> 2.15.  H = 128: no change; H = 64: 2.08 -> 2.25 (no delay there).
+            // (The backward's poll already sits behind the loads of its carry-independent operands: any delay there measured slower.)
+            if (KC >= 16) __builtin_amdgcn_s_sleep(12);
 #pragma unroll
             for (int q = 0; q < NPOLL; ++q) {
                 const int i = tid + q * NT;
