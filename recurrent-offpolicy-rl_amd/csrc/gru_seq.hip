@@ -255,20 +255,25 @@ __global__ __launch_bounds__(256) void gru_fwd_persistent_kernel(GruFwd p, u64* 
                 const float hn = an + bn;
                 const float ng = gru_tanh(gin + rgt * hn);
                 hnew = (1.f - zg) * ng + zg * hp;
+                // publish FIRST (the other slices wait for it), the step's outputs behind it
+                __hip_atomic_store(xg + (size_t)(t & 1) * RG * H + (size_t)ro * H + uo, ((u64)(unsigned)(t + 1) << 32) | __float_as_uint(hnew),
+                                   RESEL_RLX_AGENT);
                 p.h_all[tok * H + uo] = hnew;
                 if (p.gates) {
                     float* o = p.gates + tok * 4 * H;
                     o[uo] = rgt; o[H + uo] = zg; o[2 * H + uo] = ng; o[3 * H + uo] = hn;
                 }
+            } else {
+                // rows past B publish zeros so that every granule of the row group gets its tag
+                __hip_atomic_store(xg + (size_t)(t & 1) * RG * H + (size_t)ro * H + uo, ((u64)(unsigned)(t + 1) << 32), RESEL_RLX_AGENT);
             }
-            // publish (rows past B publish zeros so that every granule of the row group gets its tag)
-            __hip_atomic_store(xg + (size_t)(t & 1) * RG * H + (size_t)ro * H + uo, ((u64)(unsigned)(t + 1) << 32) | __float_as_uint(hnew),
-                               RESEL_RLX_AGENT);
         }
         // A third barrier is not needed for correctness any more (nothing behind the second one reads s_h; s_p is rewritten behind the
         // next step's first barrier) but the forward is FASTER with it: 2.71 against 3.00 us per step on the same box - the waves stay in
         // step for the next poll.  (The backward is faster without: 3.35 against 3.44.)
+#ifndef GRU_AB_NOB3
         __syncthreads();
+#endif
     }
 }
 
@@ -353,7 +358,7 @@ __global__ __launch_bounds__(256) void gru_bwd_persistent_kernel(GruBwd p, u64* 
     constexpr int NC = RC / 4;
     constexpr int PER = (RG * KC * KQMAX + 255) / 256;       // (row, unit) items per thread at the widest block
     __shared__ __attribute__((aligned(16))) float s_gbuf[RG * 3 * KC * KQMAX];
-    __shared__ float s_dz[RG][US];
+    __shared__ float s_dz[RG][US], s_dn[RG][US];
     __shared__ float s_p[KQMAX][RG][US + 1];
     __shared__ int s_fail;
     const int tid = threadIdx.x, NT = blockDim.x, KQ = NT >> 4, H = p.H;
@@ -420,18 +425,11 @@ __global__ __launch_bounds__(256) void gru_bwd_persistent_kernel(GruBwd p, u64* 
                 dr_ = dn_ * hn * rgt * (1.f - rgt);
                 dhn = dn_ * rgt;
                 dhz = dh * zg;
-                if (u / US == s) {
-                    const int64_t tok = (int64_t)(b0 + r) * p.L + t;
-                    float* o1 = p.dgi + tok * 3 * H;
-                    float* o2 = p.dgh + tok * 3 * H;
-                    o1[u] = dr_; o1[H + u] = dz_; o1[2 * H + u] = dn_;
-                    o2[u] = dr_; o2[H + u] = dz_; o2[2 * H + u] = dhn;
-                }
             }
             s_g(r)[u] = dr_;
             s_g(r)[H + u] = dz_;
             s_g(r)[2 * H + u] = dhn;
-            if (u / US == s) s_dz[r][u % US] = dhz;
+            if (u / US == s) { s_dz[r][u % US] = dhz; s_dn[r][u % US] = dn_; }
         }
         __syncthreads();
         if (s_fail) {                                // fail loudly: poison this step's projection gradients
@@ -450,7 +448,14 @@ __global__ __launch_bounds__(256) void gru_bwd_persistent_kernel(GruBwd p, u64* 
             }
             s_p[kq][r][j] = acc;
         }
-        const float dz_own = tid < RG * US ? s_dz[tid >> 4][j] : 0.f;     // read on this side of the barrier (as h_{t-1} in the forward)
+        // read on this side of the barrier (as h_{t-1} in the forward): dh z of the owned unit, and the owned projection gradients, which
+        // are stored BEHIND the publish (24 stores of one quarter-wave used to sit in front of the first barrier of every step)
+        float dz_own = 0.f, o_dr = 0.f, o_dz = 0.f, o_dhn = 0.f, o_dn = 0.f;
+        if (tid < RG * US) {
+            const int r = tid >> 4, u = s * US + j;
+            dz_own = s_dz[r][j]; o_dn = s_dn[r][j];
+            o_dr = s_g(r)[u]; o_dz = s_g(r)[H + u]; o_dhn = s_g(r)[2 * H + u];
+        }
         __syncthreads();
         if (tid < RG * US) {
             const int r = tid >> 4;
@@ -460,6 +465,14 @@ __global__ __launch_bounds__(256) void gru_bwd_persistent_kernel(GruBwd p, u64* 
             if (t == 0) { if (b0 + r < p.B) p.carry_out[(int64_t)(b0 + r) * H + s * US + j] = acc; }     // d h_0 (unused by the caller)
             else __hip_atomic_store(xg + (size_t)(k & 1) * RG * H + (size_t)r * H + s * US + j,
                                     ((u64)(unsigned)(k + 1) << 32) | __float_as_uint(acc), RESEL_RLX_AGENT);
+            if (b0 + r < p.B) {
+                const int u = s * US + j;
+                const int64_t tok = (int64_t)(b0 + r) * p.L + t;
+                float* o1 = p.dgi + tok * 3 * H;
+                float* o2 = p.dgh + tok * 3 * H;
+                o1[u] = o_dr; o1[H + u] = o_dz; o1[2 * H + u] = o_dn;
+                o2[u] = o_dr; o2[H + u] = o_dz; o2[2 * H + u] = o_dhn;
+            }
         }
         // no third barrier: s_g / s_dz are rewritten before, s_p behind the next step's first barrier - neither is read above (3.44 -> 3.35 us per step)
     }
