@@ -385,7 +385,8 @@ def rccl_one_rank_leg(args):
 
 SUITE = (('configs[2]', ['--rnn', 'cgpt_h8_l6_p0.1_ml1024_rms', '--algo', 'td3', '--rows', '32', '--horizon', '1024']),
          ('configs[4] gilr', ['--rnn', 'gilr', '--algo', 'sac', '--rows', '16', '--horizon', '2000']),
-         ('configs[4] lru', ['--rnn', 'lru', '--algo', 'sac', '--rows', '16', '--horizon', '2000']))
+         ('configs[4] lru', ['--rnn', 'lru', '--algo', 'sac', '--rows', '16', '--horizon', '2000']),
+         ('gru (configs[0] family at the configs[1] sizes)', ['--rnn', 'gru', '--algo', 'sac', '--rows', '64', '--horizon', '1024']))
 
 
 def suite_legs(args):
