@@ -85,12 +85,12 @@ def build_trainer(rnn, B, T, seed=0, algo='sac'):
 def baseline_config(args):
     """Which BASELINE.json `configs` entry the command line corresponds to."""
     if args.rnn.startswith('smamba'):
-        return 'BASELINE configs[1]; at N=8 this is configs[3], B=512 global'
+        return 'configs[1]; N=8: configs[3]'
     if args.rnn.startswith('cgpt'):
-        return 'BASELINE configs[2] family (cgpt TD3, B=32)'
+        return 'configs[2]'
     if args.rnn in ('gilr', 'lru'):
-        return 'BASELINE configs[4] family (linear-RNN scan; --horizon 2000 for the full-episode case)'
-    return 'BASELINE configs[0] family (GRU) at the configs[1] size'
+        return 'configs[4] family; --horizon 2000 = full episode'
+    return 'configs[0] layer at configs[1] size'
 
 
 def cpu_baseline(rnn, algo='sac'):
@@ -193,7 +193,7 @@ def roofline_lines(args, kern, Bsz, Tp):
             N = int(args.rnn.split('_s')[1].split('_')[0])
             o['valu_cycles_per_state_step'] = avg * 1e-6 * 1024 * 2.4e9 / (Bsz * Tp * 2 * D * N / 64)
             o['valu_floor_cycles_per_state_step'] = 17.2 if name == 'sscan_fwd_kernel' else 54.0
-            o['note'] = 'fp32 recurrence, N states per channel: bound by VALU issue below the HBM roof (DESIGN.md 4, profiles/r02_pmc_sscan.md)'
+            o['note'] = 'fp32 recurrence, VALU-issue bound below the HBM roof (DESIGN.md 4)'
         if name.startswith('gru'):
             o['us_per_step'] = avg / Tp if kern[name]['launches'] and avg > 50 else avg
         lines.append((avg * kern[name]['launches'], o))
@@ -546,8 +546,8 @@ def main():
         'metric': 'env-steps/sec trained', 'value': trained / dt, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'strong' if args.global_rows else 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'dtype_note': ('inputs, accumulators and outputs of every kernel are fp32; GEMM products: ' + {0: 'fp32 MFMA instruction', 6: 'exact 3-way bf16 split of both fp32 operands, 6 leading plane products on the bf16 MFMA (as accurate vs fp64 as the fp32 instruction: DESIGN.md 4)', 9: 'exact 3-way bf16 split of both fp32 operands, all 9 plane products on the bf16 MFMA', 3: 'two bf16 planes per fp32 operand, 3 leading plane products on the bf16 MFMA (bf16x3: float32 matmul precision "high", NOT fp32-accurate)'}[gemm_mode]), 'data': 'synthetic',
-        'config': {'workload': f'{args.rnn} {args.algo.upper()}-REDQ full-trajectory update, B={Bsz}/GPU, T={args.horizon} (row length {Tp}), obs={OBS}, act={ACT}, '
-                               f'D=256, efc-8 critic ({baseline_config(args)})',
+        'config': {'workload': f'{args.rnn} {args.algo.upper()}-REDQ update, B={Bsz}/GPU, T={args.horizon}, D=256 ({baseline_config(args)})',
+                   'row_length': Tp, 'obs': OBS, 'act': ACT, 'critic': 'efc-8',
                    'global_rows': Bsz * world, 'parallelism': f'dp{world}'},
         # collectives the timed updates ISSUED (counted where they are called, parallel/data_parallel.py), per update
         'graph_update': bool(args.graph_update), 'graph_update_leg': graph_leg,
@@ -578,12 +578,23 @@ def main():
                           3: 'two bf16 planes per operand, 3 leading plane products, fp32 accumulate (bf16x3)'}[mode],
              'ms_per_step_with_fp32_mfma_products': strict_ms,
              'ms_per_step_with_matmul_precision_high_bf16x3': high_ms,
-             'note': 'all fc / efc-E / projection GEMMs of the update (inputs, accumulation and outputs fp32): DESIGN.md 4 "The GEMMs", profiles/r02_gemm.md'}
+             'note': 'all fc / efc-E / projection GEMMs of the update, fp32 in / out (DESIGN.md 4)'}
         ranked.append((t * 1e6, o))
     ranked.sort(key=lambda x: -x[0])
     lines = [o for _, o in ranked]
     if lines:
         out['roofline'] = lines[0]                       # the hand-written kernel with the largest total time in the timed region
+    # BASELINE.json's second metric ("selective_scan HBM GB/s"): algorithmic GB/s and fraction of the 8 TB/s roof of both scan
+    # kernels, in short keys at the top level AND inside `roofline` (records that keep only the contract's keys keep it there)
+    sc = {o['kernel']: o for o in lines if o['kernel'].startswith('sscan')}
+    if sc:
+        ss = {}
+        for tag, name in (('fwd', 'sscan_fwd_kernel'), ('bwd', 'sscan_bwd_kernel')):
+            if name in sc:
+                ss.update({f'{tag}_gbs': round(sc[name]['achieved'], 1), f'{tag}_frac': round(sc[name]['frac'], 4), f'{tag}_us': round(sc[name]['avg_us'], 1),
+                           f'{tag}_traffic_mb': (round(sc[name]['traffic'] / 1e6, 1) if sc[name].get('traffic') else None)})
+        out['sscan'] = ss
+        out['roofline']['selective_scan'] = ss
     if len(lines) > 1:
         out['roofline_other'] = lines[1:]
     out['kernels'] = kern

@@ -312,7 +312,8 @@ int resel_gemm_f32(const float* A, int64_t lda, int64_t strideA, int a_kcontig,
 
 /* ---- mixed-precision GEMM for the bf16 attention projections (cgpt) ------------------------------------------------------
  * C[m][n] = sum_k bf16(A(m, k)) bf16(B(n, k)) + bf16(bias[n]): operands rounded to bf16 (round to nearest even) on their way
- * into LDS, fp32 accumulation (v_mfma_f32_32x32x16_bf16), C stored as bf16 (c_bf16 != 0) or fp32.  A / B are fp32 or bf16 in
+ * into LDS, fp32 accumulation (v_mfma_f32_32x32x16_bf16), C stored as bf16 (c_bf16 = 1), as fp32 (0), or as fp32 holding the
+ * bf16-rounded value (2: the autocast's rounding point without the cast pass that follows it).  A / B are fp32 or bf16 in
  * memory (x_bf16) and [rows][K] (x_kcontig = 1) or [K][rows]; lda / ldb / ldc in ELEMENTS; bias fp32 or NULL.  This is what
  * F.linear computes under the reference's bf16 autocast (flash-attn MHA, TransformerFlashAttention.py:67-70) without the
  * separate cast passes: forward (A = activations, B = weight [N][K]), input gradient (B = weight as [K][rows]), weight

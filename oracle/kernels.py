@@ -254,9 +254,12 @@ class DropCounter:
         return out
 
 
-def attention_alibi_varlen_ref(q, k, v, cu_seqlens, slopes=None, scale=None, p_drop=0.0, seed=0, offset=0):
+def attention_alibi_varlen_ref(q, k, v, cu_seqlens, slopes=None, scale=None, p_drop=0.0, seed=0, offset=0, p_bf16=False):
     """q, k, v: [T, H, d] packed tokens; cu_seqlens: int [S+1].  Returns out [T, H, d] (fp32 math).
-    p_drop > 0: the probabilities entering P V are masked by `attn_dropout_keep` and scaled by 1 / (1 - p)."""
+    p_drop > 0: the probabilities entering P V are masked by `attn_dropout_keep` and scaled by 1 / (1 - p).
+    p_bf16: the rounding point every bf16 flash-attention forward has (upstream flash-attn semantics, third party): the
+    un-normalised probabilities exp(s - rowmax) enter the P V product rounded to bf16 while the row sum that normalises the
+    result is taken over the unrounded fp32 values."""
     T, H, d = q.shape
     scale = (1.0 / math.sqrt(d)) if scale is None else scale
     out = torch.zeros(T, H, d, dtype=torch.float32)
@@ -273,6 +276,15 @@ def attention_alibi_varlen_ref(q, k, v, cu_seqlens, slopes=None, scale=None, p_d
         if slopes is not None:
             sc = sc - slopes.float()[:, None, None] * (i - j).abs().float()[None]
         sc = sc.masked_fill((j > i)[None], float('-inf'))
+        if p_bf16:
+            e = torch.exp(sc - sc.max(dim=-1, keepdim=True).values)
+            inv = 1.0 / e.sum(dim=-1, keepdim=True)
+            e = e.to(torch.bfloat16).float()
+            if p_drop > 0.0:
+                e = torch.where(attn_dropout_keep(seed, offset, H, a, n, p_drop), e, torch.zeros_like(e))
+                inv = inv / (1.0 - p_drop)
+            out[a:b] = torch.einsum('hij,jhd->ihd', e, vs) * inv.permute(1, 0, 2)
+            continue
         p = torch.softmax(sc, dim=-1)
         if p_drop > 0.0:
             p = torch.where(attn_dropout_keep(seed, offset, H, a, n, p_drop), p / (1.0 - p_drop), torch.zeros_like(p))

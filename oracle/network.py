@@ -388,7 +388,7 @@ def cgpt_layer(p, pre, x, cfg, flags=None, bf16=True):
         qkv = cast(F.linear(cast(h), cast(p[lp + 'mha.Wqkv.weight']), cast(p[lp + 'mha.Wqkv.bias'])))
         qkv = qkv.view(-1, 3, H, hd)
         sd, of = dc.next() if dc is not None else (0, 0)
-        a = cast(K.attention_alibi_varlen_ref(qkv[:, 0], qkv[:, 1], qkv[:, 2], cu, slopes, None, pd, sd, of))
+        a = cast(K.attention_alibi_varlen_ref(qkv[:, 0], qkv[:, 1], qkv[:, 2], cu, slopes, None, pd, sd, of, p_bf16=bf16))
         a = cast(F.linear(a.reshape(-1, D), cast(p[lp + 'mha.out_proj.weight']), cast(p[lp + 'mha.out_proj.bias'])))
         t = drop(a) + t                                             # :83
         h = _norm(p, lp + 'ffn_norm.', t, cfg['ln'])

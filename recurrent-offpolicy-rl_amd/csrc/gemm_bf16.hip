@@ -269,8 +269,8 @@ __global__ __launch_bounds__(NTH, 2) void gemm_bf16_kernel(Params p) {
                         const int m = mb + (e & 3) + 8 * (e >> 2);
                         if (m < p.M) {
                             const float v = acc[a][b][e] + bv;
-                            if (p.c_bf16) reinterpret_cast<__bf16*>(p.C)[(int64_t)m * p.ldc + n] = (__bf16)v;
-                            else reinterpret_cast<float*>(p.C)[(int64_t)m * p.ldc + n] = v;
+                            if (p.c_bf16 == 1) reinterpret_cast<__bf16*>(p.C)[(int64_t)m * p.ldc + n] = (__bf16)v;
+                            else reinterpret_cast<float*>(p.C)[(int64_t)m * p.ldc + n] = p.c_bf16 ? bf16_round(v) : v;
                         }
                     }
                 }
@@ -303,8 +303,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_fixup_kernel(Params p) {
     for (int j = 0; j < 4; ++j) {
         if (n + j >= p.N) break;
         const float x = o[j] + (p.bias ? bf16_round(p.bias[n + j]) : 0.f);
-        if (p.c_bf16) reinterpret_cast<__bf16*>(p.C)[(int64_t)m * p.ldc + n + j] = (__bf16)x;
-        else reinterpret_cast<float*>(p.C)[(int64_t)m * p.ldc + n + j] = x;
+        if (p.c_bf16 == 1) reinterpret_cast<__bf16*>(p.C)[(int64_t)m * p.ldc + n + j] = (__bf16)x;
+        else reinterpret_cast<float*>(p.C)[(int64_t)m * p.ldc + n + j] = p.c_bf16 ? bf16_round(x) : x;
     }
 }
 
@@ -350,7 +350,7 @@ extern "C" int resel_gemm_bf16(const void* A, int64_t lda, int a_kcontig, int a_
     if (lda <= 0 || ldb <= 0 || ldc <= 0 || lda >= (int64_t)1 << 22 || ldb >= (int64_t)1 << 22) return RESEL_EINVAL;
     const Plan pl = make_plan(M, N, K);
     if (pl.nsplit && (!workspace || !aligned16(workspace))) return RESEL_EINVAL;
-    Params p{A, B, bias, C, (float*)workspace, lda, ldb, ldc, M, N, K, c_bf16 ? 1 : 0,
+    Params p{A, B, bias, C, (float*)workspace, lda, ldb, ldc, M, N, K, c_bf16 == 2 ? 2 : (c_bf16 ? 1 : 0),
              (M + BM - 1) / BM, (N + BN - 1) / BN, pl.nfull, pl.nsplit, pl.nsl, pl.kslice};
     const int64_t total = (int64_t)pl.nfull + (int64_t)pl.nsplit * pl.nsl;
     dim3 grid((unsigned)std::min<int64_t>(total, GRID));

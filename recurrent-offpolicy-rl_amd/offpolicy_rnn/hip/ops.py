@@ -844,9 +844,10 @@ def atb(wide, narrow, transposed=False):
 
 # ---------------------------------------------------------------------------------------------- bf16 projections (cgpt)
 @torch.no_grad()
-def gemm_bf16(A, B, a_kcontig=True, b_kcontig=True, bias=None, out_dtype=torch.bfloat16):
+def gemm_bf16(A, B, a_kcontig=True, b_kcontig=True, bias=None, out_dtype=torch.bfloat16, round_out=False):
     """C [M, N] = bf16(A) (.) bf16(B) + bf16(bias), fp32 accumulation (include/resel_hip.h `resel_gemm_bf16`).  A: [M, K]
-    (a_kcontig) or [K, M]; B: [N, K] (b_kcontig) or [K, N]; each fp32 or bf16 (rounded to bf16 on the way into LDS); bias fp32."""
+    (a_kcontig) or [K, M]; B: [N, K] (b_kcontig) or [K, N]; each fp32 or bf16 (rounded to bf16 on the way into LDS); bias fp32.
+    round_out (fp32 output only): store the bf16-ROUNDED value as fp32 - what `F.linear(...).to(float32)` leaves under bf16 autocast."""
     _need_cuda('gemm_bf16', A, B)
     assert A.dim() == 2 and B.dim() == 2 and A.stride(-1) == 1 and B.stride(-1) == 1
     assert A.dtype in (torch.float32, torch.bfloat16) and B.dtype in (torch.float32, torch.bfloat16)
@@ -857,7 +858,7 @@ def gemm_bf16(A, B, a_kcontig=True, b_kcontig=True, bias=None, out_dtype=torch.b
     L = lib()
     ws = _ws(L.resel_gemm_bf16_workspace_bytes(M, N, K), A.device)
     check(L.resel_gemm_bf16(_p(A), A.stride(0), int(a_kcontig), int(A.dtype == torch.bfloat16), _p(B), B.stride(0), int(b_kcontig),
-                            int(B.dtype == torch.bfloat16), _p(bias), _p(out), out.stride(0), int(out_dtype == torch.bfloat16), _p(ws),
+                            int(B.dtype == torch.bfloat16), _p(bias), _p(out), out.stride(0), 1 if out_dtype == torch.bfloat16 else (2 if round_out else 0), _p(ws),
                             M, N, K, _stream()), 'gemm_bf16')
     return out
 
@@ -876,10 +877,10 @@ class LinearBf16(torch.autograd.Function):
     call, gradients back to fp32) happen inside the GEMMs."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, out_dtype):
+    def forward(ctx, x, weight, bias, out_dtype, round_out=False):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        return gemm_bf16(x, weight, True, True, bias, out_dtype)
+        return gemm_bf16(x, weight, True, True, bias, out_dtype, round_out)
 
     @staticmethod
     def backward(ctx, gy):
@@ -890,11 +891,11 @@ class LinearBf16(torch.autograd.Function):
         db = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = torch.sum(gy, 0, dtype=torch.float32)
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
-def linear_bf16(x, weight, bias, out_dtype=torch.bfloat16):
-    return LinearBf16.apply(x, weight, bias, out_dtype)
+def linear_bf16(x, weight, bias, out_dtype=torch.bfloat16, round_out=False):
+    return LinearBf16.apply(x, weight, bias, out_dtype, round_out)
 
 
 # product formation of resel_gemm_f32 (include/resel_hip.h): 0 fp32 MFMA, 9 / 6 exact three-way bf16 split on the bf16 MFMA (fp32-accurate),

@@ -4,7 +4,8 @@ oracle restates the first two rows; outputs, dx and every parameter gradient of 
 bar (1e-4, relative to the largest reference magnitude of the compared tensor; the loss ignores the other rows).
 
   configs[1] / [3]: smamba_s32_c16_b2_nln, T' = 1043 (T = 1024 + skip 18 + 1), d_inner 512, N 32, conv K 16;
-  configs[4]: gilr and lru, T' = 2003 (T = 2000 full episode), B = 16.
+  configs[4]: gilr and lru, T' = 2003 (T = 2000 full episode), B = 16;
+  gru at configs[1]'s B, T (T' = 1027, H = 256: 1026 sequential steps) and at configs[0]'s shape (B = 8, T = 128 -> T' = 130).
 Flags as the trainer builds them: the pre-step slots of a row are `start`, validity covers the trajectory, one mid-row reset."""
 import pytest
 import torch
@@ -21,7 +22,18 @@ def _close(got, ref, tol, name):
     assert torch.isfinite(got).all() and err <= tol * scale, f'{name}: max err {err:.3e} vs scale {scale:.3e}'
 
 
-@pytest.mark.parametrize('lid,B,L,skip', [('smamba_s32_c16_b2_nln', 4, 1043, 18), ('gilr', 16, 2003, 2), ('lru', 16, 2003, 2)])
+def _close_elementwise(got, ref, rtol, name, floor=1e-5):
+    """north_star's rtol read element by element: |got - ref| <= rtol * |ref| + floor * max|ref| for EVERY element
+    (the floor term only keeps elements that are zero by cancellation from being held to their own size)."""
+    got, ref = got.detach().float().cpu(), ref.detach().float()
+    bound = rtol * ref.abs() + floor * max(ref.abs().max().item(), 1e-6)
+    excess = ((got - ref).abs() - bound).max().item()
+    worst = ((got - ref).abs() / bound).max().item()
+    assert torch.isfinite(got).all() and excess <= 0, f'{name}: worst element at {worst:.2f}x its bound (rtol {rtol}, floor {floor})'
+
+
+@pytest.mark.parametrize('lid,B,L,skip', [('smamba_s32_c16_b2_nln', 4, 1043, 18), ('gilr', 16, 2003, 2), ('lru', 16, 2003, 2),
+                                          ('gru', 4, 1027, 2), ('gru', 8, 130, 2)])
 def test_embedding_tower_at_the_baseline_row_length_vs_oracle(lid, B, L, skip):
     if not torch.cuda.is_available():
         pytest.skip('needs a GPU')
@@ -43,7 +55,10 @@ def test_embedding_tower_at_the_baseline_row_length_vs_oracle(lid, B, L, skip):
     spec = dict(layer_type=['fc', lid, 'fc'], activation=['elu', 'elu', 'linear'])
     xr = x[:R].clone().requires_grad_(True)
     pr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    ref = NW.rnn_base_forward(pr, spec, xr, NW.Flags(rnn_start=start[:R], mask=mask[:R]), smamba_semantics='gpu')
+    # gru: the oracle is the reference's own layer, torch.nn.GRU on the CPU (ATen `gru`, rnn_base.py:59,247) - north_star's
+    # "reference CPU GRU path"; 1026 sequential steps at H = 256 (configs[1]'s row length for gru) and configs[0]'s B = 8, T = 128
+    ref = NW.rnn_base_forward(pr, spec, xr, NW.Flags(rnn_start=start[:R], mask=mask[:R]), smamba_semantics='gpu',
+                              gru_impl='aten')
     (ref * w[:R]).sum().backward()
     net.to('cuda')
     net.train()
@@ -54,6 +69,7 @@ def test_embedding_tower_at_the_baseline_row_length_vs_oracle(lid, B, L, skip):
     y = net.meta_forward(xg, hid)[0]
     (y * w.cuda()).sum().backward()
     _close(y[:R], ref, 1e-4, f'{lid} y')
+    _close_elementwise(y[:R], ref, 1e-4, f'{lid} y (element-wise)')
     _close(xg.grad[:R], xr.grad, 2e-4, f'{lid} dx')
     assert xg.grad[R:].abs().max().item() == 0.0           # rows are independent
     for k, p in net.named_parameters():

@@ -2,8 +2,9 @@
 
 Tolerances: fp32 kernels against an fp32 CPU restatement of the same arithmetic - rtol 1e-4 (north_star's fp32 bar),
 with an absolute floor that scales with the magnitude of the compared tensor (reductions over thousands of terms).
-Read precisely: `close()` is NORM-WISE - max |got - ref| <= (rtol + atol_scale) * max |ref| over the whole tensor - not an
-element-wise relative bound (elements near zero are held to the tensor's scale, not their own).  Trainer-level tests
+Read precisely: `close()` is NORM-WISE - max |got - ref| <= (rtol + atol_scale) * max |ref| over the whole tensor - and is what
+gradients are held to; forward OUTPUTS additionally pass `close_fwd()`, the element-wise reading of north_star's rtol:
+|got - ref| <= 1e-4 |ref| + 1e-5 max|ref| for every element.  Trainer-level tests
 (tests/test_trainer_gpu.py) hold logged scalars to 2e-3 and parameters to 1e-3 / 2e-5 after three chained optimizer steps.
 """
 import math
@@ -33,6 +34,17 @@ def close(got, ref, rtol=1e-4, atol_scale=2e-5, name=''):
     err = (got - ref).abs().max().item()
     assert torch.isfinite(got).all(), f'{name}: non-finite output'
     assert err <= rtol * scale + atol_scale * scale, f'{name}: max err {err:.3e} vs scale {scale:.3e}'
+
+
+def close_fwd(got, ref, rtol=1e-4, floor=1e-5, name=''):
+    """Forward outputs: north_star's rtol read ELEMENT-WISE - |got - ref| <= rtol * |ref| + floor * max|ref| for every element
+    (the floor keeps elements that vanish by cancellation from being held to their own size) - on top of the norm-wise bound."""
+    close(got, ref, rtol=rtol, name=name)
+    got = got.detach().float().cpu()
+    ref = ref.detach().float()
+    bound = rtol * ref.abs() + floor * max(ref.abs().max().item(), 1e-6)
+    worst = ((got - ref).abs() / bound).max().item()
+    assert worst <= 1.0, f'{name}: worst element at {worst:.2f}x its element-wise bound (rtol {rtol}, floor {floor})'
 
 
 def rnd(*shape, g=None, scale=1.0):
@@ -71,8 +83,8 @@ def test_selective_scan_fwd_bwd(ops, B, L, Di, N, with_z):
 
     o_ref, l_ref, g_ref = run('cpu', lambda u, d, A_, Bm, Cm, D_, z, db_, s: K.selective_scan_ref(u, d, A_, Bm, Cm, D_, z, db_, s, True))
     o_gpu, l_gpu, g_gpu = run('cuda', lambda u, d, A_, Bm, Cm, D_, z, db_, s: ops.selective_scan_tm(u, d, A_, Bm, Cm, D_, z, db_, s, True, True))
-    close(o_gpu, o_ref, name='out')
-    close(l_gpu, l_ref, name='last_state')
+    close_fwd(o_gpu, o_ref, name='out')
+    close_fwd(l_gpu, l_ref, name='last_state')
     for nm, a, b in zip(('dxz', 'dxdbl', 'ddelta', 'dA', 'dD', 'ddelta_bias'), g_gpu, g_ref):
         close(a, b, rtol=2e-4, atol_scale=5e-5, name=nm)
 
@@ -113,8 +125,8 @@ def test_selective_scan_slow_decay_vs_oracle(ops, monkeypatch, B, L, Di, N, segs
     (out * w.cuda()).sum().backward()
     # the carried state matters: the output with the state cut at every 32-step chunk would be far away from the reference
     assert ref_last.abs().max().item() > 1.0
-    close(out, ref, name='out')
-    close(last, ref_last, name='last_state')
+    close_fwd(out, ref, name='out')
+    close_fwd(last, ref_last, name='last_state')
     for a, b, nm in zip(dev_in, ref_in, ('du', 'ddelta', 'dA', 'dB', 'dC', 'dD', 'dz', 'dbias')):
         close(a.grad, b.grad, rtol=2e-4, atol_scale=5e-5, name=nm)
 
@@ -170,8 +182,8 @@ def test_selective_scan_golden_reference_vectors(ops):
         A, D, db = [T(k).requires_grad_(True) for k in ('A', 'D', 'delta_bias')]
         start = T('start')[:, None, :].expand(-1, u.shape[1], -1)
         out, last = ops.selective_scan_fn(u, delta, A, Bm, Cm, start, D, z, db, True, True)
-        close(out, torch.from_numpy(gold[f'{case}|out']), name=f'{case} out')
-        close(last, torch.from_numpy(gold[f'{case}|last_state']), name=f'{case} last')
+        close_fwd(out, torch.from_numpy(gold[f'{case}|out']), name=f'{case} out')
+        close_fwd(last, torch.from_numpy(gold[f'{case}|last_state']), name=f'{case} last')
         (out * T('dout')).sum().backward()
         for k, t in dict(u=u, delta=delta, z=z, Bm=Bm, Cm=Cm, A=A, D=D, delta_bias=db).items():
             close(t.grad, torch.from_numpy(gold[f'{case}|d{k}']), rtol=3e-4, atol_scale=1e-4, name=f'{case} d{k}')
@@ -215,7 +227,7 @@ def test_causal_conv1d_fwd_bwd(ops, B, L, Di, Kw):
 
     y_ref, g_ref = run('cpu', lambda x, w_, b_, m: K.causal_conv1d_silu_ref(x, w_[:, 0], b_, m))
     y_gpu, g_gpu = run('cuda', lambda x, w_, b_, m: ops.causal_conv1d_fn(x, w_, b_, m, True))
-    close(y_gpu, y_ref, name='y')
+    close_fwd(y_gpu, y_ref, name='y')
     for nm, a, b_ in zip(('dx', 'dw', 'db'), g_gpu, g_ref):
         close(a, b_, rtol=2e-4, atol_scale=5e-5, name=nm)
 
@@ -247,8 +259,8 @@ def test_add_layernorm_fwd_bwd(ops, M, C, rms, prenorm):
         return out if prenorm else (out, x_ + r_)
 
     y_gpu, res_gpu, g_gpu = run('cuda', gpu_fn)
-    close(y_gpu, y_ref, name='y')
-    close(res_gpu, res_ref, name='res')
+    close_fwd(y_gpu, y_ref, name='y')
+    close_fwd(res_gpu, res_ref, name='res')
     for i, (a, b_) in enumerate(zip(g_gpu, g_ref)):
         close(a, b_, rtol=2e-4, atol_scale=5e-5, name=f'grad{i}')
 
@@ -274,7 +286,7 @@ def test_gilr_scan_fwd_bwd(ops, B, L, C, fuse):
 
     h_ref, g_ref = run('cpu', lambda v_, f_, s, h: K.linrec_real_ref(v_, f_, s, h, fuse)[0])
     h_gpu, g_gpu = run('cuda', lambda v_, f_, s, h: ops.gilr_scan(v_, f_, s, h, fuse))
-    close(h_gpu, h_ref, name='h')
+    close_fwd(h_gpu, h_ref, name='h')
     close(g_gpu[0], g_ref[0], rtol=2e-4, atol_scale=5e-5, name='dv')
     close(g_gpu[1], g_ref[1], rtol=2e-4, atol_scale=5e-5, name='df')
 
@@ -297,8 +309,8 @@ def test_lru_scan_fwd_bwd(ops, B, L, C):
 
     r_ref = run('cpu', lambda a, b, c, d, e, s: K.linrec_complex_ref(a, b, c, d, s, gamma=e))
     r_gpu = run('cuda', lambda a, b, c, d, e, s: ops.complex_scan(a, b, c, d, e, s))
-    close(r_gpu[0], r_ref[0], name='hr')
-    close(r_gpu[1], r_ref[1], name='hi')
+    close_fwd(r_gpu[0], r_ref[0], name='hr')
+    close_fwd(r_gpu[1], r_ref[1], name='hi')
     for nm, a, b in zip(('dvr', 'dvi', 'dlam_re', 'dlam_im', 'dgamma'), r_gpu[2], r_ref[2]):
         close(a, b, rtol=3e-4, atol_scale=1e-4, name=nm)
 
@@ -322,13 +334,13 @@ def test_gru_seq_fwd_bwd_vs_aten(ops, B, L, H):
     gi = torch.nn.functional.linear(xg, ps['weight_ih_l0'], ps['bias_ih_l0'])
     y = ops.gru_seq(gi, ps['weight_hh_l0'], ps['bias_hh_l0'])
     (y * dy.cuda()).sum().backward()
-    close(y, y_ref, name='h_all')
+    close_fwd(y, y_ref, name='h_all')
     close(xg.grad, xr.grad, rtol=2e-4, atol_scale=5e-5, name='dx')
     for n, p in gru.named_parameters():
         close(ps[n].grad, p.grad, rtol=3e-4, atol_scale=1e-4, name=n)
     # the oracle's explicit-formula GRU agrees with ATen too
     y_or = K.gru_seq_ref(torch.nn.functional.linear(x, gru.weight_ih_l0, gru.bias_ih_l0), gru.weight_hh_l0, gru.bias_hh_l0)
-    close(y, y_or.detach(), name='h_all vs oracle')
+    close_fwd(y, y_or.detach(), name='h_all vs oracle')
 
 
 # ------------------------------------------------------------------------------------------------ SAC arithmetic
@@ -546,7 +558,7 @@ def test_mamba_inner_fused_vs_oracle_chain(ops, B, L, Dm, N, Kw):
 
     ref_out, ref_dx, ref_g = run(ob.mamba_inner_fn, 'cpu')
     out, dx, gr = run(ops.mamba_inner_fn, 'cuda')
-    close(out, ref_out, name='out')
+    close_fwd(out, ref_out, name='out')
     close(dx, ref_dx, name='dx')
     for k in ps:
         close(gr[k], ref_g[k], rtol=2e-4, atol_scale=5e-5, name='d' + k)
@@ -638,7 +650,7 @@ def test_linear_act_fwd_bwd_long_pass_vs_torch(ops, rows, n_in, n_out, act):
     flops0 = ops.GEMM_FLOPS[0]
     y = ops.linear_act(xs, Ws, bs, act)
     (y * w.cuda()).sum().backward()
-    close(y, yr.detach(), name='y')
+    close_fwd(y, yr.detach(), name='y')
     close(xs.grad, xr.grad, name='dx')
     close(Ws.grad, Wr.grad, rtol=2e-4, atol_scale=5e-5, name='dW')
     close(bs.grad, br.grad, rtol=2e-4, atol_scale=5e-5, name='db')
@@ -654,7 +666,7 @@ def test_linear_act_vs_torch(ops):
     xc, Wc, bc = (t.cuda().requires_grad_(True) for t in (x, W, b))
     out = ops.linear_act(xc, Wc, bc, 'elu')
     out.backward(go.cuda())
-    close(out, ref, name='out')
+    close_fwd(out, ref, name='out')
     close(xc.grad, xr.grad, name='dx')
     close(Wc.grad, Wr.grad, rtol=2e-4, atol_scale=5e-5, name='dW')
     close(bc.grad, br.grad, rtol=2e-4, atol_scale=5e-5, name='db')
@@ -922,7 +934,7 @@ def test_selective_scan_time_segments_equal_the_one_pass_scan(ops, monkeypatch, 
     ref_in = [t.clone().requires_grad_(True) for t in (u, delta, A, Bm, Cm, D, z, db)]
     ref, _ = K.selective_scan_ref(*ref_in, start, True)
     (ref * w).sum().backward()
-    close(o2, ref, name='out vs oracle')
+    close_fwd(o2, ref, name='out vs oracle')
     for a, b, nm in zip(g2, ref_in, ('du', 'ddelta', 'dA', 'dB', 'dC', 'dD', 'dz', 'dbias')):
         close(a, b.grad, rtol=2e-4, atol_scale=5e-5, name=nm + ' vs oracle')
 
@@ -1008,7 +1020,7 @@ def test_linear_act_pads_odd_widths_on_long_passes(ops, K, N, act):
     y_ref, g_ref = run('cpu', ref_fn)
     y, gr = run('cuda', lambda x_, w_, b_: ops.linear_act(x_, w_, b_, act))
     assert y.shape == y_ref.shape
-    close(y, y_ref, name='y')
+    close_fwd(y, y_ref, name='y')
     for nm, a, b_ in zip(('dx', 'dw', 'db'), gr, g_ref):
         assert a.shape == b_.shape
         close(a, b_, rtol=2e-4, atol_scale=5e-5, name=nm)

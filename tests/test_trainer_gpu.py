@@ -317,13 +317,14 @@ def test_cgpt_layer_gpu_vs_oracle():
     hid.set_attention_concat_mask(PackedSeqs(table, 90, torch.device('cuda')))
     y, _, _ = net.meta_forward(xg, hid)
     (y * w.cuda()).sum().backward()
-    scale = ref.abs().max().item()
-    assert (y.detach().cpu() - ref.detach()).abs().max().item() < 2e-2 * scale
-    gs = xr.grad.abs().max().item()
-    assert (xg.grad.cpu() - xr.grad).abs().max().item() < 4e-2 * gs
+    def rel(got, want, name, tol):
+        e = (got.detach().cpu() - want.detach()).abs().max().item() / max(want.abs().max().item(), 1e-3)
+        print(f'MEASURED cgpt small layer {name}: max err / max|ref| = {e:.3e} (bound {tol:g})')
+        assert e < tol, (name, e)
+    rel(y, ref, 'y', 2e-2)
+    rel(xg.grad, xr.grad, 'dx', 4e-2)
     for k, p in net.named_parameters():
-        g_ref = pr[k].grad
-        assert (p.grad.cpu() - g_ref).abs().max().item() < 4e-2 * max(g_ref.abs().max().item(), 1e-3), k
+        rel(p.grad, pr[k].grad, 'd ' + k, 4e-2)
 
 
 def test_cgpt_td3_update_gpu_vs_oracle():
