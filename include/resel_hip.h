@@ -310,6 +310,25 @@ int resel_gemm_f32(const float* A, int64_t lda, int64_t strideA, int a_kcontig,
                    float* C, int64_t ldc, int64_t strideC, void* workspace,
                    int M, int N, int K, int batch, int split, resel_stream_t stream);
 
+/* Mode 2 ("f16x3") of the same contract: each operand is scaled by a power of two that brings its largest magnitude into
+ * [2^14, 2^15) and split into TWO fp16 planes, h1 = fp16(x s), h2 = fp16(2^11 (x s - h1)) (22 significant bits of every element
+ * down to 2^-29 of the operand's maximum); three plane products on v_mfma_f32_32x32x16_f16, the two cross terms in their own
+ * accumulators, C = (a1 b1 + 2^-11 (a1 b2 + a2 b1)) / (sA sB).  Half the matrix instructions of mode 6; error against fp64 no
+ * larger than the fp32 instruction's (tools/eval_f16_split.py, tests/test_hip_ops.py).  amax_a / amax_b: DEVICE scalars holding
+ * an upper bound of max |A| / max |B| over the whole operand (all batch members) - resel_amax below, or a bound the producer of
+ * the operand already has; a bound 2^k too large costs k bits of the 2^-29 range, one too small overflows fp16 (inf in C).
+ * Other modes ignore the two pointers (may be NULL).  M <= 128 falls back to mode 6. */
+int resel_gemm_f32x(const float* A, int64_t lda, int64_t strideA, int a_kcontig,
+                    const float* B, int64_t ldb, int64_t strideB, int b_kcontig,
+                    const float* bias, int64_t strideBias, int act,
+                    float* C, int64_t ldc, int64_t strideC, void* workspace,
+                    int M, int N, int K, int batch, int split, const float* amax_a, const float* amax_b, resel_stream_t stream);
+/* out[0] = max |x| over a [batch][rows][cols] box (row stride ld, batch stride `stride`, cols % 4 == 0), one HBM-bound pass,
+ * no host synchronisation.  `state`: resel_amax_state_bytes() bytes, zero before its first use (left zeroed by every call);
+ * calls that share a state buffer must be ordered on one stream. */
+size_t resel_amax_state_bytes(void);
+int resel_amax(const float* x, int64_t ld, int64_t stride, int rows, int cols, int batch, float* out, void* state, resel_stream_t stream);
+
 /* ---- mixed-precision GEMM for the bf16 attention projections (cgpt) ------------------------------------------------------
  * C[m][n] = sum_k bf16(A(m, k)) bf16(B(n, k)) + bf16(bias[n]): operands rounded to bf16 (round to nearest even) on their way
  * into LDS, fp32 accumulation (v_mfma_f32_32x32x16_bf16), C stored as bf16 (c_bf16 = 1), as fp32 (0), or as fp32 holding the

@@ -25,6 +25,7 @@
 // partly filled round and for weight gradients, summed by a fix-up kernel in a fixed order (deterministic, no atomics).
 #include "resel_common.h"
 #include <algorithm>
+#include <atomic>
 
 namespace {
 using namespace resel;
@@ -47,6 +48,7 @@ struct Params {
     int act;
     int mt, nt;
     int nfull, nsplit, nsl, kslice;
+    const float *amaxA, *amaxB;                  // mode 2: device scalars >= max |A|, max |B| (resel_amax); nullptr otherwise
 };
 
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : fast_exp(x) - 1.f; }
@@ -132,6 +134,40 @@ __device__ __forceinline__ P3h split2(float x0, float x1) {
     return o;
 }
 
+// ---- mode 2 ("f16x3"): two fp16 planes of x s, s a power of two that brings the operand's largest magnitude into [2^14, 2^15):
+//   h1 = fp16(x s) (round to nearest even), h2 = fp16(2^11 (x s - h1)) - the residual is exact in fp32 and scaled into the
+//   normal range of fp16, so h1 + 2^-11 h2 carries 22 significant bits of every element down to 2^-29 of the operand's maximum.
+// sc = {s, 2048 s}.  7 vector instructions per element pair (v_pk_mul x 2, v_cvt_pk_f16_f32 x 2, v_cvt_f32_f16 x 2, v_pk_fma).
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_pair_f16(float x0, float x1, f32x2_t sc, uint32_t& p1, uint32_t& p2) {
+    const f32x2_t xs = {x0 * sc.x, x1 * sc.x};
+    const f16x2_t h = __builtin_convertvector(xs, f16x2_t);
+    const f32x2_t r = {__builtin_fmaf((float)h.x, -2048.f, x0 * sc.y), __builtin_fmaf((float)h.y, -2048.f, x1 * sc.y)};
+    p1 = __builtin_bit_cast(uint32_t, h);
+    p2 = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2_t));
+}
+__device__ __forceinline__ P3 split4_f16(const float4& v, f32x2_t sc) {
+    P3 o;
+    split_pair_f16(v.x, v.y, sc, o.p1.x, o.p2.x);
+    split_pair_f16(v.z, v.w, sc, o.p1.y, o.p2.y);
+    o.p3 = make_uint2(0u, 0u);
+    return o;
+}
+__device__ __forceinline__ P3h split2_f16(float x0, float x1, f32x2_t sc) {
+    P3h o;
+    split_pair_f16(x0, x1, sc, o.p1, o.p2);
+    o.p3 = 0u;
+    return o;
+}
+// scale of an operand from its (upper bound of the) largest magnitude a: 2^(14 - floor(log2 a)), so a s is in [2^14, 2^15);
+// a = 0 or below 2^-113: the largest finite scale the exponent field allows (the operand is zero / negligible either way)
+__device__ __forceinline__ float f16_scale(float amax) {
+    const int f = (int)((__float_as_uint(amax) >> 23) & 0xffu);
+    const int e = min(max(268 - f, 1), 254);
+    return __uint_as_float((uint32_t)e << 23);
+}
+
 // ---- one operand's share of a thread in a K step.
 // KC (P[row][k]): NPC pieces, piece i = row (tid / 8 + 64 i), k = 4 (tid % 8) .. + 3 (one float4, 8 bytes per plane).
 // !KC (P[k][row]), the 256-row operand: one 4 (k) x 4 (rows) patch, rows 4 g .., k = 4 k4 ..: four float4 along rows,
@@ -209,12 +245,12 @@ struct Src {
         base += step;
     }
     // split the staged values and store the planes of this thread's pieces into the plane set at `pl` (plane stride PL bytes)
-    template <int PL, int NP>
-    __device__ __forceinline__ void store(char* pl) const {
+    template <int PL, int NP, bool F16 = false>
+    __device__ __forceinline__ void store(char* pl, f32x2_t sc = f32x2_t{1.f, 2048.f}) const {
         if (KC) {
 #pragma unroll
             for (int i = 0; i < NPC; ++i) {
-                const P3 s = split4<NP>(r[i]);
+                const P3 s = F16 ? split4_f16(r[i], sc) : split4<NP>(r[i]);
                 *reinterpret_cast<uint2*>(pl + loff[i]) = s.p1;
                 *reinterpret_cast<uint2*>(pl + PL + loff[i]) = s.p2;
                 if (NP == 3) *reinterpret_cast<uint2*>(pl + 2 * PL + loff[i]) = s.p3;
@@ -224,7 +260,7 @@ struct Src {
                                    {r[0].z, r[1].z, r[2].z, r[3].z}, {r[0].w, r[1].w, r[2].w, r[3].w}};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const P3 s = split4<NP>(make_float4(c[j][0], c[j][1], c[j][2], c[j][3]));
+                const P3 s = F16 ? split4_f16(make_float4(c[j][0], c[j][1], c[j][2], c[j][3]), sc) : split4<NP>(make_float4(c[j][0], c[j][1], c[j][2], c[j][3]));
                 *reinterpret_cast<uint2*>(pl + loff[j]) = s.p1;
                 *reinterpret_cast<uint2*>(pl + PL + loff[j]) = s.p2;
                 if (NP == 3) *reinterpret_cast<uint2*>(pl + 2 * PL + loff[j]) = s.p3;
@@ -233,7 +269,7 @@ struct Src {
             const float c[4][2] = {{r[0].x, r[1].x}, {r[0].y, r[1].y}, {r[0].z, r[1].z}, {r[0].w, r[1].w}};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const P3h s = split2<NP>(c[j][0], c[j][1]);
+                const P3h s = F16 ? split2_f16(c[j][0], c[j][1], sc) : split2<NP>(c[j][0], c[j][1]);
                 *reinterpret_cast<uint32_t*>(pl + loff[j]) = s.p1;
                 *reinterpret_cast<uint32_t*>(pl + PL + loff[j]) = s.p2;
                 if (NP == 3) *reinterpret_cast<uint32_t*>(pl + 2 * PL + loff[j]) = s.p3;
@@ -259,6 +295,15 @@ __device__ __forceinline__ void read_b(Frag& f, const char* fb) {
     for (int pi = 0; pi < NP; ++pi)
 #pragma unroll
         for (int t = 0; t < 2; ++t) f.b[pi][t] = lds16(fb + pi * PLB + t * 32 * ROWB);
+}
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <int P, int Q>
+__device__ __forceinline__ void mfma_term_f16(f32x16 (&acc)[2][2], const Frag& f) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.a[P][a]), __builtin_bit_cast(f16x8, f.b[Q][b]), acc[a][b], 0, 0, 0);
 }
 template <int P, int Q>
 __device__ __forceinline__ void mfma_term(f32x16 (&acc)[2][2], const Frag& f) {
@@ -287,12 +332,16 @@ __device__ __forceinline__ void mfma_term(f32x16 (&acc)[2][2], const Frag& f) {
 // the small terms are added first
 template <int SPLIT>
 __device__ __forceinline__ void mfma_small(f32x16 (&acc)[2][2], const Frag& f) {
-    if (SPLIT == 3) return;                         // two planes per operand: a1 b1 + a1 b2 + a2 b1 only (mfma_lead)
+    if (SPLIT == 3 || SPLIT == 2) return;           // two planes per operand: a1 b1 + a1 b2 + a2 b1 only (mfma_lead)
     if (SPLIT == 9) { mfma_term<2, 2>(acc, f); mfma_term<2, 1>(acc, f); mfma_term<1, 2>(acc, f); }
     mfma_term<2, 0>(acc, f); mfma_term<0, 2>(acc, f); mfma_term<1, 1>(acc, f);
 }
 __device__ __forceinline__ void mfma_lead(f32x16 (&acc)[2][2], const Frag& f) {
     mfma_term<1, 0>(acc, f); mfma_term<0, 1>(acc, f); mfma_term<0, 0>(acc, f);
+}
+// mode 2: the cross terms (residual planes carry a factor 2^11) have their own accumulators
+__device__ __forceinline__ void mfma_lead_f16(f32x16 (&acc)[2][2], f32x16 (&acc2)[2][2], const Frag& f) {
+    mfma_term_f16<1, 0>(acc2, f); mfma_term_f16<0, 1>(acc2, f); mfma_term_f16<0, 0>(acc, f);
 }
 
 #define BF3_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -303,7 +352,16 @@ __device__ unsigned long long g_bf3_clock[2 * GRID];
 template <bool AKC, bool BKC, int SPLIT>
 __global__ __launch_bounds__(NTH, 2) void gemm_bf3_kernel(Params p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];           // 2 stages
-    constexpr int NP = SPLIT == 3 ? 2 : 3;                               // planes per operand element
+    constexpr int NP = (SPLIT == 3 || SPLIT == 2) ? 2 : 3;               // planes per operand element
+    constexpr bool F16 = SPLIT == 2;                                     // fp16 planes of the scaled operands (f16x3)
+    f32x2_t scA = {1.f, 2048.f}, scB = {1.f, 2048.f};
+    float unscale = 1.f;
+    if (F16) {
+        const float sa_ = f16_scale(*p.amaxA), sb_ = f16_scale(*p.amaxB);
+        scA = f32x2_t{sa_, 2048.f * sa_};
+        scB = f32x2_t{sb_, 2048.f * sb_};
+        unscale = (1.f / sa_) * (1.f / sb_);                             // powers of two: exact
+    }
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
     const int li = lane & 31, lh = lane >> 5;
@@ -334,8 +392,8 @@ __global__ __launch_bounds__(NTH, 2) void gemm_bf3_kernel(Params p) {
         }
     };
     auto stage_store = [&](int st) {
-        sa.template store<PLA, NP>(lds + st * STAGE);
-        sb.template store<PLB, NP>(lds + st * STAGE + 3 * PLA);
+        sa.template store<PLA, NP, F16>(lds + st * STAGE, scA);
+        sb.template store<PLB, NP, F16>(lds + st * STAGE + 3 * PLA, scB);
     };
     // fragment addresses: slab s of the lane = chunk 2 s + lh of row li of the wave's tile rows
     const char* fa[2];
@@ -376,6 +434,15 @@ __global__ __launch_bounds__(NTH, 2) void gemm_bf3_kernel(Params p) {
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[a][b][e] = zero;
+        f32x16 acc2[2][2];                            // mode 2 only (dead otherwise): cross terms, in units of 2^11
+        if (F16) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc2[a][b][e] = zero;
+        }
         float bv[2] = {0.f, 0.f};
 
         for (int c_k0 = cur.kbeg; c_k0 < cur.kend; c_k0 += BK) {
@@ -394,11 +461,11 @@ __global__ __launch_bounds__(NTH, 2) void gemm_bf3_kernel(Params p) {
             read_a<NP>(f1, fa[1] + so); read_b<NP>(f1, fb[1] + so);
             mfma_small<SPLIT>(acc, f0);
             stage_store(cur_st ^ 1);
-            mfma_lead(acc, f0);
+            if (F16) mfma_lead_f16(acc, acc2, f0); else mfma_lead(acc, f0);
             sa.load_sched(fast);
             sb.load_sched(fast);
             mfma_small<SPLIT>(acc, f1);
-            if (SPLIT == 3) {                       // 12 matrix instructions carry 8 fragment reads, the two-plane split, 12 LDS writes, the loads
+            if (SPLIT == 3 || SPLIT == 2) {         // 12 matrix instructions carry 8 fragment reads, the two-plane split, 12 LDS writes, the loads
 #pragma unroll
                 for (int i = 0; i < 12; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -427,7 +494,7 @@ __global__ __launch_bounds__(NTH, 2) void gemm_bf3_kernel(Params p) {
             BF3_FENCE();
             // ---- region B: the leading terms of slab 1 with the fragment reads of step s + 1's slab 0
             read_a<NP>(f0, fa[0] + sn); read_b<NP>(f0, fb[0] + sn);
-            mfma_lead(acc, f1);
+            if (F16) mfma_lead_f16(acc, acc2, f1); else mfma_lead(acc, f1);
 #pragma unroll
             for (int i = 0; i < 12; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -445,6 +512,15 @@ __global__ __launch_bounds__(NTH, 2) void gemm_bf3_kernel(Params p) {
             }
             BF3_FENCE();
             cur_st ^= 1;
+        }
+        if (F16) {                                   // C = (a1 b1 + 2^-11 (a1 b2 + a2 b1)) / (sA sB)
+            const float u2 = unscale * (1.f / 2048.f);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[a][b][e] = __builtin_fmaf(acc2[a][b][e], u2, acc[a][b][e] * unscale);
         }
 #ifdef BF3_AB_NOEPI                    // ablation (wrong results): one store per wave and tile keeps the accumulators alive
         if (lane == 0) p.C[(int64_t)cur.m0 * p.ldc + cur.n0 + w] = acc[0][0][0] + acc[0][1][1] + acc[1][0][2] + acc[1][1][3];
@@ -564,11 +640,14 @@ inline Plan make_plan(int M, int N, int K, int batch) {
 
 template <bool AKC, bool BKC, int SP>
 int launch_one(const Params& p, dim3 grid, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the attribute is per device (and the first call may come from any thread): one flag per device id, set after the call succeeds
+    static std::atomic<bool> attr_set[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return RESEL_ELAUNCH;
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute((const void*)gemm_bf3_kernel<AKC, BKC, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE) != hipSuccess)
             return RESEL_ELAUNCH;
-        attr_set = true;
+        attr_set[dev].store(true, std::memory_order_release);
     }
     launch_timed(RESEL_PROF_GEMM, gemm_bf3_kernel<AKC, BKC, SP>, grid, dim3(NTH), (size_t)(2 * STAGE), s, p);
     return RESEL_OK;
@@ -592,11 +671,12 @@ size_t gemm_bf3_workspace_bytes(int M, int N, int K, int batch) {
 // split in {3, 6, 9}, K >= 32; argument checks are the caller's (resel_gemm_f32)
 int gemm_bf3_launch(const float* A, int64_t lda, int64_t strideA, int a_kcontig, const float* B, int64_t ldb, int64_t strideB, int b_kcontig,
                     const float* bias, int64_t strideBias, int act, float* C, int64_t ldc, int64_t strideC, void* workspace,
-                    int M, int N, int K, int batch, int split, hipStream_t s) {
+                    int M, int N, int K, int batch, int split, hipStream_t s, const float* amaxA, const float* amaxB) {
+    if (split == 2 && (!amaxA || !amaxB)) return RESEL_EINVAL;
     const Plan pl = make_plan(M, N, K, batch);
     if (pl.nsplit && (!workspace || !aligned16(workspace))) return RESEL_EINVAL;
     Params p{A, B, bias, C, (float*)workspace, lda, ldb, ldc, strideA, strideB, strideC, strideBias, M, N, K, act,
-             (M + BM - 1) / BM, (N + BN - 1) / BN, pl.nfull, pl.nsplit, pl.nsl, pl.kslice};
+             (M + BM - 1) / BM, (N + BN - 1) / BN, pl.nfull, pl.nsplit, pl.nsl, pl.kslice, amaxA, amaxB};
     const int64_t total = (int64_t)pl.nfull + (int64_t)pl.nsplit * pl.nsl;
     dim3 grid((unsigned)std::min<int64_t>(total, GRID));
     int rc;
@@ -605,7 +685,7 @@ int gemm_bf3_launch(const float* A, int64_t lda, int64_t strideA, int a_kcontig,
          else if (a_kcontig) rc = launch_one<true, false, SP>(p, grid, s); \
          else if (b_kcontig) rc = launch_one<false, true, SP>(p, grid, s); \
          else rc = launch_one<false, false, SP>(p, grid, s); } while (0)
-    if (split == 9) BF3_LAUNCH(9); else if (split == 3) BF3_LAUNCH(3); else BF3_LAUNCH(6);
+    if (split == 9) BF3_LAUNCH(9); else if (split == 3) BF3_LAUNCH(3); else if (split == 2) BF3_LAUNCH(2); else BF3_LAUNCH(6);
 #undef BF3_LAUNCH
     if (rc != RESEL_OK) return rc;
     if (pl.nsplit) hipLaunchKernelGGL(gemm_bf3_fixup_kernel, dim3(TILE / 4 / 64, pl.nsplit), dim3(64, 4), 0, s, p);

@@ -41,7 +41,7 @@ namespace resel {                      // gemm_bf3.hip: the split modes with the
 size_t gemm_bf3_workspace_bytes(int M, int N, int K, int batch);
 int gemm_bf3_launch(const float* A, int64_t lda, int64_t strideA, int a_kcontig, const float* B, int64_t ldb, int64_t strideB, int b_kcontig,
                     const float* bias, int64_t strideBias, int act, float* C, int64_t ldc, int64_t strideC, void* workspace,
-                    int M, int N, int K, int batch, int split, hipStream_t s);
+                    int M, int N, int K, int batch, int split, hipStream_t s, const float* amaxA, const float* amaxB);
 }
 
 namespace {
@@ -603,9 +603,22 @@ extern "C" int resel_gemm_f32(const float* A, int64_t lda, int64_t strideA, int 
                               const float* bias, int64_t strideBias, int act,
                               float* C, int64_t ldc, int64_t strideC, void* workspace,
                               int M, int N, int K, int batch, int split, resel_stream_t stream) {
+    if (split == 2) return RESEL_EINVAL;           // mode 2 needs the operand magnitudes: resel_gemm_f32x
+    return resel_gemm_f32x(A, lda, strideA, a_kcontig, B, ldb, strideB, b_kcontig, bias, strideBias, act, C, ldc, strideC, workspace,
+                           M, N, K, batch, split, nullptr, nullptr, stream);
+}
+
+extern "C" int resel_gemm_f32x(const float* A, int64_t lda, int64_t strideA, int a_kcontig,
+                               const float* B, int64_t ldb, int64_t strideB, int b_kcontig,
+                               const float* bias, int64_t strideBias, int act,
+                               float* C, int64_t ldc, int64_t strideC, void* workspace,
+                               int M, int N, int K, int batch, int split, const float* amax_a, const float* amax_b,
+                               resel_stream_t stream) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || act < 0 || act > 2) return RESEL_EINVAL;
     // 106 / 109: modes 6 / 9 on the first-edition kernel of this file (every wave splits the fragments it reads), kept for A/B runs
-    if (split != 0 && split != 3 && split != 6 && split != 9 && split != 106 && split != 109) return RESEL_EINVAL;
+    if (split != 0 && split != 2 && split != 3 && split != 6 && split != 9 && split != 106 && split != 109) return RESEL_EINVAL;
+    if (split == 2 && (!amax_a || !amax_b)) return RESEL_EINVAL;
+    if (split == 2 && M <= 128) split = 6;         // narrow shapes stay on the first edition's fp32-accurate bf16 split
     if (K < BK) split = 0;                         // the split kernels' scheduled loads assume one whole K step per item
     if (lda % 4 || ldb % 4 || strideA % 4 || strideB % 4 || !aligned16(A) || !aligned16(B)) return RESEL_EINVAL;
     // float4 loads run along the contiguous axis: its extent must be a multiple of 4 (K for [rows][K] operands, rows otherwise)
@@ -614,9 +627,9 @@ extern "C" int resel_gemm_f32(const float* A, int64_t lda, int64_t strideA, int 
     if (lda <= 0 || ldb <= 0 || ldc <= 0 || lda >= (int64_t)1 << 22 || ldb >= (int64_t)1 << 22) return RESEL_EINVAL;
     // second edition (256 x 128 tiles) unless half of its tile rows would be padding: M <= 128 (narrow weight gradients) runs
     // 1.2-1.4x faster on the first edition's 128 x 128 tiles (66 752-token weight gradients [128, 256]: 48 vs 59 us, [80, 512]: 67 vs 95)
-    if ((split == 3 || split == 6 || split == 9) && M > 128)
+    if ((split == 2 || split == 3 || split == 6 || split == 9) && M > 128)
         return gemm_bf3_launch(A, lda, strideA, a_kcontig, B, ldb, strideB, b_kcontig, bias, strideBias, act, C, ldc, strideC, workspace,
-                               M, N, K, batch, split, (hipStream_t)stream);
+                               M, N, K, batch, split, (hipStream_t)stream, amax_a, amax_b);
     if (split > 100) split -= 100;                 // here: 6 / 9 = first-edition split kernels, 0 = fp32 MFMA
     if (split == 3) split = 6;                     // the two-plane mode exists on the second-edition kernel only: narrow shapes keep mode 6
     const Plan pl = make_plan(M, N, K, batch);

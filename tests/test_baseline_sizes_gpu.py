@@ -46,7 +46,7 @@ def test_embedding_tower_at_the_baseline_row_length_vs_oracle(lid, B, L, skip):
     x = torch.randn(B, L, 384, generator=g) * 0.5
     start = torch.zeros(B, L, 1)
     start[:, :skip] = 1                                    # pre-step slots
-    start[0, 700] = 1                                      # a packed second trajectory in row 0
+    start[0, min(700, 2 * L // 3)] = 1                     # a packed second trajectory in row 0
     mask = torch.ones(B, L, 1)
     mask[:, :skip - 1] = 0
     mask[:, -1] = 0

@@ -137,13 +137,13 @@ def test_attention_dropout_fwd_bwd_vs_oracle_with_the_shared_mask(ops, H, hd, le
     slopes = K.alibi_slopes(H)
     seed, offset = 0x1234567890ABCDEF, 0x1_0000_0004
     ref_in = qkv.float().requires_grad_(True)
-    ref = K.attention_alibi_varlen_ref(ref_in[:, 0], ref_in[:, 1], ref_in[:, 2], cu, slopes, None, p, seed, offset)
+    ref = K.attention_alibi_varlen_ref(ref_in[:, 0], ref_in[:, 1], ref_in[:, 2], cu, slopes, None, p, seed, offset, p_bf16=True)
     (ref * dout.float()).sum().backward()
     x = qkv.cuda().requires_grad_(True)
     out = ops.attn_varlen(x, cu.cuda(), max(lens), slopes.cuda(), None, p, seed, offset)
     (out.float() * dout.cuda().float()).sum().backward()
-    _close(out, ref, 2e-2, 'out')
-    _close(x.grad, ref_in.grad, 4e-2, 'dqkv')
+    _close(out, ref, 1e-2, 'out')                 # measured 1.9e-3 .. 2.7e-3 (round 4, oracle with flash-attn's bf16 P rounding)
+    _close(x.grad, ref_in.grad, 2e-2, 'dqkv')      # measured 2.6e-3 .. 4.1e-3
     plain = ops.attn_varlen(qkv.cuda(), cu.cuda(), max(lens), slopes.cuda())
     assert (plain.float() - out.float()).abs().max().item() > 0.05          # the mask is applied
 
@@ -272,15 +272,15 @@ def test_config2_layer_training_mode_fwd_bwd_vs_oracle():
     y, _, _ = net.meta_forward(xg, hid)
     assert ops.dropout_counter(torch.device('cuda', 0))[1] == off0 + 4 + 4 * 24      # 6 blocks x 4 sites
     (y * w.cuda()).sum().backward()
-    _close(y, ref, 3e-2, 'y')
-    _close(xg.grad, xr.grad, 6e-2, 'dx')
+    _close(y, ref, 1e-2, 'y')                     # north_star's bf16 bar; measured 1.3e-3 for the 6-layer configs[2] layer in training mode
+    _close(xg.grad, xr.grad, 2e-2, 'dx')           # measured 4.7e-3
     for k, p in net.named_parameters():
         g_ref = pr[k].grad
-        _close(p.grad, g_ref, 6e-2, 'd ' + k)
+        _close(p.grad, g_ref, 2e-2, 'd ' + k)       # measured <= 6.3e-3 over all 57 parameter tensors
     net.eval()
     with torch.no_grad():
         y_eval = net.meta_forward(x.cuda(), hid)[0]
-    _close(y_eval, ref_eval, 2e-2, 'eval')
+    _close(y_eval, ref_eval, 1e-2, 'eval')         # measured 9.4e-4
     assert (y_eval.cpu() - y.detach().cpu()).abs().max().item() > 0.05 * ref.abs().max().item()
 
 
@@ -321,7 +321,7 @@ def test_config2_td3_update_full_size_finite_and_first_rows_vs_oracle():
     hid.set_attention_concat_mask(PackedSeqs(table, L, torch.device('cuda')))
     with torch.no_grad():
         y = net.meta_forward(x.cuda(), hid)[0]
-    _close(y, ref, 3e-2, 'configs[2] rows 0-1')
+    _close(y, ref, 1e-2, 'configs[2] rows 0-1')    # measured 2.1e-3 at the full row length (T' = 1027), training mode
 
 
 @pytest.mark.gpu

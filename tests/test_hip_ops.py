@@ -432,13 +432,13 @@ def test_attn_varlen_alibi_fwd_bwd(ops, H, hd, lens):
     cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32)
     slopes = K.alibi_slopes(H)
     ref_in = qkv.float().requires_grad_(True)
-    ref = K.attention_alibi_varlen_ref(ref_in[:, 0], ref_in[:, 1], ref_in[:, 2], cu, slopes)
+    ref = K.attention_alibi_varlen_ref(ref_in[:, 0], ref_in[:, 1], ref_in[:, 2], cu, slopes, p_bf16=True)
     (ref * dout.float()).sum().backward()
     x = qkv.cuda().requires_grad_(True)
     out = ops.attn_varlen(x, cu.cuda(), max(lens), slopes.cuda())
     (out.float() * dout.cuda().float()).sum().backward()
-    close(out.float(), ref, rtol=1e-2, atol_scale=1e-2, name='out')
-    close(x.grad.float(), ref_in.grad, rtol=2e-2, atol_scale=2e-2, name='dqkv')
+    close(out.float(), ref, rtol=5e-3, atol_scale=5e-3, name='out')            # 1e-2 in all (north_star's bf16 bar)
+    close(x.grad.float(), ref_in.grad, rtol=1e-2, atol_scale=1e-2, name='dqkv')
 
 
 def test_attn_ragged_batch_work_list(ops):
@@ -453,13 +453,13 @@ def test_attn_ragged_batch_work_list(ops):
     cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32)
     slopes = K.alibi_slopes(H)
     ref_in = qkv.float().requires_grad_(True)
-    ref = K.attention_alibi_varlen_ref(ref_in[:, 0], ref_in[:, 1], ref_in[:, 2], cu, slopes)
+    ref = K.attention_alibi_varlen_ref(ref_in[:, 0], ref_in[:, 1], ref_in[:, 2], cu, slopes, p_bf16=True)
     (ref * dout.float()).sum().backward()
     x = qkv.cuda().requires_grad_(True)
     out = ops.attn_varlen(x, cu.cuda(), max(lens), slopes.cuda())
     (out.float() * dout.cuda().float()).sum().backward()
-    close(out.float(), ref, rtol=1e-2, atol_scale=1e-2, name='out')
-    close(x.grad.float(), ref_in.grad, rtol=2e-2, atol_scale=2e-2, name='dqkv')
+    close(out.float(), ref, rtol=5e-3, atol_scale=5e-3, name='out')            # 1e-2 in all (north_star's bf16 bar)
+    close(x.grad.float(), ref_in.grad, rtol=1e-2, atol_scale=1e-2, name='dqkv')
 
 
 def test_attn_forward_without_work_list_is_bitwise_the_same(ops):
@@ -493,13 +493,13 @@ def test_attn_more_heads_than_xcds_and_grid_bound_above_the_longest_sequence(ops
     cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32)
     slopes = K.alibi_slopes(H)
     ref_in = qkv.float().requires_grad_(True)
-    ref = K.attention_alibi_varlen_ref(ref_in[:, 0], ref_in[:, 1], ref_in[:, 2], cu, slopes)
+    ref = K.attention_alibi_varlen_ref(ref_in[:, 0], ref_in[:, 1], ref_in[:, 2], cu, slopes, p_bf16=True)
     (ref * dout.float()).sum().backward()
     x = qkv.cuda().requires_grad_(True)
     out = ops.attn_varlen(x, cu.cuda(), 1000, slopes.cuda())
     (out.float() * dout.cuda().float()).sum().backward()
-    close(out.float(), ref, rtol=1e-2, atol_scale=1e-2, name='out')
-    close(x.grad.float(), ref_in.grad, rtol=2e-2, atol_scale=2e-2, name='dqkv')
+    close(out.float(), ref, rtol=5e-3, atol_scale=5e-3, name='out')            # 1e-2 in all (north_star's bf16 bar)
+    close(x.grad.float(), ref_in.grad, rtol=1e-2, atol_scale=1e-2, name='dqkv')
 
 
 def test_attn_more_sequences_than_the_work_list_can_index(ops):

@@ -321,10 +321,10 @@ def test_cgpt_layer_gpu_vs_oracle():
         e = (got.detach().cpu() - want.detach()).abs().max().item() / max(want.abs().max().item(), 1e-3)
         print(f'MEASURED cgpt small layer {name}: max err / max|ref| = {e:.3e} (bound {tol:g})')
         assert e < tol, (name, e)
-    rel(y, ref, 'y', 2e-2)
-    rel(xg.grad, xr.grad, 'dx', 4e-2)
+    rel(y, ref, 'y', 1e-2)                        # measured 5.6e-4
+    rel(xg.grad, xr.grad, 'dx', 2e-2)             # measured 1.2e-3
     for k, p in net.named_parameters():
-        rel(p.grad, pr[k].grad, 'd ' + k, 4e-2)
+        rel(p.grad, pr[k].grad, 'd ' + k, 2e-2)   # measured <= 3.6e-3
 
 
 def test_cgpt_td3_update_gpu_vs_oracle():
