@@ -517,7 +517,7 @@ def main():
         try:
             from offpolicy_rnn.algorithm.graphed_update import GraphedUpdate
             gu = GraphedUpdate(alg, warmup=1)
-            for _ in range(2):
+            for _ in range(4):                       # one eager warm-up update, the shape's first visit (eager), the recording, one replay
                 gu.step()
                 alg.grad_num += 1
             sync()
@@ -545,7 +545,7 @@ def main():
     out = {
         'metric': 'env-steps/sec trained', 'value': trained / dt, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'strong' if args.global_rows else 'weak', 'vs_baseline': None,
-        'dtype': 'f32', 'dtype_note': ('inputs, accumulators and outputs of every kernel are fp32; GEMM products: ' + {0: 'fp32 MFMA instruction', 6: 'exact 3-way bf16 split of both fp32 operands, 6 leading plane products on the bf16 MFMA (as accurate vs fp64 as the fp32 instruction: DESIGN.md 4)', 9: 'exact 3-way bf16 split of both fp32 operands, all 9 plane products on the bf16 MFMA', 3: 'two bf16 planes per fp32 operand, 3 leading plane products on the bf16 MFMA (bf16x3: float32 matmul precision "high", NOT fp32-accurate)'}[gemm_mode]), 'data': 'synthetic',
+        'dtype': 'f32', 'dtype_note': ('inputs, accumulators and outputs of every kernel are fp32; GEMM products: ' + {0: 'fp32 MFMA instruction', 6: 'exact 3-way bf16 split of both fp32 operands, 6 leading plane products on the bf16 MFMA (as accurate vs fp64 as the fp32 instruction: DESIGN.md 4)', 9: 'exact 3-way bf16 split of both fp32 operands, all 9 plane products on the bf16 MFMA', 3: 'two bf16 planes per fp32 operand, 3 leading plane products on the bf16 MFMA (bf16x3: float32 matmul precision "high", NOT fp32-accurate)', 2: 'fp16 planes of the scaled fp32 operands (22 significant bits), 3 plane products on the f16 MFMA where the operand magnitudes are known, mode 6 elsewhere (as accurate vs fp64 as the fp32 instruction: DESIGN.md 4)'}[gemm_mode]), 'data': 'synthetic',
         'config': {'workload': f'{args.rnn} {args.algo.upper()}-REDQ update, B={Bsz}/GPU, T={args.horizon}, D=256 ({baseline_config(args)})',
                    'row_length': Tp, 'obs': OBS, 'act': ACT, 'critic': 'efc-8',
                    'global_rows': Bsz * world, 'parallelism': f'dp{world}'},
@@ -564,18 +564,20 @@ def main():
         # kernel time.  `peak`: an fp32-accurate product costs `mode` bf16 MFMA products here, so the most this formulation can
         # reach is the dense bf16 MFMA peak / mode (mode 0: the f32-input MFMA peak itself).  The fractions of the raw instruction
         # peaks are given beside it: of the bf16 peak (what the judge of round 2 asked for) and of the f32-input MFMA peak.
-        peak = 2500.0 / mode if mode else 157.3
+        nprod = {2: 3}.get(mode, mode)                  # plane products per fp32-accurate product
+        peak = 2500.0 / nprod if mode else 157.3
         ach = gemm_flops / t / 1e12
         o = {'kernel': 'gemm_f32_kernel', 'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
-             'peak_note': (f'dense bf16 MFMA peak 2500 / {mode} plane products per fp32-accurate product' if mode else 'f32-input MFMA peak'),
+             'peak_note': (f'dense bf16 / f16 MFMA peak 2500 / {nprod} plane products per fp32-accurate product' if mode else 'f32-input MFMA peak'),
              'frac_of_bf16_mfma_peak_2500': ach / 2500.0, 'frac_of_f32_mfma_peak_157': ach / 157.3,
-             'executed_bf16_tflops': ach * (mode if mode else 1),
+             'executed_bf16_tflops': ach * (nprod if mode else 1),
              'traffic': load_traffic(args, Bsz).get('gemm_f32_kernel'), 'avg_us': g['avg_us'], 'launches': g['launches'],
              'algorithmic_flops': gemm_flops / g['launches'], 'fp32_equivalent_tflops': ach,
-             'mfma': 'v_mfma_f32_32x32x16_bf16' if mode else 'v_mfma_f32_32x32x2_f32',
+             'mfma': 'v_mfma_f32_32x32x16_f16' if mode == 2 else 'v_mfma_f32_32x32x16_bf16' if mode else 'v_mfma_f32_32x32x2_f32',
              'products': {0: 'fp32 operands', 6: 'exact 3-way bf16 operand split, 6 leading plane products, fp32 accumulate',
                           9: 'exact 3-way bf16 operand split, all 9 plane products, fp32 accumulate',
-                          3: 'two bf16 planes per operand, 3 leading plane products, fp32 accumulate (bf16x3)'}[mode],
+                          3: 'two bf16 planes per operand, 3 leading plane products, fp32 accumulate (bf16x3)',
+                          2: 'fp16 planes of the scaled operands (2 + 3 planes), 3 plane products, fp32 accumulate (f16x3)'}[mode],
              'ms_per_step_with_fp32_mfma_products': strict_ms,
              'ms_per_step_with_matmul_precision_high_bf16x3': high_ms,
              'note': 'all fc / efc-E / projection GEMMs of the update, fp32 in / out (DESIGN.md 4)'}

@@ -79,7 +79,8 @@ int resel_selective_scan_fwd(const float* u, int64_t ld_u, const float* delta, i
                              const float* Bm, int64_t ld_b, const float* Cm, int64_t ld_c,
                              const float* D, const float* delta_bias, const float* start,
                              float* out, int64_t ld_out, float* ckpt, float* last_state, void* workspace,
-                             int B, int L, int Di, int N, int delta_softplus, int time_segments, resel_stream_t stream);
+                             int B, int L, int Di, int N, int delta_softplus, int time_segments,
+                             void* amax_out, unsigned amax_epoch, resel_stream_t stream);
 
 /* Backward of the above.  dout: [B*L, Di] (ld_dout).  Outputs: du, ddelta, dz: [B*L, Di] (dz may be NULL iff
  * z is NULL); dBm, dCm: [B*L, N]; dA: [Di, N]; dD, ddelta_bias: [Di] (NULL iff the input was NULL).
@@ -93,7 +94,8 @@ int resel_selective_scan_bwd(const float* u, int64_t ld_u, const float* delta, i
                              float* du, int64_t ld_du, float* ddelta, int64_t ld_ddelta, float* dz, int64_t ld_dz,
                              float* dBm, int64_t ld_db, float* dCm, int64_t ld_dc,
                              float* dA, float* dD, float* ddelta_bias, void* workspace,
-                             int B, int L, int Di, int N, int delta_softplus, int time_segments, resel_stream_t stream);
+                             int B, int L, int Di, int N, int delta_softplus, int time_segments,
+                             void* amax_dz, void* amax_ddelta, unsigned amax_epoch, resel_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * smamba depthwise causal conv1d + bias + SiLU on the masked input.  Replaces `causal_conv1d_cuda.causal_conv1d_fwd/bwd`
@@ -104,11 +106,13 @@ int resel_selective_scan_bwd(const float* u, int64_t ld_u, const float* delta, i
  * Backward: dx [B*L, Di] (ld_dx), dw [Di, K], dbias [Di]; workspace resel_causal_conv1d_bwd_workspace_bytes().
  */
 int resel_causal_conv1d_fwd(const float* x, int64_t ld_x, const float* w, const float* bias, const float* mask,
-                            float* y, int64_t ld_y, int B, int L, int Di, int K, int silu, resel_stream_t stream);
+                            float* y, int64_t ld_y, int B, int L, int Di, int K, int silu, void* amax_y, unsigned amax_epoch,
+                            resel_stream_t stream);
 size_t resel_causal_conv1d_bwd_workspace_bytes(int B, int L, int Di, int K);
 int resel_causal_conv1d_bwd(const float* x, int64_t ld_x, const float* w, const float* bias, const float* mask,
                             const float* dy, int64_t ld_dy, float* dx, int64_t ld_dx, float* dw, float* dbias,
-                            void* workspace, int B, int L, int Di, int K, int silu, resel_stream_t stream);
+                            void* workspace, int B, int L, int Di, int K, int silu, void* amax_dx, unsigned amax_epoch,
+                            resel_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Fused residual add + LayerNorm / RMSNorm.  Replaces the Triton kernels `_layer_norm_fwd_1pass_kernel` /
@@ -121,7 +125,7 @@ int resel_causal_conv1d_bwd(const float* x, int64_t ld_x, const float* w, const 
  */
 int resel_add_layernorm_fwd(const float* x, const float* residual, const float* w, const float* b,
                             float* y, float* res_out, float* stats, int M, int C, float eps, int rms,
-                            resel_stream_t stream);
+                            void* amax_y, unsigned amax_epoch, resel_stream_t stream);
 size_t resel_add_layernorm_bwd_workspace_bytes(int M, int C);
 int resel_add_layernorm_bwd(const float* dy, const float* dres_in, const float* res, const float* w,
                             const float* stats, float* dx, float* dw, float* db, void* workspace,
@@ -271,7 +275,7 @@ int resel_sumsq(const float* x, int64_t n, float* out, void* workspace, resel_st
 int resel_bias_act_fwd(float* y, const float* bias, int64_t rows, int C, int64_t rows_per_seg, int act, resel_stream_t stream);
 size_t resel_bias_act_bwd_workspace_bytes(int64_t rows, int C, int64_t rows_per_seg);
 int resel_bias_act_bwd(const float* g, const float* a, float* gy, float* dbias, void* workspace, int64_t rows, int C,
-                       int64_t rows_per_seg, int act, resel_stream_t stream);
+                       int64_t rows_per_seg, int act, void* amax_gy, unsigned amax_epoch, resel_stream_t stream);
 
 /* ---- ensemble head: last hidden layer's tail + the width-1 output layer of an efc-E MLP ----------------------------
  * The critic head of the reference is `efc-E(H) ELU -> efc-E(1)` (policy_value_models/contextual_sac_value.py via
@@ -282,7 +286,7 @@ int resel_ensemble_head_fwd(float* y, const float* b2, const float* w3, const fl
                             int64_t rows_per_seg, resel_stream_t stream);
 size_t resel_ensemble_head_bwd_workspace_bytes(int64_t rows, int H, int64_t rows_per_seg);
 int resel_ensemble_head_bwd(const float* gq, const float* a, const float* w3, float* gy, float* db2, float* dw3, void* workspace,
-                            int64_t rows, int H, int64_t rows_per_seg, resel_stream_t stream);
+                            int64_t rows, int H, int64_t rows_per_seg, void* amax_gy, unsigned amax_epoch, resel_stream_t stream);
 
 /* ---- fp32 GEMM on the matrix cores, tails fused --------------------------------------------------------------------------
  * C[b][m][n] = act( sum_k A[b](m, k) B[b](n, k) + bias[b][n] ),  b < batch (ensemble member; strides in floats).
@@ -310,24 +314,38 @@ int resel_gemm_f32(const float* A, int64_t lda, int64_t strideA, int a_kcontig,
                    float* C, int64_t ldc, int64_t strideC, void* workspace,
                    int M, int N, int K, int batch, int split, resel_stream_t stream);
 
-/* Mode 2 ("f16x3") of the same contract: each operand is scaled by a power of two that brings its largest magnitude into
- * [2^14, 2^15) and split into TWO fp16 planes, h1 = fp16(x s), h2 = fp16(2^11 (x s - h1)) (22 significant bits of every element
- * down to 2^-29 of the operand's maximum); three plane products on v_mfma_f32_32x32x16_f16, the two cross terms in their own
- * accumulators, C = (a1 b1 + 2^-11 (a1 b2 + a2 b1)) / (sA sB).  Half the matrix instructions of mode 6; error against fp64 no
- * larger than the fp32 instruction's (tools/eval_f16_split.py, tests/test_hip_ops.py).  amax_a / amax_b: DEVICE scalars holding
- * an upper bound of max |A| / max |B| over the whole operand (all batch members) - resel_amax below, or a bound the producer of
- * the operand already has; a bound 2^k too large costs k bits of the 2^-29 range, one too small overflows fp16 (inf in C).
- * Other modes ignore the two pointers (may be NULL).  M <= 128 falls back to mode 6. */
+/* Mode 2 ("f16x3") of the same contract: fp16 planes of the SCALED operands, three plane products on v_mfma_f32_32x32x16_f16,
+ * one fp32 accumulator - half the matrix instructions of mode 6.  Each operand is multiplied by a power of two s that brings its
+ * largest magnitude into [2^14, 2^15), then A -> a1 = fp16(x s), a2 = fp16(2^11 (x s - a1)); B -> b1 = fp16(x s),
+ * b2 = fp16(x s - b1), b1s = 2^-11 b1;  C = (a1 b1 + a1 b2 + a2 b1s) / (sA sB).  The residuals and the plane products are exact in
+ * fp32; the dropped term is <= 2^-22 |a b|.  Every element of A keeps 22 significant bits down to 2^-29 max|A|, of B down to
+ * 2^-18 max|B| (below: 40 - log2(max|B| / |x|) bits) - pass the weights (forward, input gradient) or the narrower-range operand
+ * as B.  Error against fp64 <= the fp32 instruction's for A over 12 decades and B over 6 (tools/eval_f16_split.py,
+ * tests/test_hip_ops.py::test_gemm_f32_f16x3_mode_error_against_fp64).  amax_a / amax_b: magnitude HANDLES (below) holding an upper bound of
+ * max |A| / max |B| over the whole operand (all batch members) - resel_amax, or what the producer of the operand published; a
+ * bound 2^k too large costs k bits of those ranges, one too small overflows fp16 (inf in C).  Other modes ignore the two pointers
+ * (may be NULL).  M <= 128 and K < 32 fall back to modes 6 / 0. */
 int resel_gemm_f32x(const float* A, int64_t lda, int64_t strideA, int a_kcontig,
                     const float* B, int64_t ldb, int64_t strideB, int b_kcontig,
                     const float* bias, int64_t strideBias, int act,
                     float* C, int64_t ldc, int64_t strideC, void* workspace,
-                    int M, int N, int K, int batch, int split, const float* amax_a, const float* amax_b, resel_stream_t stream);
-/* out[0] = max |x| over a [batch][rows][cols] box (row stride ld, batch stride `stride`, cols % 4 == 0), one HBM-bound pass,
- * no host synchronisation.  `state`: resel_amax_state_bytes() bytes, zero before its first use (left zeroed by every call);
- * calls that share a state buffer must be ordered on one stream. */
+                    int M, int N, int K, int batch, int split, const float* amax_a, const float* amax_b,
+                    void* amax_c, unsigned amax_epoch, resel_stream_t stream);
+/* Magnitude handles.  A kernel that writes a tensor which a later GEMM reads can publish max |x| of what it stored, so that mode 2
+ * needs no extra pass over the operand.  A handle is 1 KiB (8-byte aligned; NULL = off): eight 8-byte words 128 bytes apart, word j =
+ * {float bits : low 32 | epoch : high 32}; a publishing wave raises the word its workgroup id selects with one 64-bit atomicMax
+ * (eight lines: thousands of waves finishing together would serialise on one).  A larger epoch outranks any older content - handles
+ * are never zeroed, give every tensor a fresh epoch - and kernels that fill parts of one tensor may share handle and epoch.  Readers
+ * (amax_a / amax_b above) take the newest epoch among the eight words and the largest magnitude carrying it.  Publishers:
+ * resel_amax (a pre-pass), resel_gemm_f32x (amax_c: the values stored to C), resel_bias_act_bwd (gy), resel_ensemble_head_bwd (gy), resel_add_layernorm_fwd
+ * (y), resel_selective_scan_fwd (out), resel_selective_scan_bwd (dz, ddelta), resel_causal_conv1d_fwd (y), resel_causal_conv1d_bwd (dx). */
+/* Magnitude pre-pass: max |x| over a [batch][rows][cols] box (row stride ld, batch stride `stride`, cols % 4 == 0) written into the
+ * magnitude handle `out` with epoch `epoch` (see "magnitude handles" above); one HBM-bound pass, no host synchronisation.
+ * `state`: resel_amax_state_bytes() bytes, zero before its first use (left zeroed by every call); calls that share a state buffer
+ * must be ordered on one stream. */
 size_t resel_amax_state_bytes(void);
-int resel_amax(const float* x, int64_t ld, int64_t stride, int rows, int cols, int batch, float* out, void* state, resel_stream_t stream);
+int resel_amax(const float* x, int64_t ld, int64_t stride, int rows, int cols, int batch, void* out, unsigned epoch, void* state,
+               resel_stream_t stream);
 
 /* ---- mixed-precision GEMM for the bf16 attention projections (cgpt) ------------------------------------------------------
  * C[m][n] = sum_k bf16(A(m, k)) bf16(B(n, k)) + bf16(bias[n]): operands rounded to bf16 (round to nearest even) on their way

@@ -5,6 +5,7 @@
 // weight / bias gradients of the rows a wave visits in registers and leaves one partial per block; a second
 // kernel sums the partials in a fixed order (no atomics, bitwise reproducible).
 #include "resel_common.h"
+#include <algorithm>
 
 namespace {
 using namespace resel;
@@ -16,11 +17,11 @@ template <int VPL>                  // float4 per lane: C <= VPL * 256
 __global__ __launch_bounds__(WAVES * 64) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ residual,
                                                             const float* __restrict__ w, const float* __restrict__ b,
                                                             float* __restrict__ y, float* __restrict__ res_out,
-                                                            float* __restrict__ stats, int M, int C, float eps, int rms) {
+                                                            float* __restrict__ stats, int M, int C, float eps, int rms, AmaxOut amax) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * WAVES + (threadIdx.x >> 6);
-    if (row >= M) return;
     const int c4 = C / 4;
+    float ymax = 0.f;                                // max |y| over the rows of this wave (one publication per wave, at the end)
+    for (int row = blockIdx.x * WAVES + (threadIdx.x >> 6); row < M; row += gridDim.x * WAVES) {
     const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * C);
     const float4* rr = residual ? reinterpret_cast<const float4*>(residual + (int64_t)row * C) : nullptr;
     float4 v[VPL];
@@ -58,8 +59,11 @@ __global__ __launch_bounds__(WAVES * 64) void ln_fwd_kernel(const float* __restr
             o.z = (v[i].z - mean) * rstd * wv.z; o.w = (v[i].w - mean) * rstd * wv.w;
             if (b) { const float4 bb = reinterpret_cast<const float4*>(b)[c]; o.x += bb.x; o.y += bb.y; o.z += bb.z; o.w += bb.w; }
             reinterpret_cast<float4*>(y + (int64_t)row * C)[c] = o;
+            ymax = amax4(ymax, o);
         }
     }
+    }
+    amax_publish_wave(ymax, amax);
 }
 
 template <int VPL>
@@ -138,17 +142,20 @@ inline bool ln_ok(int M, int C) { return M > 0 && C > 0 && C % 4 == 0 && C <= 20
 
 extern "C" int resel_add_layernorm_fwd(const float* x, const float* residual, const float* w, const float* b,
                                        float* y, float* res_out, float* stats, int M, int C, float eps, int rms,
-                                       resel_stream_t stream) {
-    if (!x || !w || !y || !ln_ok(M, C)) return RESEL_EINVAL;
+                                       void* amax_y, unsigned amax_epoch, resel_stream_t stream) {
+    if (!x || !w || !y || !ln_ok(M, C) || (amax_y && (reinterpret_cast<uintptr_t>(amax_y) & 7u))) return RESEL_EINVAL;
+    const AmaxOut ao{(unsigned long long*)amax_y, amax_epoch};
     if (!aligned16(x) || !aligned16(y) || !aligned16(w) || (residual && !aligned16(residual)) || (b && !aligned16(b)) ||
         (res_out && !aligned16(res_out)))
         return RESEL_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid((M + WAVES - 1) / WAVES), blk(WAVES * 64);
-    if (C <= 256) hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, blk, 0, s, x, residual, w, b, y, res_out, stats, M, C, eps, rms);
-    else if (C <= 512) hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, blk, 0, s, x, residual, w, b, y, res_out, stats, M, C, eps, rms);
-    else if (C <= 1024) hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, blk, 0, s, x, residual, w, b, y, res_out, stats, M, C, eps, rms);
-    else hipLaunchKernelGGL(ln_fwd_kernel<8>, grid, blk, 0, s, x, residual, w, b, y, res_out, stats, M, C, eps, rms);
+    // with a magnitude handle: persistent waves (grid-stride over rows), so that 8 192 waves publish instead of one per row
+    const int nblk = (M + WAVES - 1) / WAVES;
+    dim3 grid(amax_y ? std::min(nblk, 2048) : nblk), blk(WAVES * 64);
+    if (C <= 256) hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, blk, 0, s, x, residual, w, b, y, res_out, stats, M, C, eps, rms, ao);
+    else if (C <= 512) hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, blk, 0, s, x, residual, w, b, y, res_out, stats, M, C, eps, rms, ao);
+    else if (C <= 1024) hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, blk, 0, s, x, residual, w, b, y, res_out, stats, M, C, eps, rms, ao);
+    else hipLaunchKernelGGL(ln_fwd_kernel<8>, grid, blk, 0, s, x, residual, w, b, y, res_out, stats, M, C, eps, rms, ao);
     return launch_status();
 }
 

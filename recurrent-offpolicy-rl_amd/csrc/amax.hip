@@ -1,5 +1,5 @@
-// Largest magnitude of a GEMM operand, on the device: the scale source of resel_gemm_f32x's mode 2 (two fp16 planes of the
-// SCALED operand).  HBM-bound single pass: float4 loads along the contiguous axis, one partial per block, and the block whose
+// Largest magnitude of a GEMM operand, on the device, written into a magnitude handle (resel_common.h): the scale source of
+// resel_gemm_f32x's mode 2 (fp16 planes of the SCALED operand) for operands whose producer published nothing.  HBM-bound single pass: float4 loads along the contiguous axis, one partial per block, and the block whose
 // ticket is the last one folds the partials in a fixed order and resets the ticket - the result does not depend on block
 // timing, needs no pre-zeroed output and no host synchronisation; `state` ([0] ticket, [1..] partials) must be zero before
 // its first use and is left zeroed.  NaNs in the operand are ignored here (fmaxf); they reach the product through the planes.
@@ -14,7 +14,8 @@ struct AmaxParams {
     const float* x;
     int64_t ld, stride;
     int rows, cols, batch;
-    float* out;
+    unsigned long long* out;
+    unsigned epoch;
     unsigned* ticket;
     float* partial;
 };
@@ -55,7 +56,8 @@ __global__ __launch_bounds__(256) void amax_kernel(AmaxParams p) {
     if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) {
-        p.out[0] = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+        // sub-slot 0 of the handle, stamped with this call's epoch (the other seven keep older epochs: readers ignore them)
+        p.out[0] = ((unsigned long long)p.epoch << 32) | __float_as_uint(fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3])));
         __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -63,13 +65,14 @@ __global__ __launch_bounds__(256) void amax_kernel(AmaxParams p) {
 
 extern "C" size_t resel_amax_state_bytes(void) { return (size_t)(AMAX_BLOCKS + 4) * sizeof(float); }
 
-extern "C" int resel_amax(const float* x, int64_t ld, int64_t stride, int rows, int cols, int batch, float* out, void* state,
+extern "C" int resel_amax(const float* x, int64_t ld, int64_t stride, int rows, int cols, int batch, void* out, unsigned epoch, void* state,
                           resel_stream_t stream) {
-    if (!x || !out || !state || rows <= 0 || cols <= 0 || batch <= 0 || (cols & 3) || (ld & 3) || (stride & 3) || !aligned16(x) || !aligned16(state))
+    if (!x || !out || !state || rows <= 0 || cols <= 0 || batch <= 0 || (cols & 3) || (ld & 3) || (stride & 3) || !aligned16(x) || !aligned16(state)
+        || (reinterpret_cast<uintptr_t>(out) & 7u))
         return RESEL_EINVAL;
     const int64_t total = (int64_t)rows * (cols >> 2) * batch;
     const int blocks = (int)std::min<int64_t>(AMAX_BLOCKS, (total + 1023) / 1024 > 0 ? (total + 1023) / 1024 : 1);
-    AmaxParams p{x, ld, stride, rows, cols, batch, out, (unsigned*)state, (float*)state + 4};
+    AmaxParams p{x, ld, stride, rows, cols, batch, (unsigned long long*)out, epoch, (unsigned*)state, (float*)state + 4};
     hipLaunchKernelGGL(amax_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
     return launch_status();
 }

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void bias_act_fwd_kernel(float* __restrict__ y
 // grid = (row blocks inside a segment, column blocks of 256 floats, segments); 256 threads = 64 float4 columns x 4 row lanes
 __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float* __restrict__ g, const float* __restrict__ a,
                                                            float* __restrict__ gy, float* __restrict__ db_part,
-                                                           int C, int64_t rows_per_seg, int act, int nrb) {
+                                                           int C, int64_t rows_per_seg, int act, int nrb, AmaxOut amax) {
     __shared__ __attribute__((aligned(16))) float s_red[4][256];
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int c = blockIdx.y * 256 + cl * 4;
@@ -45,6 +45,7 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float* __restri
     const int64_t r0 = (int64_t)blockIdx.x * BWD_ROWS;
     const int64_t r1 = r0 + BWD_ROWS < rows_per_seg ? r0 + BWD_ROWS : rows_per_seg;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float gmax = 0.f;
     if (c < C) {
         for (int64_t r = r0 + rl; r < r1; r += 4) {
             const int64_t o = (seg * rows_per_seg + r) * C + c;
@@ -56,8 +57,10 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float* __restri
             }
             if (gy != g || act == 1) st4(gy + o, v);
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            gmax = amax4(gmax, v);
         }
     }
+    amax_publish_wave(gmax, amax);
     if (db_part == nullptr) return;
     st4(&s_red[rl][cl * 4], acc);
     __syncthreads();
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(float* __restrict__ y, co
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ gq, const float* __restrict__ a,
                                                        const float* __restrict__ w3, float* __restrict__ gy,
                                                        float* __restrict__ db_part, float* __restrict__ dw_part, int H,
-                                                       int64_t rows_per_seg, int nrb) {
+                                                       int64_t rows_per_seg, int nrb, AmaxOut amax) {
     __shared__ __attribute__((aligned(16))) float s_red[2][4][256];
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int c = blockIdx.y * 256 + cl * 4;
@@ -105,6 +108,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
     const int64_t r0 = (int64_t)blockIdx.x * BWD_ROWS;
     const int64_t r1 = r0 + BWD_ROWS < rows_per_seg ? r0 + BWD_ROWS : rows_per_seg;
     float4 accb = make_float4(0.f, 0.f, 0.f, 0.f), accw = accb;
+    float gmax = 0.f;
     if (c < H) {
         const float4 w = ld4(w3 + seg * H + c);
         for (int64_t r = r0 + rl; r < r1; r += 4) {
@@ -115,10 +119,12 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
             v.x = g * w.x * (av.x > 0.f ? 1.f : av.x + 1.f); v.y = g * w.y * (av.y > 0.f ? 1.f : av.y + 1.f);
             v.z = g * w.z * (av.z > 0.f ? 1.f : av.z + 1.f); v.w = g * w.w * (av.w > 0.f ? 1.f : av.w + 1.f);
             st4(gy + row * H + c, v);
+            gmax = amax4(gmax, v);
             accb.x += v.x; accb.y += v.y; accb.z += v.z; accb.w += v.w;
             accw.x += g * av.x; accw.y += g * av.y; accw.z += g * av.z; accw.w += g * av.w;
         }
     }
+    amax_publish_wave(gmax, amax);
     st4(&s_red[0][rl][cl * 4], accb);
     st4(&s_red[1][rl][cl * 4], accw);
     __syncthreads();
@@ -156,14 +162,16 @@ extern "C" size_t resel_bias_act_bwd_workspace_bytes(int64_t rows, int C, int64_
 }
 
 extern "C" int resel_bias_act_bwd(const float* g, const float* a, float* gy, float* dbias, void* workspace, int64_t rows, int C,
-                                  int64_t rows_per_seg, int act, resel_stream_t stream) {
+                                  int64_t rows_per_seg, int act, void* amax_gy, unsigned amax_epoch, resel_stream_t stream) {
+    if (amax_gy && (reinterpret_cast<uintptr_t>(amax_gy) & 7u)) return RESEL_EINVAL;
     if (!g || !gy || !shape_ok(rows, C, rows_per_seg) || act < 0 || act > 1 || (act == 1 && !a) || (dbias && !workspace))
         return RESEL_EINVAL;
     if (!aligned16(g) || !aligned16(gy) || (a && !aligned16(a)) || (workspace && !aligned16(workspace))) return RESEL_EINVAL;
     const int nseg = (int)(rows / rows_per_seg), nrb = row_blocks(rows_per_seg);
     hipStream_t s = (hipStream_t)stream;
     float* part = dbias ? (float*)workspace : nullptr;
-    hipLaunchKernelGGL(bias_act_bwd_kernel, dim3(nrb, (C + 255) / 256, nseg), dim3(256), 0, s, g, a, gy, part, C, rows_per_seg, act, nrb);
+    hipLaunchKernelGGL(bias_act_bwd_kernel, dim3(nrb, (C + 255) / 256, nseg), dim3(256), 0, s, g, a, gy, part, C, rows_per_seg, act, nrb,
+                       AmaxOut{(unsigned long long*)amax_gy, amax_epoch});
     if (dbias) launch_colsum(part, C, nrb, C, dbias, s, 1, 0, nseg);      // dbias[sg, :] = sum over the segment's row blocks
     return launch_status();
 }
@@ -181,14 +189,17 @@ extern "C" size_t resel_ensemble_head_bwd_workspace_bytes(int64_t rows, int H, i
 }
 
 extern "C" int resel_ensemble_head_bwd(const float* gq, const float* a, const float* w3, float* gy, float* db2, float* dw3,
-                                       void* workspace, int64_t rows, int H, int64_t rows_per_seg, resel_stream_t stream) {
+                                       void* workspace, int64_t rows, int H, int64_t rows_per_seg, void* amax_gy, unsigned amax_epoch,
+                                       resel_stream_t stream) {
+    if (amax_gy && (reinterpret_cast<uintptr_t>(amax_gy) & 7u)) return RESEL_EINVAL;
     if (!gq || !a || !w3 || !gy || !db2 || !dw3 || !workspace || !shape_ok(rows, H, rows_per_seg)) return RESEL_EINVAL;
     if (!aligned16(a) || !aligned16(w3) || !aligned16(gy) || !aligned16(workspace)) return RESEL_EINVAL;
     const int nseg = (int)(rows / rows_per_seg), nrb = row_blocks(rows_per_seg);
     hipStream_t s = (hipStream_t)stream;
     float* db_part = (float*)workspace;
     float* dw_part = db_part + (size_t)nseg * nrb * H;
-    hipLaunchKernelGGL(head_bwd_kernel, dim3(nrb, (H + 255) / 256, nseg), dim3(256), 0, s, gq, a, w3, gy, db_part, dw_part, H, rows_per_seg, nrb);
+    hipLaunchKernelGGL(head_bwd_kernel, dim3(nrb, (H + 255) / 256, nseg), dim3(256), 0, s, gq, a, w3, gy, db_part, dw_part, H, rows_per_seg, nrb,
+                       AmaxOut{(unsigned long long*)amax_gy, amax_epoch});
     launch_colsum(db_part, H, nrb, H, db2, s, 1, 0, nseg);
     launch_colsum(dw_part, H, nrb, H, dw3, s, 1, 0, nseg);
     return launch_status();

@@ -17,6 +17,7 @@ struct ConvParams {
     float *y, *dx, *dw_part, *db_part;
     int64_t ld_x, ld_y, ld_dy, ld_dx;
     int B, L, Di, K, silu;
+    AmaxOut amax;                    // optional: publish max |y| (forward) / max |dx| (backward)
 };
 
 template <int KT>
@@ -74,7 +75,7 @@ constexpr int CONV_TT = 64;          // time steps per chunk (<= 64: one mask re
 template <int KT, int MODE>          // MODE 0: warm-up group (only its last step produces an output), 1: full, 2: guarded tail
 __device__ __forceinline__ void conv_fwd_group(const ConvParams& p, const float* xrow, float* yrow, int tg, int t_end,
                                                int ig, float mlo, float mhi, const f2 (&wr)[KT], f2 (&win)[KT],
-                                               f2 (&pre)[KT < 8 ? KT : 8], f2 bv) {
+                                               f2 (&pre)[KT < 8 ? KT : 8], f2 bv, float& ymax) {
     constexpr int P = KT < 8 ? KT : 8;
     const float mreg = ig < 64 ? mlo : mhi;          // KT divides 64: a group never straddles the two mask registers
 #pragma unroll
@@ -91,6 +92,7 @@ __device__ __forceinline__ void conv_fwd_group(const ConvParams& p, const float*
                 acc = __builtin_elementwise_fma(wr[kk], win[(s + 1 + kk) % KT], acc);
             if (p.silu) { acc.x = siluf_(acc.x); acc.y = siluf_(acc.y); }
             *reinterpret_cast<f2*>(yrow + (int64_t)t * p.ld_y) = acc;
+            ymax = fmaxf(ymax, fmaxf(__builtin_fabsf(acc.x), __builtin_fabsf(acc.y)));
         }
     }
 }
@@ -132,10 +134,12 @@ __global__ __launch_bounds__(128) void conv_fwd_kernel(ConvParams p) {
     f2 pre[P];
 #pragma unroll
     for (int i = 0; i < P; ++i) pre[i] = *reinterpret_cast<const f2*>(xrow + (int64_t)min(max(ts + i, 0), t_end - 1) * p.ld_x);
-    conv_fwd_group<KT, 0>(p, xrow, yrow, ts, t_end, 0, mlo, mhi, wr, win, pre, bv);
+    float ymax = 0.f;
+    conv_fwd_group<KT, 0>(p, xrow, yrow, ts, t_end, 0, mlo, mhi, wr, win, pre, bv, ymax);
     int ig = KT;
-    for (; ts + ig + KT <= t_end; ig += KT) conv_fwd_group<KT, 1>(p, xrow, yrow, ts + ig, t_end, ig, mlo, mhi, wr, win, pre, bv);
-    if (ts + ig < t_end) conv_fwd_group<KT, 2>(p, xrow, yrow, ts + ig, t_end, ig, mlo, mhi, wr, win, pre, bv);
+    for (; ts + ig + KT <= t_end; ig += KT) conv_fwd_group<KT, 1>(p, xrow, yrow, ts + ig, t_end, ig, mlo, mhi, wr, win, pre, bv, ymax);
+    if (ts + ig < t_end) conv_fwd_group<KT, 2>(p, xrow, yrow, ts + ig, t_end, ig, mlo, mhi, wr, win, pre, bv, ymax);
+    amax_publish_wave(ymax, p.amax);
 }
 
 // Backward, register-window form (K <= 16, L >= 64): the same thread ownership as the forward - 2 channels, one 64-step
@@ -155,7 +159,7 @@ template <int KT, int MODE>          // MODE 0: inputs only, 1: + g window and d
 __device__ __forceinline__ void conv_bwd_group(const ConvParams& p, const float* xrow, const float* dyrow, float* dxrow, int tg,
                                                int ig, int t_own0, float mlo, float mhi, const f2 (&wr)[KT], f2 (&xwin)[KT],
                                                f2 (&gwin)[KT], f2 (&dwr)[KT], f2& dbr, f2 (&prex)[KT < 4 ? KT : 4],
-                                               f2 (&predy)[KT < 4 ? KT : 4], f2 bv) {
+                                               f2 (&predy)[KT < 4 ? KT : 4], f2 bv, float& dxmax) {
     constexpr int P = KT < 4 ? KT : 4;
     const float mreg = ig < 64 ? mlo : mhi;
 #pragma unroll
@@ -189,7 +193,9 @@ __device__ __forceinline__ void conv_bwd_group(const ConvParams& p, const float*
             const float ma = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mlo), im & 63));
             const float mb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mhi), im & 63));
             const float mm = im < 64 ? ma : mb;
-            *reinterpret_cast<f2*>(dxrow + (int64_t)(t - (KT - 1)) * p.ld_dx) = acc * f2{mm, mm};
+            const f2 dxv = acc * f2{mm, mm};
+            *reinterpret_cast<f2*>(dxrow + (int64_t)(t - (KT - 1)) * p.ld_dx) = dxv;
+            dxmax = fmaxf(dxmax, fmaxf(__builtin_fabsf(dxv.x), __builtin_fabsf(dxv.y)));
         }
     }
 }
@@ -233,10 +239,12 @@ __global__ __launch_bounds__(128) void conv_bwd_win_kernel(ConvParams p, int nch
         prex[i] = *reinterpret_cast<const f2*>(xrow + (int64_t)min(max(ts + i, 0), p.L - 1) * p.ld_x);
         predy[i] = *reinterpret_cast<const f2*>(dyrow + (int64_t)min(max(ts + KT + i, 0), p.L - 1) * p.ld_dy);
     }
-    conv_bwd_group<KT, 0>(p, xrow, dyrow, dxrow, ts, 0, t_own0, mlo, mhi, wr, xwin, gwin, dwr, dbr, prex, predy, bv);
-    conv_bwd_group<KT, 1>(p, xrow, dyrow, dxrow, ts + KT, KT, t_own0, mlo, mhi, wr, xwin, gwin, dwr, dbr, prex, predy, bv);
+    float dxmax = 0.f;
+    conv_bwd_group<KT, 0>(p, xrow, dyrow, dxrow, ts, 0, t_own0, mlo, mhi, wr, xwin, gwin, dwr, dbr, prex, predy, bv, dxmax);
+    conv_bwd_group<KT, 1>(p, xrow, dyrow, dxrow, ts + KT, KT, t_own0, mlo, mhi, wr, xwin, gwin, dwr, dbr, prex, predy, bv, dxmax);
     for (int ig = 2 * KT; ig < 2 * KT + CB_TT; ig += KT)
-        conv_bwd_group<KT, 2>(p, xrow, dyrow, dxrow, ts + ig, ig, t_own0, mlo, mhi, wr, xwin, gwin, dwr, dbr, prex, predy, bv);
+        conv_bwd_group<KT, 2>(p, xrow, dyrow, dxrow, ts + ig, ig, t_own0, mlo, mhi, wr, xwin, gwin, dwr, dbr, prex, predy, bv, dxmax);
+    amax_publish_wave(dxmax, p.amax);
     if (c_raw < p.Di) {
         const int64_t row = (int64_t)b * nchunk + chunk;
 #pragma unroll
@@ -256,6 +264,7 @@ __global__ __launch_bounds__(128) void conv_bwd_win_kernel(ConvParams p, int nch
 //   dw[k]  = sum_t g[t] * xm[t - (K-1) + k]
 template <int KT>
 __global__ __launch_bounds__(256) void conv_bwd_kernel(ConvParams p) {
+    float dxmax = 0.f;
     __shared__ __attribute__((aligned(16))) float s_x[TT + 2 * (KT - 1)][TILE_C];   // masked x rows [t0-(KT-1), t0+TT+KT-1)
     __shared__ __attribute__((aligned(16))) float s_g[TT + KT - 1][TILE_C];         // g rows [t0, t0+TT+KT-1)
     const int tid = threadIdx.x;
@@ -317,9 +326,11 @@ __global__ __launch_bounds__(256) void conv_bwd_kernel(ConvParams p) {
                     acc.x *= m; acc.y *= m; acc.z *= m; acc.w *= m;
                 }
                 st4(p.dx + (tok0 + t) * p.ld_dx + d0 + tc4, acc);
+                dxmax = amax4(dxmax, acc);
             }
         }
     }
+    amax_publish_wave(dxmax, p.amax);
     // reduce the 16 row-threads that share a channel quad, then write the per-row partial
     __syncthreads();
     float* s_red = &s_x[0][0];                       // [16][64] floats per tap, reused tap by tap
@@ -349,9 +360,11 @@ inline bool conv_args_ok(const float* x, int64_t ld_x, const float* o, int64_t l
 
 extern "C" int resel_causal_conv1d_fwd(const float* x, int64_t ld_x, const float* w, const float* bias, const float* mask,
                                        float* y, int64_t ld_y, int B, int L, int Di, int K, int silu,
-                                       resel_stream_t stream) {
+                                       void* amax_y, unsigned amax_epoch, resel_stream_t stream) {
+    if (amax_y && (reinterpret_cast<uintptr_t>(amax_y) & 7u)) return RESEL_EINVAL;
     if (!conv_args_ok(x, ld_x, y, ld_y, B, L, Di, K) || !w || (bias && !aligned16(bias))) return RESEL_EINVAL;
-    ConvParams p{x, w, bias, mask, nullptr, y, nullptr, nullptr, nullptr, ld_x, ld_y, 0, 0, B, L, Di, K, silu};
+    ConvParams p{x, w, bias, mask, nullptr, y, nullptr, nullptr, nullptr, ld_x, ld_y, 0, 0, B, L, Di, K, silu,
+                 AmaxOut{(unsigned long long*)amax_y, amax_epoch}};
     const int KT = pad_taps(K);
     dim3 grid((Di + 255) / 256, (L + CONV_TT - 1) / CONV_TT, B);
     hipStream_t s = (hipStream_t)stream;
@@ -374,7 +387,9 @@ extern "C" size_t resel_causal_conv1d_bwd_workspace_bytes(int B, int L, int Di, 
 
 extern "C" int resel_causal_conv1d_bwd(const float* x, int64_t ld_x, const float* w, const float* bias, const float* mask,
                                        const float* dy, int64_t ld_dy, float* dx, int64_t ld_dx, float* dw, float* dbias,
-                                       void* workspace, int B, int L, int Di, int K, int silu, resel_stream_t stream) {
+                                       void* workspace, int B, int L, int Di, int K, int silu, void* amax_dx, unsigned amax_epoch,
+                                       resel_stream_t stream) {
+    if (amax_dx && (reinterpret_cast<uintptr_t>(amax_dx) & 7u)) return RESEL_EINVAL;
     if (!conv_args_ok(x, ld_x, dx, ld_dx, B, L, Di, K) || !w || !dy || !dw || !workspace || ld_dy % 4 || !aligned16(dy) ||
         (bias && !aligned16(bias)))
         return RESEL_EINVAL;
@@ -382,7 +397,8 @@ extern "C" int resel_causal_conv1d_bwd(const float* x, int64_t ld_x, const float
     const int rows = bwd_rows(B, L, KT);            // partial rows: one per (b, chunk) or one per b
     float* dw_part = (float*)workspace;
     float* db_part = dw_part + (size_t)rows * Di * KT;
-    ConvParams p{x, w, bias, mask, dy, nullptr, dx, dw_part, db_part, ld_x, 0, ld_dy, ld_dx, B, L, Di, K, silu};
+    ConvParams p{x, w, bias, mask, dy, nullptr, dx, dw_part, db_part, ld_x, 0, ld_dy, ld_dx, B, L, Di, K, silu,
+                 AmaxOut{(unsigned long long*)amax_dx, amax_epoch}};
     hipStream_t s = (hipStream_t)stream;
     if (bwd_windowed(L, KT)) {
         const int nchunk = (L + CB_TT - 1) / CB_TT;

@@ -49,6 +49,7 @@ struct Params {
     int mt, nt;
     int nfull, nsplit, nsl, kslice;
     const float *amaxA, *amaxB;                  // mode 2: device scalars >= max |A|, max |B| (resel_amax); nullptr otherwise
+    AmaxOut amaxC;                               // optional: publish max |C| (the values stored, after bias / activation / accumulate)
 };
 
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : fast_exp(x) - 1.f; }
@@ -134,37 +135,52 @@ __device__ __forceinline__ P3h split2(float x0, float x1) {
     return o;
 }
 
-// ---- mode 2 ("f16x3"): two fp16 planes of x s, s a power of two that brings the operand's largest magnitude into [2^14, 2^15):
-//   h1 = fp16(x s) (round to nearest even), h2 = fp16(2^11 (x s - h1)) - the residual is exact in fp32 and scaled into the
-//   normal range of fp16, so h1 + 2^-11 h2 carries 22 significant bits of every element down to 2^-29 of the operand's maximum.
-// sc = {s, 2048 s}.  7 vector instructions per element pair (v_pk_mul x 2, v_cvt_pk_f16_f32 x 2, v_cvt_f32_f16 x 2, v_pk_fma).
+// ---- mode 2 ("f16x3"): fp16 planes of the SCALED operands, three plane products, one accumulator.  Each operand is multiplied by
+// a power of two s that brings its largest magnitude into [2^14, 2^15) (resel_amax; exact), then
+//   A (the wide-range operand: activations, gradients):  a1 = fp16(x s),  a2 = fp16(2^11 (x s - a1))        - two planes;
+//   B (weights; the second operand of a weight gradient): b1 = fp16(x s),  b2 = fp16(x s - b1),  b1s = 2^-11 b1 - three planes;
+//   C = (a1 b1 + a1 b2 + a2 b1s) / (sA sB):  the residuals are exact in fp32, every plane product is exact in fp32, the dropped
+//   term a2 b2 is <= 2^-22 |a b|.  The 2^11 between the planes of one element sits on the A side for the a-residual (a2 is
+//   normal down to |x| = 2^-29 max|A|) and on the B side for the b-residual (b2, b1s normal down to 2^-18 max|B|; below that
+//   the element keeps 40 - d bits, d = log2(max|B| / |x|)) - a single fp16 accumulator scale cannot give both operands the
+//   full range, two accumulator sets do not fit 256 registers beside the fragments (tried: 11-31 spilled dwords, slower than mode 6).
+// sc = {s, 2048 s}.  7 vector instructions per element pair.
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void split_pair_f16(float x0, float x1, f32x2_t sc, uint32_t& p1, uint32_t& p2) {
+template <bool WIDE>
+__device__ __forceinline__ void split_pair_f16(float x0, float x1, f32x2_t sc, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
     const f32x2_t xs = {x0 * sc.x, x1 * sc.x};
     const f16x2_t h = __builtin_convertvector(xs, f16x2_t);
-    const f32x2_t r = {__builtin_fmaf((float)h.x, -2048.f, x0 * sc.y), __builtin_fmaf((float)h.y, -2048.f, x1 * sc.y)};
     p1 = __builtin_bit_cast(uint32_t, h);
-    p2 = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2_t));
+    if (WIDE) {
+        const f32x2_t r = {__builtin_fmaf((float)h.x, -2048.f, x0 * sc.y), __builtin_fmaf((float)h.y, -2048.f, x1 * sc.y)};
+        p2 = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2_t));
+        p3 = 0u;
+    } else {
+        const f32x2_t r = {xs.x - (float)h.x, xs.y - (float)h.y};
+        p2 = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2_t));
+        const f16x2_t k = {(_Float16)0.00048828125f, (_Float16)0.00048828125f};        // 2^-11
+        p3 = __builtin_bit_cast(uint32_t, h * k);
+    }
 }
+template <bool WIDE>
 __device__ __forceinline__ P3 split4_f16(const float4& v, f32x2_t sc) {
     P3 o;
-    split_pair_f16(v.x, v.y, sc, o.p1.x, o.p2.x);
-    split_pair_f16(v.z, v.w, sc, o.p1.y, o.p2.y);
-    o.p3 = make_uint2(0u, 0u);
+    split_pair_f16<WIDE>(v.x, v.y, sc, o.p1.x, o.p2.x, o.p3.x);
+    split_pair_f16<WIDE>(v.z, v.w, sc, o.p1.y, o.p2.y, o.p3.y);
     return o;
 }
+template <bool WIDE>
 __device__ __forceinline__ P3h split2_f16(float x0, float x1, f32x2_t sc) {
     P3h o;
-    split_pair_f16(x0, x1, sc, o.p1, o.p2);
-    o.p3 = 0u;
+    split_pair_f16<WIDE>(x0, x1, sc, o.p1, o.p2, o.p3);
     return o;
 }
 // scale of an operand from its (upper bound of the) largest magnitude a: 2^(14 - floor(log2 a)), so a s is in [2^14, 2^15);
-// a = 0 or below 2^-113: the largest finite scale the exponent field allows (the operand is zero / negligible either way)
+// a = 0 or tiny: a large finite scale (the operand is zero / negligible either way)
 __device__ __forceinline__ float f16_scale(float amax) {
     const int f = (int)((__float_as_uint(amax) >> 23) & 0xffu);
-    const int e = min(max(268 - f, 1), 254);
+    const int e = min(max(268 - f, 1), 240);         // 2048 s stays finite
     return __uint_as_float((uint32_t)e << 23);
 }
 
@@ -245,12 +261,12 @@ struct Src {
         base += step;
     }
     // split the staged values and store the planes of this thread's pieces into the plane set at `pl` (plane stride PL bytes)
-    template <int PL, int NP, bool F16 = false>
+    template <int PL, int NP, int F16 = 0>
     __device__ __forceinline__ void store(char* pl, f32x2_t sc = f32x2_t{1.f, 2048.f}) const {
         if (KC) {
 #pragma unroll
             for (int i = 0; i < NPC; ++i) {
-                const P3 s = F16 ? split4_f16(r[i], sc) : split4<NP>(r[i]);
+                const P3 s = F16 == 1 ? split4_f16<true>(r[i], sc) : F16 == 2 ? split4_f16<false>(r[i], sc) : split4<NP>(r[i]);
                 *reinterpret_cast<uint2*>(pl + loff[i]) = s.p1;
                 *reinterpret_cast<uint2*>(pl + PL + loff[i]) = s.p2;
                 if (NP == 3) *reinterpret_cast<uint2*>(pl + 2 * PL + loff[i]) = s.p3;
@@ -260,7 +276,8 @@ struct Src {
                                    {r[0].z, r[1].z, r[2].z, r[3].z}, {r[0].w, r[1].w, r[2].w, r[3].w}};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const P3 s = F16 ? split4_f16(make_float4(c[j][0], c[j][1], c[j][2], c[j][3]), sc) : split4<NP>(make_float4(c[j][0], c[j][1], c[j][2], c[j][3]));
+                const float4 cj = make_float4(c[j][0], c[j][1], c[j][2], c[j][3]);
+                const P3 s = F16 == 1 ? split4_f16<true>(cj, sc) : F16 == 2 ? split4_f16<false>(cj, sc) : split4<NP>(cj);
                 *reinterpret_cast<uint2*>(pl + loff[j]) = s.p1;
                 *reinterpret_cast<uint2*>(pl + PL + loff[j]) = s.p2;
                 if (NP == 3) *reinterpret_cast<uint2*>(pl + 2 * PL + loff[j]) = s.p3;
@@ -269,7 +286,7 @@ struct Src {
             const float c[4][2] = {{r[0].x, r[1].x}, {r[0].y, r[1].y}, {r[0].z, r[1].z}, {r[0].w, r[1].w}};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const P3h s = F16 ? split2_f16(c[j][0], c[j][1], sc) : split2<NP>(c[j][0], c[j][1]);
+                const P3h s = F16 == 1 ? split2_f16<true>(c[j][0], c[j][1], sc) : F16 == 2 ? split2_f16<false>(c[j][0], c[j][1], sc) : split2<NP>(c[j][0], c[j][1]);
                 *reinterpret_cast<uint32_t*>(pl + loff[j]) = s.p1;
                 *reinterpret_cast<uint32_t*>(pl + PL + loff[j]) = s.p2;
                 if (NP == 3) *reinterpret_cast<uint32_t*>(pl + 2 * PL + loff[j]) = s.p3;
@@ -339,9 +356,9 @@ __device__ __forceinline__ void mfma_small(f32x16 (&acc)[2][2], const Frag& f) {
 __device__ __forceinline__ void mfma_lead(f32x16 (&acc)[2][2], const Frag& f) {
     mfma_term<1, 0>(acc, f); mfma_term<0, 1>(acc, f); mfma_term<0, 0>(acc, f);
 }
-// mode 2: the cross terms (residual planes carry a factor 2^11) have their own accumulators
-__device__ __forceinline__ void mfma_lead_f16(f32x16 (&acc)[2][2], f32x16 (&acc2)[2][2], const Frag& f) {
-    mfma_term_f16<1, 0>(acc2, f); mfma_term_f16<0, 1>(acc2, f); mfma_term_f16<0, 0>(acc, f);
+// mode 2: a2 b1s + a1 b2 + a1 b1 (A planes {a1, a2}, B planes {b1, b2, b1s}), small terms first
+__device__ __forceinline__ void mfma_lead_f16(f32x16 (&acc)[2][2], const Frag& f) {
+    mfma_term_f16<1, 2>(acc, f); mfma_term_f16<0, 1>(acc, f); mfma_term_f16<0, 0>(acc, f);
 }
 
 #define BF3_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -352,12 +369,13 @@ __device__ unsigned long long g_bf3_clock[2 * GRID];
 template <bool AKC, bool BKC, int SPLIT>
 __global__ __launch_bounds__(NTH, 2) void gemm_bf3_kernel(Params p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];           // 2 stages
-    constexpr int NP = (SPLIT == 3 || SPLIT == 2) ? 2 : 3;               // planes per operand element
     constexpr bool F16 = SPLIT == 2;                                     // fp16 planes of the scaled operands (f16x3)
+    constexpr int NP = (SPLIT == 3 || SPLIT == 2) ? 2 : 3;               // planes per element of A
+    constexpr int NPB = SPLIT == 3 ? 2 : 3;                              // planes per element of B (mode 2: b1, b2, 2^-11 b1)
     f32x2_t scA = {1.f, 2048.f}, scB = {1.f, 2048.f};
     float unscale = 1.f;
     if (F16) {
-        const float sa_ = f16_scale(*p.amaxA), sb_ = f16_scale(*p.amaxB);
+        const float sa_ = f16_scale(amax_read(p.amaxA)), sb_ = f16_scale(amax_read(p.amaxB));
         scA = f32x2_t{sa_, 2048.f * sa_};
         scB = f32x2_t{sb_, 2048.f * sb_};
         unscale = (1.f / sa_) * (1.f / sb_);                             // powers of two: exact
@@ -392,8 +410,8 @@ __global__ __launch_bounds__(NTH, 2) void gemm_bf3_kernel(Params p) {
         }
     };
     auto stage_store = [&](int st) {
-        sa.template store<PLA, NP, F16>(lds + st * STAGE, scA);
-        sb.template store<PLB, NP, F16>(lds + st * STAGE + 3 * PLA, scB);
+        sa.template store<PLA, NP, F16 ? 1 : 0>(lds + st * STAGE, scA);
+        sb.template store<PLB, NPB, F16 ? 2 : 0>(lds + st * STAGE + 3 * PLA, scB);
     };
     // fragment addresses: slab s of the lane = chunk 2 s + lh of row li of the wave's tile rows
     const char* fa[2];
@@ -415,13 +433,14 @@ __global__ __launch_bounds__(NTH, 2) void gemm_bf3_kernel(Params p) {
 #ifdef BF3_AB_CLOCK
     const unsigned long long ck_t0 = __builtin_amdgcn_s_memtime(), ck_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
+    float cmax = 0.f;                               // max |C| over everything this lane stores (published once, at the end)
     Frag f0, f1;
     p_open();
     produce();
     stage_store(0);
     produce();
     __syncthreads();
-    read_a<NP>(f0, fa[0]); read_b<NP>(f0, fb[0]);
+    read_a<NP>(f0, fa[0]); read_b<NPB>(f0, fb[0]);
     int cur_st = 0;
     for (int c_item = blockIdx.x; c_item < total; c_item += G) {
         const Item cur = decode(p, c_item);
@@ -434,15 +453,6 @@ __global__ __launch_bounds__(NTH, 2) void gemm_bf3_kernel(Params p) {
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[a][b][e] = zero;
-        f32x16 acc2[2][2];                            // mode 2 only (dead otherwise): cross terms, in units of 2^11
-        if (F16) {
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc2[a][b][e] = zero;
-        }
         float bv[2] = {0.f, 0.f};
 
         for (int c_k0 = cur.kbeg; c_k0 < cur.kend; c_k0 += BK) {
@@ -458,20 +468,21 @@ __global__ __launch_bounds__(NTH, 2) void gemm_bf3_kernel(Params p) {
             BF3_FENCE();
             // ---- region A: 36 (54) matrix instructions; in their shadow slab 1's fragment reads, the split + LDS stores of step
             // s + 1's tile and the global loads of step s + 2 into the registers the split has just released
-            read_a<NP>(f1, fa[1] + so); read_b<NP>(f1, fb[1] + so);
+            read_a<NP>(f1, fa[1] + so); read_b<NPB>(f1, fb[1] + so);
             mfma_small<SPLIT>(acc, f0);
             stage_store(cur_st ^ 1);
-            if (F16) mfma_lead_f16(acc, acc2, f0); else mfma_lead(acc, f0);
+            if (F16) mfma_lead_f16(acc, f0); else mfma_lead(acc, f0);
             sa.load_sched(fast);
             sb.load_sched(fast);
             mfma_small<SPLIT>(acc, f1);
-            if (SPLIT == 3 || SPLIT == 2) {         // 12 matrix instructions carry 8 fragment reads, the two-plane split, 12 LDS writes, the loads
+            if (SPLIT == 3 || SPLIT == 2) {         // 12 matrix instructions carry 8 (10) fragment reads, the split, 12 (14) LDS writes, the loads
 #pragma unroll
                 for (int i = 0; i < 12; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    if (i < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if (i < 2 * (NP + NPB)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
                     __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                    if (F16 && i >= 10) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
                     if (i >= 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 }
             } else {
@@ -493,12 +504,12 @@ __global__ __launch_bounds__(NTH, 2) void gemm_bf3_kernel(Params p) {
 #endif
             BF3_FENCE();
             // ---- region B: the leading terms of slab 1 with the fragment reads of step s + 1's slab 0
-            read_a<NP>(f0, fa[0] + sn); read_b<NP>(f0, fb[0] + sn);
-            if (F16) mfma_lead_f16(acc, acc2, f1); else mfma_lead(acc, f1);
+            read_a<NP>(f0, fa[0] + sn); read_b<NPB>(f0, fb[0] + sn);
+            if (F16) mfma_lead_f16(acc, f1); else mfma_lead(acc, f1);
 #pragma unroll
             for (int i = 0; i < 12; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (i < 4 * NP) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (i < 2 * (NP + NPB)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
             BF3_FENCE();
             if (fast) {
@@ -513,14 +524,13 @@ __global__ __launch_bounds__(NTH, 2) void gemm_bf3_kernel(Params p) {
             BF3_FENCE();
             cur_st ^= 1;
         }
-        if (F16) {                                   // C = (a1 b1 + 2^-11 (a1 b2 + a2 b1)) / (sA sB)
-            const float u2 = unscale * (1.f / 2048.f);
+        if (F16) {                                   // C = (a1 b1 + a1 b2 + a2 b1s) / (sA sB): powers of two, exact
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[a][b][e] = __builtin_fmaf(acc2[a][b][e], u2, acc[a][b][e] * unscale);
+                    for (int e = 0; e < 16; ++e) acc[a][b][e] *= unscale;
         }
 #ifdef BF3_AB_NOEPI                    // ablation (wrong results): one store per wave and tile keeps the accumulators alive
         if (lane == 0) p.C[(int64_t)cur.m0 * p.ldc + cur.n0 + w] = acc[0][0][0] + acc[0][1][1] + acc[1][0][2] + acc[1][1][3];
@@ -573,10 +583,15 @@ __global__ __launch_bounds__(NTH, 2) void gemm_bf3_kernel(Params p) {
                             if (mb + dm < p.M) crow[(int64_t)dm * p.ldc] = v[e];
                         }
                     }
+                    if (p.amaxC.slot) {              // rows past M repeat row 0's products: in range of the real data
+#pragma unroll
+                        for (int e = 0; e < 16; e += 2) cmax = fmaxf(cmax, fmaxf(__builtin_fabsf(v[e]), __builtin_fabsf(v[e + 1])));
+                    }
                 }
             }
         }
     }
+    amax_publish_wave(cmax, p.amaxC);
 #ifdef BF3_AB_CLOCK
     if (tid == 0) {
         g_bf3_clock[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - ck_t0;
@@ -611,16 +626,20 @@ __global__ __launch_bounds__(256) void gemm_bf3_fixup_kernel(Params p) {
     int z, m0, n0;
     tile_origin(p, p.nfull + tr, z, m0, n0);
     const int m = m0 + ml, n = n0 + nl;
-    if (m >= p.M || n >= p.N) return;
-    float* c = p.C + (int64_t)z * p.sC + (int64_t)m * p.ldc + n;
+    float cmax = 0.f;
+    if (m < p.M && n < p.N) {
+        float* c = p.C + (int64_t)z * p.sC + (int64_t)m * p.ldc + n;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if (n + j >= p.N) break;
-        float x = o[j] + (p.bias ? p.bias[(int64_t)z * p.sBias + n + j] : 0.f);
-        if (p.act == 1) x = elu1(x);
-        if (p.act == 2) x += c[j];
-        c[j] = x;
+        for (int j = 0; j < 4; ++j) {
+            if (n + j >= p.N) break;
+            float x = o[j] + (p.bias ? p.bias[(int64_t)z * p.sBias + n + j] : 0.f);
+            if (p.act == 1) x = elu1(x);
+            if (p.act == 2) x += c[j];
+            c[j] = x;
+            cmax = fmaxf(cmax, __builtin_fabsf(x));
+        }
     }
+    amax_publish_wave(cmax, p.amaxC);                // q == 0: one whole wave (threadIdx.y selects the wave)
 }
 
 struct Plan { int nfull, nsplit, nsl, kslice; };
@@ -671,12 +690,13 @@ size_t gemm_bf3_workspace_bytes(int M, int N, int K, int batch) {
 // split in {3, 6, 9}, K >= 32; argument checks are the caller's (resel_gemm_f32)
 int gemm_bf3_launch(const float* A, int64_t lda, int64_t strideA, int a_kcontig, const float* B, int64_t ldb, int64_t strideB, int b_kcontig,
                     const float* bias, int64_t strideBias, int act, float* C, int64_t ldc, int64_t strideC, void* workspace,
-                    int M, int N, int K, int batch, int split, hipStream_t s, const float* amaxA, const float* amaxB) {
+                    int M, int N, int K, int batch, int split, hipStream_t s, const float* amaxA, const float* amaxB,
+                    unsigned long long* amax_c, unsigned amax_epoch) {
     if (split == 2 && (!amaxA || !amaxB)) return RESEL_EINVAL;
     const Plan pl = make_plan(M, N, K, batch);
     if (pl.nsplit && (!workspace || !aligned16(workspace))) return RESEL_EINVAL;
     Params p{A, B, bias, C, (float*)workspace, lda, ldb, ldc, strideA, strideB, strideC, strideBias, M, N, K, act,
-             (M + BM - 1) / BM, (N + BN - 1) / BN, pl.nfull, pl.nsplit, pl.nsl, pl.kslice, amaxA, amaxB};
+             (M + BM - 1) / BM, (N + BN - 1) / BN, pl.nfull, pl.nsplit, pl.nsl, pl.kslice, amaxA, amaxB, AmaxOut{amax_c, amax_epoch}};
     const int64_t total = (int64_t)pl.nfull + (int64_t)pl.nsplit * pl.nsl;
     dim3 grid((unsigned)std::min<int64_t>(total, GRID));
     int rc;

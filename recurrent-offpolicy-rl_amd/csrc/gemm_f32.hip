@@ -41,7 +41,8 @@ namespace resel {                      // gemm_bf3.hip: the split modes with the
 size_t gemm_bf3_workspace_bytes(int M, int N, int K, int batch);
 int gemm_bf3_launch(const float* A, int64_t lda, int64_t strideA, int a_kcontig, const float* B, int64_t ldb, int64_t strideB, int b_kcontig,
                     const float* bias, int64_t strideBias, int act, float* C, int64_t ldc, int64_t strideC, void* workspace,
-                    int M, int N, int K, int batch, int split, hipStream_t s, const float* amaxA, const float* amaxB);
+                    int M, int N, int K, int batch, int split, hipStream_t s, const float* amaxA, const float* amaxB,
+                    unsigned long long* amax_c, unsigned amax_epoch);
 }
 
 namespace {
@@ -62,6 +63,7 @@ struct GemmParams {
     int mt, nt;                                   // tiles along m and n
     int nfull;                                    // items [0, nfull): whole tiles; then nsplit tiles x nsl K slices of kslice
     int nsplit, nsl, kslice;
+    AmaxOut amaxC;                                // optional: publish max |C| of the stored values
 };
 
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : fast_exp(x) - 1.f; }
@@ -372,6 +374,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
     for (int g = 0; g < NG; ++g) read_frags<SPLIT>(f, lA, lB, g);
     if (SPLIT) { split_a(pl[0], f, 0); split_b(pl[0], f, 0); }     // the loop keeps slab 0 split and slab 1's B fragments read
     int nb = ASZ + BSZ;                                             // offset of the buffer the NEXT step goes to
+    float cmax = 0.f;                                               // max |C| of this lane's stores (published at the end)
 #ifdef GEMM_STAMP
     const bool stamp_on = blockIdx.x == 0 && tid == 0;
     int stamp_step = 0;
@@ -521,10 +524,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
                             if (mb + dm < p.M) crow[(int64_t)dm * p.ldc] = v[e];
                         }
                     }
+                    if (p.amaxC.slot) {
+#pragma unroll
+                        for (int e = 0; e < 16; e += 2) cmax = fmaxf(cmax, fmaxf(__builtin_fabsf(v[e]), __builtin_fabsf(v[e + 1])));
+                    }
                 }
             }
         }
     }
+    amax_publish_wave(cmax, p.amaxC);
 }
 
 // C tile = epi(sum over the K slices of a split tile).  Fixed summation order (deterministic): four interleaved slice groups
@@ -554,16 +562,20 @@ __global__ __launch_bounds__(256) void gemm_fixup_kernel(GemmParams p) {
     int z, m0, n0;
     tile_origin(p, p.nfull + tr, z, m0, n0);
     const int m = m0 + ml, n = n0 + nl;
-    if (m >= p.M || n >= p.N) return;
-    float* c = p.C + (int64_t)z * p.sC + (int64_t)m * p.ldc + n;
+    float cmax = 0.f;
+    if (m < p.M && n < p.N) {
+        float* c = p.C + (int64_t)z * p.sC + (int64_t)m * p.ldc + n;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if (n + j >= p.N) break;
-        float x = o[j] + (p.bias ? p.bias[(int64_t)z * p.sBias + n + j] : 0.f);
-        if (p.act == 1) x = elu1(x);
-        if (p.act == 2) x += c[j];
-        c[j] = x;
+        for (int j = 0; j < 4; ++j) {
+            if (n + j >= p.N) break;
+            float x = o[j] + (p.bias ? p.bias[(int64_t)z * p.sBias + n + j] : 0.f);
+            if (p.act == 1) x = elu1(x);
+            if (p.act == 2) x += c[j];
+            c[j] = x;
+            cmax = fmaxf(cmax, __builtin_fabsf(x));
+        }
     }
+    amax_publish_wave(cmax, p.amaxC);
 }
 
 // How the output tiles become items: whole tiles for the full rounds of the 512 block slots; the remaining r tiles are cut
@@ -605,7 +617,7 @@ extern "C" int resel_gemm_f32(const float* A, int64_t lda, int64_t strideA, int 
                               int M, int N, int K, int batch, int split, resel_stream_t stream) {
     if (split == 2) return RESEL_EINVAL;           // mode 2 needs the operand magnitudes: resel_gemm_f32x
     return resel_gemm_f32x(A, lda, strideA, a_kcontig, B, ldb, strideB, b_kcontig, bias, strideBias, act, C, ldc, strideC, workspace,
-                           M, N, K, batch, split, nullptr, nullptr, stream);
+                           M, N, K, batch, split, nullptr, nullptr, nullptr, 0u, stream);
 }
 
 extern "C" int resel_gemm_f32x(const float* A, int64_t lda, int64_t strideA, int a_kcontig,
@@ -613,11 +625,12 @@ extern "C" int resel_gemm_f32x(const float* A, int64_t lda, int64_t strideA, int
                                const float* bias, int64_t strideBias, int act,
                                float* C, int64_t ldc, int64_t strideC, void* workspace,
                                int M, int N, int K, int batch, int split, const float* amax_a, const float* amax_b,
-                               resel_stream_t stream) {
+                               void* amax_c, unsigned amax_epoch, resel_stream_t stream) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || act < 0 || act > 2) return RESEL_EINVAL;
     // 106 / 109: modes 6 / 9 on the first-edition kernel of this file (every wave splits the fragments it reads), kept for A/B runs
     if (split != 0 && split != 2 && split != 3 && split != 6 && split != 9 && split != 106 && split != 109) return RESEL_EINVAL;
     if (split == 2 && (!amax_a || !amax_b)) return RESEL_EINVAL;
+    if (amax_c && (reinterpret_cast<uintptr_t>(amax_c) & 7u)) return RESEL_EINVAL;
     if (split == 2 && M <= 128) split = 6;         // narrow shapes stay on the first edition's fp32-accurate bf16 split
     if (K < BK) split = 0;                         // the split kernels' scheduled loads assume one whole K step per item
     if (lda % 4 || ldb % 4 || strideA % 4 || strideB % 4 || !aligned16(A) || !aligned16(B)) return RESEL_EINVAL;
@@ -629,13 +642,13 @@ extern "C" int resel_gemm_f32x(const float* A, int64_t lda, int64_t strideA, int
     // 1.2-1.4x faster on the first edition's 128 x 128 tiles (66 752-token weight gradients [128, 256]: 48 vs 59 us, [80, 512]: 67 vs 95)
     if ((split == 2 || split == 3 || split == 6 || split == 9) && M > 128)
         return gemm_bf3_launch(A, lda, strideA, a_kcontig, B, ldb, strideB, b_kcontig, bias, strideBias, act, C, ldc, strideC, workspace,
-                               M, N, K, batch, split, (hipStream_t)stream, amax_a, amax_b);
+                               M, N, K, batch, split, (hipStream_t)stream, amax_a, amax_b, (unsigned long long*)amax_c, amax_epoch);
     if (split > 100) split -= 100;                 // here: 6 / 9 = first-edition split kernels, 0 = fp32 MFMA
     if (split == 3) split = 6;                     // the two-plane mode exists on the second-edition kernel only: narrow shapes keep mode 6
     const Plan pl = make_plan(M, N, K, batch);
     if (pl.nsplit && (!workspace || !aligned16(workspace))) return RESEL_EINVAL;
     GemmParams p{A, B, bias, C, (float*)workspace, lda, ldb, ldc, strideA, strideB, strideC, strideBias, M, N, K, act,
-                 (M + BM - 1) / BM, (N + BN - 1) / BN, pl.nfull, pl.nsplit, pl.nsl, pl.kslice};
+                 (M + BM - 1) / BM, (N + BN - 1) / BN, pl.nfull, pl.nsplit, pl.nsl, pl.kslice, AmaxOut{(unsigned long long*)amax_c, amax_epoch}};
     const int64_t total = (int64_t)pl.nfull + (int64_t)pl.nsplit * pl.nsl;
     dim3 grid((unsigned)std::min<int64_t>(total, GRID));
     hipStream_t s = (hipStream_t)stream;

@@ -120,6 +120,43 @@ inline void launch_timed(int slot, K kernel, dim3 grid, dim3 block, size_t lds, 
     prof_push(slot, a, b);
 }
 
+// ---- producer-side operand magnitudes (mode 2 of resel_gemm_f32x) ----------------------------------------------------
+// A kernel that WRITES a tensor a later GEMM reads can publish max |x| of what it wrote (include/resel_hip.h "magnitude handles").
+// A handle is RESEL_AMAX_SUBSLOTS 8-byte words, 128 bytes apart: word j = {epoch : high 32 | float bits : low 32}.  A publisher
+// raises the word its workgroup id selects with ONE 64-bit atomicMax per wave that has something to raise (thousands of waves
+// finishing together would serialise on a single word: 88 atomics / us; eight lines, one per XCD under round-robin placement,
+// also keep the plain read in front of the atomic fresh - an atomic drops the line from the XCD's own L2 only).  A larger epoch
+// outranks any older content, so handles are never zeroed; kernels filling parts of one tensor share a handle and an epoch.
+// A reader takes the newest epoch among the eight words and the largest magnitude carrying it.
+#define RESEL_AMAX_SUBSLOTS 8
+#define RESEL_AMAX_STRIDE 16                     /* 8-byte words between sub-slots (128 bytes) */
+struct AmaxOut { unsigned long long* slot; unsigned epoch; };
+__device__ __forceinline__ float amax4(float m, float4 v) {
+    return fmaxf(fmaxf(m, fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y))), fmaxf(__builtin_fabsf(v.z), __builtin_fabsf(v.w)));
+}
+__device__ __forceinline__ void amax_publish_wave(float m, AmaxOut o) {      // m >= 0 per lane; all 64 lanes of the wave call
+    if (o.slot == nullptr) return;
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
+    if (__lane_id() == 0) {
+        unsigned long long* w = o.slot + RESEL_AMAX_STRIDE * ((blockIdx.x + blockIdx.y + blockIdx.z) & (RESEL_AMAX_SUBSLOTS - 1));
+        const unsigned long long mine = ((unsigned long long)o.epoch << 32) | __float_as_uint(m);
+        if (*(volatile unsigned long long*)w < mine) atomicMax(w, mine);
+    }
+}
+// the magnitude a handle holds (all lanes of the calling wave get it)
+__device__ __forceinline__ float amax_read(const float* handle) {
+    const unsigned long long* h = reinterpret_cast<const unsigned long long*>(handle);
+    const int j = __lane_id() & (RESEL_AMAX_SUBSLOTS - 1);
+    unsigned long long v = h[RESEL_AMAX_STRIDE * j];
+#pragma unroll
+    for (int s = RESEL_AMAX_SUBSLOTS / 2; s > 0; s >>= 1) {
+        const unsigned long long o = __shfl_xor(v, s, 64);
+        v = o > v ? o : v;                       // newest epoch first, then the larger magnitude
+    }
+    return __uint_as_float((unsigned)(v & 0xffffffffu));
+}
+
 inline int launch_status() { return hipGetLastError() == hipSuccess ? RESEL_OK : RESEL_ELAUNCH; }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

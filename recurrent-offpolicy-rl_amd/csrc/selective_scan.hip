@@ -53,6 +53,7 @@ struct FwdParams {
     int B, L, Di, N, nck, softplus, nd, bc_vec;
     int seg_len, nseg;              // time-parallel form (MODE 1 / 2): steps per segment (multiple of the chunk), segments per row
     float *h_carry, *sdl;           // [B][nseg][N][Di] local end states -> entry states; [B][nseg][Di] delta sums
+    AmaxOut amax_out;               // optional: publish max |out| (the out_proj GEMM scales its operand with it)
 #ifdef SSCAN_STAMP
     unsigned long long* stamps;     // diagnostic build only (tools/micro/sscan_lab.hip): per-wave phase cycle sums
 #endif
@@ -279,6 +280,7 @@ __global__ __launch_bounds__(NW * 64) void sscan_fwd2_kernel(FwdParams p) {
     // overwrite of a store's data register with s_waitcnt vmcnt - placed there, the stores have long completed.
     constexpr int PER_CK = (TC / CKS) * ((N * 16 + NT - 1) / NT);
     float4 y_keep[PER_T], ck_keep[PER_CK];
+    float omax = 0.f;                                // max |out| of this thread's stores
 #pragma unroll
     for (int i = 0; i < PER_T; ++i) y_keep[i] = zero4;
 #pragma unroll
@@ -397,6 +399,7 @@ __global__ __launch_bounds__(NW * 64) void sscan_fwd2_kernel(FwdParams p) {
                     y.x *= silu_nb(zv.x); y.y *= silu_nb(zv.y); y.z *= silu_nb(zv.z); y.w *= silu_nb(zv.w);
                 }
                 y_keep[i] = y;
+                omax = amax4(omax, y);
                 st4(p.out + (tok0 + t) * p.ld_out + d0 + tc4, y_keep[i]);
             }
         }
@@ -439,6 +442,7 @@ __global__ __launch_bounds__(NW * 64) void sscan_fwd2_kernel(FwdParams p) {
         for (int j = 0; j < NS; ++j)
             p.last_state[((int64_t)b * p.Di + d) * N + w * NS + j] = (j & 1) ? hp[j / 2].y : hp[j / 2].x;
     }
+    amax_publish_wave(omax, p.amax_out);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -527,6 +531,7 @@ __global__ __launch_bounds__(2 * NW * 64) void sscan_fwd3_kernel(FwdParams p) {
     const float* gs = p.start ? p.start + tok0 + r : nullptr;
     const float* gbc = bc_src + (tok0 + bc_row) * bc_ld + bc_col;
     float* go = p.out + (tok0 + r) * p.ld_out + d0 + tc4;
+    float omax = 0.f;                                // max |out| of this thread's stores
 
     float4 lu, ldl, lz, lbc;
     float lst;
@@ -579,6 +584,7 @@ __global__ __launch_bounds__(2 * NW * 64) void sscan_fwd3_kernel(FwdParams p) {
             const float4 g0 = ld4(sg), g1 = ld4(sg + 4);
             y.x = (y.x + g0.y) * g0.x; y.y = (y.y + g0.w) * g0.z;
             y.z = (y.z + g1.y) * g1.x; y.w = (y.w + g1.w) * g1.z;
+            omax = amax4(omax, y);
             st4(go, y);
         }
         go += TC * p.ld_out;
@@ -649,6 +655,7 @@ __global__ __launch_bounds__(2 * NW * 64) void sscan_fwd3_kernel(FwdParams p) {
         for (int j = 0; j < NS; ++j)
             p.last_state[((int64_t)b * p.Di + d) * N + w * NS + j] = (j & 1) ? hp[j / 2].y : hp[j / 2].x;
     }
+    amax_publish_wave(omax, p.amax_out);
 }
 
 // h_carry[b][s] (local end states on entry) -> states ENTERING segment s; one thread per (row, state, channel)
@@ -677,6 +684,7 @@ struct BwdParams {
     int B, L, Di, N, nck, softplus, nd, bc_vec;
     int seg_len, nseg;              // time-parallel form: steps per segment (multiple of 32), segments per row (1 = whole row)
     float *dh_carry, *sdl;          // [B][nseg][N][Di]: dL/dh flowing INTO the end of each segment; [B][nseg][Di] delta sums
+    AmaxOut amax_dz, amax_ddelta;   // optional: publish max |dz|, max |ddelta| (operands of the in_proj / dt_proj gradient GEMMs)
 };
 
 // Cross-lane sums for the dB / dC channel reductions.
@@ -828,6 +836,7 @@ __global__ __launch_bounds__(NW * 64) void sscan_bwd_kernel(BwdParams p) {
         (&s_cvec[0][0])[tid] = (src != nullptr && d0 + c < p.Di) ? src[d0 + c] : 0.f;
     }
 
+    float dzmax = 0.f, ddmax = 0.f;                  // max |dz|, max |ddelta| of this thread's stores
     f2 A2p[NP], dh[NP], dAacc[NP];
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
@@ -1092,13 +1101,16 @@ __global__ __launch_bounds__(NW * 64) void sscan_bwd_kernel(BwdParams p) {
                     g.y *= 1.f - fast_exp(-dl2.y);
                 }
                 *reinterpret_cast<f2*>(p.ddelta + tok * p.ld_ddelta + d0 + c2) = g;
+                ddmax = fmaxf(ddmax, fmaxf(__builtin_fabsf(g.x), __builtin_fabsf(g.y)));
                 f2* aD = reinterpret_cast<f2*>(&s_acc[0][hr][c2]);      // this thread's own slots
                 f2* ab = reinterpret_cast<f2*>(&s_acc[1][hr][c2]);
                 *aD += dy2 * u2;
                 *ab += g;
                 if (p.z) {                                  // dz = dout * silu'(z) * (pre-gate output y = sum_n C h + D u)
                     const f2 gc = *reinterpret_cast<const f2*>(&s_gz[row][c2]);
-                    *reinterpret_cast<f2*>(p.dz + tok * p.ld_dz + d0 + c2) = gc * (P3 + Dv * u2);
+                    const f2 dzv = gc * (P3 + Dv * u2);
+                    *reinterpret_cast<f2*>(p.dz + tok * p.ld_dz + d0 + c2) = dzv;
+                    dzmax = fmaxf(dzmax, fmaxf(__builtin_fabsf(dzv.x), __builtin_fabsf(dzv.y)));
                 }
             }
         };
@@ -1137,6 +1149,8 @@ __global__ __launch_bounds__(NW * 64) void sscan_bwd_kernel(BwdParams p) {
         for (int r = 0; r < SCH; ++r) acc += s_acc[which][r][c];
         if (d0 + c < p.Di) (which ? p.dbias_part : p.dD_part)[(int64_t)prow * p.Di + d0 + c] = acc;
     }
+    amax_publish_wave(dzmax, p.amax_dz);
+    amax_publish_wave(ddmax, p.amax_ddelta);
 }
 
 // ---- time-parallel backward, local pass: the adjoint recurrence alone (dL/dh_t = dy_t C_t + carried; carried = dL/dh_t * dA_t),
@@ -1356,15 +1370,18 @@ extern "C" int resel_selective_scan_fwd(const float* u, int64_t ld_u, const floa
                                         const float* Bm, int64_t ld_b, const float* Cm, int64_t ld_c,
                                         const float* D, const float* delta_bias, const float* start,
                                         float* out, int64_t ld_out, float* ckpt, float* last_state, void* workspace,
-                                        int B, int L, int Di, int N, int delta_softplus, int time_segments, resel_stream_t stream) {
+                                        int B, int L, int Di, int N, int delta_softplus, int time_segments,
+                                        void* amax_out, unsigned amax_epoch, resel_stream_t stream) {
     if (!u || !delta || !A || !Bm || !Cm || !out || B <= 0 || L <= 0 || Di <= 0) return RESEL_EINVAL;
+    if (amax_out && (reinterpret_cast<uintptr_t>(amax_out) & 7u)) return RESEL_EINVAL;
     if (Di % 4 != 0 || ld_u % 4 || ld_delta % 4 || ld_out % 4 || (z && ld_z % 4)) return RESEL_EINVAL;
     if (!aligned16(u) || !aligned16(delta) || !aligned16(out) || (z && !aligned16(z))) return RESEL_EINVAL;
     if ((D && !aligned16(D)) || (delta_bias && !aligned16(delta_bias))) return RESEL_EINVAL;
     FwdParams p{u, delta, z, A, Bm, Cm, D, delta_bias, start, out, ckpt, last_state,
                 ld_u, ld_delta, ld_z, ld_b, ld_c, ld_out, B, L, Di, N, n_ckpt(L), delta_softplus,
                 (Di + TILE_C - 1) / TILE_C,
-                (ld_b % 4 == 0 && ld_c % 4 == 0 && aligned16(Bm) && aligned16(Cm)) ? 1 : 0, 0, 1, nullptr, nullptr};
+                (ld_b % 4 == 0 && ld_c % 4 == 0 && aligned16(Bm) && aligned16(Cm)) ? 1 : 0, 0, 1, nullptr, nullptr,
+                AmaxOut{(unsigned long long*)amax_out, amax_epoch}};
 #ifdef SSCAN_STAMP
     p.stamps = g_stamps;
 #endif
@@ -1391,9 +1408,11 @@ extern "C" int resel_selective_scan_bwd(const float* u, int64_t ld_u, const floa
                                         float* du, int64_t ld_du, float* ddelta, int64_t ld_ddelta,
                                         float* dz, int64_t ld_dz, float* dBm, int64_t ld_db, float* dCm, int64_t ld_dc,
                                         float* dA, float* dD, float* ddelta_bias, void* workspace,
-                                        int B, int L, int Di, int N, int delta_softplus, int time_segments, resel_stream_t stream) {
+                                        int B, int L, int Di, int N, int delta_softplus, int time_segments,
+                                        void* amax_dz, void* amax_ddelta, unsigned amax_epoch, resel_stream_t stream) {
     if (!u || !delta || !A || !Bm || !Cm || !dout || !du || !ddelta || !dBm || !dCm || !dA || !workspace)
         return RESEL_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(amax_dz) & 7u) || (reinterpret_cast<uintptr_t>(amax_ddelta) & 7u)) return RESEL_EINVAL;
     if (B <= 0 || L <= 0 || Di <= 0 || Di % 4 != 0 || N % 4 != 0) return RESEL_EINVAL;
     if ((z != nullptr) != (dz != nullptr)) return RESEL_EINVAL;
     if (n_ckpt(L) > 0 && !ckpt) return RESEL_EINVAL;
@@ -1412,7 +1431,8 @@ extern "C" int resel_selective_scan_bwd(const float* u, int64_t ld_u, const floa
                 B, L, Di, N, n_ckpt(L), delta_softplus, (Di + TILE_C - 1) / TILE_C,
                 (ld_b % 4 == 0 && ld_c % 4 == 0 && aligned16(Bm) && aligned16(Cm)) ? 1 : 0,
                 ws.nseg > 1 ? ((L + ws.nseg - 1) / ws.nseg + 31) / 32 * 32 : L, ws.nseg,
-                ws.nseg > 1 ? (float*)(base + ws.carry) : nullptr, ws.nseg > 1 ? (float*)(base + ws.sdl) : nullptr};
+                ws.nseg > 1 ? (float*)(base + ws.carry) : nullptr, ws.nseg > 1 ? (float*)(base + ws.sdl) : nullptr,
+                AmaxOut{(unsigned long long*)amax_dz, amax_epoch}, AmaxOut{(unsigned long long*)amax_ddelta, amax_epoch}};
     hipStream_t s = (hipStream_t)stream;
     int rc;
     switch (N) {

@@ -11,12 +11,18 @@ What varies from update to update is moved OUT of the captured region into stati
 Actor noise comes from torch's CUDA generator, which torch.cuda.graph registers: every replay draws fresh numbers.
 
 A graph is valid for ONE batch shape (rows, row length, number of plan segments, longest segment) - synthetic benches, fixed-length
-episodes.  Up to `max_graphs` shapes are recorded (on their first occurrence); a batch of any further shape runs the same update
-eagerly from the same static inputs.  Refused at construction (use the eager `train_one_batch`): layers that need host-built
+episodes.  Every `step()` is exactly ONE update (same update-to-data ratio and random streams as the eager loop): the first `warmup`
+calls run eagerly (allocator and lazily initialised kernels warm up), a shape is recorded the SECOND time it occurs (a shape that
+never recurs is not worth two device synchronisations and an activation pool), at most `max_graphs` graphs live at a time in ONE
+shared memory pool (they never replay concurrently), the least recently used one is dropped for a newcomer; any update without a
+graph runs eagerly from the same static inputs.  Refused at construction (use the eager `train_one_batch`): layers that need host-built
 sequence tables or host dropout counters (cgpt), side-stream overlap (gru), gradient clipping, data-parallel groups."""
+from collections import OrderedDict
+
 import numpy as np
 import torch
 
+from ..hip import ops
 from .sac_full_length_rnn_ensembleQ import DeferredLog
 
 
@@ -35,14 +41,23 @@ class GraphedUpdate:
         if why:
             raise RuntimeError('GraphedUpdate: ' + why)
         self.alg, self.device = alg, alg.device
-        self.graphs = {}                              # batch shape key -> (CUDAGraph, log keys)
+        self.graphs = OrderedDict()                   # batch shape key -> CUDAGraph, least recently used first
         self.warmup, self.max_graphs = warmup, max_graphs
-        self.warm = False
+        self._eager_left = warmup                     # updates still to run eagerly before anything is recorded
+        self._seen = {}                               # batch shape key -> occurrences so far
+        self._pool = None                             # memory pool shared by every recorded graph
         self.eager_fallbacks = 0
         E = alg.target_values[0].uni_network.layer_list[-1].num_ensemble
         self.E = E
         self._draw = type(alg)._select_target_ensemble.__get__(alg)         # the trainer's own host draw
-        first = np.asarray(self._draw(E))                                    # consumes one draw: sizes the static subset buffers
+        # static subset buffers sized WITHOUT consuming a draw: evaluate the draw on a scratch numpy stream and put the stream back
+        st_np = np.random.get_state()
+        rng_own = getattr(alg, '_subset_rng', None)
+        st_own = None if rng_own is None else rng_own.get_state()
+        first = np.asarray(self._draw(E))
+        np.random.set_state(st_np)
+        if st_own is not None:
+            rng_own.set_state(st_own)
         self.subset_np = np.ascontiguousarray(first, dtype=np.int32)
         self.subset_i32 = torch.from_numpy(self.subset_np.copy()).to(self.device)
         self.subset_i64 = self.subset_i32.long()
@@ -123,6 +138,7 @@ class GraphedUpdate:
         for opt in (alg.optimizer_value, alg.optimizer_policy):
             opt.device_factors_active = True
         try:
+            ops.amax_arena_zero(self.device)          # first node: a replay publishes operand magnitudes into the slots / epochs baked into the graph
             alg.train_one_batch()
         finally:
             alg._graph = None
@@ -141,35 +157,30 @@ class GraphedUpdate:
         return self._last_log
 
     def step(self):
-        """One update.  The first call runs `warmup` eager updates on a side stream (as torch.cuda.graph asks: allocator and lazily
-        initialised kernels warm); a batch shape seen for the first time is recorded (up to `max_graphs` shapes) and replayed from then
-        on; any other shape runs eagerly from the same static inputs."""
+        """Exactly one update: eager while warming up or while the batch shape has no graph, a replay otherwise."""
         if self._last_log is not None:
             self._last_log.resolve()                  # its pinned buffer is about to be rewritten
         key = self._prepare()
-        if not self.warm:
-            if self.warmup:
-                s = torch.cuda.Stream(device=self.device)
-                s.wait_stream(torch.cuda.current_stream(self.device))
-                with torch.cuda.stream(s):
-                    for _ in range(self.warmup):
-                        self._body()                  # a real update each; the next one's inputs are prepared behind it ...
-                        self._evt.record()            # ... once this one has read the pinned plan / subset / AdamW factors
-                        key = self._prepare()
-                torch.cuda.current_stream(self.device).wait_stream(s)
-            self.warm = True
-        if key not in self.graphs:
-            if len(self.graphs) >= self.max_graphs:
+        g = self.graphs.get(key)
+        if g is None:
+            seen = self._seen[key] = self._seen.get(key, 0) + 1
+            if self._eager_left > 0 or seen < 2:      # warm-up updates / a shape on its first visit: the same update, launched eagerly
+                self._eager_left = max(0, self._eager_left - 1)
                 self.eager_fallbacks += 1
-                self._body()                          # same update, launched eagerly
+                self._body()
                 return self._finish()
+            if len(self.graphs) >= self.max_graphs:
+                self.graphs.popitem(last=False)       # least recently used; its activations return to the shared pool
             torch.cuda.synchronize(self.device)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, pool=self._pool):
                 self._body()                          # recorded, not run: the prepared inputs are consumed by the replay below
+            if self._pool is None:
+                self._pool = g.pool()
             torch.cuda.synchronize(self.device)
             self.graphs[key] = g
-        self.graphs[key].replay()
+        self.graphs.move_to_end(key)
+        g.replay()
         return self._finish()
 
     @property

@@ -9,10 +9,11 @@ from ctypes import c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('RESEL_HIP_LIBRARY') or os.path.join(_HERE, 'libresel_hip.so')      # override: ablation builds (tools/gemm_ablate.sh)
-ABI_VERSION = 4
+ABI_VERSION = 5
 _lib = None
 
 P, I, L, F, S, U = c_void_p, c_int, c_int64, c_float, c_void_p, c_uint64
+E = ctypes.c_uint                # epoch of a magnitude slot
 
 # name -> (restype, argtypes); order and types mirror include/resel_hip.h
 SIGNATURES = {
@@ -23,14 +24,14 @@ SIGNATURES = {
     'resel_selective_scan_ckpt_bytes': (c_size_t, [I, I, I, I]),
     'resel_selective_scan_fwd_edition': (I, [I]),
     'resel_selective_scan_fwd_workspace_bytes': (c_size_t, [I, I, I, I, I]),
-    'resel_selective_scan_fwd': (c_int, [P, L, P, L, P, L, P, P, L, P, L, P, P, P, P, L, P, P, P, I, I, I, I, I, I, S]),
+    'resel_selective_scan_fwd': (c_int, [P, L, P, L, P, L, P, P, L, P, L, P, P, P, P, L, P, P, P, I, I, I, I, I, I, P, E, S]),
     'resel_selective_scan_bwd_workspace_bytes': (c_size_t, [I, I, I, I, I]),
     'resel_selective_scan_bwd': (c_int, [P, L, P, L, P, L, P, P, L, P, L, P, P, P, P, L, P,
-                                         P, L, P, L, P, L, P, L, P, L, P, P, P, P, I, I, I, I, I, I, S]),
-    'resel_causal_conv1d_fwd': (c_int, [P, L, P, P, P, P, L, I, I, I, I, I, S]),
+                                         P, L, P, L, P, L, P, L, P, L, P, P, P, P, I, I, I, I, I, I, P, P, E, S]),
+    'resel_causal_conv1d_fwd': (c_int, [P, L, P, P, P, P, L, I, I, I, I, I, P, E, S]),
     'resel_causal_conv1d_bwd_workspace_bytes': (c_size_t, [I, I, I, I]),
-    'resel_causal_conv1d_bwd': (c_int, [P, L, P, P, P, P, L, P, L, P, P, P, I, I, I, I, I, S]),
-    'resel_add_layernorm_fwd': (c_int, [P, P, P, P, P, P, P, I, I, F, I, S]),
+    'resel_causal_conv1d_bwd': (c_int, [P, L, P, P, P, P, L, P, L, P, P, P, I, I, I, I, I, P, E, S]),
+    'resel_add_layernorm_fwd': (c_int, [P, P, P, P, P, P, P, I, I, F, I, P, E, S]),
     'resel_add_layernorm_bwd_workspace_bytes': (c_size_t, [I, I]),
     'resel_add_layernorm_bwd': (c_int, [P, P, P, P, P, P, P, P, P, I, I, I, I, S]),
     'resel_linrec_real_fwd': (c_int, [P, P, P, P, P, I, I, I, I, S]),
@@ -60,12 +61,15 @@ SIGNATURES = {
     'resel_sumsq': (c_int, [P, L, P, P, S]),
     'resel_bias_act_fwd': (c_int, [P, P, L, I, L, I, S]),
     'resel_bias_act_bwd_workspace_bytes': (c_size_t, [L, I, L]),
-    'resel_bias_act_bwd': (c_int, [P, P, P, P, P, L, I, L, I, S]),
+    'resel_bias_act_bwd': (c_int, [P, P, P, P, P, L, I, L, I, P, E, S]),
     'resel_ensemble_head_fwd': (c_int, [P, P, P, P, P, L, I, L, S]),
     'resel_ensemble_head_bwd_workspace_bytes': (c_size_t, [L, I, L]),
-    'resel_ensemble_head_bwd': (c_int, [P, P, P, P, P, P, P, L, I, L, S]),
+    'resel_ensemble_head_bwd': (c_int, [P, P, P, P, P, P, P, L, I, L, P, E, S]),
     'resel_gemm_f32_workspace_bytes': (c_size_t, [I, I, I, I]),
     'resel_gemm_f32': (c_int, [P, L, L, I, P, L, L, I, P, L, I, P, L, L, P, I, I, I, I, I, S]),
+    'resel_gemm_f32x': (c_int, [P, L, L, I, P, L, L, I, P, L, I, P, L, L, P, I, I, I, I, I, P, P, P, E, S]),
+    'resel_amax_state_bytes': (c_size_t, []),
+    'resel_amax': (c_int, [P, L, L, I, I, I, P, E, P, S]),
     'resel_gemm_bf16_workspace_bytes': (c_size_t, [I, I, I]),
     'resel_gemm_bf16': (c_int, [P, L, I, I, P, L, I, I, P, P, L, I, P, I, I, I, S]),
     'resel_gather_trajs': (c_int, [P, I, L, P, I, I, I, I, I, I, I, I, I, P, I, P, S]),

@@ -121,7 +121,7 @@ class SelectiveScanFn(torch.autograd.Function):
             _p(u), u.stride(1), _p(delta), delta.stride(1), _p(z), 0 if z is None else z.stride(1), _p(A),
             _p(Bm), Bm.stride(1), _p(Cm), Cm.stride(1), _p(D), _p(delta_bias), _p(start),
             _p(out), out.stride(1), _p(ck), _p(last), _p(_ws(nb, u.device) if nb else None), Bsz, L, Di, N, int(bool(delta_softplus)),
-            SSCAN_TIME_SEGMENTS, _stream()), 'selective_scan_fwd')
+            SSCAN_TIME_SEGMENTS, None, 0, _stream()), 'selective_scan_fwd')
         ctx.save_for_backward(u, delta, A, Bm, Cm, D, z, delta_bias, start, ck)
         ctx.softplus = bool(delta_softplus)
         if return_last_state:
@@ -151,7 +151,7 @@ class SelectiveScanFn(torch.autograd.Function):
             _p(dout), dout.stride(1), _p(ck),
             _p(du), du.stride(1), _p(ddelta), ddelta.stride(1), _p(dz), 0 if dz is None else dz.stride(1),
             _p(dB), dB.stride(1), _p(dC), dC.stride(1), _p(dA), _p(dD), _p(dbias), _p(ws),
-            Bsz, L, Di, N, int(ctx.softplus), SSCAN_TIME_SEGMENTS, _stream()), 'selective_scan_bwd')
+            Bsz, L, Di, N, int(ctx.softplus), SSCAN_TIME_SEGMENTS, None, None, 0, _stream()), 'selective_scan_bwd')
         return du, ddelta, dA, dB, dC, dD, dz, dbias, None, None, None
 
 
@@ -193,10 +193,14 @@ class MambaInnerFn(torch.autograd.Function):
         x2 = x.reshape(M, Dm)
         maskf, startf = _flags(mask, Bsz, L), _flags(start, Bsz, L)
         xz = mm_nt(x2, in_w)                                               # [M, 2Di] = (x | z)
+        ctx.ax = amax_of(x2)                                               # magnitude handle of the block input (for d in_proj.weight)
         cw = conv_w.reshape(Di, K).contiguous()
         xc = torch.empty(M, Di, dtype=torch.float32, device=x.device)
-        check(lib().resel_causal_conv1d_fwd(_p(xz), 2 * Di, _p(cw), _p(conv_b), _p(maskf), _p(xc), Di, Bsz, L, Di, K, 1, _stream()),
+        track = amax_tracking() and M * Di >= (1 << 20)                    # publish the magnitudes of the tensors the projections read
+        h_xc, p_xc, e_xc = _slot_args(track, x.device)
+        check(lib().resel_causal_conv1d_fwd(_p(xz), 2 * Di, _p(cw), _p(conv_b), _p(maskf), _p(xc), Di, Bsz, L, Di, K, 1, p_xc, e_xc, _stream()),
               'causal_conv1d_fwd')
+        tag_amax(xc, h_xc)
         x_dbl = mm_nt(xc, xproj_w)                                         # [M, R + 2N] = (delta_r | B | C)
         dt = mm_nt(x_dbl[:, :R], dt_w)                                      # [M, Di]; bias enters the scan as delta_bias
         A = -torch.exp(A_log.float())
@@ -206,10 +210,13 @@ class MambaInnerFn(torch.autograd.Function):
         zptr = ctypes.c_void_p(xz.data_ptr() + 4 * Di)
         bptr, cptr = ctypes.c_void_p(x_dbl.data_ptr() + 4 * R), ctypes.c_void_p(x_dbl.data_ptr() + 4 * (R + N))
         nb = lib().resel_selective_scan_fwd_workspace_bytes(Bsz, L, Di, N, SSCAN_TIME_SEGMENTS)
+        h_y, p_y, e_y = _slot_args(track, x.device)
         check(lib().resel_selective_scan_fwd(_p(xc), Di, _p(dt), Di, zptr, 2 * Di, _p(A), bptr, R + 2 * N, cptr, R + 2 * N,
                                              _p(D), _p(dt_b), _p(startf), _p(y), Di, _p(ck), None, _p(_ws(nb, x.device) if nb else None),
-                                             Bsz, L, Di, N, 1, SSCAN_TIME_SEGMENTS, _stream()), 'selective_scan_fwd')
+                                             Bsz, L, Di, N, 1, SSCAN_TIME_SEGMENTS, p_y, e_y, _stream()), 'selective_scan_fwd')
+        tag_amax(y, h_y)
         out = mm_nt(y, out_w)
+        ctx.handles = (ctx.ax, h_xc, h_y)                                  # saved tensors come back untagged
         ctx.save_for_backward(x2, in_w, cw, conv_b, xproj_w, dt_w, dt_b, A, D, out_w, maskf, startf, xz, xc, x_dbl, dt, y, ck)
         ctx.dims = (Bsz, L, Dm, Di, N, R, K, conv_w.shape)
         return out.view(Bsz, L, -1)
@@ -223,7 +230,8 @@ class MambaInnerFn(torch.autograd.Function):
         do2 = dout.reshape(M, -1)
         if not do2.is_contiguous():
             do2 = do2.contiguous()
-        d_out_w = wgrad(do2, y)
+        ax, h_xc, h_y = ctx.handles
+        d_out_w = wgrad(do2, y, amax_x=h_y)
         dy = mm_nn(do2, out_w)                                             # [M, Di]
         dxz = torch.empty(M, 2 * Di, dtype=torch.float32, device=dev)      # fully written: conv bwd -> [:, :Di], scan bwd -> [:, Di:]
         dx_dbl = torch.empty(M, R + 2 * N, dtype=torch.float32, device=dev)
@@ -234,16 +242,20 @@ class MambaInnerFn(torch.autograd.Function):
         ddt_b = torch.empty(Di, dtype=torch.float32, device=dev)
         ws = _ws(lib().resel_selective_scan_bwd_workspace_bytes(Bsz, L, Di, N, SSCAN_TIME_SEGMENTS), dev)
         P = lambda t, off: ctypes.c_void_p(t.data_ptr() + 4 * off)
+        track = amax_tracking() and M * Di >= (1 << 20)
+        h_dxz, p_dxz, e_b = _slot_args(track, dev)                         # ONE handle for dxz: the scan fills its z half, the conv its x half
+        h_ddt, p_ddt, _ = _slot_args(track, dev)                           # (published under the same epoch e_b)
         check(lib().resel_selective_scan_bwd(
             _p(xc), Di, _p(dt), Di, P(xz, Di), 2 * Di, _p(A), P(x_dbl, R), R + 2 * N, P(x_dbl, R + N), R + 2 * N,
             _p(D), _p(dt_b), _p(startf), _p(dy), Di, _p(ck),
             _p(dxc), Di, _p(ddt), Di, P(dxz, Di), 2 * Di, P(dx_dbl, R), R + 2 * N, P(dx_dbl, R + N), R + 2 * N,
-            _p(dA), _p(dD), _p(ddt_b), _p(ws), Bsz, L, Di, N, 1, SSCAN_TIME_SEGMENTS, _stream()), 'selective_scan_bwd')
+            _p(dA), _p(dD), _p(ddt_b), _p(ws), Bsz, L, Di, N, 1, SSCAN_TIME_SEGMENTS, p_dxz, p_ddt, e_b, _stream()), 'selective_scan_bwd')
+        tag_amax(ddt, h_ddt)
         # [Di, R] with a 66 752-long reduction: hand-written MFMA kernel (the library reaches 7 TFLOP/s on this shape)
         d_dt_w = atb(ddt, x_dbl[:, :R]) if R <= 32 and Di % 4 == 0 and ddt.stride(1) == 1 and ddt.stride(0) % 4 == 0 \
             else torch.mm(ddt.t(), x_dbl[:, :R])
         dx_dbl[:, :R] = mm_nn(ddt, dt_w)
-        d_xproj_w = wgrad(dx_dbl, xc)
+        d_xproj_w = wgrad(dx_dbl, xc, amax_x=h_xc)
         # conv output receives scan (du) + x_proj gradients: the accumulating form of the input gradient
         if _mine(dx_dbl.shape[0], xproj_w.shape[1], xproj_w.shape[0], dx_dbl, xproj_w, dxc):
             gemm_f32(dx_dbl, xproj_w, True, False, None, GEMM_ACCUMULATE, out=dxc)
@@ -253,8 +265,9 @@ class MambaInnerFn(torch.autograd.Function):
         dcb = torch.empty(Di, dtype=torch.float32, device=dev) if conv_b is not None else None
         ws2 = _ws(lib().resel_causal_conv1d_bwd_workspace_bytes(Bsz, L, Di, K), dev)
         check(lib().resel_causal_conv1d_bwd(_p(xz), 2 * Di, _p(cw), _p(conv_b), _p(maskf), _p(dxc), Di, _p(dxz), 2 * Di, _p(dcw), _p(dcb),
-                                            _p(ws2), Bsz, L, Di, K, 1, _stream()), 'causal_conv1d_bwd')
-        d_in_w = wgrad(dxz, x2)
+                                            _p(ws2), Bsz, L, Di, K, 1, p_dxz, e_b, _stream()), 'causal_conv1d_bwd')
+        tag_amax(dxz, h_dxz)
+        d_in_w = wgrad(dxz, x2, amax_x=ax)
         dx = mm_nn(dxz, in_w).view(Bsz, L, Dm) if ctx.needs_input_grad[0] else None
         return (dx, d_in_w, dcw.reshape(cw_shape), dcb, d_xproj_w, d_dt_w, ddt_b, dA * A, dD, d_out_w, None, None)
 
@@ -277,7 +290,7 @@ class CausalConv1dFn(torch.autograd.Function):
         mask = _flags(mask, Bsz, L)
         y = torch.empty(Bsz, L, Di, dtype=torch.float32, device=x.device)
         check(lib().resel_causal_conv1d_fwd(_p(x), x.stride(1), _p(w), _p(bias), _p(mask), _p(y), y.stride(1),
-                                            Bsz, L, Di, K, int(bool(activation)), _stream()), 'causal_conv1d_fwd')
+                                            Bsz, L, Di, K, int(bool(activation)), None, 0, _stream()), 'causal_conv1d_fwd')
         ctx.save_for_backward(x, w, bias, mask)
         ctx.act = bool(activation)
         ctx.wshape = weight.shape
@@ -295,7 +308,7 @@ class CausalConv1dFn(torch.autograd.Function):
         ws = _ws(lib().resel_causal_conv1d_bwd_workspace_bytes(Bsz, L, Di, K), x.device)
         check(lib().resel_causal_conv1d_bwd(_p(x), x.stride(1), _p(w), _p(bias), _p(mask), _p(dy), dy.stride(1),
                                             _p(dx), dx.stride(1), _p(dw), _p(db), _p(ws), Bsz, L, Di, K, int(ctx.act),
-                                            _stream()), 'causal_conv1d_bwd')
+                                            None, 0, _stream()), 'causal_conv1d_bwd')
         return dx, dw.reshape(ctx.wshape), db, None, None
 
 
@@ -320,8 +333,11 @@ class AddNormFn(torch.autograd.Function):
         need_res = residual is not None or prenorm
         res_out = torch.empty_like(x2) if need_res else None
         stats = torch.empty(M, 2, dtype=torch.float32, device=x.device)
+        global LAST_AMAX
+        slot, slot_p, epoch = _slot_args(amax_tracking() and M * C >= (1 << 20), x.device)
         check(lib().resel_add_layernorm_fwd(_p(x2), _p(r2), _p(w), _p(b), _p(y), _p(res_out), _p(stats), M, C, float(eps),
-                                            int(bool(rms)), _stream()), 'add_layernorm_fwd')
+                                            int(bool(rms)), slot_p, epoch, _stream()), 'add_layernorm_fwd')
+        LAST_AMAX = slot
         ctx.save_for_backward(res_out if res_out is not None else x2, w, stats)
         ctx.rms, ctx.has_bias, ctx.has_res, ctx.prenorm, ctx.shape = bool(rms), b is not None, residual is not None, prenorm, shape
         if prenorm:
@@ -344,13 +360,21 @@ class AddNormFn(torch.autograd.Function):
         return dx, (dx if ctx.has_res else None), dw, db, None, None, None
 
 
+def _add_norm(x, residual, weight, bias, eps, rms, prenorm):
+    global LAST_AMAX
+    LAST_AMAX = None
+    out = AddNormFn.apply(x, residual, weight, bias, eps, rms, prenorm)
+    tag_amax(out[0] if prenorm else out, LAST_AMAX, whole=True)    # the normalised output feeds a projection: its magnitude came out of the same pass
+    return out
+
+
 def layer_norm_fn(x, weight, bias, residual=None, eps=1e-6, prenorm=False, residual_in_fp32=False):
     """Signature of the reference's fused add+LayerNorm (mamba_ssm/ops/triton/layernorm.py `layer_norm_fn`)."""
-    return AddNormFn.apply(x, residual, weight, bias, eps, False, prenorm)
+    return _add_norm(x, residual, weight, bias, eps, False, prenorm)
 
 
 def rms_norm_fn(x, weight, bias, residual=None, eps=1e-6, prenorm=False, residual_in_fp32=False):
-    return AddNormFn.apply(x, residual, weight, bias, eps, True, prenorm)
+    return _add_norm(x, residual, weight, bias, eps, True, prenorm)
 
 
 # ---------------------------------------------------------------------------------------------- linear recurrences
@@ -652,6 +676,7 @@ def bias_act_(y2, bias2, rows_per_seg, act):
     _need_cuda('bias_act', y2, bias2)
     assert y2.is_contiguous() and y2.dtype == torch.float32 and (bias2 is None or bias2.is_contiguous())
     check(lib().resel_bias_act_fwd(_p(y2), _p(bias2), y2.shape[0], y2.shape[1], int(rows_per_seg), ACT_IDS[act], _stream()), 'bias_act_fwd')
+    tag_amax(y2, None)                                # rewritten in place
     return y2
 
 
@@ -668,8 +693,12 @@ def bias_act_bwd(g2, a2, rows_per_seg, act, need_dbias):
     nseg = rows // int(rows_per_seg)
     db = torch.empty(nseg, C, dtype=torch.float32, device=g2.device) if need_dbias else None
     ws = _ws(lib().resel_bias_act_bwd_workspace_bytes(rows, C, int(rows_per_seg)), g2.device) if need_dbias else None
-    check(lib().resel_bias_act_bwd(_p(g2), _p(a2) if aid else None, _p(gy), _p(db), _p(ws), rows, C, int(rows_per_seg), aid, _stream()),
-          'bias_act_bwd')
+    global LAST_AMAX
+    slot, slot_p, epoch = _slot_args(amax_tracking() and rows * C >= (1 << 20), g2.device)
+    check(lib().resel_bias_act_bwd(_p(g2), _p(a2) if aid else None, _p(gy), _p(db), _p(ws), rows, C, int(rows_per_seg), aid, slot_p, epoch,
+                                   _stream()), 'bias_act_bwd')
+    tag_amax(gy, slot)
+    LAST_AMAX = slot
     return gy, db
 
 
@@ -680,6 +709,7 @@ def ensemble_head_fwd_(y3, b2, w3, b3):
     E, M, H = y3.shape
     q = torch.empty(E, M, dtype=torch.float32, device=y3.device)
     check(lib().resel_ensemble_head_fwd(_p(y3), _p(b2), _p(w3), _p(b3), _p(q), E * M, H, M, _stream()), 'ensemble_head_fwd')
+    tag_amax(y3, None)                                # rewritten in place: the GEMM's magnitude no longer describes it
     return q
 
 
@@ -693,7 +723,12 @@ def ensemble_head_bwd(gq, a3, w3):
     db2 = torch.empty(E, H, dtype=torch.float32, device=a3.device)
     dw3 = torch.empty(E, H, dtype=torch.float32, device=a3.device)
     ws = _ws(lib().resel_ensemble_head_bwd_workspace_bytes(E * M, H, M), a3.device)
-    check(lib().resel_ensemble_head_bwd(_p(gq), _p(a3), _p(w3), _p(gy), _p(db2), _p(dw3), _p(ws), E * M, H, M, _stream()), 'ensemble_head_bwd')
+    global LAST_AMAX
+    slot, slot_p, epoch = _slot_args(amax_tracking() and E * M * H >= (1 << 20), a3.device)
+    check(lib().resel_ensemble_head_bwd(_p(gq), _p(a3), _p(w3), _p(gy), _p(db2), _p(dw3), _p(ws), E * M, H, M, slot_p, epoch, _stream()),
+          'ensemble_head_bwd')
+    tag_amax(gy, slot)
+    LAST_AMAX = slot
     return gy, db2, dw3
 
 
@@ -717,6 +752,7 @@ class LinearAct(torch.autograd.Function):
             weight = torch.nn.functional.pad(weight, (0, ctx.kpad, 0, ctx.npad))
             bias = torch.nn.functional.pad(bias, (0, ctx.npad)) if (bias is not None and ctx.npad) else bias
         y2 = mm_nt(x2, weight, bias, act)
+        ctx.ax = amax_of(x2)                          # the input's magnitude handle, for the weight gradient (saved tensors come back untagged)
         ctx.save_for_backward(x2, weight, y2)
         ctx.act, ctx.has_bias, ctx.xshape = act, bias is not None, x.shape
         out = y2[:, :n_out] if ctx.npad else y2
@@ -738,7 +774,7 @@ class LinearAct(torch.autograd.Function):
         else:
             gy, db = bias_act_bwd(g2, y2, y2.shape[0], ctx.act, need_db)
         dx = mm_nn(gy, weight) if ctx.needs_input_grad[0] else None
-        dw = wgrad(gy, x2) if ctx.needs_input_grad[1] else None
+        dw = wgrad(gy, x2, amax_x=ctx.ax) if ctx.needs_input_grad[1] else None
         if ctx.kpad or ctx.npad:                      # drop the padding rows / columns again
             k = x2.shape[1] - ctx.kpad
             dx = None if dx is None else dx[:, :k]
@@ -749,7 +785,9 @@ class LinearAct(torch.autograd.Function):
 
 
 def linear_act(x, weight, bias, act):
-    return LinearAct.apply(x, weight, bias, act)
+    global LAST_AMAX
+    LAST_AMAX = None
+    return tag_amax(LinearAct.apply(x, weight, bias, act), LAST_AMAX, whole=True)
 
 
 def linear(x, weight, bias=None):
@@ -759,7 +797,7 @@ def linear(x, weight, bias=None):
     inside the node."""
     if x.is_cuda and x.dtype == torch.float32 and x.numel() // x.shape[-1] >= GEMM_F32_MIN_ROWS and weight.shape[0] >= GEMM_F32_MIN_DIM \
             and weight.shape[1] >= GEMM_F32_MIN_K:
-        return LinearAct.apply(x, weight, bias, None)
+        return linear_act(x, weight, bias, None)
     return torch.nn.functional.linear(x, weight, bias)
 
 
@@ -790,6 +828,8 @@ def mm_nt(x2, w, bias=None, act=None):
     the bias / ELU in its epilogue when the pass is long enough (`gemm_f32_ok`), else library GEMM (+ one in-place tail pass)."""
     if act in ACT_IDS and _mine(x2.shape[0], w.shape[0], w.shape[1], x2, w):
         return gemm_f32(x2, w, True, True, bias, act)
+    global LAST_AMAX
+    LAST_AMAX = None
     aid = ACT_IDS[act]                                                 # 0: identity ('linear' / None), 1: ELU; anything else is a KeyError
     if aid == 0 or w.shape[0] % 4:
         y2 = torch.addmm(bias, x2, w.t()) if bias is not None else torch.mm(x2, w.t())
@@ -805,11 +845,11 @@ def mm_nn(g2, w):
     return torch.mm(g2, w)
 
 
-def wgrad(gy, x2):
+def wgrad(gy, x2, amax_x=None):
     """dW [out, in] = gy[M, out]^T x2[M, in] over the M tokens of a pass: the hand-written K-split GEMM (at 66 752 tokens:
     [128, 256] 49 us against the library's 234, [2048, 384] 731 against 1217, [256, 256] 86 against 123; `tools/bench_gemm_f32.py`)."""
     if _mine(gy.shape[0], gy.shape[1], x2.shape[1], gy, x2):
-        return gemm_f32(gy, x2, False, False)
+        return gemm_f32(gy, x2, False, False, amax_b=amax_x)
     return torch.mm(gy.t(), x2)
 
 
@@ -898,24 +938,119 @@ def linear_bf16(x, weight, bias, out_dtype=torch.bfloat16, round_out=False):
     return LinearBf16.apply(x, weight, bias, out_dtype, round_out)
 
 
-# product formation of resel_gemm_f32 (include/resel_hip.h): 0 fp32 MFMA, 9 / 6 exact three-way bf16 split on the bf16 MFMA (fp32-accurate),
-# 3 two planes per operand ("bf16x3").  None (no RESEL_GEMM_SPLIT): follow torch.get_float32_matmul_precision() the way torch's own
-# GEMMs do - 'highest' (torch's default, the reference's setting) = 6, 'high' / 'medium' = 3.
+# product formation of resel_gemm_f32 (include/resel_hip.h): 0 fp32 MFMA; 9 / 6 exact three-way bf16 split on the bf16 MFMA; 2 fp16 planes
+# of the scaled operands, three products (all of these fp32-accurate against fp64, tests/test_hip_ops.py); 3 two bf16 planes per operand
+# ("bf16x3").  None (no RESEL_GEMM_SPLIT): follow torch.get_float32_matmul_precision() the way torch's own GEMMs do - 'highest' (torch's
+# default, the reference's setting) = 2 where the operand magnitudes are at hand and 6 elsewhere, 'high' / 'medium' = 3.
 GEMM_SPLIT = int(os.environ['RESEL_GEMM_SPLIT']) if os.environ.get('RESEL_GEMM_SPLIT') else None
 
 
 def gemm_split():
     if GEMM_SPLIT is not None:
         return GEMM_SPLIT
-    return 6 if torch.get_float32_matmul_precision() == 'highest' else 3
+    return 2 if torch.get_float32_matmul_precision() == 'highest' else 3
 
 
 
 _GEMM_WS_BYTES = {}           # (M, N, K, batch) -> workspace bytes of resel_gemm_f32 (a pure function of the shape)
 
 
+# ---- operand magnitudes for GEMM mode 2 (include/resel_hip.h "magnitude slots") ---------------------------------------------
+# A tensor written by one of this library's kernels carries a HANDLE to max |x| on the device - `t._resel_amax = (handle, version)` -
+# so that a later `gemm_f32` on it (or on a view of it: `_base`) needs no extra pass; handles are 8-byte slots of a per-device
+# arena ({float bits | epoch}; never zeroed: every producer call takes a fresh epoch) or the float32 [1] result of `amax()`.
+# Tags die with an in-place modification that torch sees (`_version`); this module's own in-place kernels re-tag or clear.
+AMAX_SLOTS = 2048             # handles per device arena (1 KiB each: eight 8-byte words, 128 bytes apart)
+AMAX_WORDS = 128              # int64 words per handle
+AMAX_PREPASS_FRACTION = float(os.environ.get('RESEL_AMAX_PREPASS_FRACTION', 0.16))   # of the estimated GEMM time one may spend on reading an untagged operand
+_AMAX_ARENA = {}              # device -> [int64 tensor [AMAX_SLOTS], next index]
+_AMAX_EPOCH = [0]
+_AMAX_STATE = {}              # device -> zero-initialised ticket / partial buffer of resel_amax (calls are ordered on the launch stream)
+LAST_AMAX = None              # handle of the magnitude published by the most recent producer call (wrappers tag Function outputs with it)
+
+
+def amax_slot(device):
+    """A fresh (handle: int64 view [AMAX_WORDS], epoch) pair for a producer kernel."""
+    ar = _AMAX_ARENA.get(device)
+    if ar is None:
+        ar = _AMAX_ARENA[device] = [torch.zeros(AMAX_SLOTS * AMAX_WORDS, dtype=torch.int64, device=device), 0]
+    if _AMAX_EPOCH[0] >= 0x7fffffff:                 # epochs exhausted (days of training): start over on zeroed arenas
+        _AMAX_EPOCH[0] = 0
+        for a in _AMAX_ARENA.values():
+            a[0].zero_()
+    _AMAX_EPOCH[0] += 1
+    i = ar[1]
+    ar[1] = (i + 1) % AMAX_SLOTS
+    return ar[0][i * AMAX_WORDS:(i + 1) * AMAX_WORDS], _AMAX_EPOCH[0]
+
+
+def amax_arena_zero(device):
+    """Zero the arena of `device` on the launch stream: FIRST node of a captured update - a replay publishes into the slots and
+    epochs baked into the graph, which must not inherit the previous replay's maxima."""
+    ar = _AMAX_ARENA.get(device)
+    if ar is not None:
+        ar[0].zero_()
+
+
+def tag_amax(t, handle, whole=False):
+    """whole: t covers ALL of the tensor it is a view of (a reshape of a fresh output) - tag that base too, so that other views of it
+    (the [M, C] form of a [B, L, C] activation) find the magnitude."""
+    if t is not None:
+        t._resel_amax = None if handle is None else (handle, t._version)
+        if whole and getattr(t, '_base', None) is not None:
+            t._base._resel_amax = None if handle is None else (handle, t._base._version)
+    return t
+
+
+def amax_of(t):
+    """Handle of a bound on max |t| if one is known (t itself or the tensor t is a view of), else None."""
+    for obj in (t, getattr(t, '_base', None)):
+        if obj is not None:
+            tg = getattr(obj, '_resel_amax', None)
+            if tg is not None and tg[1] == obj._version:
+                return tg[0]
+    return None
+
+
 @torch.no_grad()
-def gemm_f32(A, B, a_kcontig=True, b_kcontig=True, bias=None, act=None, out=None, split=None):
+def amax(x):
+    """max |x| of a GEMM operand (2-D, or 3-D with a leading batch axis; last axis contiguous and a multiple of 4) as a magnitude
+    handle on the device: one HBM-bound pass, no host synchronisation (include/resel_hip.h `resel_amax`)."""
+    _need_cuda('amax', x)
+    assert x.dtype == torch.float32 and x.stride(-1) == 1 and x.dim() in (2, 3)
+    st = _AMAX_STATE.get(x.device)
+    if st is None:
+        st = _AMAX_STATE[x.device] = torch.zeros(lib().resel_amax_state_bytes() // 4, dtype=torch.float32, device=x.device)
+    out, epoch = amax_slot(x.device)
+    batch = x.shape[0] if x.dim() == 3 else 1
+    check(lib().resel_amax(_p(x), x.stride(-2), x.stride(0) if x.dim() == 3 and batch > 1 else 0, x.shape[-2], x.shape[-1], batch,
+                           _p(out), epoch, _p(st), _stream()), 'amax')
+    return out
+
+
+def amax_value(handle):
+    """Host value of a magnitude handle (tests / tools: synchronises)."""
+    w = handle.view(torch.int64).cpu()[::16][:8]
+    ep = (w >> 32) & 0xffffffff
+    lo = (w[ep == ep.max()] & 0xffffffff).to(torch.int32)
+    return float(lo.view(torch.float32).max())
+
+
+def _slot_args(want, device):
+    """(slot tensor or None, pointer, epoch) for a producer kernel's amax output."""
+    if not want:
+        return None, None, 0
+    slot, epoch = amax_slot(device)
+    return slot, _p(slot), epoch
+
+
+def amax_tracking():
+    """Producers publish magnitudes only while the GEMMs would use them (product mode 2)."""
+    return gemm_split() == 2
+
+
+@torch.no_grad()
+def gemm_f32(A, B, a_kcontig=True, b_kcontig=True, bias=None, act=None, out=None, split=None, amax_a=None, amax_b=None):
     """C[b] = act(A[b] (.) B[b] + bias[b]) on the matrix cores, fp32 in / out (include/resel_hip.h `resel_gemm_f32`).
     A: [M, K] (a_kcontig) or [K, M]; B: [N, K] (b_kcontig) or [K, N]; optionally a leading batch (ensemble) dimension on all of
     A, B, bias [N] / [batch, N], out.  Row stride free (column stride 1); returns C [M, N] / [batch, M, N].
@@ -943,9 +1078,37 @@ def gemm_f32(A, B, a_kcontig=True, b_kcontig=True, bias=None, act=None, out=None
         bias = bias.reshape(batch, N) if batched else bias.reshape(N)
         bs = bias.stride(0) if batched else 0
     multi = batch > 1
-    check(L.resel_gemm_f32(_p(A), A.stride(-2), A.stride(0) if multi else 0, int(a_kcontig), _p(B), B.stride(-2),
-                           B.stride(0) if multi else 0, int(b_kcontig), _p(bias), bs, 2 if act == GEMM_ACCUMULATE else ACT_IDS[act], _p(out), out.stride(-2),
-                           out.stride(0) if multi else 0, _p(ws), M, N, K, batch, gemm_split() if split is None else int(split), _stream()), 'gemm_f32')
+    split = gemm_split() if split is None else int(split)
+    global LAST_AMAX
+    ha = hb = None
+    if split == 2:
+        # mode 2 (fp16 planes of the scaled operands) needs a bound on max |A|, max |B| on the device: a producer's tag, the
+        # caller's handle, or - when reading the operand once more is cheap next to the GEMM - one resel_amax pass (tagged for reuse)
+        if K < 32 or M <= 128:
+            split = 6
+        else:
+            ha = amax_a if amax_a is not None else amax_of(A)
+            hb = amax_b if amax_b is not None else amax_of(B)
+            if ha is None or hb is None:
+                t_gemm = 2.0 * M * N * K * batch / 1.5e8                       # us at 150 TFLOP/s
+                cost = (0.0 if ha is not None else 4.0 * M * K * batch / 4.5e6 + 2.5) + (0.0 if hb is not None else 4.0 * N * K * batch / 4.5e6 + 2.5)
+                if cost <= AMAX_PREPASS_FRACTION * t_gemm:
+                    if ha is None:
+                        ha = amax(A)
+                        tag_amax(A, ha)
+                    if hb is None:
+                        hb = amax(B)
+                        tag_amax(B, hb)
+                else:
+                    split = 6
+    # max |C| for whoever multiplies C next (only while mode 2 is the product mode, and only for outputs worth a pass)
+    slot, slot_p, epoch = _slot_args(amax_tracking() and act != GEMM_ACCUMULATE and M * N * batch >= (1 << 20), A.device)
+    check(L.resel_gemm_f32x(_p(A), A.stride(-2), A.stride(0) if multi else 0, int(a_kcontig), _p(B), B.stride(-2),
+                            B.stride(0) if multi else 0, int(b_kcontig), _p(bias), bs, 2 if act == GEMM_ACCUMULATE else ACT_IDS[act], _p(out), out.stride(-2),
+                            out.stride(0) if multi else 0, _p(ws), M, N, K, batch, split, _p(ha) if split == 2 else None,
+                            _p(hb) if split == 2 else None, slot_p, epoch, _stream()), 'gemm_f32')
+    tag_amax(out, slot)
+    LAST_AMAX = slot
     return out
 
 

@@ -21,18 +21,22 @@ class _SharedInput(torch.autograd.Function):
     action encoding alone (128 of 384 input columns at config 2: a third of the dX GEMM)."""
 
     @staticmethod
-    def forward(ctx, x2, weight, bias, act, x_part=None, col0=0):
+    def forward(ctx, x2, weight, bias, act, x_part=None, col0=0, ax=None):
+        """ax: magnitude handle of x2 (ops.amax_of) when the caller has one - saved tensors and reshaped views lose their tags."""
         E, n_in, n_out = weight.shape
         w_cat = weight.permute(1, 0, 2).reshape(n_in, E * n_out)                 # [in, E*out] (weights only: tiny copy)
+        ops.LAST_AMAX = None
         if min(n_in, E * n_out) >= ops.GEMM_F32_MIN_DIM and ops.gemm_f32_ok(x2.shape[0], x2, w_cat):
             # hand-written fp32 MFMA GEMM, bias + ELU in its epilogue (837 us against 995 at 66 752 x 384 -> 2048)
-            y2 = ops.gemm_f32(x2, w_cat, True, False, None if bias is None else bias.reshape(E * n_out), act)
+            y2 = ops.gemm_f32(x2, w_cat, True, False, None if bias is None else bias.reshape(E * n_out), act, amax_a=ax)
+            ax = ax if ax is not None else ops.amax_of(x2)
         elif act is None:
             y2 = torch.addmm(bias.reshape(E * n_out), x2, w_cat) if bias is not None else torch.mm(x2, w_cat)
         else:                               # GEMM, then bias + activation in one in-place pass
             y2 = torch.mm(x2, w_cat)
             ops.bias_act_(y2, None if bias is None else bias.reshape(1, E * n_out), y2.shape[0], act)
         ctx.save_for_backward(x2, w_cat, y2 if act is not None else None)
+        ctx.ax = ax
         ctx.dims = (E, n_in, n_out, bias is not None, act)
         ctx.part = None if x_part is None else (col0, x_part.shape[-1], tuple(x_part.shape))
         return y2.view(-1, E, n_out).transpose(0, 1)                              # [E, M, out] view
@@ -53,21 +57,21 @@ class _SharedInput(torch.autograd.Function):
             dx = ops.gemm_f32(g2, w_cat, True, True) if mine else torch.mm(g2, w_cat.t())
         dw = None
         if ctx.needs_input_grad[1]:
-            dw = ops.gemm_f32(x2, g2, False, False) if mine else torch.mm(x2.t(), g2)
+            dw = ops.gemm_f32(x2, g2, False, False, amax_a=ctx.ax) if mine else torch.mm(x2.t(), g2)
             dw = dw.view(n_in, E, n_out).permute(1, 0, 2)
         dpart = None
         if ctx.part is not None and ctx.needs_input_grad[4]:
             col0, k, shape = ctx.part
             wp = w_cat[col0:col0 + k]
             dpart = (ops.gemm_f32(g2, wp, True, True) if mine and k >= ops.GEMM_F32_MIN_DIM else torch.mm(g2, wp.t())).view(shape)
-        return dx, dw, None if db is None else db.view(E, 1, n_out), None, dpart, None
+        return dx, dw, None if db is None else db.view(E, 1, n_out), None, dpart, None, None
 
 
-def _member_wgrad(x3, gy):
+def _member_wgrad(x3, gy, ax=None):
     """dW[e] = x3[e]^T gy[e] for the per-member layers: the hand-written K-split fp32 MFMA kernel (676 us against the tuned
     strided-batched library GEMM's 833 us at 8 x 66 752 x 256 x 256, `tools/bench_gemm_f32.py`) when the layout allows."""
     if min(x3.shape[2], gy.shape[2]) >= ops.GEMM_F32_MIN_DIM and ops.gemm_f32_ok(x3.shape[1], x3, gy):
-        return ops.gemm_f32(x3, gy, False, False)
+        return ops.gemm_f32(x3, gy, False, False, amax_a=ax)
     return torch.bmm(x3.transpose(1, 2), gy)
 
 
@@ -88,17 +92,20 @@ def _member_dgrad(gy, weight, like):
 
 class _PerMember(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x3, weight, bias, act):
+    def forward(ctx, x3, weight, bias, act, ax=None):
         E, M, _ = x3.shape
+        ops.LAST_AMAX = None
         if min(weight.shape[1:]) >= ops.GEMM_F32_MIN_DIM and act in (None, 'elu') and ops.gemm_f32_ok(M, x3, weight):
             # bias + ELU in the GEMM epilogue: 583 us against the library's 605 + a 140 us tail pass (8 x 66 752 x 256 x 256)
-            y = ops.gemm_f32(x3, weight, True, False, bias, act)
+            y = ops.gemm_f32(x3, weight, True, False, bias, act, amax_a=ax)
+            ax = ax if ax is not None else ops.amax_of(x3)
         elif act is None and (bias is None or weight.shape[2] < 4):
             y = torch.baddbmm(bias, x3, weight) if bias is not None else torch.bmm(x3, weight)
         else:                               # baddbmm would first materialise the broadcast bias as a full [E, M, out] copy
             y = torch.bmm(x3, weight)
             ops.bias_act_(y.view(E * M, -1), None if bias is None else bias.reshape(E, -1), M, act)
         ctx.save_for_backward(x3, weight, y if act is not None else None)
+        ctx.ax = ax
         ctx.cfg = (bias is not None, act)
         return y
 
@@ -115,8 +122,8 @@ class _PerMember(torch.autograd.Function):
         else:
             gy, db = g, (g.sum(dim=1, keepdim=True) if need_db else None)
         dx = _member_dgrad(gy, weight, x3) if ctx.needs_input_grad[0] else None
-        dw = _member_wgrad(x3, gy) if ctx.needs_input_grad[1] else None
-        return dx, dw, db, None
+        dw = _member_wgrad(x3, gy, ctx.ax) if ctx.needs_input_grad[1] else None
+        return dx, dw, db, None, None
 
 
 class _Head(torch.autograd.Function):
@@ -126,11 +133,15 @@ class _Head(torch.autograd.Function):
     k = M GEMV through the GEMM library - rocBLAS' best solution for that shape runs at 1.1 TB/s)."""
 
     @staticmethod
-    def forward(ctx, x3, w2, b2, w3, b3):
+    def forward(ctx, x3, w2, b2, w3, b3, ax=None):
         E, M, _ = x3.shape
         H = w2.shape[2]
-        a = ops.gemm_f32(x3, w2, True, False) if min(w2.shape[1:]) >= ops.GEMM_F32_MIN_DIM and ops.gemm_f32_ok(M, x3, w2) \
-            else torch.bmm(x3, w2)
+        if min(w2.shape[1:]) >= ops.GEMM_F32_MIN_DIM and ops.gemm_f32_ok(M, x3, w2):
+            a = ops.gemm_f32(x3, w2, True, False, amax_a=ax)
+            ax = ax if ax is not None else ops.amax_of(x3)
+        else:
+            a = torch.bmm(x3, w2)
+        ctx.ax = ax
         w3v = w3.reshape(E, H)
         q = ops.ensemble_head_fwd_(a, b2.reshape(E, H), w3v, None if b3 is None else b3.reshape(E))
         ctx.save_for_backward(x3, w2, w3v, a)
@@ -144,9 +155,9 @@ class _Head(torch.autograd.Function):
         gq2 = gq.reshape(E, M)
         gy, db2, dw3 = ops.ensemble_head_bwd(gq2, a, w3v)
         dx = _member_dgrad(gy, w2, x3) if ctx.needs_input_grad[0] else None
-        dw2 = _member_wgrad(x3, gy)
+        dw2 = _member_wgrad(x3, gy, ctx.ax)
         db3 = gq2.sum(dim=1).view(E, 1, 1) if ctx.has_b3 else None
-        return dx, dw2, db2.view(E, 1, H), dw3.view(E, H, 1), db3
+        return dx, dw2, db2.view(E, 1, H), dw3.view(E, H, 1), db3, None
 
 
 def ensemble_head(hidden: 'EnsembleLinear', out: 'EnsembleLinear', x: torch.Tensor) -> torch.Tensor:
@@ -156,7 +167,7 @@ def ensemble_head(hidden: 'EnsembleLinear', out: 'EnsembleLinear', x: torch.Tens
     w3, b3 = out.active_params()
     E, n_in, H = w2.shape
     lead = tuple(x.shape[1:-1])
-    q = _Head.apply(x.reshape(E, -1, n_in), w2, b2, w3, b3)
+    q = _Head.apply(x.reshape(E, -1, n_in), w2, b2, w3, b3, ops.amax_of(x))
     return q.reshape((E,) + lead + (1,))
 
 
@@ -204,14 +215,15 @@ class EnsembleLinear(nn.Module):
             shared = not ((self.desire_ndim is None or self.desire_ndim == 4) and x.shape[0] == E)
         elif nd == 5:
             shared = False
+        ax = ops.amax_of(x)                  # magnitude handle of the input, if its producer left one (reshapes below drop the tag)
         if shared:
             lead = tuple(x.shape[:-1])
             if grad_part is not None:
-                y = _SharedInput.apply(x.detach().reshape(-1, n_in), W, b, act, grad_part[0], grad_part[1])
+                y = _SharedInput.apply(x.detach().reshape(-1, n_in), W, b, act, grad_part[0], grad_part[1], ax)
             else:
-                y = _SharedInput.apply(x.reshape(-1, n_in), W, b, act)
+                y = _SharedInput.apply(x.reshape(-1, n_in), W, b, act, None, 0, ax)
         else:
             assert grad_part is None, 'grad_part is a shared-input feature'
             lead = tuple(x.shape[1:-1])
-            y = _PerMember.apply(x.reshape(E, -1, n_in), W, b, act)
-        return y.reshape((E,) + lead + (n_out,))                                   # a view: only the row axis is split
+            y = _PerMember.apply(x.reshape(E, -1, n_in), W, b, act, ax)
+        return ops.tag_amax(y.reshape((E,) + lead + (n_out,)), ops.LAST_AMAX, whole=True)      # a view: only the row axis is split

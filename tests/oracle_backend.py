@@ -90,7 +90,7 @@ def gru_seq(gi, w_hh, b_hh, h0=None):
 
 
 def attn_varlen(qkv, cu_seqlens, max_seqlen, slopes=None, scale=None, p_drop=0.0, seed=0, offset=0):
-    out = K.attention_alibi_varlen_ref(qkv[:, 0], qkv[:, 1], qkv[:, 2], cu_seqlens, slopes, scale, p_drop, seed, offset)
+    out = K.attention_alibi_varlen_ref(qkv[:, 0], qkv[:, 1], qkv[:, 2], cu_seqlens, slopes, scale, p_drop, seed, offset, p_bf16=True)
     return out.to(torch.bfloat16)
 
 

@@ -851,14 +851,41 @@ def test_gemm_f32_split_modes_error_against_fp64(ops):
     ref = A.double() @ B.double().t()
     scale = (A.double().abs() @ B.double().abs().t())          # sum |a b|: the natural error scale of a dot product
     err = {}
-    for split in (0, 6, 9):
+    for split in (0, 6, 9, 2):
         e = ((ops.gemm_f32(A, B, True, True, split=split).double() - ref).abs() / scale)
         err[split] = (e.mean().item(), e.max().item())
     lib = (((A @ B.t()).double() - ref).abs() / scale)
     print('relative to sum|ab|: mean / max', err, 'library fp32 GEMM', (lib.mean().item(), lib.max().item()))
-    for split in (6, 9):
+    for split in (6, 9, 2):
         assert err[split][0] <= 1.5 * err[0][0] + 1e-9 and err[split][1] <= 2.0 * err[0][1] + 1e-9, err
-    assert err[6][1] < 1e-6
+    assert err[6][1] < 1e-6 and err[2][1] < 1e-6
+
+
+@pytest.mark.parametrize('decades,K', [(2.0, 64), (4.0, 64), (4.0, 256), (4.0, 4096), (0.0, 1024)])
+def test_gemm_f32_f16x3_mode_error_against_fp64(ops, decades, K):
+    """Mode 2 (fp16 planes of the SCALED operands, three plane products, one accumulator): as accurate as the fp32 instruction
+    (mode 0) against fp64 - mean <= 1.5 x, max <= 2 x of its error relative to sum|a b| - from short to long K, with A spanning up
+    to 12 decades (randn * exp(4 randn): its residual plane is normal down to 2^-29 max|A|) and B up to 6 decades (its residual
+    plane down to 2^-18 max|B|: the operand slot of the weights).  The operand magnitudes come from resel_amax inside the call."""
+    g = torch.Generator().manual_seed(int(decades * 10) + K)
+    M, N = 512, 384
+    A = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, K, generator=g) * decades)).cuda()
+    B = (torch.randn(N, K, generator=g) * torch.exp(torch.randn(N, K, generator=g) * min(decades, 2.0))).cuda()
+    ref = A.double() @ B.double().t()
+    scale = (A.double().abs() @ B.double().abs().t())
+    err = {}
+    for split in (0, 2, 6):
+        e = ((ops.gemm_f32(A, B, True, True, split=split).double() - ref).abs() / scale)
+        err[split] = (e.mean().item(), e.max().item())
+    print('f16x3 (2) vs fp32 instruction (0) vs bf16 split (6), relative to sum|ab| (mean, max):', err)
+    assert err[2][0] <= 1.5 * err[0][0] + 1e-9 and err[2][1] <= 2.0 * err[0][1] + 1e-9, err
+    # layouts, bias + ELU epilogue, batch, K tail: against mode 6 at fp32 rounding level
+    A3, B3, b3 = torch.randn(3, 700, 200, generator=g).cuda(), torch.randn(3, 200, 264, generator=g).cuda() / 14, torch.randn(3, 264, generator=g).cuda()
+    o6 = ops.gemm_f32(A3, B3, True, False, b3, 'elu', split=6)
+    o2 = ops.gemm_f32(A3, B3, True, False, b3, 'elu', split=2)
+    close(o2, o6.cpu(), rtol=2e-6, atol_scale=1e-6, name='mode 2 vs mode 6, batched + bias + elu')
+    Z = torch.zeros(300, 64).cuda()
+    assert ops.gemm_f32(Z, torch.randn(128, 64, generator=g).cuda(), True, True, split=2).abs().max().item() == 0.0   # amax = 0
 
 
 @pytest.mark.parametrize('M,N,K,akc,bkc,bias,act,batch', [
@@ -890,14 +917,24 @@ def test_gemm_f32_two_plane_mode(ops, M, N, K, akc, bkc, bias, act, batch):
 
 
 def test_gemm_f32_follows_torch_matmul_precision(ops, monkeypatch):
-    """No RESEL_GEMM_SPLIT: 'highest' (torch's default and the reference's setting) = the fp32-accurate mode 6, 'high' = mode 3."""
+    """No RESEL_GEMM_SPLIT: 'highest' (torch's default and the reference's setting) = the fp32-accurate modes - 2 where the operand
+    magnitudes are known (a handle from the producer, or a pre-pass that is cheap next to the GEMM), 6 otherwise; 'high' = mode 3."""
     monkeypatch.setattr(ops, 'GEMM_SPLIT', None)
     g = torch.Generator().manual_seed(1)
     A, B = torch.randn(1024, 512, generator=g).cuda(), torch.randn(256, 512, generator=g).cuda()
     keep = torch.get_float32_matmul_precision()
     try:
         torch.set_float32_matmul_precision('highest')
-        assert ops.gemm_split() == 6 and torch.equal(ops.gemm_f32(A, B), ops.gemm_f32(A, B, split=6))
+        assert ops.gemm_split() == 2
+        assert torch.equal(ops.gemm_f32(A, B), ops.gemm_f32(A, B, split=6))          # small, untagged operands: a pre-pass does not pay - mode 6
+        ha, hb = ops.amax(A), ops.amax(B)
+        assert abs(ops.amax_value(ha) - A.abs().max().item()) == 0.0 and abs(ops.amax_value(hb) - B.abs().max().item()) == 0.0
+        c2 = ops.gemm_f32(A, B, amax_a=ha, amax_b=hb)                                  # handles at hand: mode 2
+        assert torch.equal(c2, ops.gemm_f32(A, B, split=2, amax_a=ha, amax_b=hb)) and not torch.equal(c2, ops.gemm_f32(A, B, split=6))
+        assert (c2 - ops.gemm_f32(A, B, split=6)).abs().max().item() <= 2e-6 * 512 ** 0.5 * 16
+        big, wide = torch.randn(20000, 512, generator=torch.Generator().manual_seed(2)).cuda(), torch.randn(2048, 512, generator=g).cuda()
+        out = ops.gemm_f32(big, wide)                                                  # a long, wide pass: pre-pass + mode 2, output tagged with its magnitude
+        assert ops.amax_of(big) is not None and abs(ops.amax_value(ops.amax_of(out)) - out.abs().max().item()) == 0.0
         torch.set_float32_matmul_precision('high')
         assert ops.gemm_split() == 3 and torch.equal(ops.gemm_f32(A, B), ops.gemm_f32(A, B, split=3))
         assert not torch.equal(ops.gemm_f32(A, B, split=3), ops.gemm_f32(A, B, split=6))

@@ -387,7 +387,7 @@ def test_graphed_update_equals_the_eager_update(rnn, ragged, algo, monkeypatch):
         return [alg.policy.store.flat.detach().clone(), alg.values[0].store.flat.detach().clone(), alg.target_values[0].store.flat.detach().clone(),
                 alg.log_sac_alpha.detach().clone()]
 
-    n_upd = 8 if ragged else 4
+    n_upd = 16 if ragged else 4
     rs_new = np.random.RandomState(99)
     fresh = [_synth(rs_new, n, 5, 3) for n in (12, 6)]         # trajectories that enter the ring in the middle of the run
 
@@ -403,22 +403,27 @@ def test_graphed_update_equals_the_eager_update(rnn, ragged, algo, monkeypatch):
         logs_e.append(dict(eager.train_one_batch()))
         eager.grad_num += 1
     graphed = build()
-    # the first step() = one eager warm-up update + capture + first replay; ragged: two shapes are recorded, the others run eagerly
+    # every step() is ONE update: update 0 runs eagerly (warm-up), a batch shape is recorded on its second visit and replayed from
+    # then on; ragged: at most two graphs live at a time (least recently used dropped), the other updates run eagerly
+    st0 = np.random.get_state()[1].copy()
     g = GraphedUpdate(graphed, warmup=1, max_graphs=2 if ragged else 4)
-    np.random.seed(11)                                          # the constructor sized its buffers with one subset draw
+    assert (np.random.get_state()[1] == st0).all()              # the constructor consumes no draw of the trainer's random streams
     logs_g = []
-    for i in range(1, n_upd):                                   # update 0 is the warm-up inside the first step()
+    for i in range(n_upd):
         if i == n_upd - 2:
             push_fresh(graphed)                                 # the ring mirror is refreshed outside the graph, in place
         logs_g.append(dict(g.step()))
         graphed.grad_num += 1
     torch.cuda.synchronize()
-    assert g.graph is not None and (g.eager_fallbacks > 0 if ragged else (g.eager_fallbacks == 0 and 1 <= len(g.graphs) <= 4))
+    print(f'graphs recorded {len(g.graphs)}, eager updates {g.eager_fallbacks} of {n_upd}')
+    assert len(g.graphs) <= (2 if ragged else 4) and g.eager_fallbacks >= 1
+    # equal lengths: warm-up + at most one first visit per shape (the ring refill adds one); ragged shapes must recur to be recorded
+    assert ragged or (g.graph is not None and g.eager_fallbacks <= 3)
     # not bit for bit: the entropy coefficient's torch AdamW runs in its `capturable` form (step count and bias corrections as
     # fp32 device tensors instead of Python floats), and the coefficient enters every loss
     for nm, a, b in zip(('policy', 'value', 'target value', 'log alpha'), state(graphed), state(eager)):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-5, atol=2e-7, err_msg=nm)
-    for le, lg in zip(logs_e[1:], logs_g):
+    for le, lg in zip(logs_e, logs_g):
         assert set(le) == set(lg)
         for k in le:
             ve = le[k][0] if isinstance(le[k], tuple) else le[k]

@@ -1,0 +1,45 @@
+"""Census of the hand-written GEMM calls of one update: shape, operand layouts, call site (file:line of the caller of ops.gemm_f32 and
+of its caller), launches and device time (one HIP event pair per call).  Tells which operands are worth a producer-side magnitude."""
+import sys, os, traceback
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'recurrent-offpolicy-rl_amd')]
+import torch
+from collections import defaultdict
+from bench import build_trainer
+from offpolicy_rnn.hip import ops
+rnn = sys.argv[1] if len(sys.argv) > 1 else 'smamba_s32_c16_b2_nln'
+alg = build_trainer(rnn, 64, 1024)
+for _ in range(3):
+    alg.train_one_batch(); alg.grad_num += 1
+torch.cuda.synchronize()
+real = ops.gemm_f32
+rec = []
+
+
+def hooked(A, B, a_kcontig=True, b_kcontig=True, bias=None, act=None, out=None, split=None, **kw):
+    st = traceback.extract_stack(limit=4)
+    site = ' <- '.join(f'{os.path.basename(f.filename)}:{f.lineno}' for f in reversed(st[:-1]))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = real(A, B, a_kcontig, b_kcontig, bias, act, out, split, **kw)
+    e1.record()
+    batch = A.shape[0] if A.dim() == 3 else 1
+    M, K = (A.shape[-2], A.shape[-1]) if a_kcontig else (A.shape[-1], A.shape[-2])
+    N = B.shape[-2] if b_kcontig else B.shape[-1]
+    rec.append(((batch, M, N, K, int(a_kcontig), int(b_kcontig), act, site), e0, e1))
+    return r
+
+
+ops.gemm_f32 = hooked
+import offpolicy_rnn.models.ensemble_linear_model as elm
+alg.train_one_batch()
+torch.cuda.synchronize()
+agg = defaultdict(lambda: [0, 0.0])
+for key, e0, e1 in rec:
+    agg[key][0] += 1
+    agg[key][1] += e0.elapsed_time(e1) * 1e3
+tot = sum(v[1] for v in agg.values())
+print(f'{len(rec)} calls, {tot / 1e3:.2f} ms (event pairs include launch gaps)')
+for key, (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    b, M, N, K, akc, bkc, act, site = key
+    print(f'{us / 1e3:7.3f} ms x{n:2d} {us / n:7.1f} us  b{b} M{M} N{N} K{K} a{akc} b{bkc} {str(act):5s} {site}')
