@@ -245,6 +245,17 @@ int resel_sac_target(const float* q, const int32_t* subset, int m, const float* 
 int resel_sac_target_phase(int phase, const float* q, const int32_t* subset, int m, const float* next_logp, const float* log_alpha,
                            const float* reward, const float* done, const float* mask, float gamma, float* guard,
                            float* target, float* stats, float* extrema, void* workspace, int E, int M, resel_stream_t stream);
+/* Data parallel with ONE collective per optimizer step (north_star: "a RCCL all-reduce of gradients ... and no other collectives"):
+ * resel_sac_target_local forms the target from the rank's own rows with the guard AS IT STANDS (an uninitialised guard does not
+ * clamp - on one process its first interval is the batch's own range, so the first clamp is the identity there too) and writes
+ * the rank-local extrema [4] = {-min v, max v, -min(y mask), max(y mask)}; the caller puts them into its own row of a zero-filled
+ * [world][4] tail of the critic gradient bucket, and after the SUM all-reduce resel_guard_apply_slots initialises / updates the
+ * guard from the maxima over the rows - the guard of update k + 1 is then the one a single process over the global batch has
+ * (the guard of the reference acts on the NEXT target only: utility/q_value_guard.py:22-38). */
+int resel_sac_target_local(const float* q, const int32_t* subset, int m, const float* next_logp, const float* log_alpha,
+                           const float* reward, const float* done, const float* mask, float gamma, const float* guard,
+                           float* target, float* stats, float* extrema, void* workspace, int E, int M, resel_stream_t stream);
+int resel_guard_apply_slots(const float* slots, int world, float* guard, resel_stream_t stream);
 size_t resel_sac_target_workspace_bytes(int M);
 
 /* Flat-buffer optimizer tail.  All parameter / gradient / moment tensors of one network live in ONE fp32 buffer.

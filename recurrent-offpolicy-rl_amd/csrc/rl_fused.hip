@@ -107,7 +107,8 @@ __global__ __launch_bounds__(256) void target_y_kernel(const float* __restrict__
                                                        const float* __restrict__ done, const float* __restrict__ mask, float gamma,
                                                        const float* __restrict__ guard, float* __restrict__ target,
                                                        float* __restrict__ part, int M) {
-    const float lo = guard[0], hi = guard[1];
+    const bool ready = guard[2] != 0.f;              // an uninitialised guard does not clamp (its first interval is the batch's own range)
+    const float lo = ready ? guard[0] : -INFINITY, hi = ready ? guard[1] : INFINITY;
     float mn = INFINITY, mx = -INFINITY, ma = 0.f, sm = 0.f;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < M; i += gridDim.x * 256) {
         const float c = fminf(fmaxf(v[i], lo), hi);
@@ -133,6 +134,23 @@ __global__ __launch_bounds__(256) void extrema_out_kernel(const float* __restric
         ext[0] = -res[0]; ext[1] = res[1];
         if (stats) { stats[0] = res[2]; stats[1] = res[3]; }
     }
+}
+// data-parallel, one collective per step: slots [world][4] = every rank's {-min v, max v, -min(y mask), max(y mask)} (each rank
+// wrote its own row into a zero-filled tail of the gradient bucket; the SUM all-reduce delivered all rows everywhere).  The guard
+// is initialised (first call) and updated from the extrema of the GLOBAL batch, exactly as q_value_guard.py:22-38 on one process.
+__global__ void guard_apply_slots_kernel(const float* __restrict__ slots, int world, float* guard) {
+    if (threadIdx.x != 0) return;
+    float e[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    for (int r = 0; r < world; ++r)
+        for (int j = 0; j < 4; ++j) e[j] = fmaxf(e[j], slots[4 * r + j]);
+    if (guard[2] == 0.f) { guard[0] = -e[0]; guard[1] = e[1]; guard[2] = 1.f; }
+    const float decay = guard[3], bmin = -e[2], bmax = e[3];
+    float gmin = fminf(guard[0], bmin), gmax = fmaxf(guard[1], bmax);
+    if (decay < 1.f) {
+        gmin = decay * gmin + (1.f - decay) * bmin;
+        gmax = decay * gmax + (1.f - decay) * bmax;
+    }
+    guard[0] = gmin; guard[1] = gmax;
 }
 __global__ void guard_init_from_kernel(const float* __restrict__ ext, float* guard) {
     if (threadIdx.x == 0 && guard[2] == 0.f) { guard[0] = -ext[0]; guard[1] = ext[1]; guard[2] = 1.f; }
@@ -279,6 +297,29 @@ extern "C" int resel_sac_target_phase(int phase, const float* q, const int32_t* 
     } else {                           // extrema[2:4] now global: running min / max update
         hipLaunchKernelGGL(guard_update_from_kernel, dim3(1), dim3(64), 0, s, extrema + 2, guard);
     }
+    return launch_status();
+}
+
+extern "C" int resel_sac_target_local(const float* q, const int32_t* subset, int m, const float* next_logp, const float* log_alpha,
+                                      const float* reward, const float* done, const float* mask, float gamma, const float* guard,
+                                      float* target, float* stats, float* extrema, void* workspace, int E, int M, resel_stream_t stream) {
+    if (!q || !subset || m <= 0 || !reward || !done || !guard || !target || !extrema || !workspace || E <= 0 || M <= 0) return RESEL_EINVAL;
+    if (next_logp && !log_alpha) return RESEL_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    float* v = (float*)workspace;
+    float* part1 = v + M;
+    float* part2 = part1 + 4 * RED_BLOCKS;
+    const int nblk = (M + 255) / 256 < RED_BLOCKS ? (M + 255) / 256 : RED_BLOCKS;
+    hipLaunchKernelGGL(target_v_kernel, dim3(nblk), dim3(256), 0, s, q, subset, m, next_logp, log_alpha, v, part1, E, M);
+    hipLaunchKernelGGL(extrema_out_kernel, dim3(1), dim3(256), 0, s, part1, nblk, extrema, (float*)nullptr);
+    hipLaunchKernelGGL(target_y_kernel, dim3(nblk), dim3(256), 0, s, v, reward, done, mask, gamma, guard, target, part2, M);
+    hipLaunchKernelGGL(extrema_out_kernel, dim3(1), dim3(256), 0, s, part2, nblk, extrema + 2, stats);
+    return launch_status();
+}
+
+extern "C" int resel_guard_apply_slots(const float* slots, int world, float* guard, resel_stream_t stream) {
+    if (!slots || world <= 0 || !guard) return RESEL_EINVAL;
+    hipLaunchKernelGGL(guard_apply_slots_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, slots, world, guard);
     return launch_status();
 }
 

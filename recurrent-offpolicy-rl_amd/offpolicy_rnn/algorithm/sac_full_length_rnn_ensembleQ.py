@@ -328,8 +328,18 @@ class SACFullLengthRNNEnsembleQ(SAC):
         return self._subset_rng if self._subset_rng is not None else np.random
 
     def _guard_exchange(self):
-        """Data parallel: the Q-guard sees the extrema of the global batch (two 2-float MAX all-reduces inside the target)."""
-        return dict(reduce_max=self.grad_sync.all_reduce_max_) if self.grad_sync.active else {}
+        """Data parallel: the Q-guard sees the extrema of the GLOBAL batch.  Default: no collective of its own - the rank-local
+        extrema ride in the critic's gradient bucket (`_finish_step`) and reach the guard behind that all-reduce; the guard of the
+        reference acts on the NEXT update's target only (utility/q_value_guard.py:22-38), so this is the single-process guard, not
+        an approximation.  RESEL_DP_GUARD=allreduce keeps the three-phase form with two 2-float MAX all-reduces inside the target."""
+        if not self.grad_sync.active:
+            return {}
+        if os.environ.get('RESEL_DP_GUARD', 'bucket') == 'allreduce':
+            return dict(reduce_max=self.grad_sync.all_reduce_max_)
+        if getattr(self, '_guard_ext', None) is None or self._guard_ext.device != self.Q_guard.state.device:
+            self._guard_ext = torch.zeros(4, dtype=torch.float32, device=self.Q_guard.state.device)
+        self._guard_ext_fresh = True
+        return dict(local_ext=self._guard_ext)
 
     def _target_Q_discrete(self, b, policy_hidden, target_hiddens, stats):
         """Discrete-action target (reference sac_full_length_rnn_redq.py:52-72): V(s') = sum_a pi(a|s') (min_subset Q'(s', a) -
@@ -404,17 +414,26 @@ class SACFullLengthRNNEnsembleQ(SAC):
             gnorm = 0.0
         return gnorm
 
-    def _finish_step(self, optimizer, store, local_count, overlap=None):
+    def _finish_step(self, optimizer, store, local_count, overlap=None, guard=False):
         """Exchange (sum) the flat gradient + the local valid count, then AdamW with grad / global count.  Data parallel: the
         all-reduce is issued on the exchange stream as soon as the last gradient is in the flat buffer; `overlap()` (work
         that does not touch the gradient buffer: the step's log scalars) runs on the compute stream meanwhile, which
         joins before anything reads the reduced buffer."""
         store.collect_grads()
+        gs = self.grad_sync
+        guard_slots = gs.active and guard and getattr(self, '_guard_ext_fresh', False)
+        if guard_slots:                                # this rank's row of the [world][4] extrema block behind the four standing slots
+            store.ensure_grad_extra(4 + 4 * gs.world)
+            o = store.numel + 4 + 4 * gs.rank
+            store.grad[o:o + 4] = self._guard_ext
         store.grad[store.numel] = local_count
-        self.grad_sync.all_reduce_async_(store.grad)
+        gs.all_reduce_async_(store.grad)
         if overlap is not None:
             overlap()
-        self.grad_sync.wait()
+        gs.wait()
+        if guard_slots:                                # every rank's extrema are here: initialise / update the guard from the global batch
+            ops.guard_apply_slots(store.grad[store.numel + 4:store.numel + 4 + 4 * gs.world], gs.world, self.Q_guard.state)
+            self._guard_ext_fresh = False
         return 1.0 / store.grad[store.numel:store.numel + 1]
 
     # ------------------------------------------------------------------------------------------ the update
@@ -487,7 +506,7 @@ class SACFullLengthRNNEnsembleQ(SAC):
             q_loss_sum = ((q - target_Q.unsqueeze(0)).pow(2).sum(dim=0) * mask).sum()
             self.optimizer_value.zero_grad()
             q_loss_sum.backward()
-            scale = self._finish_step(self.optimizer_value, value.store, valid_num,
+            scale = self._finish_step(self.optimizer_value, value.store, valid_num, guard=True,
                                       overlap=lambda: scal.update(critic_loss=q_loss_sum.detach() / valid_num))
             q_grad_norm = self._clip(value.store, value, par.value_max_gradnorm, par.value_embedding_max_gradnorm, scale)
             self.optimizer_value.step(grad_scale=scale)

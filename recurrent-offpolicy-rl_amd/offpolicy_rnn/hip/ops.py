@@ -640,10 +640,12 @@ def tanh_gaussian(out2, noise):
 
 
 @torch.no_grad()
-def sac_target(q, subset, next_logp, log_alpha, reward, done, mask, gamma, guard, stats=None, reduce_max=None):
+def sac_target(q, subset, next_logp, log_alpha, reward, done, mask, gamma, guard, stats=None, reduce_max=None, local_ext=None):
     """q [E, ...]; subset int32 [m] (device); guard fp32[4] device state {min, max, initialised, decay}.
-    reduce_max (data parallel): in-place MAX all-reduce of a small device tensor - the guard then sees the extrema of the
-    global batch, exactly as one process would (three phases with two 2-float exchanges, see resel_hip.h)."""
+    Data parallel, either
+      local_ext (fp32 [4], default of the trainer): the target of the rank's own rows with the guard as it stands; the rank-local
+        extrema go to local_ext, travel in the gradient bucket and reach the guard through `guard_apply_slots` - no collective here;
+      reduce_max: in-place MAX all-reduce of a small device tensor - three phases with two 2-float exchanges inside the target."""
     _need_cuda('sac_target', q, reward, done, guard)
     E = q.shape[0]
     M = reward.numel()
@@ -652,6 +654,10 @@ def sac_target(q, subset, next_logp, log_alpha, reward, done, mask, gamma, guard
     ws = _ws(lib().resel_sac_target_workspace_bytes(M), q.device)
     f = lambda t: None if t is None else t.float().reshape(-1).contiguous()
     nl, rw, dn, mk = f(next_logp), f(reward), f(done), f(mask)
+    if local_ext is not None:
+        check(lib().resel_sac_target_local(_p(qf), _p(subset), int(subset.numel()), _p(nl), _p(log_alpha), _p(rw), _p(dn), _p(mk),
+                                           float(gamma), _p(guard), _p(target), _p(stats), _p(local_ext), _p(ws), E, M, _stream()), 'sac_target_local')
+        return target.reshape(reward.shape)
     if reduce_max is not None:
         ext = torch.empty(4, dtype=torch.float32, device=q.device)
         for phase in range(3):
@@ -663,6 +669,14 @@ def sac_target(q, subset, next_logp, log_alpha, reward, done, mask, gamma, guard
     check(lib().resel_sac_target(_p(qf), _p(subset), int(subset.numel()), _p(nl), _p(log_alpha), _p(rw), _p(dn), _p(mk),
                                  float(gamma), _p(guard), _p(target), _p(stats), _p(ws), E, M, _stream()), 'sac_target')
     return target.reshape(reward.shape)
+
+
+@torch.no_grad()
+def guard_apply_slots(slots, world, guard):
+    """slots fp32 [world * 4] (every rank's extrema, delivered by the gradient all-reduce) -> first-call initialisation + running
+    update of the Q guard from the extrema of the global batch (include/resel_hip.h `resel_guard_apply_slots`)."""
+    _need_cuda('guard_apply_slots', slots, guard)
+    check(lib().resel_guard_apply_slots(_p(slots), int(world), _p(guard), _stream()), 'guard_apply_slots')
 
 
 # ---------------------------------------------------------------------------------------------- bias + activation tail

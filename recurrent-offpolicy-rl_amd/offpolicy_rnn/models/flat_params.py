@@ -46,6 +46,19 @@ class FlatParameterStore:
             p.data = self.flat[o:o + n].view(p.shape)
             p.grad = self.grad[o:o + n].view(p.shape)
 
+    def ensure_grad_extra(self, n: int):
+        """At least n trailing slots behind the gradients (the parameter buffer keeps its own tail): data-parallel runs carry every
+        rank's Q-guard extrema there, four floats per rank, behind the four standing slots."""
+        have = self.grad.numel() - self.numel
+        if have >= n:
+            return
+        grad = torch.zeros(self.numel + n, dtype=torch.float32, device=self.grad.device)
+        grad[:self.grad.numel()].copy_(self.grad)
+        self.grad = grad
+        for p, o, k in self.slices:
+            if p.grad is not None:
+                p.grad = self.grad[o:o + k].view(p.shape)
+
     def to(self, device):
         if self.flat.device != torch.device(device):
             self.flat = self.flat.to(device)

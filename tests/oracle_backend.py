@@ -116,11 +116,19 @@ def tanh_gaussian(out2, noise):
 
 
 @torch.no_grad()
-def sac_target(q, subset, next_logp, log_alpha, reward, done, mask, gamma, guard, stats=None, reduce_max=None):
+def sac_target(q, subset, next_logp, log_alpha, reward, done, mask, gamma, guard, stats=None, reduce_max=None, local_ext=None):
     idx = subset.long()
     v = q[idx].min(dim=0).values
     if next_logp is not None:
         v = v - log_alpha.exp() * next_logp
+    if local_ext is not None:                       # one-collective data parallelism: guard as it stands, extrema handed out
+        lo, hi = (guard[0].item(), guard[1].item()) if guard[2] != 0 else (-float('inf'), float('inf'))
+        y = reward + (1 - done) * gamma * v.clamp(min=lo, max=hi)
+        ym = y * mask
+        local_ext.copy_(torch.stack((-v.min(), v.max(), -ym.min(), ym.max())))
+        if stats is not None:
+            stats[0], stats[1] = y.abs().max(), mask.sum()
+        return y
     ext = torch.stack((-v.min(), v.max()))
     if reduce_max is not None:
         reduce_max(ext)
@@ -140,6 +148,19 @@ def sac_target(q, subset, next_logp, log_alpha, reward, done, mask, gamma, guard
     if stats is not None:
         stats[0], stats[1] = y.abs().max(), mask.sum()
     return y
+
+
+@torch.no_grad()
+def guard_apply_slots(slots, world, guard):
+    e = slots.reshape(world, 4).max(dim=0).values
+    if guard[2] == 0:
+        guard[0], guard[1], guard[2] = -e[0], e[1], 1.0
+    bmin, bmax = -e[2], e[3]
+    lo, hi = torch.minimum(guard[0], bmin), torch.maximum(guard[1], bmax)
+    decay = guard[3]
+    if decay < 1:
+        lo, hi = decay * lo + (1 - decay) * bmin, decay * hi + (1 - decay) * bmax
+    guard[0], guard[1] = lo, hi
 
 
 @torch.no_grad()
@@ -170,7 +191,7 @@ def install(monkeypatch):
     from offpolicy_rnn.hip import ops
     table = dict(ensemble_head_fwd_=ensemble_head_fwd_, ensemble_head_bwd=ensemble_head_bwd, bias_act_=bias_act_, bias_act_bwd=bias_act_bwd, linear_act=linear_act, mamba_inner_fn=mamba_inner_fn, selective_scan_tm=selective_scan_tm, causal_conv1d_fn=causal_conv1d_fn, layer_norm_fn=_norm(False),
                  rms_norm_fn=_norm(True), gilr_scan=gilr_scan, complex_scan=complex_scan, gru_seq=gru_seq, tanh_gaussian=tanh_gaussian, attn_varlen=attn_varlen, dropout_counter=dropout_counter, counter_dropout=counter_dropout,
-                 sac_target=sac_target, soft_update_=soft_update_, adamw_flat_=adamw_flat_, sumsq=sumsq)
+                 sac_target=sac_target, guard_apply_slots=guard_apply_slots, soft_update_=soft_update_, adamw_flat_=adamw_flat_, sumsq=sumsq)
     for k, fn in table.items():
         monkeypatch.setattr(ops, k, fn)
     return ops

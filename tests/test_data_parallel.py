@@ -74,8 +74,9 @@ def _worker(rank, world, port, mode, out_dir):
     for _ in range(2):
         log = alg.train_one_batch()
         alg.grad_num += 1
-    torch.save(dict(policy=alg.policy.store.flat.clone(), value=alg.values[0].store.flat.clone(),
-                    alpha=alg.log_sac_alpha.detach().clone(), critic_loss=log['critic_loss']), os.path.join(out_dir, f'rank{rank}.pt'))
+    torch.save(dict(policy=alg.policy.store.flat.clone(), value=alg.values[0].store.flat.clone(), guard=alg.Q_guard.state.detach().clone(),
+                    alpha=alg.log_sac_alpha.detach().clone(), critic_loss=log['critic_loss'], calls=dict(alg.grad_sync.calls)),
+               os.path.join(out_dir, f'rank{rank}.pt'))
     dist.destroy_process_group()
 
 
@@ -87,11 +88,16 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize('mode', ['different', 'same', 'union'])
-def test_two_rank_update(tmp_path, mode, monkeypatch):
+@pytest.mark.parametrize('mode,guard', [('different', 'bucket'), ('same', 'bucket'), ('union', 'bucket'), ('union', 'allreduce')])
+def test_two_rank_update(tmp_path, mode, guard, monkeypatch):
+    """guard = bucket (default): one collective per optimizer step, the ranks' Q-guard extrema ride in the critic's gradient bucket
+    (4 floats per rank in a zero-filled tail); allreduce: two MAX all-reduces inside the target.  Either way the parameters AND the
+    guard state equal the single-process update over the union batch."""
+    monkeypatch.setenv('RESEL_DP_GUARD', guard)
     mp.spawn(_worker, args=(2, _free_port(), mode, str(tmp_path)), nprocs=2, join=True)
     r0, r1 = (torch.load(os.path.join(tmp_path, f'rank{i}.pt')) for i in range(2))
-    for k in ('policy', 'value', 'alpha'):
+    assert r0['calls']['all_reduce_sum'] == 4 and r0['calls']['all_reduce_max'] == (0 if guard == 'bucket' else 4), r0['calls']
+    for k in ('policy', 'value', 'alpha', 'guard'):
         assert torch.equal(r0[k], r1[k]), f'{k} diverged across ranks'
     if mode != 'different':
         sys.path[:0] = [HERE]
@@ -107,6 +113,7 @@ def test_two_rank_update(tmp_path, mode, monkeypatch):
         n = alg.values[0].store.numel
         np.testing.assert_allclose(r0['value'][:n], alg.values[0].store.flat[:n], rtol=1e-5, atol=1e-7)
         np.testing.assert_allclose(r0['alpha'], alg.log_sac_alpha.detach(), rtol=1e-6)
+        np.testing.assert_allclose(r0['guard'], alg.Q_guard.state.detach(), rtol=1e-6)
 
 
 # ---- the launcher: `python bench.py --gpus N` starts its own ranks; the torchrun form keeps working (no GPU needed: --spawn-dry-run) ----

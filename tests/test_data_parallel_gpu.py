@@ -55,7 +55,7 @@ def _run(alg, steps=2):
     torch.cuda.synchronize()
     return dict(policy=alg.policy.store.flat[:alg.policy.store.numel].detach().cpu(),
                 value=alg.values[0].store.flat[:alg.values[0].store.numel].detach().cpu(),
-                alpha=alg.log_sac_alpha.detach().cpu(), critic_loss=log['critic_loss'])
+                alpha=alg.log_sac_alpha.detach().cpu(), critic_loss=log['critic_loss'], guard=alg.Q_guard.state.detach().cpu())
 
 
 def _worker(rank, world, port, rnn, out_dir, union=False, backend='gloo'):
@@ -69,6 +69,7 @@ def _worker(rank, world, port, rnn, out_dir, union=False, backend='gloo'):
     assert alg.grad_sync.world == world and alg.device.type == 'cuda' and alg.grad_sync.backend == backend
     res = _run(alg)
     res['calls'] = dict(alg.grad_sync.calls)
+    res['guard'] = alg.Q_guard.state.detach().cpu()
     torch.save(res, os.path.join(out_dir, f'rank{rank}.pt'))
     dist.destroy_process_group()
 
@@ -87,19 +88,24 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_process_update(tmp_path, rnn)
         np.testing.assert_allclose(r0[k].numpy(), ref[k].numpy(), rtol=2e-4, atol=2e-6, err_msg=k)
 
 
+@pytest.mark.parametrize('guard', ['bucket', 'allreduce'])
 @pytest.mark.parametrize('rnn', ['smamba_s8_c4_b1_nln', 'gilr'])
-def test_two_ranks_with_disjoint_rows_reproduce_the_union_batch_update(tmp_path, rnn, monkeypatch):
+def test_two_ranks_with_disjoint_rows_reproduce_the_union_batch_update(tmp_path, rnn, guard, monkeypatch):
+    """guard = bucket (default): ONE collective per optimizer step - the ranks' Q-guard extrema ride in the critic's gradient bucket;
+    allreduce: the three-phase target with two MAX all-reduces.  Both give the single-process update over the union batch and its
+    guard state (the guard acts on the next update's target only)."""
     if not torch.cuda.is_available():
         pytest.skip('needs a GPU')
     from test_data_parallel import _free_port
+    monkeypatch.setenv('RESEL_DP_GUARD', guard)
     mp.spawn(_worker, args=(2, _free_port(), rnn, str(tmp_path), True), nprocs=2, join=True)
     r0, r1 = (torch.load(os.path.join(tmp_path, f'rank{i}.pt')) for i in range(2))
-    for k in ('policy', 'value', 'alpha'):
+    for k in ('policy', 'value', 'alpha', 'guard'):
         assert torch.equal(r0[k], r1[k]), f'{k} diverged across ranks'
-    # 2 updates x (critic step + actor step) flat-gradient all-reduces, 2 x 2 MAX all-reduces of the guard extrema
-    assert r0['calls']['all_reduce_sum'] == 4 and r0['calls']['all_reduce_max'] == 4, r0['calls']
+    # 2 updates x (critic step + actor step) flat-gradient all-reduces; the guard: nothing of its own / 2 x 2 MAX all-reduces
+    assert r0['calls']['all_reduce_sum'] == 4 and r0['calls']['all_reduce_max'] == (0 if guard == 'bucket' else 4), r0['calls']
     ref = _run(_build(rnn, batch=sum(LENS), quiet=True, patcher=monkeypatch))       # one process, all five trajectories in one batch
-    for k in ('policy', 'value', 'alpha'):
+    for k in ('policy', 'value', 'alpha', 'guard'):
         np.testing.assert_allclose(r0[k].numpy(), ref[k].numpy(), rtol=2e-4, atol=2e-6, err_msg=k)
 
 
@@ -114,9 +120,9 @@ def test_two_ranks_over_rccl_reproduce_the_union_batch_update(tmp_path, monkeypa
     r0, r1 = (torch.load(os.path.join(tmp_path, f'rank{i}.pt')) for i in range(2))
     for k in ('policy', 'value', 'alpha'):
         assert torch.equal(r0[k], r1[k]), f'{k} diverged across ranks'
-    assert r0['calls']['all_reduce_sum'] == 4 and r0['calls']['all_reduce_max'] == 4, r0['calls']
+    assert r0['calls']['all_reduce_sum'] == 4 and r0['calls']['all_reduce_max'] == 0, r0['calls']
     ref = _run(_build(rnn, batch=sum(LENS), quiet=True, patcher=monkeypatch))
-    for k in ('policy', 'value', 'alpha'):
+    for k in ('policy', 'value', 'alpha', 'guard'):
         np.testing.assert_allclose(r0[k].numpy(), ref[k].numpy(), rtol=2e-4, atol=2e-6, err_msg=k)
 
 
@@ -137,7 +143,7 @@ def _assert_collectives_ran(line):
     assert line['n_gpus'] == 1 and np.isfinite(line['value']) and line['value'] > 0
     assert line['backend'] == 'nccl' and line['rccl_ranks'] == 1
     # per update: critic step + actor step = 2 flat-gradient all-reduces; the target's Q-guard = 2 MAX all-reduces
-    assert line['collectives_per_step']['all_reduce_sum'] == 2 and line['collectives_per_step']['all_reduce_max'] == 2, line['collectives_per_step']
+    assert line['collectives_per_step']['all_reduce_sum'] == 2 and line['collectives_per_step']['all_reduce_max'] == 0, line['collectives_per_step']
     assert line['parameter_broadcasts'] >= 3 and line['collective_bytes_per_step']['all_reduce_sum'] > 1e6
 
 
@@ -186,7 +192,7 @@ def test_bench_launcher_end_to_end_with_two_ranks_sharing_the_gpu():
     line = json.loads(js[0])
     assert line['n_gpus'] == 2 and line['config']['global_rows'] == 8 and line['config']['parallelism'] == 'dp2'
     assert line['rccl_ranks'] == 2 and line['backend'] == 'gloo' and 'spawned its own ranks' in line['launcher']
-    assert line['collectives_per_step']['all_reduce_sum'] == 2 and line['collectives_per_step']['all_reduce_max'] == 2
+    assert line['collectives_per_step']['all_reduce_sum'] == 2 and line['collectives_per_step']['all_reduce_max'] == 0
     assert np.isfinite(line['value']) and line['value'] > 0
     # strong scaling form: a fixed global batch split over the ranks
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--global-rows', '8', '--steps', '2', '--warmup', '1', '--horizon', '128'],
