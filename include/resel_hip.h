@@ -56,7 +56,10 @@ int resel_profile_collect(int kernel_id, double* total_us, int* launches);
  * smamba selective scan.  Replaces `selective_scan_cuda.fwd / .bwd` (modified Mamba CUDA extension with the
  * extra `start` reset input) bound at offpolicy_rnn/models/smamba/mamba_ssm/ops/selective_scan_interface_new.py:47
  * and :72; arithmetic spec = `selective_scan_ref`, same file :96-166.
- *   delta' = softplus(delta + delta_bias)            (softplus iff delta_softplus != 0)
+ *   delta' = softplus(delta + delta_bias)            (delta_softplus = 1; 0: delta' = delta + delta_bias;
+ *                                                      2: `delta` already IS softplus(raw + bias) - the producing GEMM's epilogue applied
+ *                                                      it (resel_gemm_f32x act 3) - the forward uses it as it stands and the backward
+ *                                                      returns the gradient with respect to the RAW value: x (1 - exp(-delta)))
  *   h_t    = exp(delta'_t * A) * (1 - start_t) * h_{t-1} + delta'_t * Bm_t * u_t          h: [Di, N]
  *   out_t  = (<Cm_t, h_t> + D * u_t) * silu(z_t)     (gate skipped when z == NULL, skip term when D == NULL)
  * u, delta, z, out: [B*L, Di] (ld_u, ld_delta, ld_z, ld_out; 16-byte aligned); A: [Di, N] dense;
@@ -258,6 +261,21 @@ int resel_sac_target_local(const float* q, const int32_t* subset, int m, const f
 int resel_guard_apply_slots(const float* slots, int world, float* guard, resel_stream_t stream);
 size_t resel_sac_target_workspace_bytes(int M);
 
+/* Masked losses of the update, one forward and one backward pass each (reference sac_full_length_rnn_ensembleQ.py:80-81 `_mask_mean`,
+ * :105-114 `_Q_loss`, sac_full_length_rnn_redq.py:37-49 / td3_full_length_rnn_redq.py:39-51 `_policy_loss`, :130-132 `_alpha_loss`);
+ * UN-normalised sums (the global valid count divides the gradient inside AdamW).  q [E][M], y / mask / logp [M] (mask NULL = ones).
+ *   critic  out2[0] = sum_m mask sum_e (q - y)^2;                           dq = 2 g[0] mask (q - y)
+ *   actor   out2[0] = sum_m mask (use_logp exp(log_alpha) logp - red_e q),  out2[1] = sum_m mask logp;   red = mean (reduce_min 0) / min (1)
+ *           dlogp = g[0] exp(log_alpha) mask;  dq = -g[0] mask / E (mean)  or  -g[0] mask at the FIRST minimal member, 0 elsewhere (min)
+ * g: device scalar (the incoming gradient of the sum).  Fixed-order two-stage sums; workspace: resel_masked_loss_workspace_bytes(). */
+size_t resel_masked_loss_workspace_bytes(void);
+int resel_q_loss_fwd(const float* q, const float* y, const float* mask, float* out2, void* workspace, int E, int M, resel_stream_t stream);
+int resel_q_loss_bwd(const float* q, const float* y, const float* mask, const float* g, float* dq, int E, int M, resel_stream_t stream);
+int resel_actor_loss_fwd(const float* logp, const float* q, const float* mask, const float* log_alpha, float* out2, void* workspace,
+                         int E, int M, int use_logp, int reduce_min, resel_stream_t stream);
+int resel_actor_loss_bwd(const float* q, const float* mask, const float* log_alpha, const float* g, float* dlogp, float* dq,
+                         int E, int M, int use_logp, int reduce_min, resel_stream_t stream);
+
 /* Flat-buffer optimizer tail.  All parameter / gradient / moment tensors of one network live in ONE fp32 buffer.
  * soft update: rnn_base.py:490-491   target <- tau * target + (1 - tau) * online
  * adamw: torch.optim.AdamW (sac.py:61) with a per-segment learning rate table (RESeL groups,
@@ -307,7 +325,7 @@ int resel_ensemble_head_bwd(const float* gq, const float* a, const float* w3, fl
  *   dgrad    dx = dy W                 A = dy (1), B = W (0)      EnsembleLinear (models/ensemble_linear_model.py:36-49)
  *   wgrad    dW = dy^T x               A = dy (0), B = x (0)      K = number of tokens: split over blocks, partial tiles summed in
  *                                                                  a fixed order (workspace: resel_gemm_f32_workspace_bytes)
- * act: 0 none, 1 ELU, 2 accumulate (C += product + bias: the accumulating form of an input gradient; no activation).  The contiguous extent of each operand (K or rows) must be a multiple of 4, pointers 16-byte aligned.
+ * act: 0 none, 1 ELU, 2 accumulate (C += product + bias: the accumulating form of an input gradient; no activation), 3 softplus (resel_gemm_f32x only).  The contiguous extent of each operand (K or rows) must be a multiple of 4, pointers 16-byte aligned.
  * split selects how the fp32 products are formed (inputs, accumulation and outputs are fp32 in every mode):
  *   0  v_mfma_f32_32x32x2_f32 (fp32 operands, exact products);
  *   9  each operand split EXACTLY into three bf16 planes (8 + 8 + 8 significant bits), all nine plane products - each exact -

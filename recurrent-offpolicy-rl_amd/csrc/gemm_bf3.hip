@@ -564,6 +564,10 @@ __global__ __launch_bounds__(NTH, 2) void gemm_bf3_kernel(Params p) {
 #pragma unroll
                         for (int e = 0; e < 16; ++e) v[e] = elu1(v[e]);
                     }
+                    if (p.act == 3) {                                // softplus (dt_proj of the Mamba mixer: the scan then reads delta itself)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) v[e] = softplus_nb(v[e]);
+                    }
                     const int mb = cur.m0 + wm + 32 * a + 4 * lh;
                     float* crow = C + (int64_t)mb * p.ldc + n;
                     if (p.act == 2) {                                // C += product (the accumulating form of an input gradient)
@@ -634,6 +638,7 @@ __global__ __launch_bounds__(256) void gemm_bf3_fixup_kernel(Params p) {
             if (n + j >= p.N) break;
             float x = o[j] + (p.bias ? p.bias[(int64_t)z * p.sBias + n + j] : 0.f);
             if (p.act == 1) x = elu1(x);
+            if (p.act == 3) x = softplus_nb(x);
             if (p.act == 2) x += c[j];
             c[j] = x;
             cmax = fmaxf(cmax, __builtin_fabsf(x));

@@ -505,6 +505,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
 #pragma unroll
                         for (int e = 0; e < 16; ++e) v[e] = elu1(v[e]);
                     }
+                    if (p.act == 3) {                                // softplus (dt_proj of the Mamba mixer: the scan then reads delta itself)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) v[e] = softplus_nb(v[e]);
+                    }
                     const int mb = cur.m0 + wm + 32 * a + 4 * lh;
                     float* crow = C + (int64_t)mb * p.ldc + n;
                     if (p.act == 2) {                                // C += product (the accumulating form of an input gradient)
@@ -570,6 +574,7 @@ __global__ __launch_bounds__(256) void gemm_fixup_kernel(GemmParams p) {
             if (n + j >= p.N) break;
             float x = o[j] + (p.bias ? p.bias[(int64_t)z * p.sBias + n + j] : 0.f);
             if (p.act == 1) x = elu1(x);
+            if (p.act == 3) x = softplus_nb(x);
             if (p.act == 2) x += c[j];
             c[j] = x;
             cmax = fmaxf(cmax, __builtin_fabsf(x));
@@ -626,7 +631,7 @@ extern "C" int resel_gemm_f32x(const float* A, int64_t lda, int64_t strideA, int
                                float* C, int64_t ldc, int64_t strideC, void* workspace,
                                int M, int N, int K, int batch, int split, const float* amax_a, const float* amax_b,
                                void* amax_c, unsigned amax_epoch, resel_stream_t stream) {
-    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || act < 0 || act > 2) return RESEL_EINVAL;
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || act < 0 || act > 3) return RESEL_EINVAL;
     // 106 / 109: modes 6 / 9 on the first-edition kernel of this file (every wave splits the fragments it reads), kept for A/B runs
     if (split != 0 && split != 2 && split != 3 && split != 6 && split != 9 && split != 106 && split != 109) return RESEL_EINVAL;
     if (split == 2 && (!amax_a || !amax_b)) return RESEL_EINVAL;

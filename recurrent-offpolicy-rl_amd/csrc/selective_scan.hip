@@ -306,7 +306,7 @@ __global__ __launch_bounds__(NW * 64) void sscan_fwd2_kernel(FwdParams p) {
             float4 dv = pd[i];
             const float4 uv = pu[i];
             dv.x += bv.x; dv.y += bv.y; dv.z += bv.z; dv.w += bv.w;
-            if (p.softplus) {
+            if (p.softplus == 1) {
                 dv.x = softplus_nb(dv.x); dv.y = softplus_nb(dv.y); dv.z = softplus_nb(dv.z); dv.w = softplus_nb(dv.w);
             }
             float4 du4 = make_float4(dv.x * uv.x, dv.y * uv.y, dv.z * uv.z, dv.w * uv.w);
@@ -553,7 +553,7 @@ __global__ __launch_bounds__(2 * NW * 64) void sscan_fwd3_kernel(FwdParams p) {
     auto stage = [&](int c0, int buf) {            // the loaded registers -> LDS tiles of buffer `buf`
         float4 dv = ldl;
         dv.x += bv.x; dv.y += bv.y; dv.z += bv.z; dv.w += bv.w;
-        if (p.softplus) { dv.x = softplus_nb(dv.x); dv.y = softplus_nb(dv.y); dv.z = softplus_nb(dv.z); dv.w = softplus_nb(dv.w); }
+        if (p.softplus == 1) { dv.x = softplus_nb(dv.x); dv.y = softplus_nb(dv.y); dv.z = softplus_nb(dv.z); dv.w = softplus_nb(dv.w); }
         float4 du4 = make_float4(dv.x * lu.x, dv.y * lu.y, dv.z * lu.z, dv.w * lu.w);
         if (c0 + TC > L) {                                                      // last chunk(s) only (uniform branch)
             if (c0 + r >= L) { dv = zero4; du4 = zero4; }                      // identity step past the end of the row
@@ -940,7 +940,7 @@ __global__ __launch_bounds__(NW * 64) void sscan_bwd_kernel(BwdParams p) {
             const float4 bv = ld4(&s_cvec[0][tc4]);
             float4 dl4 = ld4(&s_dl[tr][tc4]);
             dl4.x += bv.x; dl4.y += bv.y; dl4.z += bv.z; dl4.w += bv.w;
-            if (p.softplus) {
+            if (p.softplus == 1) {
                 dl4.x = softplus_nb(dl4.x); dl4.y = softplus_nb(dl4.y); dl4.z = softplus_nb(dl4.z); dl4.w = softplus_nb(dl4.w);
             }
             st4(&s_dl[tr][tc4], dl4);
@@ -1210,7 +1210,7 @@ __global__ __launch_bounds__(NW * 64) void sscan_bwd_local_kernel(BwdParams p) {
                 dv = ld4(p.delta + tok * p.ld_delta + d0 + tc4);
                 dy = ld4(p.dout + tok * p.ld_dout + d0 + tc4);
                 dv.x += bv.x; dv.y += bv.y; dv.z += bv.z; dv.w += bv.w;
-                if (p.softplus) { dv.x = softplus_nb(dv.x); dv.y = softplus_nb(dv.y); dv.z = softplus_nb(dv.z); dv.w = softplus_nb(dv.w); }
+                if (p.softplus == 1) { dv.x = softplus_nb(dv.x); dv.y = softplus_nb(dv.y); dv.z = softplus_nb(dv.z); dv.w = softplus_nb(dv.w); }
                 if (p.z) {
                     const float4 zv = ld4(p.z + tok * p.ld_z + d0 + tc4);
                     dy.x *= silu_nb(zv.x); dy.y *= silu_nb(zv.y); dy.z *= silu_nb(zv.z); dy.w *= silu_nb(zv.w);

@@ -84,6 +84,8 @@ class GraphedUpdate:
         if getattr(alg, '_needs_seq_table', False):
             return 'attention layers build their sequence tables and dropout counters on the host'
         if getattr(alg, 'overlap_value_embedding', False):
+            # tried in round 4: with the refusal lifted the capture of the gru trainer (target pass and prefetched value embeddings on
+            # side streams, forked / joined with events) ends in a segmentation fault inside capture_end on this ROCm build
             return 'side-stream overlap (gru) is not captured'
         if getattr(alg, 'grad_sync', None) is None or alg.grad_sync.active:
             return 'data-parallel groups are not captured (or not a full-trajectory trainer)'

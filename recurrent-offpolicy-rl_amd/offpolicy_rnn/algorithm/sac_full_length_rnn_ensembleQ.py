@@ -29,6 +29,9 @@ from ..models.flash_attention.TransformerFlashAttention import PackedSeqs
 from ..parallel.data_parallel import GradSync
 from ..policy_value_models.make_models import make_policy_model
 from ..utility.pinned import PinnedRing
+
+_FL = os.environ.get('RESEL_FUSED_LOSSES', '1')                        # A/B switch: 0 = the masked losses spelt in torch autograd
+FUSED_LOSSES, FUSED_Q, FUSED_A = _FL != '0', _FL in ('1', 'q'), _FL in ('1', 'a')
 from ..utility.q_value_guard import QValueGuard
 from .sac import SAC
 
@@ -390,6 +393,8 @@ class SACFullLengthRNNEnsembleQ(SAC):
                                   b['done'], b['mask'], self.parameter.gamma, self.Q_guard.state, stats, **self._guard_exchange())
 
     # ------------------------------------------------------------------------------------------ losses
+    actor_q_reduce = 'min'                           # how the actor objective reduces the critics (REDQ trainers: 'mean'); names the fused kernel's mode
+
     def _q_for_policy(self, qs: torch.Tensor) -> torch.Tensor:
         return qs.min(dim=0).values                                  # (REDQ trainers use the ensemble mean)
 
@@ -503,7 +508,10 @@ class SACFullLengthRNNEnsembleQ(SAC):
                 target_Q.record_stream(main)
             if self.discrete_env:                                   # Q of the action taken (reference :158)
                 q = q.gather(-1, b['action'].long().unsqueeze(0).expand(q.shape[0], -1, -1, -1))
-            q_loss_sum = ((q - target_Q.unsqueeze(0)).pow(2).sum(dim=0) * mask).sum()
+            if FUSED_Q and q.is_cuda and q.dtype == torch.float32:
+                q_loss_sum = ops.masked_q_loss(q, target_Q, mask)         # one forward + one backward kernel (reference :105-114, :80-81)
+            else:
+                q_loss_sum = ((q - target_Q.unsqueeze(0)).pow(2).sum(dim=0) * mask).sum()
             self.optimizer_value.zero_grad()
             q_loss_sum.backward()
             scale = self._finish_step(self.optimizer_value, value.store, valid_num, guard=True,
@@ -536,17 +544,25 @@ class SACFullLengthRNNEnsembleQ(SAC):
                 if self.discrete_env:                               # expectation over the action distribution (reference redq :85-86)
                     objective = (self._actor_objective(alpha_detach, log_prob, self._q_for_policy(q_pi)) * log_prob.exp()).sum(dim=-1, keepdim=True)
                     log_prob = (log_prob * log_prob.exp()).sum(dim=-1, keepdim=True)          # logged as -entropy (:425)
+                    actor_sum = (objective * mask).sum()
+                    lp_sum = None
+                elif FUSED_A and q_pi.is_cuda and q_pi.dtype == torch.float32 and self.base_algorithm == 'sac' and self.actor_q_reduce in ('min', 'mean'):
+                    # sum mask (alpha logp - red_e Q) and sum mask logp from one pass, gradients from one more (reference redq :37-49)
+                    actor_sum, lp_sum = ops.masked_actor_loss(log_prob, q_pi, mask, self.log_sac_alpha, True, self.actor_q_reduce == 'min')
                 else:
                     objective = self._actor_objective(alpha_detach, log_prob, self._q_for_policy(q_pi))
-                actor_sum = (objective * mask).sum()
+                    actor_sum = (objective * mask).sum()
+                    lp_sum = None
+                if lp_sum is None:
+                    lp_sum = (log_prob.detach() * mask).sum()
                 self.optimizer_policy.zero_grad()
                 actor_sum.backward(inputs=self.policy.parameters())
                 pstore = self.policy.store
                 tune_alpha = not par.no_alpha_auto_tune
                 if tune_alpha:     # d/d log_alpha of -sum(mask * log_alpha * (logp + H)) rides in the second spare slot
-                    pstore.grad[pstore.numel + 1] = -((log_prob.detach() + self.target_entropy) * mask).sum()
+                    pstore.grad[pstore.numel + 1] = -(lp_sum + self.target_entropy * valid_num)
                 scale = self._finish_step(self.optimizer_policy, pstore, valid_num, overlap=lambda: scal.update(
-                    log_prob=(log_prob.detach() * mask).sum() / valid_num, actor_loss=actor_sum.detach() / valid_num))
+                    log_prob=lp_sum / valid_num, actor_loss=actor_sum.detach() / valid_num))
                 pi_grad_norm = self._clip(pstore, self.policy, par.policy_max_gradnorm, par.policy_embedding_max_gradnorm, scale)
                 self.optimizer_policy.step(grad_scale=scale)
                 if tune_alpha:

@@ -10,5 +10,7 @@ class SACFullLengthRNNREDQ(SACFullLengthRNNEnsembleQ):
         # one process: the global numpy stream, draw for draw as the reference; data parallel: a stream shared by all ranks
         return self._subset_stream().permutation(num_ensemble)[:self.parameter.redq_m]
 
+    actor_q_reduce = 'mean'
+
     def _q_for_policy(self, qs):
         return qs.mean(dim=0)

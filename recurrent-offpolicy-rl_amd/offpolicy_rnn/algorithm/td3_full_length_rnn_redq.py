@@ -10,5 +10,7 @@ class TD3FullLengthRNNREDQ(TD3FullLengthRNNEnsembleQ):
     def _select_target_ensemble(self, num_ensemble: int) -> np.ndarray:
         return self._subset_stream().permutation(num_ensemble)[:self.parameter.redq_m]
 
+    actor_q_reduce = 'mean'
+
     def _q_for_policy(self, qs):
         return qs.mean(dim=0)

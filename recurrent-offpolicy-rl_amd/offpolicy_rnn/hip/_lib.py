@@ -53,6 +53,11 @@ SIGNATURES = {
     'resel_tanh_gaussian_bwd': (c_int, [P, P, P, P, P, I, I, S]),
     'resel_sac_target': (c_int, [P, P, I, P, P, P, P, P, F, P, P, P, P, I, I, S]),
     'resel_sac_target_phase': (c_int, [I, P, P, I, P, P, P, P, P, F, P, P, P, P, P, I, I, S]),
+    'resel_masked_loss_workspace_bytes': (c_size_t, []),
+    'resel_q_loss_fwd': (c_int, [P, P, P, P, P, I, I, S]),
+    'resel_q_loss_bwd': (c_int, [P, P, P, P, P, I, I, S]),
+    'resel_actor_loss_fwd': (c_int, [P, P, P, P, P, P, I, I, I, I, S]),
+    'resel_actor_loss_bwd': (c_int, [P, P, P, P, P, P, I, I, I, I, S]),
     'resel_sac_target_local': (c_int, [P, P, I, P, P, P, P, P, F, P, P, P, P, P, I, I, S]),
     'resel_guard_apply_slots': (c_int, [P, I, P, S]),
     'resel_sac_target_workspace_bytes': (c_size_t, [I]),

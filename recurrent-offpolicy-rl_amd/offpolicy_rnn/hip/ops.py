@@ -174,6 +174,9 @@ def selective_scan_fn(u, delta, A, B, C, start, D=None, z=None, delta_bias=None,
 
 
 # ---------------------------------------------------------------------------------------------- fused Mamba mixer
+FOLD_SOFTPLUS = os.environ.get('RESEL_FOLD_SOFTPLUS', '1') != '0'      # A/B switch: 0 = softplus inside the scan kernels (delta_softplus = 1)
+
+
 class MambaInnerFn(torch.autograd.Function):
     """in_proj -> masked causal conv + SiLU -> x_proj -> dt_proj -> selective scan (gate, skip, resets) -> out_proj as ONE
     autograd node (interface counterpart of the reference's `MambaInnerFn`, selective_scan_interface_new.py:169-335, which
@@ -202,7 +205,11 @@ class MambaInnerFn(torch.autograd.Function):
               'causal_conv1d_fwd')
         tag_amax(xc, h_xc)
         x_dbl = mm_nt(xc, xproj_w)                                         # [M, R + 2N] = (delta_r | B | C)
-        dt = mm_nt(x_dbl[:, :R], dt_w)                                      # [M, Di]; bias enters the scan as delta_bias
+        fold = FOLD_SOFTPLUS and _mine(M, Di, R, x_dbl[:, :R], dt_w)
+        if fold:       # delta = softplus(dt_proj(.) + bias) leaves the GEMM epilogue: the scan kernels spend no vector issue on it
+            dt = gemm_f32(x_dbl[:, :R], dt_w, True, True, dt_b, GEMM_SOFTPLUS)
+        else:
+            dt = mm_nt(x_dbl[:, :R], dt_w)                                  # [M, Di]; bias enters the scan as delta_bias
         A = -torch.exp(A_log.float())
         need_grad = any(ctx.needs_input_grad)
         ck = _ws(lib().resel_selective_scan_ckpt_bytes(Bsz, L, Di, N), x.device) if need_grad else None
@@ -212,13 +219,14 @@ class MambaInnerFn(torch.autograd.Function):
         nb = lib().resel_selective_scan_fwd_workspace_bytes(Bsz, L, Di, N, SSCAN_TIME_SEGMENTS)
         h_y, p_y, e_y = _slot_args(track, x.device)
         check(lib().resel_selective_scan_fwd(_p(xc), Di, _p(dt), Di, zptr, 2 * Di, _p(A), bptr, R + 2 * N, cptr, R + 2 * N,
-                                             _p(D), _p(dt_b), _p(startf), _p(y), Di, _p(ck), None, _p(_ws(nb, x.device) if nb else None),
-                                             Bsz, L, Di, N, 1, SSCAN_TIME_SEGMENTS, p_y, e_y, _stream()), 'selective_scan_fwd')
+                                             _p(D), None if fold else _p(dt_b), _p(startf), _p(y), Di, _p(ck), None, _p(_ws(nb, x.device) if nb else None),
+                                             Bsz, L, Di, N, 2 if fold else 1, SSCAN_TIME_SEGMENTS, p_y, e_y, _stream()), 'selective_scan_fwd')
         tag_amax(y, h_y)
         out = mm_nt(y, out_w)
         ctx.handles = (ctx.ax, h_xc, h_y)                                  # saved tensors come back untagged
         ctx.save_for_backward(x2, in_w, cw, conv_b, xproj_w, dt_w, dt_b, A, D, out_w, maskf, startf, xz, xc, x_dbl, dt, y, ck)
         ctx.dims = (Bsz, L, Dm, Di, N, R, K, conv_w.shape)
+        ctx.fold = fold
         return out.view(Bsz, L, -1)
 
     @staticmethod
@@ -247,9 +255,9 @@ class MambaInnerFn(torch.autograd.Function):
         h_ddt, p_ddt, _ = _slot_args(track, dev)                           # (published under the same epoch e_b)
         check(lib().resel_selective_scan_bwd(
             _p(xc), Di, _p(dt), Di, P(xz, Di), 2 * Di, _p(A), P(x_dbl, R), R + 2 * N, P(x_dbl, R + N), R + 2 * N,
-            _p(D), _p(dt_b), _p(startf), _p(dy), Di, _p(ck),
+            _p(D), None if ctx.fold else _p(dt_b), _p(startf), _p(dy), Di, _p(ck),
             _p(dxc), Di, _p(ddt), Di, P(dxz, Di), 2 * Di, P(dx_dbl, R), R + 2 * N, P(dx_dbl, R + N), R + 2 * N,
-            _p(dA), _p(dD), _p(ddt_b), _p(ws), Bsz, L, Di, N, 1, SSCAN_TIME_SEGMENTS, p_dxz, p_ddt, e_b, _stream()), 'selective_scan_bwd')
+            _p(dA), _p(dD), _p(ddt_b), _p(ws), Bsz, L, Di, N, 2 if ctx.fold else 1, SSCAN_TIME_SEGMENTS, p_dxz, p_ddt, e_b, _stream()), 'selective_scan_bwd')
         tag_amax(ddt, h_ddt)
         # [Di, R] with a 66 752-long reduction: hand-written MFMA kernel (the library reaches 7 TFLOP/s on this shape)
         d_dt_w = atb(ddt, x_dbl[:, :R]) if R <= 32 and Di % 4 == 0 and ddt.stride(1) == 1 and ddt.stride(0) % 4 == 0 \
@@ -671,6 +679,74 @@ def sac_target(q, subset, next_logp, log_alpha, reward, done, mask, gamma, guard
     return target.reshape(reward.shape)
 
 
+class MaskedQLossFn(torch.autograd.Function):
+    """sum_m mask[m] sum_e (q[e, m] - y[m])^2 as ONE node (include/resel_hip.h `resel_q_loss_*`)."""
+
+    @staticmethod
+    def forward(ctx, q, y, mask):
+        _need_cuda('q_loss', q, y)
+        E = q.shape[0]
+        q2, y1, m1 = q.float().reshape(E, -1).contiguous(), y.float().reshape(-1).contiguous(), None if mask is None else mask.float().reshape(-1).contiguous()
+        M = y1.numel()
+        out = torch.empty(2, dtype=torch.float32, device=q.device)
+        ws = _ws(lib().resel_masked_loss_workspace_bytes(), q.device)
+        check(lib().resel_q_loss_fwd(_p(q2), _p(y1), _p(m1), _p(out), _p(ws), E, M, _stream()), 'q_loss_fwd')
+        ctx.save_for_backward(q2, y1, m1)
+        ctx.shape = q.shape
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        q2, y1, m1 = ctx.saved_tensors
+        E, M = q2.shape
+        dq = torch.empty_like(q2)
+        check(lib().resel_q_loss_bwd(_p(q2), _p(y1), _p(m1), _p(g.float().reshape(1).contiguous()), _p(dq), E, M, _stream()), 'q_loss_bwd')
+        return dq.view(ctx.shape), None, None
+
+
+def masked_q_loss(q, y, mask):
+    return MaskedQLossFn.apply(q, y, mask)
+
+
+class MaskedActorLossFn(torch.autograd.Function):
+    """(sum_m mask (use_logp alpha logp - red_e q[e]), sum_m mask logp) as ONE node; red = mean (REDQ) or min (ensemble-min); alpha =
+    exp(log_alpha) is a constant of the objective (the entropy coefficient has its own loss).  The second output carries no gradient."""
+
+    @staticmethod
+    def forward(ctx, logp, q, mask, log_alpha, use_logp, reduce_min):
+        _need_cuda('actor_loss', q)
+        E = q.shape[0]
+        q2 = q.float().reshape(E, -1).contiguous()
+        M = q2.shape[1]
+        lp = None if logp is None else logp.float().reshape(-1).contiguous()
+        m1 = None if mask is None else mask.float().reshape(-1).contiguous()
+        la = log_alpha.detach().float().reshape(-1).contiguous()
+        out = torch.empty(2, dtype=torch.float32, device=q.device)
+        ws = _ws(lib().resel_masked_loss_workspace_bytes(), q.device)
+        check(lib().resel_actor_loss_fwd(_p(lp), _p(q2), _p(m1), _p(la), _p(out), _p(ws), E, M, int(bool(use_logp)), int(bool(reduce_min)), _stream()),
+              'actor_loss_fwd')
+        ctx.save_for_backward(q2, m1, la)
+        ctx.cfg = (bool(use_logp), bool(reduce_min), q.shape, None if logp is None else logp.shape)
+        return out                                    # ONE output [2] = (objective sum, sum mask logp): the caller indexes it
+
+    @staticmethod
+    def backward(ctx, g2):
+        q2, m1, la = ctx.saved_tensors
+        g = g2[0:1]                                   # the second entry is a statistic (used detached)
+        use_logp, reduce_min, qshape, lshape = ctx.cfg
+        E, M = q2.shape
+        dq = torch.empty_like(q2)
+        dlp = torch.empty(M, dtype=torch.float32, device=q2.device) if use_logp else None
+        check(lib().resel_actor_loss_bwd(_p(q2), _p(m1), _p(la), _p(g.float().reshape(1).contiguous()), _p(dlp), _p(dq), E, M, int(use_logp),
+                                         int(reduce_min), _stream()), 'actor_loss_bwd')
+        return (None if dlp is None or lshape is None else dlp.view(lshape)), dq.view(qshape), None, None, None, None
+
+
+def masked_actor_loss(logp, q, mask, log_alpha, use_logp=True, reduce_min=False):
+    out = MaskedActorLossFn.apply(logp, q, mask, log_alpha, use_logp, reduce_min)
+    return out[0], out[1].detach()
+
+
 @torch.no_grad()
 def guard_apply_slots(slots, world, guard):
     """slots fp32 [world * 4] (every rank's extrema, delivered by the gradient all-reduce) -> first-call initialisation + running
@@ -681,6 +757,7 @@ def guard_apply_slots(slots, world, guard):
 
 # ---------------------------------------------------------------------------------------------- bias + activation tail
 ACT_IDS = {None: 0, 'linear': 0, 'elu': 1}
+GEMM_SOFTPLUS = 'softplus'           # resel_gemm_f32x only: softplus(product + bias) (epilogue code 3)
 GEMM_ACCUMULATE = 'accumulate'       # resel_gemm_f32 only: C += product (epilogue code 2)
 
 
@@ -987,7 +1064,8 @@ def amax_slot(device):
     """A fresh (handle: int64 view [AMAX_WORDS], epoch) pair for a producer kernel."""
     ar = _AMAX_ARENA.get(device)
     if ar is None:
-        ar = _AMAX_ARENA[device] = [torch.zeros(AMAX_SLOTS * AMAX_WORDS, dtype=torch.int64, device=device), 0]
+        buf = torch.zeros(AMAX_SLOTS * AMAX_WORDS, dtype=torch.int64, device=device)
+        ar = _AMAX_ARENA[device] = [buf, 0, list(buf.view(AMAX_SLOTS, AMAX_WORDS).unbind(0))]     # handle views made once (this sits on the launch path)
     if _AMAX_EPOCH[0] >= 0x7fffffff:                 # epochs exhausted (days of training): start over on zeroed arenas
         _AMAX_EPOCH[0] = 0
         for a in _AMAX_ARENA.values():
@@ -995,7 +1073,7 @@ def amax_slot(device):
     _AMAX_EPOCH[0] += 1
     i = ar[1]
     ar[1] = (i + 1) % AMAX_SLOTS
-    return ar[0][i * AMAX_WORDS:(i + 1) * AMAX_WORDS], _AMAX_EPOCH[0]
+    return ar[2][i], _AMAX_EPOCH[0]
 
 
 def amax_arena_zero(device):
@@ -1118,7 +1196,7 @@ def gemm_f32(A, B, a_kcontig=True, b_kcontig=True, bias=None, act=None, out=None
     # max |C| for whoever multiplies C next (only while mode 2 is the product mode, and only for outputs worth a pass)
     slot, slot_p, epoch = _slot_args(amax_tracking() and act != GEMM_ACCUMULATE and M * N * batch >= (1 << 20), A.device)
     check(L.resel_gemm_f32x(_p(A), A.stride(-2), A.stride(0) if multi else 0, int(a_kcontig), _p(B), B.stride(-2),
-                            B.stride(0) if multi else 0, int(b_kcontig), _p(bias), bs, 2 if act == GEMM_ACCUMULATE else ACT_IDS[act], _p(out), out.stride(-2),
+                            B.stride(0) if multi else 0, int(b_kcontig), _p(bias), bs, 2 if act == GEMM_ACCUMULATE else 3 if act == GEMM_SOFTPLUS else ACT_IDS[act], _p(out), out.stride(-2),
                             out.stride(0) if multi else 0, _p(ws), M, N, K, batch, split, _p(ha) if split == 2 else None,
                             _p(hb) if split == 2 else None, slot_p, epoch, _stream()), 'gemm_f32')
     tag_amax(out, slot)

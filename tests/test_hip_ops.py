@@ -1061,3 +1061,36 @@ def test_linear_act_pads_odd_widths_on_long_passes(ops, K, N, act):
     for nm, a, b_ in zip(('dx', 'dw', 'db'), gr, g_ref):
         assert a.shape == b_.shape
         close(a, b_, rtol=2e-4, atol_scale=5e-5, name=nm)
+
+
+# ------------------------------------------------------------------------------------------ masked losses
+@pytest.mark.parametrize('E,shape', [(8, (5, 37, 1)), (2, (3, 1043, 1)), (1, (2, 9, 1))])
+def test_masked_losses_vs_torch_autograd(ops, E, shape):
+    """`resel_q_loss_*` / `resel_actor_loss_*` (reference sac_full_length_rnn_ensembleQ.py:80-81,105-114, sac_full_length_rnn_redq.py:37-49)
+    against the same sums spelt in torch autograd on the CPU: values at 1e-6 of their scale, gradients element-wise at 1e-6."""
+    g = torch.Generator().manual_seed(E + shape[1])
+    q = torch.randn(E, *shape, generator=g)
+    y = torch.randn(*shape, generator=g)
+    mask = (torch.rand(*shape, generator=g) > 0.3).float()
+    logp = torch.randn(*shape, generator=g)
+    la = torch.tensor([-0.7])
+    qr = q.clone().requires_grad_(True)
+    ref = ((qr - y.unsqueeze(0)).pow(2).sum(dim=0) * mask).sum()
+    (ref * 1.5).backward()
+    qc = q.cuda().requires_grad_(True)
+    got = ops.masked_q_loss(qc, y.cuda(), mask.cuda())
+    (got * 1.5).backward()
+    assert abs(got.item() - ref.item()) <= 1e-5 * abs(ref.item())
+    close(qc.grad, qr.grad, rtol=1e-6, atol_scale=1e-7, name='dq (critic loss)')
+    for reduce_min in (False, True):
+        qr, lr = q.clone().requires_grad_(True), logp.clone().requires_grad_(True)
+        red = qr.min(dim=0).values if reduce_min else qr.mean(dim=0)
+        ref = ((la.exp() * lr - red) * mask).sum()
+        ref.backward()
+        qc, lc = q.cuda().requires_grad_(True), logp.cuda().requires_grad_(True)
+        got, lps = ops.masked_actor_loss(lc, qc, mask.cuda(), la.cuda(), True, reduce_min)
+        got.backward()
+        assert abs(got.item() - ref.item()) <= 1e-5 * max(1.0, abs(ref.item()))
+        assert abs(lps.item() - (logp * mask).sum().item()) <= 1e-5 * max(1.0, (logp * mask).abs().sum().item())
+        close(qc.grad, qr.grad, rtol=1e-6, atol_scale=1e-7, name=f'dq (actor loss, min={reduce_min})')
+        close(lc.grad, lr.grad, rtol=1e-6, atol_scale=1e-7, name='dlogp')

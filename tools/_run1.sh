@@ -1,4 +1,3 @@
-python -m pytest tests -m gpu -q -x 2>&1 | tail -8
-for m in 6 2 6 2; do RESEL_GEMM_SPLIT=$m python bench.py --no-suite --no-cpu-baseline --no-rccl-leg --no-graph-leg --no-strict-leg --steps 10 --warmup 3 2>gpurun_out/err_$m.txt | python -c "import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('split', $m, round(j['ms_per_step'],3), j['kernels']['gemm_f32_kernel'], j['sscan'])" || tail -5 gpurun_out/err_$m.txt; done
-cd /tmp && export TMPDIR=/tmp && RESEL_GEMM_SPLIT=2 timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_f16 -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --no-suite --no-cpu-baseline --no-rccl-leg --no-graph-leg --no-strict-leg --steps 5 --warmup 2 > /dev/null 2>&1
-rm -f $GRAFT_REPO_ROOT/gpurun_out/prof_f16/*kernel_trace.csv $GRAFT_REPO_ROOT/gpurun_out/prof_f16/*.db
+python -m pytest tests/test_trainer_gpu.py -m gpu -q -x -k "graphed" -s 2>&1 | grep -v "^$" | tail -12
+python bench.py --rnn gru --steps 5 --warmup 3 --no-cpu-baseline --no-strict-leg --no-rccl-leg --no-suite > gpurun_out/bgru.out 2>gpurun_out/bgru.err; echo rc=$?; python -c "
+import json; j=json.loads(open('gpurun_out/bgru.out').read().strip().splitlines()[-1]); print('gru', j['ms_per_step'], j['graph_update_leg'])"
