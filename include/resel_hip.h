@@ -71,7 +71,7 @@ int resel_profile_collect(int kernel_id, double* total_us, int* launches);
  *   batches are cut into time segments scanned in parallel: local pass, carry of the segment states, final pass), 1 = never
  *   split, k > 1 = k segments; workspace: resel_selective_scan_fwd_workspace_bytes(...) for the same arguments (NULL if 0).
  */
-#define RESEL_SSCAN_CKPT 16
+#define RESEL_SSCAN_CKPT 8
 /* A/B switch of the one-pass forward kernel: 3 (default) = third edition (one barrier per 16-step chunk, csrc/selective_scan.hip
  * sscan_fwd3_kernel) where it applies (N = 8, 16, 32), 2 = second edition.  Process-global; tests and tools only. */
 int resel_selective_scan_fwd_edition(int edition);

@@ -14,10 +14,10 @@
 //   * block id -> (b, channel tile) is XCD-aware: blocks are dealt round-robin over the 8 XCDs, so the
 //     Di/64 channel tiles of one row b are given ids that differ by multiples of 8 and share one L2 for the
 //     B_t / C_t rows they all read (speed only; any placement is correct).
-// Backward: reverse-time recurrence with recomputation - the forward leaves a state checkpoint every 16 steps
-// (free: the forward is VALU-bound, not HBM-bound), the backward stages one 16-step interval in LDS, replays it from
-// the checkpoint in two 8-step halves whose (state, decay) history lives in registers, and sweeps each half in
-// reverse.  Reductions over channels (dB, dC) use an in-wave multi-value butterfly (DPP) plus per-tile partial
+// Backward: reverse-time recurrence with recomputation - the forward leaves a state checkpoint every 8 steps
+// (straight from the state registers; the forward is VALU-bound, not HBM-bound), the backward stages a 16-step sub-chunk in
+// LDS, replays each of its 8-step halves ONCE from that half's checkpoint with the (state, decay) history in registers, and
+// sweeps the half in reverse.  Reductions over channels (dB, dC) use an in-wave multi-value butterfly (DPP) plus per-tile partial
 // slabs summed by a second kernel: no float atomics, bitwise reproducible.
 // Rates that shape both kernels (tools/micro/valu_rate2.hip, MI355X, issue cycles per wave64 instruction on one SIMD):
 // v_fma/v_mul_f32 2.25 with two waves per SIMD (4.5 alone), v_pk_fma/v_pk_mul_f32 4.5 (two results), v_exp_f32 8.2 -
@@ -44,7 +44,7 @@ constexpr int TILE_C = 64;            // channels per workgroup
 constexpr int CKS = RESEL_SSCAN_CKPT; // checkpoint stride
 constexpr int SC = 16;                // backward sub-chunk = one checkpoint interval staged in LDS
 constexpr int SCH = 8;                // steps of (h, dA) history kept in registers
-static_assert(CKS == SC, "the backward replays one checkpoint interval per sub-chunk");
+static_assert(2 * CKS == SC && CKS == SCH, "a backward sub-chunk is two checkpoint intervals: each 8-step half starts from a stored state");
 
 struct FwdParams {
     const float *u, *delta, *z, *A, *Bm, *Cm, *D, *delta_bias, *start;
@@ -139,6 +139,18 @@ __device__ __forceinline__ f2v pk_mul_hi(f2v p, f2v x) {         // {p.y * x.x, 
     return r;
 }
 
+// a lane's NS states -> its checkpoint slot (NS contiguous floats; 16-byte stores when NS is a multiple of 4)
+template <int NS>
+__device__ __forceinline__ void store_ckpt(float* q, const f2 (&hp)[(NS + 1) / 2]) {
+    if constexpr (NS % 4 == 0) {
+#pragma unroll
+        for (int i = 0; i < NS / 4; ++i) st4(q + 4 * i, make_float4(hp[2 * i].x, hp[2 * i].y, hp[2 * i + 1].x, hp[2 * i + 1].y));
+    } else {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) q[j] = (j & 1) ? hp[j / 2].y : hp[j / 2].x;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Forward.  Ownership: workgroup = (row b, 64 channels[, time segment]), lane = channel, wave = NS-state group, time in
 // TC-step chunks staged through LDS.  What keeps the per-step overhead down (phase stamps / PMC: tools/micro/sscan_lab.hip):
@@ -175,7 +187,6 @@ __global__ __launch_bounds__(NW * 64) void sscan_fwd2_kernel(FwdParams p) {
     __shared__ __attribute__((aligned(16))) float s_y[MODE == 1 ? 1 : NW][TC][TILE_C];
     __shared__ __attribute__((aligned(16))) float s_B[TC][N];
     __shared__ __attribute__((aligned(16))) float s_C[MODE == 1 ? 1 : TC][N];
-    __shared__ __attribute__((aligned(16))) float s_ck[MODE == 1 ? 1 : TC / CKS][N][TILE_C];   // the chunk's checkpoints, stored with the output tile
 
     int b, dt;
     if (!decode_block(blockIdx.x, p.nd, p.B, b, dt)) return;
@@ -278,19 +289,20 @@ __global__ __launch_bounds__(NW * 64) void sscan_fwd2_kernel(FwdParams p) {
     retire_prefetch();
     // Data registers of the output-phase stores stay LIVE until the end of the next scan phase: hipcc guards the first
     // overwrite of a store's data register with s_waitcnt vmcnt - placed there, the stores have long completed.
-    constexpr int PER_CK = (TC / CKS) * ((N * 16 + NT - 1) / NT);
-    float4 y_keep[PER_T], ck_keep[PER_CK];
+    float4 y_keep[PER_T];
     float omax = 0.f;                                // max |out| of this thread's stores
 #pragma unroll
     for (int i = 0; i < PER_T; ++i) y_keep[i] = zero4;
-#pragma unroll
-    for (int i = 0; i < PER_CK; ++i) ck_keep[i] = zero4;
     auto release_store_data = [&]() {
 #pragma unroll
         for (int i = 0; i < PER_T; ++i) asm volatile("" :: "v"(y_keep[i].x), "v"(y_keep[i].y), "v"(y_keep[i].z), "v"(y_keep[i].w));
-#pragma unroll
-        for (int i = 0; i < PER_CK; ++i) asm volatile("" :: "v"(ck_keep[i].x), "v"(ck_keep[i].y), "v"(ck_keep[i].z), "v"(ck_keep[i].w));
     };
+    // checkpoints (the state after every CKS = 8 steps, so that each 8-step half of a backward sub-chunk starts from a stored state
+    // instead of a replay): one dword per lane and state straight from the state registers - a wave's row of a state is 256
+    // contiguous bytes, and gfx950 needs no wait between a store and the next write of its data register
+    // layout [row][checkpoint][wave][channel][NS states]: a lane's NS states are contiguous (two 16-byte stores at NS = 8, the
+    // backward fetches them with two LDS-DMA pieces), a wave's store is one contiguous 64 * 4 NS byte run
+    float* ck_row = (MODE != 1 && p.ckpt != nullptr && d_ok) ? p.ckpt + ((((int64_t)b * p.nck + t_begin / CKS) * NW + w) * p.Di + d) * NS : nullptr;
 #ifdef SSCAN_STAMP
     unsigned long long st_stage = 0, st_b1 = 0, st_scan = 0, st_b2 = 0, st_out = 0, st_last = 0, st_dummy = 0;
     const unsigned long long st_r0 = __builtin_amdgcn_s_memrealtime();
@@ -340,7 +352,6 @@ __global__ __launch_bounds__(NW * 64) void sscan_fwd2_kernel(FwdParams p) {
         f2v Pr[TC];
 #pragma unroll
         for (int t = 0; t < TC; ++t) Pr[t] = *reinterpret_cast<const f2v*>(&s_p[t][lane][0]);
-        const bool ck_on = p.ckpt != nullptr;
         f2 Bq[2][NP], Cq[2][NP];                      // operand rows one step ahead of their use (two register sets)
         lds_coef2<NS>(&s_B[0][w * NS], Bq[0]);
         if (MODE != 1) lds_coef2<NS>(&s_C[0][w * NS], Cq[0]);
@@ -365,9 +376,10 @@ __global__ __launch_bounds__(NW * 64) void sscan_fwd2_kernel(FwdParams p) {
                 sdl += Pt.x;
             } else {
                 s_y[w][t][lane] = yacc.x + yacc.y;
-                if ((t + 1) % CKS == 0 && ck_on) {                           // c0 is a multiple of TC, TC of CKS
-#pragma unroll
-                    for (int j = 0; j < NS; ++j) s_ck[t / CKS][w * NS + j][lane] = (j & 1) ? hp[j / 2].y : hp[j / 2].x;
+                if ((t + 1) % CKS == 0) {                                    // c0 is a multiple of TC, TC of CKS
+                    const int tabs = c0 + t + 1;                             // the state after `tabs` steps = checkpoint tabs / CKS - 1
+                    if (ck_row != nullptr && tabs < p.L && tabs <= t_end) store_ckpt<NS>(ck_row, hp);
+                    if (ck_row != nullptr) ck_row += (int64_t)N * p.Di;
                 }
             }
         }
@@ -401,22 +413,6 @@ __global__ __launch_bounds__(NW * 64) void sscan_fwd2_kernel(FwdParams p) {
                 y_keep[i] = y;
                 omax = amax4(omax, y);
                 st4(p.out + (tok0 + t) * p.ld_out + d0 + tc4, y_keep[i]);
-            }
-        }
-        if (ck_on) {                                 // checkpoints of this chunk: [N][64] rows of 256 B each, float4 per thread
-#pragma unroll
-            for (int e = 0; e < TC / CKS; ++e) {
-                const int tabs = c0 + (e + 1) * CKS;
-                float* dst = p.ckpt + ((int64_t)b * p.nck + (tabs / CKS - 1)) * N * p.Di + d0;
-#pragma unroll
-                for (int q = 0; q < (N * 16 + NT - 1) / NT; ++q) {
-                    const int it = tid + q * NT;
-                    const int n = it >> 4, c4 = (it & 15) * 4;
-                    if (tabs < p.L && tabs <= t_end && it < N * 16 && d0 + c4 < p.Di) {
-                        ck_keep[e * ((N * 16 + NT - 1) / NT) + q] = ld4(&s_ck[e][n][c4]);
-                        st4(dst + (int64_t)n * p.Di + c4, ck_keep[e * ((N * 16 + NT - 1) / NT) + q]);
-                    }
-                }
             }
         }
         STAMP(st_out, st_last);
@@ -474,7 +470,7 @@ __global__ __launch_bounds__(2 * NW * 64) void sscan_fwd3_kernel(FwdParams p) {
     constexpr int NT = 2 * NW * 64;
     constexpr int N = NS * NW;
     constexpr int NP = NS / 2;
-    static_assert(NT == 512 && NS % 2 == 0 && TC == CKS && TC * N / 4 <= 128, "tile passes: one float4 per thread and tile");
+    static_assert(NT == 512 && NS % 2 == 0 && TC == 2 * CKS && TC * N / 4 <= 128, "tile passes: one float4 per thread and tile");
     __shared__ __attribute__((aligned(16))) float s_p[2][TC][CW][2];           // {softplus(delta + bias) (+inf at a reset), that * u}
     __shared__ __attribute__((aligned(16))) float s_g[2][TC][CW][2];           // {silu(z) (1 without a gate), D * u}
     __shared__ __attribute__((aligned(16))) float s_y[2][NW][TC][CW];          // per-wave partial sums over its states
@@ -597,6 +593,7 @@ __global__ __launch_bounds__(2 * NW * 64) void sscan_fwd3_kernel(FwdParams p) {
         lds_coef2<NS>(&s_B[buf][t][w * NS], Bq[t & 1]);
         lds_coef2<NS>(&s_C[buf][t][w * NS], Cq[t & 1]);
     };
+    float* ck_mid = nullptr;                        // where the state after the chunk's first CKS steps goes (set per chunk; nullptr: not stored)
     auto scan_steps = [&](int buf, auto T0c, auto T1c) {
         constexpr int T0 = decltype(T0c)::value, T1 = decltype(T1c)::value;
 #pragma unroll
@@ -615,6 +612,7 @@ __global__ __launch_bounds__(2 * NW * 64) void sscan_fwd3_kernel(FwdParams p) {
                 yacc = k == 0 ? Cq[t & 1][k] * hp[k] : __builtin_elementwise_fma(Cq[t & 1][k], hp[k], yacc);
             }
             s_y[buf][w][t][cl] = yacc.x + yacc.y;
+            if (t + 1 == CKS && ck_mid != nullptr) store_ckpt<NS>(ck_mid, hp);   // mid-chunk checkpoint, straight from the state registers
         }
     };
     using I0 = std::integral_constant<int, 0>;
@@ -627,9 +625,10 @@ __global__ __launch_bounds__(2 * NW * 64) void sscan_fwd3_kernel(FwdParams p) {
     issue_loads(TC);
     __syncthreads();
     const bool ck_on = p.ckpt != nullptr;
-    float* ck_ptr = p.ckpt + ((int64_t)b * p.nck * N + w * NS) * p.Di + d;     // checkpoint 0, state w * NS, this lane's channel
+    float* ck_ptr = p.ckpt + (((int64_t)b * p.nck * NW + w) * p.Di + d) * NS;   // checkpoint 0, this wave's state group, this lane's channel
     for (int i = 0; i < nchunk; ++i) {
         const int c0 = i * TC, buf = i & 1;
+        ck_mid = (ck_on && c0 + CKS < L && d_ok) ? ck_ptr + (int64_t)(2 * i) * N * p.Di : nullptr;     // checkpoint 2 i: the state after c0 + CKS steps
         scan_fetch(buf, 0);
         if (half == 0) {                            // tile passes around the scan
             if (i > 0) output(c0 - TC, buf ^ 1);
@@ -641,10 +640,8 @@ __global__ __launch_bounds__(2 * NW * 64) void sscan_fwd3_kernel(FwdParams p) {
             stage(c0 + TC, buf ^ 1);
             scan_steps(buf, IH{}, I1{});
         }
-        if (ck_on && c0 + TC < L && d_ok) {         // the state after step c0 + TC - 1 is checkpoint c0 / TC
-            float* q = ck_ptr + (int64_t)i * N * p.Di;
-#pragma unroll
-            for (int j = 0; j < NS; ++j) q[(int64_t)j * p.Di] = (j & 1) ? hp[j / 2].y : hp[j / 2].x;
+        if (ck_on && c0 + TC < L && d_ok) {         // the state after step c0 + TC - 1 is checkpoint 2 i + 1
+            store_ckpt<NS>(ck_ptr + (int64_t)(2 * i + 1) * N * p.Di, hp);
         }
         issue_loads(c0 + 2 * TC);                   // chunk i + 2: a whole iteration ahead of its staging
         __syncthreads();
@@ -898,30 +895,49 @@ __global__ __launch_bounds__(NW * 64) void sscan_bwd_kernel(BwdParams p) {
         }
         if (p.start && tid < SC && ts + tid < p.L) glds4(p.start + tok0 + ts + tid, &s_st[buf][0]);   // wave 0, lanes < SC
     };
-    // state at the start of sub-chunk sc: checkpoint sc-1 (written by the forward after step sc*SC).  Each wave fetches
-    // and later reads only its own NS rows of s_h0.
-    auto issue_h0 = [&](int sc) {
-        if (sc > 0 && d_ok) {
+    // Checkpoint c holds the state after (c + 1) * CKS steps.  A sub-chunk (SC = 2 CKS steps) is swept in two halves, each starting
+    // from a stored state: the first half from checkpoint 2 sc - 1 (sc = 0: the zero state), the second half from checkpoint 2 sc.
+    // Each wave fetches (LDS-DMA) and later reads only its own NS rows of s_h0, so the one buffer is refilled as soon as the wave has
+    // its rows in registers: the second half's state arrives during the previous sub-chunk's first half, the first half's state
+    // during this sub-chunk's second half.
+    float* const s_h0w = &s_h0[0][0] + w * NS * TILE_C;                       // this wave's NS * 64 floats of s_h0
+    auto issue_ck = [&](int c) {
+        if (c >= 0 && d_ok) {
+            const float* src = p.ckpt + ((((int64_t)b * p.nck + c) * NW + w) * p.Di + d) * NS;   // this lane's NS contiguous states
+            if constexpr (NS % 4 == 0) {
 #pragma unroll
-            for (int j = 0; j < NS; ++j)
-                glds4(p.ckpt + (((int64_t)b * p.nck + (sc - 1)) * N + w * NS + j) * p.Di + d, &s_h0[w * NS + j][0]);
+                for (int i = 0; i < NS / 4; ++i) glds16(src + 4 * i, s_h0w + i * 4 * TILE_C);      // LDS image [piece][lane][4]
+            } else {
+#pragma unroll
+                for (int j = 0; j < NS; ++j) glds4(src + j, s_h0w + j * TILE_C);                   // LDS image [state][lane]
+            }
         }
     };
-    auto read_h0 = [&](int sc, f2 (&h)[NP]) {
+    auto read_ck = [&](bool valid, f2 (&h)[NP]) {
+        if constexpr (NS % 4 == 0) {
 #pragma unroll
-        for (int k = 0; k < NP; ++k) {
-            float a[2] = {0.f, 0.f};
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int j = 2 * k + e;
-                if (sc > 0 && j < NS) a[e] = s_h0[w * NS + j][lane];
+            for (int i = 0; i < NS / 4; ++i) {
+                const float4 v = valid ? ld4(s_h0w + (i * TILE_C + lane) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                h[2 * i] = f2{v.x, v.y};
+                h[2 * i + 1] = f2{v.z, v.w};
             }
-            h[k] = f2{a[0], a[1]};
+        } else {
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                float a[2] = {0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int j = 2 * k + e;
+                    if (valid && j < NS) a[e] = s_h0w[j * TILE_C + lane];
+                }
+                h[k] = f2{a[0], a[1]};
+            }
         }
     };
     __syncthreads();                                   // the clears above precede the first DMA
     stage_issue(nsc - 1);
-    issue_h0(nsc - 1);
+    // the state the LAST sub-chunk needs first: its second half's (checkpoint 2 sc) - or, on a short tail without a second half, its own start
+    issue_ck(min(SC, p.L - (nsc - 1) * SC) > SCH ? 2 * (nsc - 1) : 2 * (nsc - 1) - 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // later iterations find their DMA retired by barrier_vm (C) / (E)
 
     for (int sc = nsc - 1; sc >= sc_begin; --sc) {
@@ -954,9 +970,9 @@ __global__ __launch_bounds__(NW * 64) void sscan_bwd_kernel(BwdParams p) {
         if (sc > sc_begin) stage_issue(sc - 1);            // in flight during the whole replay / reverse phase
 
         // ---------------- replay + reverse, in two halves of SCH steps (later half first) ----------------
-        // The (h, dA) history of SCH = 8 steps x NS states lives in registers.  The second half starts from the state
-        // after step SCH-1, obtained by a plain replay of the first half (no history kept): the first half is thus
-        // replayed twice, which costs ~15 % of a half's work and lets a lane carry twice the states.
+        // The (h, dA) history of SCH = 8 steps x NS states lives in registers.  Each half starts from a STORED state (the forward
+        // leaves one every CKS = 8 steps; until round 4 it left one every 16 and the second half's start was obtained by
+        // replaying the first half without history - 8 exp + 12 packed instructions per step and wave, executed twice).
         // Operand sets are fetched from LDS one step ahead of their use (the LDS round trip would otherwise sit at the
         // head of every step of a wave that has only one partner on its SIMD): the replay keeps two sets in flight, the
         // reverse sweep refills its single set between a step's arithmetic and its channel reduction, which no longer
@@ -978,21 +994,6 @@ __global__ __launch_bounds__(NW * 64) void sscan_bwd_kernel(BwdParams p) {
                 dAo[k].x = fast_exp2(arg.x);
                 dAo[k].y = fast_exp2(arg.y);
                 h[k] = __builtin_elementwise_fma(dAo[k], h[k], du2 * o.Bq[k]);
-            }
-        };
-        // plain replay of steps [0, SCH) (no history)
-        auto replay_plain = [&](f2 (&h)[NP]) {
-            RepOps o0, o1;
-            f2 scratch[NP];
-            fetch_rep(0, o0);
-#pragma unroll
-            for (int i = 0; i < SCH; i += 2) {
-                fetch_rep(i + 1, o1);
-                __builtin_amdgcn_sched_barrier(0);
-                replay_step(o0, h, scratch);
-                fetch_rep(min(i + 2, SC - 1), o0);
-                __builtin_amdgcn_sched_barrier(0);
-                replay_step(o1, h, scratch);
             }
         };
         struct RevOps { f2 Bq[NP], Cq[NP]; float dl, dy, u; };
@@ -1116,8 +1117,9 @@ __global__ __launch_bounds__(NW * 64) void sscan_bwd_kernel(BwdParams p) {
         };
         if (sl > SCH) {
             f2 hm[NP];
-            read_h0(sc, hm);
-            replay_plain(hm);
+            read_ck(true, hm);                             // checkpoint 2 sc: the state after the first half's steps
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // rows in registers: the slots take the first half's start state
+            issue_ck(2 * sc - 1);
             half(SCH, sl - SCH, hm);
             // (C) the tile DMA of the next sub-chunk was issued before this half's sl - SCH partial-slab stores
             if (sl == SC) barrier_vm<SCH>(); else barrier_vm<0>();
@@ -1126,9 +1128,9 @@ __global__ __launch_bounds__(NW * 64) void sscan_bwd_kernel(BwdParams p) {
         }
         {
             f2 h0[NP];
-            read_h0(sc, h0);
+            read_ck(sc > 0, h0);                           // checkpoint 2 sc - 1 (retired by (C); a short tail fetched it in the prologue)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the checkpoint rows are in registers: their LDS slots may be refilled
-            if (sc > sc_begin) issue_h0(sc - 1);
+            if (sc > sc_begin) issue_ck(2 * (sc - 1));     // the next sub-chunk (always a whole one) starts with its second half
             half(0, min(sl, SCH), h0);
         }
         // (E) retires the checkpoint DMA (and, on a short tail sub-chunk that skipped (C), the tile DMA)

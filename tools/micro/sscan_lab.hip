@@ -55,12 +55,12 @@ int main(int argc, char** argv) {
     { const size_t nb = resel_selective_scan_fwd_workspace_bytes(B, L, Di, N, tseg); if (nb) CK(hipMalloc(&d_fws, nb)); printf("forward time segments workspace: %zu bytes\n", nb); }
     auto fwd = [&]() {
         return resel_selective_scan_fwd(d_xz, ldx, d_delta, Di, d_xz + Di, ldx, d_A, d_xdbl + R, ldb, d_xdbl + R + N, ldb, d_D, d_db, d_start,
-                                        d_out, Di, d_ckpt, nullptr, d_fws, B, L, Di, N, 1, tseg, s);
+                                        d_out, Di, d_ckpt, nullptr, d_fws, B, L, Di, N, 1, tseg, nullptr, 0u, s);
     };
     auto bwd = [&]() {
         return resel_selective_scan_bwd(d_xz, ldx, d_delta, Di, d_xz + Di, ldx, d_A, d_xdbl + R, ldb, d_xdbl + R + N, ldb, d_D, d_db, d_start,
                                         d_dout, Di, d_ckpt, d_dxz, ldx, d_ddelta, Di, d_dxz + Di, ldx, d_dxdbl + R, ldb, d_dxdbl + R + N, ldb,
-                                        d_dA, d_dD, d_ddb, d_ws, B, L, Di, N, 1, tseg, s);
+                                        d_dA, d_dD, d_ddb, d_ws, B, L, Di, N, 1, tseg, nullptr, nullptr, 0u, s);
     };
 #ifdef SSCAN_STAMP
     const size_t nst = (size_t)((B + 7) / 8 * 8) * ((Di + 63) / 64) * 8 * 8;
