@@ -420,8 +420,9 @@ def main():
                     help='strong scaling: a FIXED global batch of this many trajectories per update, split evenly over the --gpus ranks '
                          '(BASELINE configs[3]: 512)')
     ap.add_argument('--horizon', type=int, default=1024)
-    ap.add_argument('--graph-update', action='store_true', help='replay the whole update as one hipGraph (fixed batch shape; small per-GPU batches)')
-    ap.add_argument('--no-graph-leg', action='store_true', help='skip the extra updates that time the hipGraph replay of the update')
+    ap.add_argument('--graph-update', action='store_true', help='(default where the trainer allows it) replay the whole update as one hipGraph')
+    ap.add_argument('--no-graph-update', action='store_true', help='time the eagerly launched update even where the hipGraph replay is available')
+    ap.add_argument('--no-graph-leg', action='store_true', help='skip the extra updates that time the OTHER launch form (eager beside a graph headline and vice versa)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-strict-leg', action='store_true', help='skip the 4 extra updates that time the fp32-MFMA product mode')
     ap.add_argument('--envs', type=int, default=1, help='rollout mode: also time one graph replay over this many environments')
@@ -465,16 +466,22 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # The update is launched the way the product launches it (algorithm/sac.py `train`): ONE hipGraph replay per update where the
+    # trainer allows it (one process, device-resident replay ring, no host-side clipping: GraphedUpdate.refusal), eagerly otherwise.
+    from offpolicy_rnn.algorithm.graphed_update import GraphedUpdate
+    why_eager = 'requested (--no-graph-update)' if args.no_graph_update else GraphedUpdate.refusal(alg)
+    args.graph_update = why_eager is None
     step_fn = alg.train_one_batch
+    gu = None
     if args.graph_update:
-        from offpolicy_rnn.algorithm.graphed_update import GraphedUpdate
-        step_fn = GraphedUpdate(alg).step
-    for _ in range(args.warmup):
+        gu = GraphedUpdate(alg, warmup=1)
+        step_fn = gu.step
+    for _ in range(args.warmup + (3 if args.graph_update else 0)):     # graph: + the eager warm-up update, the shape's first visit, the recording
         step_fn()
         alg.grad_num += 1
-    ops.profile_enable(not args.graph_update)          # per-dispatch events are not capturable                            # HIP event pair bound to each scan dispatch, timed region only
     ops.GEMM_FLOPS[0] = 0.0
     alg.grad_sync.reset_counters()
+    ops.profile_enable(not args.graph_update)          # eager: a HIP event pair bound to each sequence-kernel / GEMM dispatch of the timed region
     sync()
     t0 = time.perf_counter()
     trained = 0
@@ -485,6 +492,23 @@ def main():
     dt = time.perf_counter() - t0
     coll = {k: v / args.steps for k, v in alg.grad_sync.calls.items() if k != 'broadcast'}
     coll_bytes = {k: v / args.steps for k, v in alg.grad_sync.bytes.items() if k != 'broadcast'}
+    eager_ms = None
+    if args.graph_update:
+        # Events cannot be bound to dispatches inside a graph replay: the per-kernel times of the roofline objects come from the SAME
+        # update launched eagerly right behind the timed region (same kernels, same shapes, same stream), which also gives the
+        # eager time per update reported beside the headline.
+        n_prof = max(3, min(args.steps, 5))
+        alg.train_one_batch()
+        alg.grad_num += 1
+        ops.GEMM_FLOPS[0] = 0.0
+        ops.profile_enable(True)
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(n_prof):
+            alg.train_one_batch()
+            alg.grad_num += 1
+        sync()
+        eager_ms = 1e3 * (time.perf_counter() - t1) / n_prof
     prof = ops.profile_collect()
     ops.profile_enable(False)
     gemm_flops = ops.GEMM_FLOPS[0]
@@ -503,32 +527,18 @@ def main():
         sync()
         ops.GEMM_SPLIT = keep
         return 1e3 * (time.perf_counter() - t1) / 3
-    if gemm_mode != 0 and not args.no_strict_leg and not args.graph_update:
+    if gemm_mode != 0 and not args.no_strict_leg:
         # the same update with the GEMM products formed by the fp32 MFMA instruction (reported beside the headline, never as it)
         strict_ms = leg_with_products(0)
-    if gemm_mode != 3 and not args.no_strict_leg and not args.graph_update:
+    if gemm_mode != 3 and not args.no_strict_leg:
         # ... and with two bf16 planes per operand ("bf16x3" = torch.set_float32_matmul_precision('high'), SURVEY 8(d)'s 'TF32-class'
         # option): NOT the reference's precision setting, so never the headline either
         high_ms = leg_with_products(3)
     graph_leg = None
-    if world == 1 and not alg.grad_sync.active and not args.graph_update and not args.no_graph_leg:
-        # the same update replayed from ONE hipGraph (algorithm/graphed_update.py), reported beside the headline: what the launch
-        # sequence costs on the host side of this box (decisive at small per-GPU batches, a few percent at 64 rows)
-        try:
-            from offpolicy_rnn.algorithm.graphed_update import GraphedUpdate
-            gu = GraphedUpdate(alg, warmup=1)
-            for _ in range(4):                       # one eager warm-up update, the shape's first visit (eager), the recording, one replay
-                gu.step()
-                alg.grad_num += 1
-            sync()
-            t1 = time.perf_counter()
-            for _ in range(10):
-                gu.step()
-                alg.grad_num += 1
-            sync()
-            graph_leg = {'ms_per_step': 1e3 * (time.perf_counter() - t1) / 10, 'graphs': len(gu.graphs), 'eager_fallbacks': gu.eager_fallbacks}
-        except Exception as e:                       # refused configurations (cgpt, gru, clipping ...) say why
-            graph_leg = {'not_captured': str(e)[:160]}
+    if args.graph_update:
+        graph_leg = {'ms_per_step': 1e3 * dt / args.steps, 'graphs': len(gu.graphs), 'eager_fallbacks': gu.eager_fallbacks, 'is_headline': True}
+    elif why_eager is not None:
+        graph_leg = {'not_captured': str(why_eager)[:160]}
     stat = torch.tensor([dt, float(trained)], dtype=torch.float64, device='cuda')
     if world > 1:
         tmax = stat[:1].clone()
@@ -550,7 +560,8 @@ def main():
                    'row_length': Tp, 'obs': OBS, 'act': ACT, 'critic': 'efc-8',
                    'global_rows': Bsz * world, 'parallelism': f'dp{world}'},
         # collectives the timed updates ISSUED (counted where they are called, parallel/data_parallel.py), per update
-        'graph_update': bool(args.graph_update), 'graph_update_leg': graph_leg,
+        'launch': 'one hipGraph replay per update (algorithm/graphed_update.py)' if args.graph_update else f'eager ({why_eager})',
+        'graph_update': bool(args.graph_update), 'graph_update_leg': graph_leg, 'eager_ms_per_step': eager_ms if args.graph_update else 1e3 * dt / args.steps,
         'rccl_ranks': alg.grad_sync.world if alg.grad_sync.active else 0, 'backend': alg.grad_sync.backend,
         'collectives_per_step': coll, 'collective_bytes_per_step': coll_bytes, 'parameter_broadcasts': bcast,
     }
@@ -584,6 +595,9 @@ def main():
         ranked.append((t * 1e6, o))
     ranked.sort(key=lambda x: -x[0])
     lines = [o for _, o in ranked]
+    for o in lines:
+        o['measured_over'] = ('HIP event pair per dispatch, the same update launched eagerly right behind the timed graph replays'
+                              if args.graph_update else 'HIP event pair per dispatch, timed region')
     if lines:
         out['roofline'] = lines[0]                       # the hand-written kernel with the largest total time in the timed region
     # BASELINE.json's second metric ("selective_scan HBM GB/s"): algorithmic GB/s and fraction of the 8 TB/s roof of both scan

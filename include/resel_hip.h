@@ -216,9 +216,10 @@ int resel_dropout(const float* x, float* y, int64_t n, float p_drop, uint64_t se
 /* y = dropout(gelu(x)) (erf form) in one pass and its backward dx = dy * keep / (1 - p) * gelu'(x) from the pre-activation x; same
  * counter-keyed mask as resel_dropout (p_drop = 0: plain GELU).  FFN hidden of the cgpt block (reference
  * models/flash_attention/TransformerFlashAttention.py:46-53: nn.GELU() followed by nn.Dropout). */
-int resel_gelu_dropout_fwd(const float* x, float* y, int64_t n, float p_drop, uint64_t seed, uint64_t offset, resel_stream_t stream);
+int resel_gelu_dropout_fwd(const float* x, float* y, int64_t n, float p_drop, uint64_t seed, uint64_t offset,
+                           void* amax_y, unsigned amax_epoch, resel_stream_t stream);
 int resel_gelu_dropout_bwd(const float* x, const float* dy, float* dx, int64_t n, float p_drop, uint64_t seed, uint64_t offset,
-                           resel_stream_t stream);
+                           void* amax_dx, unsigned amax_epoch, resel_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * SAC / TD3 head, target and loss arithmetic + optimizer tail (the "fusions" of SURVEY.md section 8 row a16-a18).
@@ -367,7 +368,8 @@ int resel_gemm_f32x(const float* A, int64_t lda, int64_t strideA, int a_kcontig,
  * are never zeroed, give every tensor a fresh epoch - and kernels that fill parts of one tensor may share handle and epoch.  Readers
  * (amax_a / amax_b above) take the newest epoch among the eight words and the largest magnitude carrying it.  Publishers:
  * resel_amax (a pre-pass), resel_gemm_f32x (amax_c: the values stored to C), resel_bias_act_bwd (gy), resel_ensemble_head_bwd (gy), resel_add_layernorm_fwd
- * (y), resel_selective_scan_fwd (out), resel_selective_scan_bwd (dz, ddelta), resel_causal_conv1d_fwd (y), resel_causal_conv1d_bwd (dx). */
+ * (y: the analytic bound sqrt(C) max|w| + max|b|, published by one wave), resel_selective_scan_fwd (out), resel_selective_scan_bwd (dz, ddelta),
+ * resel_causal_conv1d_fwd (y), resel_causal_conv1d_bwd (dx), resel_gelu_dropout_fwd / _bwd (y / dx). */
 /* Magnitude pre-pass: max |x| over a [batch][rows][cols] box (row stride ld, batch stride `stride`, cols % 4 == 0) written into the
  * magnitude handle `out` with epoch `epoch` (see "magnitude handles" above); one HBM-bound pass, no host synchronisation.
  * `state`: resel_amax_state_bytes() bytes, zero before its first use (left zeroed by every call); calls that share a state buffer

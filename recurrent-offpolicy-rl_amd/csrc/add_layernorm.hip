@@ -19,9 +19,9 @@ __global__ __launch_bounds__(WAVES * 64) void ln_fwd_kernel(const float* __restr
                                                             float* __restrict__ y, float* __restrict__ res_out,
                                                             float* __restrict__ stats, int M, int C, float eps, int rms, AmaxOut amax) {
     const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * WAVES + (threadIdx.x >> 6);
+    if (row >= M) return;
     const int c4 = C / 4;
-    float ymax = 0.f;                                // max |y| over the rows of this wave (one publication per wave, at the end)
-    for (int row = blockIdx.x * WAVES + (threadIdx.x >> 6); row < M; row += gridDim.x * WAVES) {
     const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * C);
     const float4* rr = residual ? reinterpret_cast<const float4*>(residual + (int64_t)row * C) : nullptr;
     float4 v[VPL];
@@ -49,6 +49,7 @@ __global__ __launch_bounds__(WAVES * 64) void ln_fwd_kernel(const float* __restr
     }
     const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
     if (stats && lane == 0) { stats[2 * (int64_t)row] = mean; stats[2 * (int64_t)row + 1] = rstd; }
+    float wmax = 0.f;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
         const int c = i * 64 + lane;
@@ -59,11 +60,25 @@ __global__ __launch_bounds__(WAVES * 64) void ln_fwd_kernel(const float* __restr
             o.z = (v[i].z - mean) * rstd * wv.z; o.w = (v[i].w - mean) * rstd * wv.w;
             if (b) { const float4 bb = reinterpret_cast<const float4*>(b)[c]; o.x += bb.x; o.y += bb.y; o.z += bb.z; o.w += bb.w; }
             reinterpret_cast<float4*>(y + (int64_t)row * C)[c] = o;
-            ymax = amax4(ymax, o);
+            wmax = amax4(wmax, wv);
         }
     }
+    // Magnitude of the output for the projection that reads it (GEMM mode 2): a normalised row obeys |x_i - mean| * rstd <= sqrt(C)
+    // (LayerNorm and RMSNorm alike), so sqrt(C) max|w| + max|b| bounds every |y| - no per-row work, ONE wave publishes it.  The bound
+    // is ~4x the typical maximum at C = 256: two of the 29 bits of element range of the scaled operand (include/resel_hip.h).
+    if (amax.slot != nullptr && row == 0) {
+        float bmax = 0.f;
+        if (b) {
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                const int c = i * 64 + lane;
+                if (c < c4) bmax = amax4(bmax, reinterpret_cast<const float4*>(b)[c]);
+            }
+        }
+#pragma unroll
+        for (int sh = 32; sh > 0; sh >>= 1) { wmax = fmaxf(wmax, __shfl_xor(wmax, sh, 64)); bmax = fmaxf(bmax, __shfl_xor(bmax, sh, 64)); }
+        amax_publish_wave(sqrtf((float)C) * wmax + bmax, amax);
     }
-    amax_publish_wave(ymax, amax);
 }
 
 template <int VPL>
@@ -149,9 +164,7 @@ extern "C" int resel_add_layernorm_fwd(const float* x, const float* residual, co
         (res_out && !aligned16(res_out)))
         return RESEL_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    // with a magnitude handle: persistent waves (grid-stride over rows), so that 8 192 waves publish instead of one per row
-    const int nblk = (M + WAVES - 1) / WAVES;
-    dim3 grid(amax_y ? std::min(nblk, 2048) : nblk), blk(WAVES * 64);
+    dim3 grid((M + WAVES - 1) / WAVES), blk(WAVES * 64);
     if (C <= 256) hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, blk, 0, s, x, residual, w, b, y, res_out, stats, M, C, eps, rms, ao);
     else if (C <= 512) hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, blk, 0, s, x, residual, w, b, y, res_out, stats, M, C, eps, rms, ao);
     else if (C <= 1024) hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, blk, 0, s, x, residual, w, b, y, res_out, stats, M, C, eps, rms, ao);

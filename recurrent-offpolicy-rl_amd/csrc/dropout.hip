@@ -52,9 +52,10 @@ __device__ __forceinline__ float gelu_or_grad(float x, float g) {
 }
 template <bool BWD>
 __global__ __launch_bounds__(256) void gelu_dropout_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ out,
-                                                           int64_t n, uint32_t thr16, float rp, uint64_t seed, uint64_t offset) {
+                                                           int64_t n, uint32_t thr16, float rp, uint64_t seed, uint64_t offset, AmaxOut amax) {
     const uint32_t key = stream_key(seed, offset);
     const int64_t n4 = n >> 2;
+    float omax = 0.f;                                // max |out| of this thread's stores (the fc2 / fc1-gradient GEMMs scale their operand with it)
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const uint32_t w0 = mix32(((uint32_t)(2 * i) * 0x9E3779B1u) ^ key), w1 = mix32(((uint32_t)(2 * i + 1) * 0x9E3779B1u) ^ key);
         const float4 v = ld4(x + 4 * i);
@@ -66,36 +67,41 @@ __global__ __launch_bounds__(256) void gelu_dropout_kernel(const float* __restri
         o.z = (w1 & 0xffffu) < thr16 ? gelu_or_grad<BWD>(v.z, g.z) * rp : 0.f;
         o.w = (w1 >> 16) < thr16 ? gelu_or_grad<BWD>(v.w, g.w) * rp : 0.f;
         st4(out + 4 * i, o);
+        omax = amax4(omax, o);
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {                 // ragged tail
         const int64_t i = (n4 << 2) + threadIdx.x;
         const uint32_t w = mix32(((uint32_t)(i >> 1) * 0x9E3779B1u) ^ key);
         out[i] = ((i & 1) ? (w >> 16) : (w & 0xffffu)) < thr16 ? gelu_or_grad<BWD>(x[i], BWD ? dy[i] : 1.f) * rp : 0.f;
+        omax = fmaxf(omax, __builtin_fabsf(out[i]));
     }
+    amax_publish_wave(omax, amax);
 }
 
 }  // namespace
 
-extern "C" int resel_gelu_dropout_fwd(const float* x, float* y, int64_t n, float p_drop, uint64_t seed, uint64_t offset, resel_stream_t stream) {
-    if (!x || !y || n < 0 || !(p_drop >= 0.f && p_drop < 1.f) || !aligned16(x) || !aligned16(y)) return RESEL_EINVAL;
+extern "C" int resel_gelu_dropout_fwd(const float* x, float* y, int64_t n, float p_drop, uint64_t seed, uint64_t offset,
+                                      void* amax_y, unsigned amax_epoch, resel_stream_t stream) {
+    if (!x || !y || n < 0 || !(p_drop >= 0.f && p_drop < 1.f) || !aligned16(x) || !aligned16(y) || (reinterpret_cast<uintptr_t>(amax_y) & 7u)) return RESEL_EINVAL;
     if (n == 0) return RESEL_OK;
     const uint32_t thr16 = (uint32_t)lrintf((1.f - p_drop) * 65536.f);
     const int64_t n4 = (n + 3) >> 2;
     const int blocks = (int)(n4 + 255) / 256 < 2048 ? (int)((n4 + 255) / 256) : 2048;
     hipLaunchKernelGGL(gelu_dropout_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (const float*)nullptr, y, n, thr16,
-                       1.f / (1.f - p_drop), seed, offset);
+                       1.f / (1.f - p_drop), seed, offset, AmaxOut{(unsigned long long*)amax_y, amax_epoch});
     return launch_status();
 }
 
 extern "C" int resel_gelu_dropout_bwd(const float* x, const float* dy, float* dx, int64_t n, float p_drop, uint64_t seed, uint64_t offset,
-                                      resel_stream_t stream) {
-    if (!x || !dy || !dx || n < 0 || !(p_drop >= 0.f && p_drop < 1.f) || !aligned16(x) || !aligned16(dy) || !aligned16(dx)) return RESEL_EINVAL;
+                                      void* amax_dx, unsigned amax_epoch, resel_stream_t stream) {
+    if (!x || !dy || !dx || n < 0 || !(p_drop >= 0.f && p_drop < 1.f) || !aligned16(x) || !aligned16(dy) || !aligned16(dx)
+        || (reinterpret_cast<uintptr_t>(amax_dx) & 7u)) return RESEL_EINVAL;
     if (n == 0) return RESEL_OK;
     const uint32_t thr16 = (uint32_t)lrintf((1.f - p_drop) * 65536.f);
     const int64_t n4 = (n + 3) >> 2;
     const int blocks = (int)(n4 + 255) / 256 < 2048 ? (int)((n4 + 255) / 256) : 2048;
     hipLaunchKernelGGL(gelu_dropout_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, dy, dx, n, thr16, 1.f / (1.f - p_drop), seed,
-                       offset);
+                       offset, AmaxOut{(unsigned long long*)amax_dx, amax_epoch});
     return launch_status();
 }
 

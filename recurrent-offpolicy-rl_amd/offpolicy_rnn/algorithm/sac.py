@@ -216,11 +216,11 @@ class SAC:
         self.env_reset()
         ep_ret, ep_len = 0.0, 0
         update = self.train_one_batch
-        if os.environ.get('RESEL_GRAPH_UPDATE') == '1':      # whole update as one hipGraph replay per batch shape (graphed_update.py)
+        if os.environ.get('RESEL_GRAPH_UPDATE', '1') != '0':  # default: the whole update as one hipGraph replay per recurring batch shape (graphed_update.py)
             from .graphed_update import GraphedUpdate
             why = GraphedUpdate.refusal(self)
             if why:
-                self.logger(f'RESEL_GRAPH_UPDATE: eager updates ({why})')
+                self.logger(f'updates are launched eagerly ({why})')
             else:
                 update = GraphedUpdate(self).step
         for it in range(self.parameter.total_iteration):

@@ -47,8 +47,8 @@ SIGNATURES = {
     'resel_attn_varlen_bwd_workspace_bytes': (c_size_t, [I, I, I, I, I]),
     'resel_attn_varlen_bwd': (c_int, [P, P, P, P, P, P, P, P, I, I, I, I, I, F, F, U, U, S]),
     'resel_dropout': (c_int, [P, P, L, F, U, U, S]),
-    'resel_gelu_dropout_fwd': (c_int, [P, P, L, F, U, U, S]),
-    'resel_gelu_dropout_bwd': (c_int, [P, P, P, L, F, U, U, S]),
+    'resel_gelu_dropout_fwd': (c_int, [P, P, L, F, U, U, P, E, S]),
+    'resel_gelu_dropout_bwd': (c_int, [P, P, P, L, F, U, U, P, E, S]),
     'resel_tanh_gaussian_fwd': (c_int, [P, P, P, P, P, I, I, S]),
     'resel_tanh_gaussian_bwd': (c_int, [P, P, P, P, P, I, I, S]),
     'resel_sac_target': (c_int, [P, P, I, P, P, P, P, P, F, P, P, P, P, I, I, S]),

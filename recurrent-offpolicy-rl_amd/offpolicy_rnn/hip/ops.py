@@ -590,7 +590,10 @@ class GeluDropoutFn(torch.autograd.Function):
         assert x.dtype == torch.float32
         x = x.contiguous()
         y = torch.empty_like(x)
-        check(lib().resel_gelu_dropout_fwd(_p(x), _p(y), x.numel(), float(p_drop), int(seed), int(offset), _stream()), 'gelu_dropout_fwd')
+        global LAST_AMAX
+        slot, slot_p, epoch = _slot_args(amax_tracking() and x.numel() >= (1 << 20), x.device)
+        check(lib().resel_gelu_dropout_fwd(_p(x), _p(y), x.numel(), float(p_drop), int(seed), int(offset), slot_p, epoch, _stream()), 'gelu_dropout_fwd')
+        LAST_AMAX = slot
         ctx.save_for_backward(x)
         ctx.drop = (float(p_drop), int(seed), int(offset))
         return y
@@ -600,8 +603,9 @@ class GeluDropoutFn(torch.autograd.Function):
         x, = ctx.saved_tensors
         dy = dy.contiguous()
         dx = torch.empty_like(dy)
-        check(lib().resel_gelu_dropout_bwd(_p(x), _p(dy), _p(dx), dy.numel(), *ctx.drop, _stream()), 'gelu_dropout_bwd')
-        return dx, None, None, None
+        slot, slot_p, epoch = _slot_args(amax_tracking() and dy.numel() >= (1 << 20), dy.device)
+        check(lib().resel_gelu_dropout_bwd(_p(x), _p(dy), _p(dx), dy.numel(), *ctx.drop, slot_p, epoch, _stream()), 'gelu_dropout_bwd')
+        return tag_amax(dx, slot), None, None, None
 
 
 def gelu_dropout(x, p_drop, seed=None, offset=None):
@@ -609,7 +613,9 @@ def gelu_dropout(x, p_drop, seed=None, offset=None):
     (seed, offset) - one `dropout_counter` draw when p_drop > 0, none otherwise (plain GELU)."""
     if p_drop > 0.0 and seed is None:
         seed, offset = dropout_counter(x.device)
-    return GeluDropoutFn.apply(x, p_drop if p_drop > 0.0 else 0.0, seed or 0, offset or 0)
+    global LAST_AMAX
+    LAST_AMAX = None
+    return tag_amax(GeluDropoutFn.apply(x, p_drop if p_drop > 0.0 else 0.0, seed or 0, offset or 0), LAST_AMAX)
 
 
 # ---------------------------------------------------------------------------------------------- SAC / TD3 arithmetic
@@ -1058,6 +1064,7 @@ _AMAX_ARENA = {}              # device -> [int64 tensor [AMAX_SLOTS], next index
 _AMAX_EPOCH = [0]
 _AMAX_STATE = {}              # device -> zero-initialised ticket / partial buffer of resel_amax (calls are ordered on the launch stream)
 LAST_AMAX = None              # handle of the magnitude published by the most recent producer call (wrappers tag Function outputs with it)
+LAST_SPLIT = [None]
 
 
 def amax_slot(device):
@@ -1201,6 +1208,7 @@ def gemm_f32(A, B, a_kcontig=True, b_kcontig=True, bias=None, act=None, out=None
                             _p(hb) if split == 2 else None, slot_p, epoch, _stream()), 'gemm_f32')
     tag_amax(out, slot)
     LAST_AMAX = slot
+    LAST_SPLIT[0] = split                            # tools/gemm_census.py: which product mode the call took
     return out
 
 

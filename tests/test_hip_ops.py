@@ -1094,3 +1094,24 @@ def test_masked_losses_vs_torch_autograd(ops, E, shape):
         assert abs(lps.item() - (logp * mask).sum().item()) <= 1e-5 * max(1.0, (logp * mask).abs().sum().item())
         close(qc.grad, qr.grad, rtol=1e-6, atol_scale=1e-7, name=f'dq (actor loss, min={reduce_min})')
         close(lc.grad, lr.grad, rtol=1e-6, atol_scale=1e-7, name='dlogp')
+
+
+def test_producers_publish_operand_magnitudes(ops, monkeypatch):
+    """With product mode 2 in force the producing kernels leave a magnitude handle on their outputs (include/resel_hip.h "magnitude
+    handles"): exact maxima for GEMM / bias_act_bwd / gelu_dropout outputs, the analytic bound sqrt(C) max|w| + max|b| for the norms."""
+    monkeypatch.setattr(ops, 'GEMM_SPLIT', 2)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(5000, 256, generator=g).cuda()
+    w, b = (1 + 0.1 * torch.randn(256, generator=g)).cuda(), (0.1 * torch.randn(256, generator=g)).cuda()
+    y = ops.layer_norm_fn(x, w, b, eps=1e-5)
+    bound = ops.amax_value(ops.amax_of(y))
+    assert y.abs().max().item() <= bound <= 16 * w.abs().max().item() + b.abs().max().item() + 1e-4
+    h = ops.gelu_dropout(x, 0.1)
+    assert ops.amax_value(ops.amax_of(h)) == h.abs().max().item()
+    gy, _ = ops.bias_act_bwd(x, torch.nn.functional.elu(x), x.shape[0], 'elu', True)
+    assert ops.amax_value(ops.amax_of(gy)) == gy.abs().max().item()
+    W = torch.randn(2048, 256, generator=g).cuda() / 16
+    out = ops.gemm_f32(y, W, True, True)                  # operand magnitude from the norm's handle: no pre-pass, mode 2
+    assert ops.LAST_SPLIT[0] == 2 and ops.amax_value(ops.amax_of(out)) == out.abs().max().item()
+    ref = y.double() @ W.double().t()
+    assert ((out.double() - ref).abs() / (y.double().abs() @ W.double().abs().t())).max().item() < 5e-7

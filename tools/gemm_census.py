@@ -26,7 +26,7 @@ def hooked(A, B, a_kcontig=True, b_kcontig=True, bias=None, act=None, out=None, 
     batch = A.shape[0] if A.dim() == 3 else 1
     M, K = (A.shape[-2], A.shape[-1]) if a_kcontig else (A.shape[-1], A.shape[-2])
     N = B.shape[-2] if b_kcontig else B.shape[-1]
-    rec.append(((batch, M, N, K, int(a_kcontig), int(b_kcontig), act, site), e0, e1))
+    rec.append(((batch, M, N, K, int(a_kcontig), int(b_kcontig), act, ops.LAST_SPLIT[0], site), e0, e1))
     return r
 
 
@@ -41,5 +41,5 @@ for key, e0, e1 in rec:
 tot = sum(v[1] for v in agg.values())
 print(f'{len(rec)} calls, {tot / 1e3:.2f} ms (event pairs include launch gaps)')
 for key, (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-    b, M, N, K, akc, bkc, act, site = key
-    print(f'{us / 1e3:7.3f} ms x{n:2d} {us / n:7.1f} us  b{b} M{M} N{N} K{K} a{akc} b{bkc} {str(act):5s} {site}')
+    b, M, N, K, akc, bkc, act, mode, site = key
+    print(f'{us / 1e3:7.3f} ms x{n:2d} {us / n:7.1f} us  mode {mode} b{b} M{M} N{N} K{K} a{akc} b{bkc} {str(act):5s} {site}')

@@ -7,7 +7,7 @@
 TAG=${1:-r01}; shift
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_$TAG
-ARGS=${@:---steps 5 --warmup 2 --no-cpu-baseline --no-strict-leg --no-graph-leg --no-rccl-leg --no-suite}
+ARGS=${@:---steps 5 --warmup 2 --no-cpu-baseline --no-strict-leg --no-graph-update --no-rccl-leg --no-suite}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout 600 python3 $R/bench.py $ARGS 2>/dev/null | tail -1 > $OUT/${TAG}_bench.json

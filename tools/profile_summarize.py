@@ -13,6 +13,8 @@ TRAFFIC_NAME = sys.argv[2] if len(sys.argv) > 2 else 'traffic.json'      # secon
 shutil.copy(os.path.join(src, f'{tag}_bench.json'), os.path.join(dst, f'{tag}_bench.json'))
 bench = json.loads(open(os.path.join(src, f'{tag}_bench.json')).read())
 n_upd = bench['steps'] + bench['warmup']
+assert not bench.get('graph_update') and not bench.get('suite') and not bench.get('rccl_one_rank_leg'), \
+    'profile the eager update alone: --no-graph-update --no-suite --no-rccl-leg --no-strict-leg (the traces are divided by steps + warmup)'
 
 
 def pmc(name):
@@ -34,6 +36,15 @@ def pmc(name):
     return {k: sum(v) / len(v) for k, v in agg.items()}
 
 
+def pmc_clusters(name, pat):
+    """Distinct per-launch values of one kernel's counter (launches of the forward scan with and without checkpoints differ 5x)."""
+    f = os.path.join(src, f'{tag}_{name}_counter_collection.csv')
+    if not os.path.exists(f):
+        return {}
+    c = collections.Counter(round(float(r['Counter_Value']) * 1024 / 1e6, 1) for r in csv.DictReader(open(f)) if pat in r['Kernel_Name'])
+    return {f'{k} MB': n for k, n in sorted(c.items())}
+
+
 fetch, write = pmc('fetch'), pmc('write')
 traffic = {}
 # FETCH_SIZE counts wide coalesced reads (8 / 16 bytes per lane) at half their bytes on gfx950 (MI355X_MICROARCH.md 'HBM'): x 2.  The
@@ -46,7 +57,10 @@ import bench as _bench
 cfgw = bench['config']['workload']
 json.dump({'source': f'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over `python3 bench.py` ({tag}); FETCH_SIZE KB x 1024 x 2 (gfx950), WRITE_SIZE KB x 1024',
            'kernel_source_stamp': _bench.kernel_source_stamp(), 'rnn': cfgw.split(' ')[0], 'rows': bench['config']['global_rows'] // bench['n_gpus'],
-           'per_launch_bytes': {k: v['total'] for k, v in traffic.items()}, 'detail': traffic},
+           'per_launch_bytes': {k: v['total'] for k, v in traffic.items()}, 'detail': traffic,
+           # forward scan: launches without a graph write the output only, launches of a pass that will be differentiated also write
+           # the state checkpoints (one every 8 steps) - the distinct per-launch WRITE_SIZE values and how many launches had each
+           'sscan_fwd_write_mb_by_launch_kind': pmc_clusters('write', 'sscan_fwd')},
           open(os.path.join(dst, TRAFFIC_NAME), 'w'), indent=1)
 rows = list(csv.DictReader(open(os.path.join(src, f'{tag}_kernel_stats.csv'))))
 tot = sum(float(r['TotalDurationNs']) for r in rows)
