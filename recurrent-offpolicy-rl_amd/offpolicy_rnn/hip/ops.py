@@ -1067,8 +1067,12 @@ LAST_AMAX = None              # handle of the magnitude published by the most re
 LAST_SPLIT = [None]
 
 
+_AMAX_SERIAL = [0]            # handles handed out so far: a tag older than one lap of the arena points at a recycled handle
+
+
 def amax_slot(device):
     """A fresh (handle: int64 view [AMAX_WORDS], epoch) pair for a producer kernel."""
+    _AMAX_SERIAL[0] += 1
     ar = _AMAX_ARENA.get(device)
     if ar is None:
         buf = torch.zeros(AMAX_SLOTS * AMAX_WORDS, dtype=torch.int64, device=device)
@@ -1091,22 +1095,32 @@ def amax_arena_zero(device):
         ar[0].zero_()
 
 
+def _taggable(t):
+    """Tags live on activations and gradients - tensors that are written once and die with the update.  Parameters are NOT tagged:
+    this library's optimizer and soft-update kernels rewrite them through the flat buffers without bumping `_version`, so a tag
+    would outlive the values it describes (their magnitudes come from a pre-pass per call: a few KB)."""
+    return not (isinstance(t, torch.nn.Parameter) or (t.is_leaf and t.requires_grad))
+
+
 def tag_amax(t, handle, whole=False):
     """whole: t covers ALL of the tensor it is a view of (a reshape of a fresh output) - tag that base too, so that other views of it
-    (the [M, C] form of a [B, L, C] activation) find the magnitude."""
+    (the [M, C] form of a [B, L, C] activation) find the magnitude.  A tag = (handle, tensor version, handle serial)."""
     if t is not None:
-        t._resel_amax = None if handle is None else (handle, t._version)
-        if whole and getattr(t, '_base', None) is not None:
-            t._base._resel_amax = None if handle is None else (handle, t._base._version)
+        ok = handle is not None and _taggable(t)
+        t._resel_amax = (handle, t._version, _AMAX_SERIAL[0]) if ok else None
+        base = getattr(t, '_base', None)
+        if whole and base is not None:
+            base._resel_amax = (handle, base._version, _AMAX_SERIAL[0]) if (ok and _taggable(base)) else None
     return t
 
 
 def amax_of(t):
-    """Handle of a bound on max |t| if one is known (t itself or the tensor t is a view of), else None."""
+    """Handle of a bound on max |t| if one is known (t itself or the tensor t is a view of), else None.  A tag is void once torch has
+    seen an in-place write to its tensor, or once the arena has handed out enough handles since to have recycled this one."""
     for obj in (t, getattr(t, '_base', None)):
         if obj is not None:
             tg = getattr(obj, '_resel_amax', None)
-            if tg is not None and tg[1] == obj._version:
+            if tg is not None and tg[1] == obj._version and _AMAX_SERIAL[0] - tg[2] < AMAX_SLOTS - 64:
                 return tg[0]
     return None
 
