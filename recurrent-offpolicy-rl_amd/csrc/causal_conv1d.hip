@@ -18,6 +18,8 @@ struct ConvParams {
     int64_t ld_x, ld_y, ld_dy, ld_dx;
     int B, L, Di, K, silu;
     AmaxOut amax;                    // optional: publish max |y| (forward) / max |dx| (backward)
+    const float* dy2 = nullptr;      // backward: optional second gradient of the output, summed with dy on load (the Mamba mixer's conv output
+    int64_t ld_dy2 = 0;              // receives the scan's du AND the x_proj input gradient: no accumulating GEMM, no add pass)
 };
 
 template <int KT>
@@ -155,11 +157,11 @@ __global__ __launch_bounds__(128) void conv_fwd_kernel(ConvParams p) {
 // owns only its own steps.  Per-chunk dw / db partials are summed by colsum_kernel (fixed order, no atomics).
 constexpr int CB_TT = 64;
 
-template <int KT, int MODE>          // MODE 0: inputs only, 1: + g window and dw / db, 2: + dx
-__device__ __forceinline__ void conv_bwd_group(const ConvParams& p, const float* xrow, const float* dyrow, float* dxrow, int tg,
+template <int KT, int MODE, bool TWO>          // MODE 0: inputs only, 1: + g window and dw / db, 2: + dx; TWO: dy + dy2
+__device__ __forceinline__ void conv_bwd_group(const ConvParams& p, const float* xrow, const float* dyrow, const float* dy2row, float* dxrow, int tg,
                                                int ig, int t_own0, float mlo, float mhi, const f2 (&wr)[KT], f2 (&xwin)[KT],
                                                f2 (&gwin)[KT], f2 (&dwr)[KT], f2& dbr, f2 (&prex)[KT < 4 ? KT : 4],
-                                               f2 (&predy)[KT < 4 ? KT : 4], f2 bv, float& dxmax) {
+                                               f2 (&predy)[KT < 4 ? KT : 4], f2 (&predy2)[KT < 4 ? KT : 4], f2 bv, float& dxmax) {
     constexpr int P = KT < 4 ? KT : 4;
     const float mreg = ig < 64 ? mlo : mhi;
 #pragma unroll
@@ -170,8 +172,12 @@ __device__ __forceinline__ void conv_bwd_group(const ConvParams& p, const float*
         const int tl = min(max(t + P, 0), p.L - 1);
         prex[s % P] = *reinterpret_cast<const f2*>(xrow + (int64_t)tl * p.ld_x);
         if (MODE >= 1) {
-            const f2 dyv = predy[s % P];
+            f2 dyv = predy[s % P];
             predy[s % P] = *reinterpret_cast<const f2*>(dyrow + (int64_t)tl * p.ld_dy);
+            if (TWO) {                                                         // a second load per step, as static as the first
+                dyv += predy2[s % P];
+                predy2[s % P] = *reinterpret_cast<const f2*>(dy2row + (int64_t)tl * p.ld_dy2);
+            }
             f2 acc = bv;
 #pragma unroll
             for (int kk = 0; kk < KT; ++kk) acc = __builtin_elementwise_fma(wr[kk], xwin[(s + 1 + kk) % KT], acc);
@@ -200,7 +206,7 @@ __device__ __forceinline__ void conv_bwd_group(const ConvParams& p, const float*
     }
 }
 
-template <int KT>
+template <int KT, bool TWO>
 __global__ __launch_bounds__(128) void conv_bwd_win_kernel(ConvParams p, int nchunk) {
     constexpr int P = KT < 4 ? KT : 4;
     const int lane = threadIdx.x & 63;
@@ -213,6 +219,7 @@ __global__ __launch_bounds__(128) void conv_bwd_win_kernel(ConvParams p, int nch
     const int64_t tok0 = (int64_t)b * p.L;
     const float* xrow = p.x + tok0 * p.ld_x + c;
     const float* dyrow = p.dy + tok0 * p.ld_dy + c;
+    const float* dy2row = TWO ? p.dy2 + tok0 * p.ld_dy2 + c : nullptr;
     float* dxrow = p.dx + tok0 * p.ld_dx + c;
     f2 wr[KT], xwin[KT], gwin[KT], dwr[KT];
 #pragma unroll
@@ -233,17 +240,18 @@ __global__ __launch_bounds__(128) void conv_bwd_win_kernel(ConvParams p, int nch
         mlo = (ta >= 0 && ta < p.L) ? va : 0.f;
         mhi = (tb >= 0 && tb < p.L) ? vb : 0.f;
     }
-    f2 prex[P], predy[P];
+    f2 prex[P], predy[P], predy2[P];
 #pragma unroll
     for (int i = 0; i < P; ++i) {
         prex[i] = *reinterpret_cast<const f2*>(xrow + (int64_t)min(max(ts + i, 0), p.L - 1) * p.ld_x);
         predy[i] = *reinterpret_cast<const f2*>(dyrow + (int64_t)min(max(ts + KT + i, 0), p.L - 1) * p.ld_dy);
+        predy2[i] = TWO ? *reinterpret_cast<const f2*>(dy2row + (int64_t)min(max(ts + KT + i, 0), p.L - 1) * p.ld_dy2) : f2{0.f, 0.f};
     }
     float dxmax = 0.f;
-    conv_bwd_group<KT, 0>(p, xrow, dyrow, dxrow, ts, 0, t_own0, mlo, mhi, wr, xwin, gwin, dwr, dbr, prex, predy, bv, dxmax);
-    conv_bwd_group<KT, 1>(p, xrow, dyrow, dxrow, ts + KT, KT, t_own0, mlo, mhi, wr, xwin, gwin, dwr, dbr, prex, predy, bv, dxmax);
+    conv_bwd_group<KT, 0, TWO>(p, xrow, dyrow, dy2row, dxrow, ts, 0, t_own0, mlo, mhi, wr, xwin, gwin, dwr, dbr, prex, predy, predy2, bv, dxmax);
+    conv_bwd_group<KT, 1, TWO>(p, xrow, dyrow, dy2row, dxrow, ts + KT, KT, t_own0, mlo, mhi, wr, xwin, gwin, dwr, dbr, prex, predy, predy2, bv, dxmax);
     for (int ig = 2 * KT; ig < 2 * KT + CB_TT; ig += KT)
-        conv_bwd_group<KT, 2>(p, xrow, dyrow, dxrow, ts + ig, ig, t_own0, mlo, mhi, wr, xwin, gwin, dwr, dbr, prex, predy, bv, dxmax);
+        conv_bwd_group<KT, 2, TWO>(p, xrow, dyrow, dy2row, dxrow, ts + ig, ig, t_own0, mlo, mhi, wr, xwin, gwin, dwr, dbr, prex, predy, predy2, bv, dxmax);
     amax_publish_wave(dxmax, p.amax);
     if (c_raw < p.Di) {
         const int64_t row = (int64_t)b * nchunk + chunk;
@@ -296,6 +304,10 @@ __global__ __launch_bounds__(256) void conv_bwd_kernel(ConvParams p) {
                     acc.z = __builtin_fmaf(wr[kk].z, xv.z, acc.z); acc.w = __builtin_fmaf(wr[kk].w, xv.w, acc.w);
                 }
                 g = ld4(p.dy + (tok0 + t) * p.ld_dy + d0 + tc4);
+                if (p.dy2) {
+                    const float4 g2 = ld4(p.dy2 + (tok0 + t) * p.ld_dy2 + d0 + tc4);
+                    g.x += g2.x; g.y += g2.y; g.z += g2.z; g.w += g2.w;
+                }
                 if (p.silu) { g.x *= dsiluf_(acc.x); g.y *= dsiluf_(acc.y); g.z *= dsiluf_(acc.z); g.w *= dsiluf_(acc.w); }
                 if (r < TT) {                       // rows owned by this tile contribute to dw / dbias
                     dbr.x += g.x; dbr.y += g.y; dbr.z += g.z; dbr.w += g.w;
@@ -389,7 +401,16 @@ extern "C" int resel_causal_conv1d_bwd(const float* x, int64_t ld_x, const float
                                        const float* dy, int64_t ld_dy, float* dx, int64_t ld_dx, float* dw, float* dbias,
                                        void* workspace, int B, int L, int Di, int K, int silu, void* amax_dx, unsigned amax_epoch,
                                        resel_stream_t stream) {
+    return resel_causal_conv1d_bwd2(x, ld_x, w, bias, mask, dy, ld_dy, nullptr, 0, dx, ld_dx, dw, dbias, workspace, B, L, Di, K, silu, amax_dx,
+                                    amax_epoch, stream);
+}
+
+extern "C" int resel_causal_conv1d_bwd2(const float* x, int64_t ld_x, const float* w, const float* bias, const float* mask,
+                                        const float* dy, int64_t ld_dy, const float* dy2, int64_t ld_dy2, float* dx, int64_t ld_dx,
+                                        float* dw, float* dbias, void* workspace, int B, int L, int Di, int K, int silu,
+                                        void* amax_dx, unsigned amax_epoch, resel_stream_t stream) {
     if (amax_dx && (reinterpret_cast<uintptr_t>(amax_dx) & 7u)) return RESEL_EINVAL;
+    if (dy2 && (ld_dy2 % 4 || !aligned16(dy2))) return RESEL_EINVAL;
     if (!conv_args_ok(x, ld_x, dx, ld_dx, B, L, Di, K) || !w || !dy || !dw || !workspace || ld_dy % 4 || !aligned16(dy) ||
         (bias && !aligned16(bias)))
         return RESEL_EINVAL;
@@ -398,16 +419,19 @@ extern "C" int resel_causal_conv1d_bwd(const float* x, int64_t ld_x, const float
     float* dw_part = (float*)workspace;
     float* db_part = dw_part + (size_t)rows * Di * KT;
     ConvParams p{x, w, bias, mask, dy, nullptr, dx, dw_part, db_part, ld_x, 0, ld_dy, ld_dx, B, L, Di, K, silu,
-                 AmaxOut{(unsigned long long*)amax_dx, amax_epoch}};
+                 AmaxOut{(unsigned long long*)amax_dx, amax_epoch}, dy2, ld_dy2};
     hipStream_t s = (hipStream_t)stream;
     if (bwd_windowed(L, KT)) {
         const int nchunk = (L + CB_TT - 1) / CB_TT;
         dim3 grid((Di + 255) / 256, nchunk, B);
+#define CONV_BWD_WIN(KTv) do { if (dy2) launch_timed(RESEL_PROF_CONV_BWD, conv_bwd_win_kernel<KTv, true>, grid, dim3(128), 0, s, p, nchunk); \
+                               else launch_timed(RESEL_PROF_CONV_BWD, conv_bwd_win_kernel<KTv, false>, grid, dim3(128), 0, s, p, nchunk); } while (0)
         switch (KT) {
-            case 4: launch_timed(RESEL_PROF_CONV_BWD, conv_bwd_win_kernel<4>, grid, dim3(128), 0, s, p, nchunk); break;
-            case 8: launch_timed(RESEL_PROF_CONV_BWD, conv_bwd_win_kernel<8>, grid, dim3(128), 0, s, p, nchunk); break;
-            default: launch_timed(RESEL_PROF_CONV_BWD, conv_bwd_win_kernel<16>, grid, dim3(128), 0, s, p, nchunk); break;
+            case 4: CONV_BWD_WIN(4); break;
+            case 8: CONV_BWD_WIN(8); break;
+            default: CONV_BWD_WIN(16); break;
         }
+#undef CONV_BWD_WIN
     } else {
         dim3 grid(B, (Di + TILE_C - 1) / TILE_C);
         switch (KT) {

@@ -174,6 +174,7 @@ def selective_scan_fn(u, delta, A, B, C, start, D=None, z=None, delta_bias=None,
 
 
 # ---------------------------------------------------------------------------------------------- fused Mamba mixer
+CONV_TWO_DY = os.environ.get('RESEL_CONV_TWO_DY', '1') != '0'          # A/B switch: 0 = x_proj input gradient accumulated into the scan's du by the GEMM epilogue
 FOLD_SOFTPLUS = os.environ.get('RESEL_FOLD_SOFTPLUS', '1') != '0'      # A/B switch: 0 = softplus inside the scan kernels (delta_softplus = 1)
 
 
@@ -264,16 +265,21 @@ class MambaInnerFn(torch.autograd.Function):
             else torch.mm(ddt.t(), x_dbl[:, :R])
         dx_dbl[:, :R] = mm_nn(ddt, dt_w)
         d_xproj_w = wgrad(dx_dbl, xc, amax_x=h_xc)
-        # conv output receives scan (du) + x_proj gradients: the accumulating form of the input gradient
-        if _mine(dx_dbl.shape[0], xproj_w.shape[1], xproj_w.shape[0], dx_dbl, xproj_w, dxc):
-            gemm_f32(dx_dbl, xproj_w, True, False, None, GEMM_ACCUMULATE, out=dxc)
-        else:
-            dxc.addmm_(dx_dbl, xproj_w)
+        # the conv output's gradient = the scan's du (in dxc) + the x_proj input gradient: handed to the conv backward as TWO tensors
+        # (summed on load) - the accumulating GEMM epilogue cost 150-214 us per call against 67 for the plain product
+        if CONV_TWO_DY:
+            gx = mm_nn(dx_dbl, xproj_w)
+        else:                                          # A/B: the accumulating epilogue
+            gx = None
+            if _mine(dx_dbl.shape[0], xproj_w.shape[1], xproj_w.shape[0], dx_dbl, xproj_w, dxc):
+                gemm_f32(dx_dbl, xproj_w, True, False, None, GEMM_ACCUMULATE, out=dxc)
+            else:
+                dxc.addmm_(dx_dbl, xproj_w)
         dcw = torch.empty(Di, K, dtype=torch.float32, device=dev)
         dcb = torch.empty(Di, dtype=torch.float32, device=dev) if conv_b is not None else None
         ws2 = _ws(lib().resel_causal_conv1d_bwd_workspace_bytes(Bsz, L, Di, K), dev)
-        check(lib().resel_causal_conv1d_bwd(_p(xz), 2 * Di, _p(cw), _p(conv_b), _p(maskf), _p(dxc), Di, _p(dxz), 2 * Di, _p(dcw), _p(dcb),
-                                            _p(ws2), Bsz, L, Di, K, 1, p_dxz, e_b, _stream()), 'causal_conv1d_bwd')
+        check(lib().resel_causal_conv1d_bwd2(_p(xz), 2 * Di, _p(cw), _p(conv_b), _p(maskf), _p(dxc), Di, _p(gx), gx.stride(0) if gx is not None else 0, _p(dxz), 2 * Di,
+                                             _p(dcw), _p(dcb), _p(ws2), Bsz, L, Di, K, 1, p_dxz, e_b, _stream()), 'causal_conv1d_bwd')
         tag_amax(dxz, h_dxz)
         d_in_w = wgrad(dxz, x2, amax_x=ax)
         dx = mm_nn(dxz, in_w).view(Bsz, L, Dm) if ctx.needs_input_grad[0] else None
