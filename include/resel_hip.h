@@ -139,7 +139,7 @@ int resel_add_layernorm_fwd(const float* x, const float* residual, const float* 
 size_t resel_add_layernorm_bwd_workspace_bytes(int M, int C);
 int resel_add_layernorm_bwd(const float* dy, const float* dres_in, const float* res, const float* w,
                             const float* stats, float* dx, float* dw, float* db, void* workspace,
-                            int M, int C, int rms, int has_bias, resel_stream_t stream);
+                            int M, int C, int rms, int has_bias, void* amax_dx, unsigned amax_epoch, resel_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Linear-recurrence scans (gilr, lru).  Replace the Triton kernels
@@ -375,7 +375,7 @@ int resel_gemm_f32x(const float* A, int64_t lda, int64_t strideA, int a_kcontig,
  * are never zeroed, give every tensor a fresh epoch - and kernels that fill parts of one tensor may share handle and epoch.  Readers
  * (amax_a / amax_b above) take the newest epoch among the eight words and the largest magnitude carrying it.  Publishers:
  * resel_amax (a pre-pass), resel_gemm_f32x (amax_c: the values stored to C), resel_bias_act_bwd (gy), resel_ensemble_head_bwd (gy), resel_add_layernorm_fwd
- * (y: the analytic bound sqrt(C) max|w| + max|b|, published by one wave), resel_selective_scan_fwd (out), resel_selective_scan_bwd (dz, ddelta),
+ * (y: the analytic bound sqrt(C) max|w| + max|b|, published by one wave), resel_add_layernorm_bwd (dx), resel_selective_scan_fwd (out), resel_selective_scan_bwd (dz, ddelta),
  * resel_causal_conv1d_fwd (y), resel_causal_conv1d_bwd (dx), resel_gelu_dropout_fwd / _bwd (y / dx). */
 /* Magnitude pre-pass: max |x| over a [batch][rows][cols] box (row stride ld, batch stride `stride`, cols % 4 == 0) written into the
  * magnitude handle `out` with epoch `epoch` (see "magnitude handles" above); one HBM-bound pass, no host synchronisation.

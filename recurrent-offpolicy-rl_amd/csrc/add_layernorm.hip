@@ -86,7 +86,7 @@ __global__ __launch_bounds__(WAVES * 64) void ln_bwd_kernel(const float* __restr
                                                             const float* __restrict__ res, const float* __restrict__ w,
                                                             const float* __restrict__ stats, float* __restrict__ dx,
                                                             float* __restrict__ dw_part, float* __restrict__ db_part,
-                                                            int M, int C, int rms) {
+                                                            int M, int C, int rms, AmaxOut amax) {
     __shared__ __attribute__((aligned(16))) float s_acc[2][WAVES][VPL * 256];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int c4 = C / 4;
@@ -98,6 +98,7 @@ __global__ __launch_bounds__(WAVES * 64) void ln_bwd_kernel(const float* __restr
         const int c = i * 64 + lane;
         wreg[i] = c < c4 ? reinterpret_cast<const float4*>(w)[c] : dwa[i];
     }
+    float dxmax = 0.f;
     for (int row = blockIdx.x * WAVES + wv; row < M; row += gridDim.x * WAVES) {
         const float mean = stats[2 * (int64_t)row], rstd = stats[2 * (int64_t)row + 1];
         float4 xh[VPL], g[VPL];
@@ -132,9 +133,11 @@ __global__ __launch_bounds__(WAVES * 64) void ln_bwd_kernel(const float* __restr
                     o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w;
                 }
                 reinterpret_cast<float4*>(dx + (int64_t)row * C)[c] = o;
+                dxmax = amax4(dxmax, o);
             }
         }
     }
+    amax_publish_wave(dxmax, amax);                  // persistent waves: one publication each (dx feeds the out_proj gradient GEMMs of the block below)
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
         st4(&s_acc[0][wv][(i * 64 + lane) * 4], dwa[i]);
@@ -178,8 +181,9 @@ extern "C" size_t resel_add_layernorm_bwd_workspace_bytes(int M, int C) {
 
 extern "C" int resel_add_layernorm_bwd(const float* dy, const float* dres_in, const float* res, const float* w,
                                        const float* stats, float* dx, float* dw, float* db, void* workspace,
-                                       int M, int C, int rms, int has_bias, resel_stream_t stream) {
-    if (!dy || !res || !w || !stats || !dx || !dw || !workspace || !ln_ok(M, C)) return RESEL_EINVAL;
+                                       int M, int C, int rms, int has_bias, void* amax_dx, unsigned amax_epoch, resel_stream_t stream) {
+    if (!dy || !res || !w || !stats || !dx || !dw || !workspace || !ln_ok(M, C) || (reinterpret_cast<uintptr_t>(amax_dx) & 7u)) return RESEL_EINVAL;
+    const AmaxOut ao{(unsigned long long*)amax_dx, amax_epoch};
     if (!aligned16(dy) || !aligned16(res) || !aligned16(w) || !aligned16(dx) || (dres_in && !aligned16(dres_in)))
         return RESEL_EINVAL;
     hipStream_t s = (hipStream_t)stream;
@@ -187,10 +191,10 @@ extern "C" int resel_add_layernorm_bwd(const float* dy, const float* dres_in, co
     float* dw_part = (float*)workspace;
     float* db_part = dw_part + (size_t)nblk * C;
     dim3 grid(nblk), blk(WAVES * 64);
-    if (C <= 256) hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, blk, 0, s, dy, dres_in, res, w, stats, dx, dw_part, db_part, M, C, rms);
-    else if (C <= 512) hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, blk, 0, s, dy, dres_in, res, w, stats, dx, dw_part, db_part, M, C, rms);
-    else if (C <= 1024) hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, blk, 0, s, dy, dres_in, res, w, stats, dx, dw_part, db_part, M, C, rms);
-    else hipLaunchKernelGGL(ln_bwd_kernel<8>, grid, blk, 0, s, dy, dres_in, res, w, stats, dx, dw_part, db_part, M, C, rms);
+    if (C <= 256) hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, blk, 0, s, dy, dres_in, res, w, stats, dx, dw_part, db_part, M, C, rms, ao);
+    else if (C <= 512) hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, blk, 0, s, dy, dres_in, res, w, stats, dx, dw_part, db_part, M, C, rms, ao);
+    else if (C <= 1024) hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, blk, 0, s, dy, dres_in, res, w, stats, dx, dw_part, db_part, M, C, rms, ao);
+    else hipLaunchKernelGGL(ln_bwd_kernel<8>, grid, blk, 0, s, dy, dres_in, res, w, stats, dx, dw_part, db_part, M, C, rms, ao);
     launch_colsum(dw_part, C, nblk, C, dw, s);
     if (has_bias && db) launch_colsum(db_part, C, nblk, C, db, s);
     return launch_status();

@@ -368,9 +368,10 @@ class AddNormFn(torch.autograd.Function):
         dw = torch.empty(C, dtype=torch.float32, device=res.device)
         db = torch.empty(C, dtype=torch.float32, device=res.device) if ctx.has_bias else None
         ws = _ws(lib().resel_add_layernorm_bwd_workspace_bytes(M, C), res.device)
+        slot, slot_p, epoch = _slot_args(amax_tracking() and M * C >= (1 << 20), res.device)
         check(lib().resel_add_layernorm_bwd(_p(dy2), _p(dr2), _p(res), _p(w), _p(stats), _p(dx), _p(dw), _p(db), _p(ws),
-                                            M, C, int(ctx.rms), int(ctx.has_bias), _stream()), 'add_layernorm_bwd')
-        dx = dx.reshape(ctx.shape)
+                                            M, C, int(ctx.rms), int(ctx.has_bias), slot_p, epoch, _stream()), 'add_layernorm_bwd')
+        dx = tag_amax(dx.reshape(ctx.shape), slot, whole=True)      # the gradient the block below multiplies with its out_proj weight
         return dx, (dx if ctx.has_res else None), dw, db, None, None, None
 
 

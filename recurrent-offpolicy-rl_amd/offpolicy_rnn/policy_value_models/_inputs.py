@@ -35,17 +35,29 @@ def register_encoders(owner):
             owner.contextual_register_rnn_base_module(mod, name)
 
 
-def encode_concat(pairs) -> torch.Tensor:
+def _fusable(act_mod, x, mods) -> bool:
+    """The activation module behind the encoders is a plain ELU and the pass is a long fp32 GPU pass of Linear encoders: it rides in
+    the encoder GEMM's epilogue (and its derivative in the backward's bias pass) instead of two element-wise ATen passes."""
+    return (isinstance(act_mod, torch.nn.ELU) and act_mod.alpha == 1.0 and x.is_cuda and x.dtype == torch.float32
+            and x.numel() // x.shape[-1] >= ops.GEMM_F32_MIN_ROWS and all(isinstance(m, torch.nn.Linear) and m.bias is not None for m in mods))
+
+
+def encode_concat(pairs, act_mod=None) -> torch.Tensor:
     """cat([enc_i(x_i)], -1) for Linear encoders as ONE library GEMM: the (narrow) inputs are concatenated instead of the
     (wide) outputs and multiplied by the block-diagonal of the encoder weights with the biases fused (addmm epilogue) -
     per update this removes three skinny GEMMs, three bias-add passes and the 384-wide cat per call.  The zero blocks
     add exact zeros to every dot product; autograd splits the gradients back through block_diag / cat."""
+    """act_mod: the activation module applied to the result (None: none) - fused into the GEMM when `_fusable`."""
     mods = [m for m, _ in pairs]
     xs = [x for _, x in pairs]
+    fuse = act_mod is not None and _fusable(act_mod, xs[0], mods)
+    post = (lambda t: t) if (act_mod is None or fuse) else act_mod
     if not all(isinstance(m, torch.nn.Linear) and m.bias is not None for m in mods):
-        return torch.cat([m(x) for m, x in pairs], dim=-1)
+        return post(torch.cat([m(x) for m, x in pairs], dim=-1))
     if len(pairs) == 1:                       # one encoder alone (the actor step's action encoding): still the hand-written GEMM
-        return ops.linear(xs[0], mods[0].weight, mods[0].bias)
+        if fuse and mods[0].weight.shape[0] >= ops.GEMM_F32_MIN_DIM and mods[0].weight.shape[1] >= ops.GEMM_F32_MIN_K:
+            return ops.linear_act(xs[0], mods[0].weight, mods[0].bias, 'elu')
+        return (act_mod if fuse else post)(ops.linear(xs[0], mods[0].weight, mods[0].bias))
     w = torch.block_diag(*[m.weight for m in mods])
     b = torch.cat([m.bias for m in mods])
     pad = (-w.shape[1]) % 4                  # 17 + 17 + 6 + 1 = 41 input columns: three zero columns make the rows 16-byte multiples,
@@ -53,8 +65,11 @@ def encode_concat(pairs) -> torch.Tensor:
         xs = xs + [torch.zeros(*xs[0].shape[:-1], pad, dtype=xs[0].dtype, device=xs[0].device)]
         w = torch.nn.functional.pad(w, (0, pad))
     x = torch.cat(xs, dim=-1)
-    y = ops.linear(x.reshape(-1, x.shape[-1]), w, b)
-    return y.view(*x.shape[:-1], w.shape[0])
+    x2 = x.reshape(-1, x.shape[-1])
+    if fuse and w.shape[0] >= ops.GEMM_F32_MIN_DIM and w.shape[1] >= ops.GEMM_F32_MIN_K:
+        return ops.linear_act(x2, w, b, 'elu').view(*x.shape[:-1], w.shape[0])
+    y = ops.linear(x2, w, b)
+    return (act_mod if fuse else post)(y.view(*x.shape[:-1], w.shape[0]))
 
 
 def embedding_input(owner, state, lst_state, lst_action, reward) -> torch.Tensor:

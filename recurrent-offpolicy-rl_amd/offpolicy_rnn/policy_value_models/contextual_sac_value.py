@@ -46,8 +46,8 @@ class ContextualSACValue(ContextualModel):
         return _inputs.embedding_input(self, state, lst_state, lst_action, reward)
 
     def state_action(self, state, action):
-        sa = _inputs.encode_concat([(self.state_input_encoder, state), (self.action_input_encoder, action)])
-        return self.uni_model_input_mapping_activation_func(sa) if self.separate_encoder else sa
+        return _inputs.encode_concat([(self.state_input_encoder, state), (self.action_input_encoder, action)],
+                                     self.uni_model_input_mapping_activation_func if self.separate_encoder else None)
 
     def forward(self, state, lst_state, lst_action, action, rnn_memory: Optional[RNNHidden], reward, detach_embedding=False
                 ) -> Tuple[torch.Tensor, torch.Tensor, RNNHidden, Optional[RNNHidden]]:
@@ -58,8 +58,8 @@ class ContextualSACValue(ContextualModel):
             # Encode state and action separately so that the first layer's backward forms just that column block of dX.
             act_fn = self.uni_model_input_mapping_activation_func
             with torch.no_grad():
-                sa_s = act_fn(_inputs.encode_concat([(self.state_input_encoder, state)]))
-            sa_a = act_fn(_inputs.encode_concat([(self.action_input_encoder, action)]))
+                sa_s = _inputs.encode_concat([(self.state_input_encoder, state)], act_fn)
+            sa_a = _inputs.encode_concat([(self.action_input_encoder, action)], act_fn)
             sa = torch.cat((sa_s, sa_a.detach()), dim=-1)
             part = (sa_a, sa_s.shape[-1])
         else:
