@@ -381,6 +381,11 @@ int resel_gemm_f32x(const float* A, int64_t lda, int64_t strideA, int a_kcontig,
  * magnitude handle `out` with epoch `epoch` (see "magnitude handles" above); one HBM-bound pass, no host synchronisation.
  * `state`: resel_amax_state_bytes() bytes, zero before its first use (left zeroed by every call); calls that share a state buffer
  * must be ordered on one stream. */
+/* Magnitudes of every tensor of a flat parameter buffer in ONE launch: segment g = flat[begin[g], begin[g] + len[g]) (device int64
+ * tables) publishes into the g-th of `nseg` consecutive 1 KiB handles at `handles` under `epoch` (the weights change once per optimizer
+ * step / soft update; the GEMMs of the update then find their weight's magnitude without a pre-pass per call). */
+int resel_amax_segments(const float* flat, const int64_t* begin, const int64_t* len, int nseg, void* handles, unsigned epoch,
+                        resel_stream_t stream);
 size_t resel_amax_state_bytes(void);
 int resel_amax(const float* x, int64_t ld, int64_t stride, int rows, int cols, int batch, void* out, unsigned epoch, void* state,
                resel_stream_t stream);

@@ -63,6 +63,26 @@ __global__ __launch_bounds__(256) void amax_kernel(AmaxParams p) {
 }
 }  // namespace
 
+// ---- magnitudes of ALL tensors of a flat parameter buffer in one launch: segment g = flat[begin[g], begin[g] + len[g]) publishes into the
+// handle at handles + g * RESEL_AMAX_STRIDE * RESEL_AMAX_SUBSLOTS words.  grid (chunks, nseg): block (c, g) covers a 1/chunks share of g.
+namespace {
+__global__ __launch_bounds__(256) void amax_segments_kernel(const float* __restrict__ flat, const int64_t* __restrict__ begin,
+                                                            const int64_t* __restrict__ len, unsigned long long* handles, unsigned epoch) {
+    const int g = blockIdx.y;
+    const int64_t b = begin[g], n = len[g];
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(flat[b + i]));
+    amax_publish_wave(m, AmaxOut{handles + (int64_t)g * RESEL_AMAX_STRIDE * RESEL_AMAX_SUBSLOTS, epoch});
+}
+}  // namespace
+
+extern "C" int resel_amax_segments(const float* flat, const int64_t* begin, const int64_t* len, int nseg, void* handles, unsigned epoch,
+                                   resel_stream_t stream) {
+    if (!flat || !begin || !len || nseg <= 0 || !handles || (reinterpret_cast<uintptr_t>(handles) & 7u)) return RESEL_EINVAL;
+    hipLaunchKernelGGL(amax_segments_kernel, dim3(8, nseg), dim3(256), 0, (hipStream_t)stream, flat, begin, len, (unsigned long long*)handles, epoch);
+    return launch_status();
+}
+
 extern "C" size_t resel_amax_state_bytes(void) { return (size_t)(AMAX_BLOCKS + 4) * sizeof(float); }
 
 extern "C" int resel_amax(const float* x, int64_t ld, int64_t stride, int rows, int cols, int batch, void* out, unsigned epoch, void* state,

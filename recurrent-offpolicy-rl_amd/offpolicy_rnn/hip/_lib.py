@@ -76,6 +76,7 @@ SIGNATURES = {
     'resel_gemm_f32_workspace_bytes': (c_size_t, [I, I, I, I]),
     'resel_gemm_f32': (c_int, [P, L, L, I, P, L, L, I, P, L, I, P, L, L, P, I, I, I, I, I, S]),
     'resel_gemm_f32x': (c_int, [P, L, L, I, P, L, L, I, P, L, I, P, L, L, P, I, I, I, I, I, P, P, P, E, S]),
+    'resel_amax_segments': (c_int, [P, P, P, I, P, E, S]),
     'resel_amax_state_bytes': (c_size_t, []),
     'resel_amax': (c_int, [P, L, L, I, I, I, P, E, P, S]),
     'resel_gemm_bf16_workspace_bytes': (c_size_t, [I, I, I]),

@@ -1156,6 +1156,27 @@ def amax_value(handle):
     return float(lo.view(torch.float32).max())
 
 
+WEIGHT_AMAX = os.environ.get('RESEL_WEIGHT_AMAX', '1') != '0'        # A/B switch: 0 = a magnitude pre-pass per call for weights
+PARAM_EPOCH = [0]             # bumped by every kernel of this module that rewrites parameters in place (flat AdamW, soft update)
+
+
+@torch.no_grad()
+def amax_segments(flat, begin, length, handles):
+    """One launch: max |.| of every segment flat[begin[g] : begin[g] + length[g]] into the g-th handle of `handles` (int64 [nseg * AMAX_WORDS])."""
+    _need_cuda('amax_segments', flat, begin, length, handles)
+    _AMAX_EPOCH[0] += 1
+    check(lib().resel_amax_segments(_p(flat), _p(begin), _p(length), int(begin.numel()), _p(handles), _AMAX_EPOCH[0], _stream()), 'amax_segments')
+
+
+def weight_amax(p):
+    """Magnitude handle of a parameter held in a FlatParameterStore (models/flat_params.py keeps one handle per tensor, refreshed by ONE
+    launch after the buffer was rewritten), or None (the caller's GEMM then decides about a pre-pass)."""
+    ref = getattr(p, '_resel_store', None)
+    if ref is None or not WEIGHT_AMAX or not amax_tracking():
+        return None
+    return ref[0].amax_handle(ref[1], p)
+
+
 def _slot_args(want, device):
     """(slot tensor or None, pointer, epoch) for a producer kernel's amax output."""
     if not want:
@@ -1209,6 +1230,8 @@ def gemm_f32(A, B, a_kcontig=True, b_kcontig=True, bias=None, act=None, out=None
         else:
             ha = amax_a if amax_a is not None else amax_of(A)
             hb = amax_b if amax_b is not None else amax_of(B)
+            ha = weight_amax(A) if ha is None else ha
+            hb = weight_amax(B) if hb is None else hb
             if ha is None or hb is None:
                 t_gemm = 2.0 * M * N * K * batch / 1.5e8                       # us at 150 TFLOP/s
                 cost = (0.0 if ha is not None else 4.0 * M * K * batch / 4.5e6 + 2.5) + (0.0 if hb is not None else 4.0 * N * K * batch / 4.5e6 + 2.5)
@@ -1295,12 +1318,14 @@ def attn_decode(qkv, kv_cache, pos, slopes, scale):
 @torch.no_grad()
 def soft_update_(target_flat, online_flat, tau):
     _need_cuda('soft_update', target_flat, online_flat)
+    PARAM_EPOCH[0] += 1
     check(lib().resel_soft_update(_p(target_flat), _p(online_flat), float(tau), target_flat.numel(), _stream()), 'soft_update')
 
 
 @torch.no_grad()
 def adamw_flat_(p, g, m, v, seg_end, seg_lr, seg_wd, step, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=None):
     _need_cuda('adamw_flat', p, g, m, v, seg_end, seg_lr, seg_wd)
+    PARAM_EPOCH[0] += 1
     check(lib().resel_adamw_flat(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(seg_end), _p(seg_lr), _p(seg_wd), int(seg_end.numel()),
                                  float(beta1), float(beta2), float(eps), int(step), _p(grad_scale), _stream()), 'adamw_flat')
 
@@ -1309,6 +1334,7 @@ def adamw_flat_(p, g, m, v, seg_end, seg_lr, seg_wd, step, beta1=0.9, beta2=0.99
 def adamw_flat_dev_(p, g, m, v, seg_end, seg_lr, seg_wd, bias_corrections, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=None):
     """`adamw_flat_` with (1 - beta1^t, sqrt(1 - beta2^t)) read from the 2-element device tensor `bias_corrections` (captured updates)."""
     _need_cuda('adamw_flat_dev', p, g, m, v, seg_end, seg_lr, seg_wd, bias_corrections)
+    PARAM_EPOCH[0] += 1
     check(lib().resel_adamw_flat_dev(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(seg_end), _p(seg_lr), _p(seg_wd), int(seg_end.numel()),
                                      float(beta1), float(beta2), float(eps), _p(bias_corrections), _p(grad_scale), _stream()), 'adamw_flat_dev')
 

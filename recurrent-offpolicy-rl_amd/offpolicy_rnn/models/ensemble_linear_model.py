@@ -28,7 +28,8 @@ class _SharedInput(torch.autograd.Function):
         ops.LAST_AMAX = None
         if min(n_in, E * n_out) >= ops.GEMM_F32_MIN_DIM and ops.gemm_f32_ok(x2.shape[0], x2, w_cat):
             # hand-written fp32 MFMA GEMM, bias + ELU in its epilogue (837 us against 995 at 66 752 x 384 -> 2048)
-            y2 = ops.gemm_f32(x2, w_cat, True, False, None if bias is None else bias.reshape(E * n_out), act, amax_a=ax)
+            y2 = ops.gemm_f32(x2, w_cat, True, False, None if bias is None else bias.reshape(E * n_out), act, amax_a=ax,
+                              amax_b=ops.weight_amax(weight))          # w_cat holds the same values as the parameter
             ax = ax if ax is not None else ops.amax_of(x2)
         elif act is None:
             y2 = torch.addmm(bias.reshape(E * n_out), x2, w_cat) if bias is not None else torch.mm(x2, w_cat)

@@ -39,12 +39,37 @@ class FlatParameterStore:
         with torch.no_grad():
             for p, o, n in self.slices:
                 self.flat[o:o + n].copy_(p.detach().reshape(-1))
+        self._amax = None            # per-tensor magnitude handles (GEMM product mode 2): (handles, PARAM_EPOCH at refresh, versions)
         self._repoint()
 
     def _repoint(self):
-        for p, o, n in self.slices:
+        for i, (p, o, n) in enumerate(self.slices):
             p.data = self.flat[o:o + n].view(p.shape)
             p.grad = self.grad[o:o + n].view(p.shape)
+            p._resel_store = (self, i)
+        self._amax = None
+
+    def amax_handle(self, index: int, p):
+        """Magnitude handle of parameter `index` (hip/ops.py `weight_amax`).  All tensors of the buffer are refreshed by ONE launch when
+        the buffer was rewritten since the last refresh: by this library's in-place kernels (ops.PARAM_EPOCH) or by an in-place torch op
+        on any of the parameters (their `_version`s; load_state_dict, initialisers)."""
+        from ..hip import ops
+        if self.flat.device.type != 'cuda' or p.data_ptr() != self.flat.data_ptr() + 4 * self.slices[index][1]:
+            return None                                   # not (or no longer) a view of this buffer
+        st = self._amax
+        if st is None or st[1] != ops.PARAM_EPOCH[0] or st[2][index] != p._version or st[0].device != self.flat.device:
+            vers = [q._version for q, _, _ in self.slices]
+            if st is None or st[0].device != self.flat.device:
+                dev = self.flat.device
+                handles = torch.zeros(len(self.slices) * ops.AMAX_WORDS, dtype=torch.int64, device=dev)
+                begin = torch.tensor([o for _, o, _ in self.slices], dtype=torch.int64, device=dev)
+                length = torch.tensor([n for _, _, n in self.slices], dtype=torch.int64, device=dev)
+                views = list(handles.view(len(self.slices), ops.AMAX_WORDS).unbind(0))
+            else:
+                handles, begin, length, views = st[0], st[3], st[4], st[5]
+            ops.amax_segments(self.flat, begin, length, handles)
+            st = self._amax = (handles, ops.PARAM_EPOCH[0], vers, begin, length, views)
+        return st[5][index]
 
     def ensure_grad_extra(self, n: int):
         """At least n trailing slots behind the gradients (the parameter buffer keeps its own tail): data-parallel runs carry every

@@ -1115,3 +1115,25 @@ def test_producers_publish_operand_magnitudes(ops, monkeypatch):
     assert ops.LAST_SPLIT[0] == 2 and ops.amax_value(ops.amax_of(out)) == out.abs().max().item()
     ref = y.double() @ W.double().t()
     assert ((out.double() - ref).abs() / (y.double().abs() @ W.double().abs().t())).max().item() < 5e-7
+
+
+def test_flat_store_publishes_weight_magnitudes_in_one_launch(ops, monkeypatch):
+    """`FlatParameterStore.amax_handle`: one `resel_amax_segments` launch covers every tensor of the buffer; the handles follow the buffer -
+    refreshed after this library's in-place kernels (ops.PARAM_EPOCH) and after torch-visible in-place writes (`_version`)."""
+    from collections import OrderedDict
+    from offpolicy_rnn.models.flat_params import FlatParameterStore
+    monkeypatch.setattr(ops, 'GEMM_SPLIT', 2)
+    torch.manual_seed(0)
+    mods = OrderedDict(a=torch.nn.Linear(64, 32), b=torch.nn.Linear(32, 8)).copy()
+    for m in mods.values():
+        m.cuda()
+    st = FlatParameterStore(mods)
+    ps = [p for p, _, _ in st.slices]
+    for p in ps:
+        assert ops.amax_value(ops.weight_amax(p)) == p.detach().abs().max().item()
+    h0 = ops.weight_amax(ps[0])
+    with torch.no_grad():
+        ps[2].mul_(3.0)                                   # torch-visible write to one tensor: that tensor's lookup refreshes the table
+    assert ops.amax_value(ops.weight_amax(ps[2])) == ps[2].detach().abs().max().item()
+    ops.soft_update_(st.flat, st.flat * 2, 0.5)           # this library's kernel: PARAM_EPOCH moves, next lookup refreshes
+    assert ops.amax_value(ops.weight_amax(ps[0])) == ps[0].detach().abs().max().item() and ops.weight_amax(ps[0]) is h0

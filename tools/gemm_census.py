@@ -31,6 +31,17 @@ def hooked(A, B, a_kcontig=True, b_kcontig=True, bias=None, act=None, out=None, 
 
 
 ops.gemm_f32 = hooked
+real_amax = ops.amax
+pre = []
+
+
+def hooked_amax(x):
+    st = traceback.extract_stack(limit=5)
+    pre.append((tuple(x.shape), ' <- '.join(f'{os.path.basename(f.filename)}:{f.lineno}' for f in reversed(st[:-1]))))
+    return real_amax(x)
+
+
+ops.amax = hooked_amax
 import offpolicy_rnn.models.ensemble_linear_model as elm
 alg.train_one_batch()
 torch.cuda.synchronize()
@@ -43,3 +54,10 @@ print(f'{len(rec)} calls, {tot / 1e3:.2f} ms (event pairs include launch gaps)')
 for key, (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     b, M, N, K, akc, bkc, act, mode, site = key
     print(f'{us / 1e3:7.3f} ms x{n:2d} {us / n:7.1f} us  mode {mode} b{b} M{M} N{N} K{K} a{akc} b{bkc} {str(act):5s} {site}')
+
+print(f'{len(pre)} magnitude pre-passes')
+cnt = defaultdict(int)
+for k in pre:
+    cnt[k] += 1
+for (shape, site), n in sorted(cnt.items(), key=lambda kv: -kv[1] * (kv[0][0][0] * kv[0][0][-1])):
+    print(f'  x{n} {shape} {site}')

@@ -6,7 +6,8 @@ import torch
 from bench import build_trainer
 rnn = sys.argv[1] if len(sys.argv) > 1 else 'smamba_s32_c16_b2_nln'
 rows = int(sys.argv[2]) if len(sys.argv) > 2 else 64
-alg = build_trainer(rnn, rows, 1024)
+algo = sys.argv[3] if len(sys.argv) > 3 else 'sac'
+alg = build_trainer(rnn, rows, 1024, algo=algo)
 alg.defer_log = True
 
 
@@ -31,6 +32,8 @@ host = 1e3 * (time.perf_counter() - t0)
 torch.cuda.synchronize()
 print('host side of one eager update (returns before the GPU is done)', round(host, 3), 'ms')
 from offpolicy_rnn.algorithm.graphed_update import GraphedUpdate
+if GraphedUpdate.refusal(alg):
+    print('no graph:', GraphedUpdate.refusal(alg)); sys.exit(0)
 gu = GraphedUpdate(alg, warmup=1)
 for _ in range(4):
     gu.step(); alg.grad_num += 1
