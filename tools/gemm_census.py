@@ -61,3 +61,18 @@ for k in pre:
     cnt[k] += 1
 for (shape, site), n in sorted(cnt.items(), key=lambda kv: -kv[1] * (kv[0][0][0] * kv[0][0][-1])):
     print(f'  x{n} {shape} {site}')
+
+# by shape: time against the two floors of the call - three fp16 plane products at the dense fp16 matrix rate (2.5 PFLOP/s) and the
+# operand + output bytes at 5 TB/s
+print('by shape: ms total | us per call | floor us (matrix, bytes) | calls')
+shp = defaultdict(lambda: [0, 0.0])
+for (b, M, N, K, akc, bkc, act, mode, site), (n, us) in agg.items():
+    shp[(b, M, N, K, akc, bkc, mode)][0] += n
+    shp[(b, M, N, K, akc, bkc, mode)][1] += us
+fl_tot = 0.0
+for (b, M, N, K, akc, bkc, mode), (n, us) in sorted(shp.items(), key=lambda kv: -kv[1][1]):
+    t_m = 3 * 2.0 * b * M * N * K / 2.5e9
+    t_b = 4.0 * b * (M * K + N * K + M * N) / 5e6
+    fl_tot += n * max(t_m, t_b)
+    print(f'{us / 1e3:7.3f} | {us / n:7.1f} | {t_m:6.1f} {t_b:6.1f} | x{n:2d} mode {mode} b{b} M{M} N{N} K{K} a{akc} b{bkc}')
+print(f'sum of floors {fl_tot / 1e3:.2f} ms of {tot / 1e3:.2f}')
