@@ -26,8 +26,6 @@
 #include "resel_common.h"
 #include <algorithm>
 #include <atomic>
-#include <cstdlib>
-#include <type_traits>
 
 namespace {
 using namespace resel;
@@ -201,7 +199,6 @@ __device__ __forceinline__ float f16_scale(float amax) {
 template <bool KC, int ROWS>
 struct Src {
     static constexpr int NPC = ROWS / 64;          // KC pieces
-    static constexpr bool is_kc = KC;
     static constexpr int NR = KC ? NPC : (ROWS == 256 ? 4 : 2);
     const char* base;
     const char* base0;                             // the tile's step at k = 0: always a whole, valid K step (K >= 32)
@@ -258,12 +255,7 @@ struct Src {
         for (int i = 0; i < NR; ++i) r[i] = *reinterpret_cast<const float4*>(b + off[i]);
         if (full) base += step;
     }
-    __device__ __forceinline__ void load(int k0, int kend) { load_to(r, k0, kend); }
-    __device__ __forceinline__ void load_to(float4 (&r)[NR], int k0, int kend) {
-#ifdef BF3_AB_NOLOAD
-        asm volatile("" : "+v"(r[0].x));
-        return;
-#endif
+    __device__ __forceinline__ void load(int k0, int kend) {
         if (k0 + BK <= kend) {
 #pragma unroll
             for (int i = 0; i < NR; ++i) r[i] = *reinterpret_cast<const float4*>(base + off[i]);
@@ -276,34 +268,9 @@ struct Src {
         }
         base += step;
     }
-    // third edition (producer waves): one piece of a register set at a time, so that a register is reloaded for two K steps ahead
-    // as soon as its values have been split (KC layouts; the transposed layouts need all NR registers of a patch together)
-    __device__ __forceinline__ void load_piece(float4& v, int i, int k0, int kend) const {
-#ifdef BF3_AB_NOLOAD
-        asm volatile("" : "+v"(v.x));
-        return;
-#endif
-        if (k0 + BK <= kend) {
-            v = *reinterpret_cast<const float4*>(base + off[i]);
-        } else {
-            v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k0 + kofs + (KC ? 0 : i) < kend) v = *reinterpret_cast<const float4*>(base + off[i]);
-        }
-    }
-    __device__ __forceinline__ void advance() { base += step; }
-    template <int PL, int NP, int F16>
-    __device__ __forceinline__ void store_piece(const float4& v, int i, char* pl, f32x2_t sc) const {
-        static_assert(KC, "pieces exist in the [rows][K] layout only");
-        const P3 s = F16 == 1 ? split4_f16<true>(v, sc) : F16 == 2 ? split4_f16<false>(v, sc) : split4<NP>(v);
-        *reinterpret_cast<uint2*>(pl + loff[i]) = s.p1;
-        *reinterpret_cast<uint2*>(pl + PL + loff[i]) = s.p2;
-        if (NP == 3) *reinterpret_cast<uint2*>(pl + 2 * PL + loff[i]) = s.p3;
-    }
     // split the staged values and store the planes of this thread's pieces into the plane set at `pl` (plane stride PL bytes)
     template <int PL, int NP, int F16 = 0>
-    __device__ __forceinline__ void store(char* pl, f32x2_t sc = f32x2_t{1.f, 2048.f}) const { store_from<PL, NP, F16>(r, pl, sc); }
-    template <int PL, int NP, int F16 = 0>
-    __device__ __forceinline__ void store_from(const float4 (&r)[NR], char* pl, f32x2_t sc = f32x2_t{1.f, 2048.f}) const {
+    __device__ __forceinline__ void store(char* pl, f32x2_t sc = f32x2_t{1.f, 2048.f}) const {
         if (KC) {
 #pragma unroll
             for (int i = 0; i < NPC; ++i) {
@@ -650,328 +617,6 @@ __global__ __launch_bounds__(NTH, 2) void gemm_bf3_kernel(Params p) {
 #endif
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------------
-// Third edition: the same tiles, planes, LDS image, item walk and epilogue, with the two jobs of a K step given to different waves.
-// In the second edition every wave loads, splits, stores planes, reads fragments, issues matrix instructions and stores C, in
-// program order: a wave parked on `vmcnt` (a tile load that has not landed, or - after an epilogue - its own 64 C stores, which
-// the in-order counter puts in front of every later load) issues no matrix instruction either, and the ablations of round 4
-// (profiles/r04_gemm.md) show the parts ADDING: data path 192 us + split 50 + C stores 113 + matrix instructions 158 = 513 against 455
-// measured at 66 752 x 2048 x 384.  Here
-//   * waves 0..7 (consumers, 4 x 2 over the 256 x 128 tile, wave tile 64 x 64) only read fragments, issue matrix instructions and
-//     store C: they never wait for a load, and their C stores drain while they work on the next tile (nothing later in their
-//     program order needs `vmcnt` except the bias values / the accumulate form's reads of C);
-//   * waves 8..11 (producers, one per SIMD) load the fp32 tiles TWO K steps ahead (two register sets), split them and store the
-//     planes of step s + 1 while the consumers multiply step s; each producer thread does the work of second-edition threads
-//     t and t + 256 (same addresses, same LDS image);
-//   * one `s_barrier` per K step for all twelve waves, as before: stage s + 1 written, stage s read.
-// 768 threads, 168 registers per wave (three waves per SIMD), 2 x STAGE of LDS: one block per CU, persistent.
-constexpr int NTH_WS = 768;
-#ifndef WS_TOUCH
-#define WS_TOUCH 4
-#endif
-constexpr int WS_LDS = 2 * STAGE + 256;          // + the touch scratch
-
-template <bool F16>
-__device__ __forceinline__ void ws_epilogue(const Params& p, const Item& cur, f32x16 (&acc)[2][2], const float (&bv)[2], float unscale,
-                                            int wm, int wn, int li, int lh, float& cmax) {
-    if (F16) {
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[a][b][e] *= unscale;
-    }
-#ifdef BF3_AB_NOEPI
-    if (li == 0 && lh == 0) p.C[(int64_t)cur.m0 * p.ldc + cur.n0 + (wm >> 5) + (wn >> 6)] = acc[0][0][0] + acc[0][1][1] + acc[1][0][2] + acc[1][1][3];
-    return;
-#endif
-    if (cur.split) {
-        float* o = p.slab + (int64_t)(cur.split - 1) * TILE + (wm + 4 * lh) * BN + wn + li;
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) o[(32 * a + (e & 3) + 8 * (e >> 2)) * BN + 32 * b] = acc[a][b][e];
-        return;
-    }
-    float* C = p.C + (int64_t)cur.z * p.sC;
-    const bool full_m = cur.m0 + BM <= p.M;
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int n = cur.n0 + wn + 32 * b + li;
-        if (n >= p.N) continue;
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            float v[16];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) v[e] = acc[a][b][e] + bv[b];
-            if (p.act == 1) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) v[e] = elu1(v[e]);
-            }
-            if (p.act == 3) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) v[e] = softplus_nb(v[e]);
-            }
-            const int mb = cur.m0 + wm + 32 * a + 4 * lh;
-            float* crow = C + (int64_t)mb * p.ldc + n;
-            if (p.act == 2) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int dm = (e & 3) + 8 * (e >> 2);
-                    if (mb + dm < p.M) v[e] += crow[(int64_t)dm * p.ldc];
-                }
-            }
-            if (full_m) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) crow[(int64_t)((e & 3) + 8 * (e >> 2)) * p.ldc] = v[e];
-            } else {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int dm = (e & 3) + 8 * (e >> 2);
-                    if (mb + dm < p.M) crow[(int64_t)dm * p.ldc] = v[e];
-                }
-            }
-            if (p.amaxC.slot) {
-#pragma unroll
-                for (int e = 0; e < 16; e += 2) cmax = fmaxf(cmax, fmaxf(__builtin_fabsf(v[e]), __builtin_fabsf(v[e + 1])));
-            }
-        }
-    }
-}
-
-#define WS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-
-template <bool AKC, bool BKC, int SPLIT>
-__global__ __launch_bounds__(NTH_WS, 1) void gemm_ws_kernel(Params p) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];           // 2 stages
-    constexpr bool F16 = SPLIT == 2;
-    constexpr int NP = (SPLIT == 3 || SPLIT == 2) ? 2 : 3;
-    constexpr int NPB = SPLIT == 3 ? 2 : 3;
-    const int tid = threadIdx.x;
-    const int total = p.nfull + p.nsplit * p.nsl;
-    const int G = gridDim.x;
-    if ((int)blockIdx.x >= total) return;
-    float sa_ = 1.f, sb_ = 1.f;
-    if (F16) { sa_ = f16_scale(amax_read(p.amaxA)); sb_ = f16_scale(amax_read(p.amaxB)); }
-
-    if (tid >= 512) {
-        // ------------------------------------------------------------------------------------------------ producers
-        const int pt = tid - 512;
-        const f32x2_t scA = {sa_, 2048.f * sa_}, scB = {sb_, 2048.f * sb_};
-        typedef Src<AKC, BM> SA;
-        typedef Src<BKC, BN> SB;
-        SA a0, a1;
-        SB b0, b1;
-        a0.init_lds(pt); a1.init_lds(pt + 256);
-        b0.init_lds(pt); b1.init_lds(pt + 256);
-        float4 ra[2][2][SA::NR], rb[2][2][SB::NR];                       // [register set][virtual thread]
-        int nsteps = 0;
-        for (int it = blockIdx.x; it < total; it += G) {
-            const Item i = decode(p, it);
-            nsteps += (i.kend - i.kbeg + BK - 1) / BK;
-        }
-        int p_item = blockIdx.x, p_k0 = 0, p_kend = 0;
-        bool p_live = true;
-        auto p_open = [&]() {
-            const Item it = decode(p, p_item);
-            const float* Ab = p.A + (int64_t)it.z * p.sA;
-            const float* Bb = p.B + (int64_t)it.z * p.sB;
-            a0.init(Ab, p.lda, p.M, it.m0, it.kbeg, pt); a1.init(Ab, p.lda, p.M, it.m0, it.kbeg, pt + 256);
-            b0.init(Bb, p.ldb, p.N, it.n0, it.kbeg, pt); b1.init(Bb, p.ldb, p.N, it.n0, it.kbeg, pt + 256);
-            p_k0 = it.kbeg; p_kend = it.kend;
-        };
-        auto load_step = [&](auto SET) {                                // a whole K step into register set S; cursor one step on
-            constexpr int S = decltype(SET)::value;
-            if (!p_live) return;
-            a0.load_to(ra[S][0], p_k0, p_kend); a1.load_to(ra[S][1], p_k0, p_kend);
-            b0.load_to(rb[S][0], p_k0, p_kend); b1.load_to(rb[S][1], p_k0, p_kend);
-            p_k0 += BK;
-            if (p_k0 >= p_kend) {
-                p_item += G;
-                if (p_item < total) p_open(); else p_live = false;
-            }
-        };
-        auto store_step = [&](auto SET) {                               // register set S -> LDS stage S
-            constexpr int S = decltype(SET)::value;
-            char* st = lds + S * STAGE;
-            a0.template store_from<PLA, NP, F16 ? 1 : 0>(ra[S][0], st, scA);
-            a1.template store_from<PLA, NP, F16 ? 1 : 0>(ra[S][1], st, scA);
-            b0.template store_from<PLB, NPB, F16 ? 2 : 0>(rb[S][0], st + 3 * PLA, scB);
-            b1.template store_from<PLB, NPB, F16 ? 2 : 0>(rb[S][1], st + 3 * PLA, scB);
-        };
-        // set S -> stage S with every register reloaded (the step at the cursor: two steps on) right behind ITS split, so that
-        // nearly two whole steps of loads are in flight at any time (reloading after the whole set's split leaves one).  Straight-line:
-        // the compiler fences keep the memory instructions in this order and the in-order `vmcnt` waits exact.
-#define WS_CFENCE() __builtin_amdgcn_sched_barrier(0)
-        auto recycle = [&](auto SET) {
-            constexpr int S = decltype(SET)::value;
-            char* st = lds + S * STAGE;
-            constexpr int FA = F16 ? 1 : 0, FB = F16 ? 2 : 0;
-            auto one = [&](auto& src, auto& regs, char* pl, f32x2_t sc, auto PLc, auto NPc, auto Fc) {
-                constexpr int PL = decltype(PLc)::value, NPP = decltype(NPc)::value, FF = decltype(Fc)::value;
-                typedef std::remove_reference_t<decltype(src)> ST;
-                if constexpr (ST::is_kc) {
-#pragma unroll
-                    for (int i = 0; i < ST::NR; ++i) {
-                        src.template store_piece<PL, NPP, FF>(regs[i], i, pl, sc);
-                        WS_CFENCE();
-                        regs[i] = *reinterpret_cast<const float4*>(src.base + src.off[i]);
-                        WS_CFENCE();
-                    }
-                } else {
-                    src.template store_from<PL, NPP, FF>(regs, pl, sc);
-                    WS_CFENCE();
-#pragma unroll
-                    for (int i = 0; i < ST::NR; ++i) regs[i] = *reinterpret_cast<const float4*>(src.base + src.off[i]);
-                    WS_CFENCE();
-                }
-                src.base += src.step;
-            };
-            using IA = std::integral_constant<int, PLA>;
-            using IB = std::integral_constant<int, PLB>;
-            one(a0, ra[S][0], st, scA, IA{}, std::integral_constant<int, NP>{}, std::integral_constant<int, FA>{});
-            one(a1, ra[S][1], st, scA, IA{}, std::integral_constant<int, NP>{}, std::integral_constant<int, FA>{});
-            one(b0, rb[S][0], st + 3 * PLA, scB, IB{}, std::integral_constant<int, NPB>{}, std::integral_constant<int, FB>{});
-            one(b1, rb[S][1], st + 3 * PLA, scB, IB{}, std::integral_constant<int, NPB>{}, std::integral_constant<int, FB>{});
-            p_k0 += BK;
-            if (p_k0 >= p_kend) {
-                p_item += G;
-                if (p_item < total) p_open(); else p_live = false;
-            }
-        };
-        using S0 = std::integral_constant<int, 0>;
-        using S1 = std::integral_constant<int, 1>;
-        auto produce = [&](auto SET, bool do_store) {   // one K step of production into stage / from set S
-            if (do_store && p_live && p_k0 + BK <= p_kend) { recycle(SET); return; }
-            if (do_store) store_step(SET);
-            load_step(SET);
-        };
-        p_open();
-        load_step(S0{});                                // step 0
-        load_step(S1{});                                // step 1
-        produce(S0{}, true);                            // stage 0 <- step 0, set 0 <- step 2
-        WS_BARRIER();
-        for (int s = 0; s < nsteps; s += 2) {
-            produce(S1{}, s + 1 < nsteps);              // consumers are on stage 0 (step s)
-            WS_BARRIER();
-            if (s + 1 >= nsteps) break;
-            produce(S0{}, s + 2 < nsteps);              // consumers are on stage 1 (step s + 1)
-            WS_BARRIER();
-        }
-        return;
-    }
-
-    // ---------------------------------------------------------------------------------------------------- consumers
-    const float unscale = (1.f / sa_) * (1.f / sb_);
-    const int lane = tid & 63, w = tid >> 6;
-    const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
-    const int li = lane & 31, lh = lane >> 5;
-    const char* fa[2];
-    const char* fb[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        fa[s] = lds + wm * ROWB + plane_off(li, 2 * s + lh);
-        fb[s] = lds + 3 * PLA + wn * ROWB + plane_off(li, 2 * s + lh);
-    }
-    float cmax = 0.f;
-    Frag f0, f1;
-#ifdef BF3_AB_CLOCK
-    const unsigned long long ck_t0 = __builtin_amdgcn_s_memtime(), ck_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
-    // L2 touches: the consumers ask for ONE dword of every 128-byte line of the tiles WS_TOUCH K steps ahead (LDS-DMA into a
-    // 256-byte scratch behind the stages: no register, nobody waits for it), so that the producers' loads find the lines in L2
-    // instead of waiting - in `vmcnt` order, every load of a step behind the slowest - for HBM (A) or the Infinity Cache (B).
-    const uint32_t touch_lds = (uint32_t)(size_t)(lds + 2 * STAGE);
-    auto touch = [&](const Item& it, int kk, int kend) {
-#if WS_TOUCH > 0
-        const float* ptr = nullptr;
-        if (tid < 256) {
-            const float* Ab = p.A + (int64_t)it.z * p.sA;
-            if (AKC) ptr = Ab + (int64_t)min(it.m0 + tid, p.M - 1) * p.lda + kk;
-            else ptr = Ab + (int64_t)min(kk + (tid >> 3), kend - 1) * p.lda + min(it.m0 + (tid & 7) * 32, p.M - 4);
-        } else if (tid < 384) {
-            const int u = tid - 256;
-            const float* Bb = p.B + (int64_t)it.z * p.sB;
-            if (BKC) ptr = Bb + (int64_t)min(it.n0 + u, p.N - 1) * p.ldb + kk;
-            else ptr = Bb + (int64_t)min(kk + (u >> 2), kend - 1) * p.ldb + min(it.n0 + (u & 3) * 32, p.N - 4);
-        }
-        if (ptr) asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dword %0, off" :: "v"(ptr), "s"(touch_lds) : "memory");
-#endif
-    };
-    WS_BARRIER();
-    read_a<NP>(f0, fa[0]); read_b<NPB>(f0, fb[0]);
-    int cur_st = 0;
-    for (int c_item = blockIdx.x; c_item < total; c_item += G) {
-        const Item cur = decode(p, c_item);
-        float zero = 0.f;
-        asm volatile("" : "+v"(zero));
-        f32x16 acc[2][2];
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[a][b][e] = zero;
-        float bv[2] = {0.f, 0.f};
-#if WS_TOUCH > 0
-        const bool has_next = c_item + G < total;
-        Item nxt = cur;
-        if (has_next) nxt = decode(p, c_item + G);
-#endif
-        for (int c_k0 = cur.kbeg; c_k0 < cur.kend; c_k0 += BK) {
-            const int so = cur_st * STAGE, sn = (cur_st ^ 1) * STAGE;
-            if (c_k0 + BK >= cur.kend && p.bias && !cur.split) {
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const int n = cur.n0 + wn + 32 * b + li;
-                    bv[b] = p.bias[(int64_t)cur.z * p.sBias + (n < p.N ? n : 0)];
-                }
-            }
-#if WS_TOUCH > 0
-            {
-                const int tk = c_k0 + WS_TOUCH * BK;
-                if (tk < cur.kend) touch(cur, tk, cur.kend);
-                else if (has_next && nxt.kbeg + (tk - cur.kend) < nxt.kend) touch(nxt, nxt.kbeg + (tk - cur.kend), nxt.kend);
-            }
-#endif
-            BF3_FENCE();
-            read_a<NP>(f1, fa[1] + so); read_b<NPB>(f1, fb[1] + so);
-            mfma_small<SPLIT>(acc, f0);
-            if (F16) mfma_lead_f16(acc, f0); else mfma_lead(acc, f0);
-            mfma_small<SPLIT>(acc, f1);
-#pragma unroll
-            for (int i = 0; i < 2 * (NP + NPB); ++i) {                   // one fragment read behind each of the first matrix instructions
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-            BF3_FENCE();
-            WS_BARRIER();
-            BF3_FENCE();
-            read_a<NP>(f0, fa[0] + sn); read_b<NPB>(f0, fb[0] + sn);
-            if (F16) mfma_lead_f16(acc, f1); else mfma_lead(acc, f1);
-#pragma unroll
-            for (int i = 0; i < 2 * (NP + NPB); ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-            BF3_FENCE();
-            cur_st ^= 1;
-        }
-        ws_epilogue<F16>(p, cur, acc, bv, unscale, wm, wn, li, lh, cmax);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the touches are invisible to the compiler: nothing in flight when the wave ends
-    amax_publish_wave(cmax, p.amaxC);
-#ifdef BF3_AB_CLOCK
-    if (tid == 0) {
-        g_bf3_clock[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - ck_t0;
-        g_bf3_clock[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - ck_r0;
-    }
-#endif
-}
-
 // C tile = epi(sum over the K slices of a split tile), fixed summation order: as gemm_fixup_kernel of gemm_f32.hip for 256 x 128 tiles
 __global__ __launch_bounds__(256) void gemm_bf3_fixup_kernel(Params p) {
     __shared__ float4 part[3][64];
@@ -1045,23 +690,6 @@ int launch_one(const Params& p, dim3 grid, hipStream_t s) {
     return RESEL_OK;
 }
 
-template <bool AKC, bool BKC, int SP>
-int launch_ws(const Params& p, dim3 grid, hipStream_t s) {
-    static std::atomic<bool> attr_set[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return RESEL_ELAUNCH;
-    if (!attr_set[dev].load(std::memory_order_acquire)) {
-        if (hipFuncSetAttribute((const void*)gemm_ws_kernel<AKC, BKC, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS) != hipSuccess)
-            return RESEL_ELAUNCH;
-        attr_set[dev].store(true, std::memory_order_release);
-    }
-    launch_timed(RESEL_PROF_GEMM, gemm_ws_kernel<AKC, BKC, SP>, grid, dim3(NTH_WS), (size_t)WS_LDS, s, p);
-    return RESEL_OK;
-}
-
-// edition of the split GEMM: 3 = producer / consumer waves (gemm_ws_kernel), 2 = every wave does everything (gemm_bf3_kernel)
-int g_edition = [] { const char* e = getenv("RESEL_GEMM_EDITION"); return e ? atoi(e) : 2; }();
-
 }  // namespace
 
 #ifdef BF3_AB_CLOCK
@@ -1095,15 +723,7 @@ int gemm_bf3_launch(const float* A, int64_t lda, int64_t strideA, int a_kcontig,
          else if (a_kcontig) rc = launch_one<true, false, SP>(p, grid, s); \
          else if (b_kcontig) rc = launch_one<false, true, SP>(p, grid, s); \
          else rc = launch_one<false, false, SP>(p, grid, s); } while (0)
-#define WS_LAUNCH(SP) \
-    do { if (a_kcontig && b_kcontig) rc = launch_ws<true, true, SP>(p, grid, s); \
-         else if (a_kcontig) rc = launch_ws<true, false, SP>(p, grid, s); \
-         else if (b_kcontig) rc = launch_ws<false, true, SP>(p, grid, s); \
-         else rc = launch_ws<false, false, SP>(p, grid, s); } while (0)
-    if (g_edition == 3 && split == 2) WS_LAUNCH(2);
-    else if (g_edition == 3 && split == 6) WS_LAUNCH(6);
-    else if (split == 9) BF3_LAUNCH(9); else if (split == 3) BF3_LAUNCH(3); else if (split == 2) BF3_LAUNCH(2); else BF3_LAUNCH(6);
-#undef WS_LAUNCH
+    if (split == 9) BF3_LAUNCH(9); else if (split == 3) BF3_LAUNCH(3); else if (split == 2) BF3_LAUNCH(2); else BF3_LAUNCH(6);
 #undef BF3_LAUNCH
     if (rc != RESEL_OK) return rc;
     if (pl.nsplit) hipLaunchKernelGGL(gemm_bf3_fixup_kernel, dim3(TILE / 4 / 64, pl.nsplit), dim3(64, 4), 0, s, p);
