@@ -493,6 +493,8 @@ def main():
     coll = {k: v / args.steps for k, v in alg.grad_sync.calls.items() if k != 'broadcast'}
     coll_bytes = {k: v / args.steps for k, v in alg.grad_sync.bytes.items() if k != 'broadcast'}
     eager_ms = None
+    if gu is not None:
+        gu.close()                                       # the eager legs below draw their dropout offsets from torch's generator again
     if args.graph_update:
         # Events cannot be bound to dispatches inside a graph replay: the per-kernel times of the roofline objects come from the SAME
         # update launched eagerly right behind the timed region (same kernels, same shapes, same stream), which also gives the

@@ -220,6 +220,12 @@ int resel_attn_varlen_bwd(const uint16_t* qkv, const int32_t* cu_seqlens, const 
  * decoder block (TransformerFlashAttention.py:48,52,72,84-85) in training-mode passes; the backward is the same call on dy
  * with the same (seed, offset).  In place (y == x) allowed. */
 int resel_dropout(const float* x, float* y, int64_t n, float p_drop, uint64_t seed, uint64_t offset, resel_stream_t stream);
+/* Offset base of the counter-keyed masks: while `base` (a device uint64, 8-byte aligned; NULL switches it off) is set, every mask
+ * kernel launched afterwards - resel_dropout, resel_gelu_dropout_fwd / _bwd, resel_attn_varlen_fwd / _bwd with p_drop > 0 - adds
+ * *base to its `offset` argument WHEN IT RUNS.  A captured update (algorithm/graphed_update.py) bakes the host-drawn offsets into
+ * its kernel nodes; a node of the same graph advances *base, so every replay draws fresh masks while the forward and backward
+ * kernels of one replay agree.  Process-wide host state (one device per process); not a per-call argument. */
+int resel_dropout_offset_base(const void* base);
 /* y = dropout(gelu(x)) (erf form) in one pass and its backward dx = dy * keep / (1 - p) * gelu'(x) from the pre-activation x; same
  * counter-keyed mask as resel_dropout (p_drop = 0: plain GELU).  FFN hidden of the cgpt block (reference
  * models/flash_attention/TransformerFlashAttention.py:46-53: nn.GELU() followed by nn.Dropout). */

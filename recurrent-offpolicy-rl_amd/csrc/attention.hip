@@ -118,6 +118,7 @@ struct AttnParams {
     uint32_t thr;               // dropout: keep iff random byte < thr (256 = keep all)
     float rp;                   // 1 / (1 - p)
     uint64_t seed, offset;
+    const unsigned long long* obase;   // device word added to `offset` when the kernel runs (resel_dropout_offset_base), or nullptr
 };
 
 // stage a [KT keys][HD] tile of K or V (which = 1 / 2) row-major and / or transposed into LDS
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(256 * KSPL, KSPL == 2 && HD == 32 ? 4 : 1) void att
     // dropout: per-lane query word and the four key-quad offsets of a tile (rows 8g + 4hh + {0..3} = keys of one quad)
     uint32_t dq_word = 0, dk_off[4] = {0, 0, 0, 0};
     if (DROP) {
-        dq_word = ((uint32_t)(t0 + q) * DROP_CQ) ^ drop_head_key(p.seed, p.offset, h);
+        dq_word = ((uint32_t)(t0 + q) * DROP_CQ) ^ drop_head_key(p.seed, p.offset + (p.obase ? *p.obase : 0ull), h);
 #pragma unroll
         for (int g = 0; g < 4; ++g) dk_off[g] = (uint32_t)(2 * g + hh) * DROP_CK;
     }
@@ -730,7 +731,7 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnParams p) {
     uint32_t dk_word = 0, dq_off[4] = {0, 0, 0, 0};
     const int dsh = 8 * (r & 3);
     if (DROP) {
-        dk_word = ((uint32_t)(key >> 2) * DROP_CK) ^ drop_head_key(p.seed, p.offset, h);
+        dk_word = ((uint32_t)(key >> 2) * DROP_CK) ^ drop_head_key(p.seed, p.offset + (p.obase ? *p.obase : 0ull), h);
 #pragma unroll
         for (int g = 0; g < 4; ++g) dq_off[g] = (uint32_t)((r & 3) + 8 * g + 4 * hh) * DROP_CQ;
     }
@@ -891,6 +892,7 @@ inline void set_dropout(AttnParams& p, float p_drop, uint64_t seed, uint64_t off
     p.rp = 1.f / (1.f - p_drop);
     p.seed = seed;
     p.offset = offset;
+    p.obase = p_drop > 0.f ? resel::dropout_offset_base() : nullptr;
 }
 
 template <int HD, bool DROP>

@@ -21,8 +21,8 @@ __device__ __forceinline__ uint32_t stream_key(uint64_t seed, uint64_t offset) {
 }
 
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, uint32_t thr16,
-                                                      float rp, uint64_t seed, uint64_t offset) {
-    const uint32_t key = stream_key(seed, offset);
+                                                      float rp, uint64_t seed, uint64_t offset, const unsigned long long* obase) {
+    const uint32_t key = stream_key(seed, offset + (obase ? *obase : 0ull));
     const int64_t n4 = n >> 2;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const uint32_t w0 = mix32(((uint32_t)(2 * i) * 0x9E3779B1u) ^ key), w1 = mix32(((uint32_t)(2 * i + 1) * 0x9E3779B1u) ^ key);
@@ -52,8 +52,8 @@ __device__ __forceinline__ float gelu_or_grad(float x, float g) {
 }
 template <bool BWD>
 __global__ __launch_bounds__(256) void gelu_dropout_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ out,
-                                                           int64_t n, uint32_t thr16, float rp, uint64_t seed, uint64_t offset, AmaxOut amax) {
-    const uint32_t key = stream_key(seed, offset);
+                                                           int64_t n, uint32_t thr16, float rp, uint64_t seed, uint64_t offset, const unsigned long long* obase, AmaxOut amax) {
+    const uint32_t key = stream_key(seed, offset + (obase ? *obase : 0ull));
     const int64_t n4 = n >> 2;
     float omax = 0.f;                                // max |out| of this thread's stores (the fc2 / fc1-gradient GEMMs scale their operand with it)
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
@@ -88,7 +88,7 @@ extern "C" int resel_gelu_dropout_fwd(const float* x, float* y, int64_t n, float
     const int64_t n4 = (n + 3) >> 2;
     const int blocks = (int)(n4 + 255) / 256 < 2048 ? (int)((n4 + 255) / 256) : 2048;
     hipLaunchKernelGGL(gelu_dropout_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (const float*)nullptr, y, n, thr16,
-                       1.f / (1.f - p_drop), seed, offset, AmaxOut{(unsigned long long*)amax_y, amax_epoch});
+                       1.f / (1.f - p_drop), seed, offset, resel::dropout_offset_base(), AmaxOut{(unsigned long long*)amax_y, amax_epoch});
     return launch_status();
 }
 
@@ -101,7 +101,7 @@ extern "C" int resel_gelu_dropout_bwd(const float* x, const float* dy, float* dx
     const int64_t n4 = (n + 3) >> 2;
     const int blocks = (int)(n4 + 255) / 256 < 2048 ? (int)((n4 + 255) / 256) : 2048;
     hipLaunchKernelGGL(gelu_dropout_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, dy, dx, n, thr16, 1.f / (1.f - p_drop), seed,
-                       offset, AmaxOut{(unsigned long long*)amax_dx, amax_epoch});
+                       offset, resel::dropout_offset_base(), AmaxOut{(unsigned long long*)amax_dx, amax_epoch});
     return launch_status();
 }
 
@@ -111,6 +111,6 @@ extern "C" int resel_dropout(const float* x, float* y, int64_t n, float p_drop, 
     const uint32_t thr16 = (uint32_t)lrintf((1.f - p_drop) * 65536.f);
     const int64_t n4 = (n + 3) >> 2;
     const int blocks = (int)(n4 + 255) / 256 < 2048 ? (int)((n4 + 255) / 256) : 2048;
-    hipLaunchKernelGGL(dropout_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, n, thr16, 1.f / (1.f - p_drop), seed, offset);
+    hipLaunchKernelGGL(dropout_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, n, thr16, 1.f / (1.f - p_drop), seed, offset, resel::dropout_offset_base());
     return launch_status();
 }

@@ -1,7 +1,19 @@
 // Library identification.
 #include "resel_common.h"
+#include <cstdint>
 
-extern "C" int resel_abi_version(void) { return 5; }
+extern "C" int resel_abi_version(void) { return 6; }
+
+// ---- dropout offset base: a device word that every counter-keyed mask kernel (resel_dropout, resel_gelu_dropout_*, resel_attn_varlen_*
+// with p_drop > 0) adds to its `offset` argument when it RUNS.  A captured update bakes the host-drawn offsets into its kernel nodes; with
+// the base advanced by a node of the same graph every replay draws fresh masks (forward and backward of one replay read the same value).
+namespace { const unsigned long long* g_drop_base = nullptr; }
+namespace resel { const unsigned long long* dropout_offset_base() { return g_drop_base; } }
+extern "C" int resel_dropout_offset_base(const void* base) {
+    if (base && ((uintptr_t)base & 7)) return RESEL_EINVAL;
+    g_drop_base = (const unsigned long long*)base;
+    return RESEL_OK;
+}
 extern "C" const char* resel_build_info(void) { return "resel_hip gfx950 (CDNA4, wave64) built " __DATE__ " " __TIME__; }
 
 // ---- per-dispatch timing registry (see resel_common.h launch_timed) ----

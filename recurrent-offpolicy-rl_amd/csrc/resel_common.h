@@ -158,6 +158,8 @@ __device__ __forceinline__ float amax_read(const float* handle) {
 }
 
 inline int launch_status() { return hipGetLastError() == hipSuccess ? RESEL_OK : RESEL_ELAUNCH; }
+// device word added to the `offset` of every counter-keyed dropout mask (resel_dropout_offset_base; nullptr: none)
+const unsigned long long* dropout_offset_base();
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace resel

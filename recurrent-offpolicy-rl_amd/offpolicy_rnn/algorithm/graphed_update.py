@@ -15,14 +15,20 @@ episodes.  Every `step()` is exactly ONE update (same update-to-data ratio and r
 calls run eagerly (allocator and lazily initialised kernels warm up), a shape is recorded the SECOND time it occurs (a shape that
 never recurs is not worth two device synchronisations and an activation pool), at most `max_graphs` graphs live at a time in ONE
 shared memory pool (they never replay concurrently), the least recently used one is dropped for a newcomer; any update without a
-graph runs eagerly from the same static inputs.  Refused at construction (use the eager `train_one_batch`): layers that need host-built
-sequence tables or host dropout counters (cgpt), side-stream overlap (gru), gradient clipping, data-parallel groups."""
+graph runs eagerly from the same static inputs.
+Attention layers (cgpt): the token index / cu_seqlens tables of the batch are built by `_prepare` into pinned buffers (copy nodes in the
+graph; their sizes and the longest sequence are part of the shape key), and the counter-keyed dropout masks take their offsets from a
+per-update host count (0, 4, 8, ... in program order - baked into the kernel nodes) PLUS a device word that a node of the graph
+advances (`ops.dropout_offset_base`): every replay draws fresh masks, forward and backward kernels of one replay agree, and an eager
+fallback through `step()` draws exactly what a replay would.
+Refused at construction (use the eager `train_one_batch`): side-stream overlap (gru), gradient clipping, data-parallel groups."""
 from collections import OrderedDict
 
 import numpy as np
 import torch
 
 from ..hip import ops
+from ..models.flash_attention.TransformerFlashAttention import PackedSeqs
 from .sac_full_length_rnn_ensembleQ import DeferredLog
 
 
@@ -75,14 +81,71 @@ class GraphedUpdate:
         self._evt = torch.cuda.Event()
         self._log_host = torch.empty(64, dtype=torch.float32, pin_memory=True)      # static target of the log's D2H node
         self._last_log = None
+        # attention layers: static sequence tables (two descriptions per batch: the batch and its one-slot shift) and the dropout base
+        self._seq = None
+        self._drop_base = None
+        self._drop_seed = 0
+        if getattr(alg, '_needs_seq_table', False):
+            self._drop_base = torch.zeros(1, dtype=torch.int64, device=self.device)
+            ops.dropout_offset_base(self._drop_base)
+            if not torch.cuda.default_generators:
+                torch.cuda.init()
+            dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+            self._drop_seed = torch.cuda.default_generators[dev_index].initial_seed() & ((1 << 64) - 1)
+
+    DROP_STRIDE = 1 << 16                             # offsets one update may consume (4 per mask: 16 384 masks)
+
+    def close(self):
+        """Detach the process-wide dropout base again (eager trainers of the same process go back to torch's generator offsets)."""
+        if self._drop_base is not None:
+            ops.dropout_offset_base(None)
+            self._drop_base = None
+
+    def _seq_buffers(self, n_idx, n_cu):
+        """Static pinned + device buffers of the two sequence descriptions; growing them invalidates every recorded graph."""
+        sq = self._seq
+        if sq is None or sq['cap_idx'] < n_idx or sq['cap_cu'] < n_cu:
+            ci, cc = max(2 * n_idx, 1024), max(2 * n_cu, 64)
+            self.graphs.clear()
+            sq = self._seq = dict(cap_idx=ci, cap_cu=cc,
+                                  idx_host=[torch.empty(ci, dtype=torch.int64, pin_memory=True) for _ in range(2)],
+                                  cu_host=[torch.empty(cc, dtype=torch.int32, pin_memory=True) for _ in range(2)],
+                                  idx_dev=[torch.empty(ci, dtype=torch.int64, device=self.device) for _ in range(2)],
+                                  cu_dev=[torch.empty(cc, dtype=torch.int32, device=self.device) for _ in range(2)])
+        return sq
+
+    @staticmethod
+    def _build_seqs(pl):
+        """Host half of `_batch_views` for attention layers (runs while the previous replay is still on the GPU)."""
+        rows, T, table = pl['nrow'], pl['longest'], pl['table']
+        am = np.zeros((rows, T), dtype=np.int32)
+        am[:, :table.shape[1]] = table
+        tam = np.concatenate((am[:, 1:], np.zeros((rows, 1), dtype=np.int32)), axis=1)
+        return [PackedSeqs.build_host(a, T) for a in (am, tam)]
+
+    def _prepare_seqs(self, built):
+        """Both descriptions into the pinned buffers (the previous replay has read them); returns their part of the shape key."""
+        sq = self._seq_buffers(max(b[0].size for b in built), max(b[1].size for b in built))
+        for i, (idx, cu, mx, tb) in enumerate(built):
+            sq['idx_host'][i][:idx.size].copy_(torch.from_numpy(idx))
+            sq['cu_host'][i][:cu.size].copy_(torch.from_numpy(cu))
+        self._seq_now = [(b[0].size, b[1].size, b[2], b[3]) for b in built]
+        return tuple(x for b in built for x in (b[0].size, b[1].size, b[2]))
+
+    def packed_seqs(self):
+        """Called by the trainer's `_batch_views` while this object drives the update: copy nodes + static device views."""
+        sq, out = self._seq, []
+        for i, (n_idx, n_cu, mx, tb) in enumerate(self._seq_now):
+            sq['idx_dev'][i][:n_idx].copy_(sq['idx_host'][i][:n_idx], non_blocking=True)
+            sq['cu_dev'][i][:n_cu].copy_(sq['cu_host'][i][:n_cu], non_blocking=True)
+            out.append(PackedSeqs.from_static(sq['idx_dev'][i][:n_idx], sq['cu_dev'][i][:n_cu], mx, tb))
+        return out
 
     @staticmethod
     def refusal(alg):
         par = alg.parameter
         if alg.device.type != 'cuda':
             return 'needs a GPU'
-        if getattr(alg, '_needs_seq_table', False):
-            return 'attention layers build their sequence tables and dropout counters on the host'
         if getattr(alg, 'overlap_value_embedding', False):
             # tried in round 4: with the refusal lifted the capture of the gru trainer (target pass and prefetched value embeddings on
             # side streams, forked / joined with events) ends in a segmentation fault inside capture_end on this ROCm build
@@ -122,7 +185,10 @@ class GraphedUpdate:
         if n > self.PLAN_CAPACITY:
             raise RuntimeError(f'GraphedUpdate: {n} plan segments exceed the static plan buffer ({self.PLAN_CAPACITY})')
         key = (pl['nrow'], pl['longest'], pl['max_len'], n)
+        built = self._build_seqs(pl) if self._drop_base is not None else None
         self._evt.synchronize()                                              # the previous update has read the pinned plan
+        if built is not None:
+            key = key + self._prepare_seqs(built)
         self._plan_host[:n].copy_(torch.from_numpy(pl['seg']))
         self._plan = pl
         sub = np.ascontiguousarray(np.asarray(self._draw(self.E)), dtype=np.int32)
@@ -139,10 +205,15 @@ class GraphedUpdate:
         alg._select_target_ensemble = lambda E: self.subset_np
         for opt in (alg.optimizer_value, alg.optimizer_policy):
             opt.device_factors_active = True
+        if self._drop_base is not None:
+            ops.DROP_OVERRIDE = [self._drop_seed, 0]
         try:
             ops.amax_arena_zero(self.device)          # first node: a replay publishes operand magnitudes into the slots / epochs baked into the graph
+            if self._drop_base is not None:
+                self._drop_base.add_(self.DROP_STRIDE)                       # a node: every replay moves the masks of the whole update on
             alg.train_one_batch()
         finally:
+            ops.DROP_OVERRIDE = None
             alg._graph = None
             del alg._select_target_ensemble
             for opt in (alg.optimizer_value, alg.optimizer_policy):

@@ -252,7 +252,10 @@ class SACFullLengthRNNEnsembleQ(SAC):
         out['valid'], out['total_valid'], out['total_start'] = dev[..., W:W + 1], dev[..., W + 1:W + 2], dev[..., W + 2:W + 3]
         # per-row sequence-length tables (reference :358-366) are consumed by attention layers only
         out['attention_mask'] = out['target_attention_mask'] = None
-        if self._needs_seq_table:
+        if self._needs_seq_table and self._graph is not None:
+            # captured update: the tables were built by GraphedUpdate._prepare into pinned buffers; copy nodes + static device views
+            out['attention_mask'], out['target_attention_mask'] = self._graph.packed_seqs()
+        elif self._needs_seq_table:
             am = np.zeros((rows, T), dtype=np.int32)
             am[:, :table.shape[1]] = table
             tam = np.concatenate((am[:, 1:], np.zeros((rows, 1), dtype=np.int32)), axis=1)

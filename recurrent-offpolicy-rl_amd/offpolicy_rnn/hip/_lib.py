@@ -9,7 +9,7 @@ from ctypes import c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('RESEL_HIP_LIBRARY') or os.path.join(_HERE, 'libresel_hip.so')      # override: ablation builds (tools/gemm_ablate.sh)
-ABI_VERSION = 5
+ABI_VERSION = 6
 _lib = None
 
 P, I, L, F, S, U = c_void_p, c_int, c_int64, c_float, c_void_p, c_uint64
@@ -48,6 +48,7 @@ SIGNATURES = {
     'resel_attn_varlen_bwd_workspace_bytes': (c_size_t, [I, I, I, I, I]),
     'resel_attn_varlen_bwd': (c_int, [P, P, P, P, P, P, P, P, I, I, I, I, I, F, F, U, U, S]),
     'resel_dropout': (c_int, [P, P, L, F, U, U, S]),
+    'resel_dropout_offset_base': (c_int, [P]),
     'resel_gelu_dropout_fwd': (c_int, [P, P, L, F, U, U, P, E, S]),
     'resel_gelu_dropout_bwd': (c_int, [P, P, P, L, F, U, U, P, E, S]),
     'resel_tanh_gaussian_fwd': (c_int, [P, P, P, P, P, I, I, S]),

@@ -542,10 +542,29 @@ class AttnVarlenFn(torch.autograd.Function):
 _MASK64 = (1 << 64) - 1
 
 
+DROP_OVERRIDE = None           # [seed, next offset] while a GraphedUpdate body runs (recorded or eager): see dropout_offset_base
+_DROP_BASE_KEEP = []           # the device words handed to resel_dropout_offset_base stay alive as long as the process
+
+
+def dropout_offset_base(word):
+    """Install (None: remove) the device int64 word that every counter-keyed mask kernel adds to its offset when it runs
+    (include/resel_hip.h `resel_dropout_offset_base`): a captured update advances it with a node of its own graph, so that a replay
+    - whose kernel nodes carry the host-drawn offsets of the recording - draws fresh masks."""
+    if word is not None:
+        assert word.is_cuda and word.dtype == torch.int64 and word.numel() == 1
+        _DROP_BASE_KEEP.append(word)
+    check(lib().resel_dropout_offset_base(_p(word)), 'dropout_offset_base')
+
+
 def dropout_counter(device):
     """(seed, offset) for one counter-keyed dropout mask, taken from the device's default torch generator the way ATen's
     own dropout kernels reserve Philox offsets: host-side bookkeeping only (no sync), deterministic under
-    `torch.manual_seed`, and every call gets a fresh offset."""
+    `torch.manual_seed`, and every call gets a fresh offset.  Inside a GraphedUpdate body (torch's generator may not be
+    queried while a stream is capturing) the draws count up from 0 per update and the device-side base makes updates differ."""
+    if DROP_OVERRIDE is not None:
+        off = DROP_OVERRIDE[1]
+        DROP_OVERRIDE[1] = off + 4
+        return DROP_OVERRIDE[0], off
     if not torch.cuda.default_generators:            # first CUDA touch of the process: the generator tuple is filled by the lazy init
         torch.cuda.init()
     gen = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]

@@ -351,3 +351,44 @@ def test_fused_gelu_dropout_equals_gelu_then_counter_dropout(p, shape):
     scale = ref.abs().max().item()
     assert (out - ref).abs().max().item() <= 2e-6 * scale
     assert (xs.grad - xr.grad).abs().max().item() <= 2e-6 * xr.grad.abs().max().item()
+
+
+@pytest.mark.gpu
+def test_dropout_offset_base_shifts_every_mask_kernel():
+    """`resel_dropout_offset_base`: with the device word holding k, every counter-keyed mask kernel draws the mask of offset + k -
+    the element-wise dropout, the fused GELU + dropout pair and the attention forward / backward (GraphedUpdate advances the word with
+    a node of its graph)."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from offpolicy_rnn.hip import ops
+    dev = torch.device('cuda')
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.randn(4099, device=dev, generator=g)
+    word = torch.zeros(1, dtype=torch.int64, device=dev)
+    T, H, hd = 96, 2, 32
+    qkv = (torch.randn(T, 3, H, hd, device=dev, generator=g) * 0.5).to(torch.bfloat16)
+    cu = torch.tensor([0, 40, 96], dtype=torch.int32, device=dev)
+    slopes = torch.tensor([0.5, 0.25], device=dev)
+
+    def run(offset):
+        q = qkv.clone().requires_grad_(True)
+        o = ops.attn_varlen(q, cu, 56, slopes, None, 0.3, 77, offset)
+        o.float().square().sum().backward()
+        xg = x.clone().requires_grad_(True)
+        y = ops.gelu_dropout(xg, 0.3, 77, offset)
+        y.sum().backward()
+        return ops.counter_dropout(x, 0.3, 77, offset), y.detach(), xg.grad, o.detach().float(), q.grad.float()
+
+    want = run(40)
+    base_off = run(8)
+    try:
+        ops.dropout_offset_base(word)
+        word.fill_(32)
+        got = run(8)
+        word.fill_(0)
+        same = run(8)
+    finally:
+        ops.dropout_offset_base(None)
+    for a, b, c, d in zip(got, want, same, base_off):
+        assert torch.equal(a, b) and torch.equal(c, d)
+    assert not torch.equal(got[0], base_off[0]) and not torch.equal(got[3], base_off[3])

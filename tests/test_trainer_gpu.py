@@ -357,7 +357,7 @@ def test_cgpt_td3_update_gpu_vs_oracle():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('rnn,ragged,algo', [('smamba_s8_c4_b1_nln', False, 'sac'), ('gilr', False, 'sac'), ('smamba_s8_c4_b1_nln', True, 'sac'),
-                                              ('lru', False, 'td3')])
+                                              ('lru', False, 'td3'), ('cgpt_h1_l2_p0.0_ml64_rms', False, 'td3')])
 def test_graphed_update_equals_the_eager_update(rnn, ragged, algo, monkeypatch):
     """The whole update replayed from ONE hipGraph (algorithm/graphed_update.py: sampling plan, REDQ subset and AdamW step factors in
     static buffers refreshed before each replay) against the eager update: same seeds, actor noise off (the captured generator draws
@@ -421,11 +421,63 @@ def test_graphed_update_equals_the_eager_update(rnn, ragged, algo, monkeypatch):
     assert ragged or (g.graph is not None and g.eager_fallbacks <= 3)
     # not bit for bit: the entropy coefficient's torch AdamW runs in its `capturable` form (step count and bias corrections as
     # fp32 device tensors instead of Python floats), and the coefficient enters every loss
+    # cgpt: the attention runs in bf16 - an operand that differs in its last fp32 bit (the replayed GEMMs scale their fp16 planes with
+    # magnitude handles accumulated over replays, the eager ones with fresh ones) can round to the next bf16 value, 4e-3 of an element
+    rtol, atol = (5e-3, 1e-4) if rnn.startswith('cgpt') else (2e-5, 2e-7)
     for nm, a, b in zip(('policy', 'value', 'target value', 'log alpha'), state(graphed), state(eager)):
-        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-5, atol=2e-7, err_msg=nm)
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=rtol, atol=atol, err_msg=nm)
     for le, lg in zip(logs_e, logs_g):
         assert set(le) == set(lg)
         for k in le:
             ve = le[k][0] if isinstance(le[k], tuple) else le[k]
             vg = lg[k][0] if isinstance(lg[k], tuple) else lg[k]
-            assert abs(ve - vg) <= 2e-5 * max(1.0, abs(ve)), (k, ve, vg)
+            assert abs(ve - vg) <= max(rtol, 100 * atol if rnn.startswith('cgpt') else 0) * max(1.0, abs(ve)), (k, ve, vg)
+
+
+@pytest.mark.gpu
+def test_graphed_update_with_dropout_replays_what_its_eager_path_runs(monkeypatch):
+    """cgpt with dropout 0.1 (configs[2]'s layer id at a small size) through GraphedUpdate: the masks of an update are keyed on a
+    per-update host count baked into the kernel nodes + a device word that a node of the graph advances, so (a) a trainer stepped
+    through replays and one stepped through the SAME object's eager path (warm-up never ends) agree update by update, and (b) two
+    replays of one batch shape do not repeat each other's masks (the logged losses of consecutive updates differ)."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    import numpy as np
+    from test_host_logic import _push, _synth, make_parameter
+    from offpolicy_rnn import alg_init
+    from offpolicy_rnn.utility import rng
+    from offpolicy_rnn.algorithm.graphed_update import GraphedUpdate
+    monkeypatch.setattr(rng, 'randn', lambda shape, device, dtype=torch.float32: torch.zeros(tuple(shape), dtype=dtype, device=device))
+    monkeypatch.setattr(rng, 'randn_like', lambda t: torch.zeros_like(t))
+
+    def build():
+        torch.manual_seed(0)
+        np.random.seed(0)
+        alg = alg_init(make_parameter('cgpt_h1_l2_p0.1_ml64_rms', algo='td3', sac_batch_size=4 * 12 - 1, cuda_inference=True))
+        rs = np.random.RandomState(3)
+        for i in range(8):
+            o, a, r = _synth(rs, 12, 5, 3)
+            _push(alg.replay_buffer, o, a, r, early_done=False)
+        np.random.seed(11)
+        return alg
+
+    runs = []
+    for warmup in (1, 10 ** 6):
+        alg = build()
+        g = GraphedUpdate(alg, warmup=warmup)
+        logs = []
+        for _ in range(5):
+            logs.append(dict(g.step()))
+            alg.grad_num += 1
+        torch.cuda.synchronize()
+        runs.append((logs, alg.policy.store.flat.detach().clone(), alg.values[0].store.flat.detach().clone(), len(g.graphs), g.eager_fallbacks))
+        g.close()
+    (lg, pg, vg, ng, eg), (le, pe, ve, ne, ee) = runs
+    assert ng == 1 and eg <= 3 and ne == 0 and ee == 5
+    np.testing.assert_allclose(pg.cpu().numpy(), pe.cpu().numpy(), rtol=5e-3, atol=1e-4)          # bf16 attention: see the test above
+    np.testing.assert_allclose(vg.cpu().numpy(), ve.cpu().numpy(), rtol=5e-3, atol=1e-4)
+    val = lambda v: v[0] if isinstance(v, tuple) else v
+    for a, b in zip(lg, le):
+        for k in a:
+            assert abs(val(a[k]) - val(b[k])) <= 1e-2 * max(1.0, abs(val(b[k]))), (k, a[k], b[k])
+    assert len({round(val(l['critic_loss']), 7) for l in lg}) == len(lg)
