@@ -411,6 +411,12 @@ int resel_gemm_bf16(const void* A, int64_t lda, int a_kcontig, int a_bf16, const
                     const float* bias, void* C, int64_t ldc, int c_bf16, void* workspace, int M, int N, int K,
                     resel_stream_t stream);
 
+/* Bias gradient of such a projection: out[n] = sum_m x[m][n] in fp32 for a bf16 matrix (row stride ld elements, ld % 8 == 0, N % 8 == 0,
+ * N <= 2048, 16-byte aligned base) - the `gy.sum(0)` of the reference's autocast nn.Linear backward (TransformerFlashAttention.py:67-70
+ * through flash-attn's MHA).  Fixed summation order (per-256-row partials, then their sum): bitwise reproducible. */
+size_t resel_colsum_bf16_workspace_bytes(int M, int N);
+int resel_colsum_bf16(const uint16_t* x, int64_t ld, int M, int N, float* out, void* workspace, resel_stream_t stream);
+
 /* ---- packed trajectory batch from a device-resident replay ring --------------------------------------------------
  * Device counterpart of NestedMemoryArray.sample_trajs' packing loop (reference buffers/transition_buffer/
  * nested_replay_memory.py:140-176) plus the trainer's flag surgery (algorithm/sac_full_length_rnn_ensembleQ.py:338-342).

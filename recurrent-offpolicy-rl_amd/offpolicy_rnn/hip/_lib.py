@@ -82,6 +82,8 @@ SIGNATURES = {
     'resel_amax': (c_int, [P, L, L, I, I, I, P, E, P, S]),
     'resel_gemm_bf16_workspace_bytes': (c_size_t, [I, I, I]),
     'resel_gemm_bf16': (c_int, [P, L, I, I, P, L, I, I, P, P, L, I, P, I, I, I, S]),
+    'resel_colsum_bf16_workspace_bytes': (c_size_t, [I, I]),
+    'resel_colsum_bf16': (c_int, [P, L, I, I, P, P, S]),
     'resel_gather_trajs': (c_int, [P, I, L, P, I, I, I, I, I, I, I, I, I, P, I, P, S]),
     'resel_mamba_conv_step': (c_int, [P, L, P, L, P, L, L, L, I, P, P, P, I, I, I, I, S]),
     'resel_selective_state_update': (c_int, [P, L, P, L, P, P, L, P, P, P, P, P, L, P, I, I, I, I, S]),

@@ -1033,6 +1033,19 @@ def gemm_bf16_ok(x, w):
             and x.data_ptr() % 16 == 0 and w.is_contiguous() and w.data_ptr() % 16 == 0)
 
 
+@torch.no_grad()
+def colsum_bf16(x):
+    """x [M, N] bf16 -> column sums fp32 [N] (include/resel_hip.h `resel_colsum_bf16`); shapes the kernel does not take go to ATen."""
+    M, N = x.shape
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.stride(1) == 1 and N % 8 == 0 and N <= 2048 and x.stride(0) % 8 == 0
+            and x.data_ptr() % 16 == 0 and M >= 256):
+        return torch.sum(x, 0, dtype=torch.float32)
+    out = torch.empty(N, dtype=torch.float32, device=x.device)
+    ws = _ws(lib().resel_colsum_bf16_workspace_bytes(M, N), x.device)
+    check(lib().resel_colsum_bf16(_p(x), x.stride(0), M, N, _p(out), _p(ws), _stream()), 'colsum_bf16')
+    return out
+
+
 class LinearBf16(torch.autograd.Function):
     """F.linear under the reference's bf16 autocast (flash-attn MHA's Wqkv / out_proj, TransformerFlashAttention.py:67-70) as ONE
     node on `resel_gemm_bf16`: x fp32 or bf16, fp32 master weight and bias; forward output in `out_dtype`; the input gradient comes
@@ -1053,7 +1066,10 @@ class LinearBf16(torch.autograd.Function):
         dw = gemm_bf16(gy, x, False, False, None, torch.float32) if ctx.needs_input_grad[1] else None
         db = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = torch.sum(gy, 0, dtype=torch.float32)
+            if gy.dtype == torch.float32 and gy.shape[1] % 4 == 0 and gy.shape[0] >= 256:
+                db = bias_act_bwd(gy, gy, gy.shape[0], None, True)[1].reshape(-1)          # fp32 column sums (one read of gy, fixed order)
+            else:
+                db = colsum_bf16(gy)
         return dx, dw, db, None, None
 
 

@@ -1137,3 +1137,20 @@ def test_flat_store_publishes_weight_magnitudes_in_one_launch(ops, monkeypatch):
     assert ops.amax_value(ops.weight_amax(ps[2])) == ps[2].detach().abs().max().item()
     ops.soft_update_(st.flat, st.flat * 2, 0.5)           # this library's kernel: PARAM_EPOCH moves, next lookup refreshes
     assert ops.amax_value(ops.weight_amax(ps[0])) == ps[0].detach().abs().max().item() and ops.weight_amax(ps[0]) is h0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('M,N,pad', [(32832, 256, 0), (1000, 768, 8), (257, 1024, 0), (4099, 8, 16)])
+def test_colsum_bf16_matches_fp64_sum(ops, M, N, pad):
+    """`resel_colsum_bf16` (bias gradient of the bf16 projections) against the fp64 column sums of the same bf16 values: fp32
+    accumulation error only; repeated calls are bitwise equal (fixed summation order)."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    g = torch.Generator(device='cuda').manual_seed(M + N)
+    x = (torch.randn(M, N + pad, device='cuda', generator=g) * 3).to(torch.bfloat16)[:, :N]
+    got = ops.colsum_bf16(x)
+    want = x.double().sum(0)
+    scale = x.double().abs().sum(0)
+    assert got.dtype == torch.float32 and got.shape == (N,)
+    assert ((got.double() - want).abs() <= 2e-6 * scale + 1e-30).all()
+    assert torch.equal(got, ops.colsum_bf16(x))
