@@ -64,22 +64,30 @@ __global__ __launch_bounds__(256) void amax_kernel(AmaxParams p) {
 }  // namespace
 
 // ---- magnitudes of ALL tensors of a flat parameter buffer in one launch: segment g = flat[begin[g], begin[g] + len[g]) publishes into the
-// handle at handles + g * RESEL_AMAX_STRIDE * RESEL_AMAX_SUBSLOTS words.  grid (chunks, nseg): block (c, g) covers a 1/chunks share of g.
+// handle at handles + g * RESEL_AMAX_STRIDE * RESEL_AMAX_SUBSLOTS words.  grid (64, nseg): block (c, g) covers every 64th 256-element piece of g
+// (first version: 8 blocks per segment, one load in flight per thread - 73 us per call on the 3 MB ensemble weights).
 namespace {
 __global__ __launch_bounds__(256) void amax_segments_kernel(const float* __restrict__ flat, const int64_t* __restrict__ begin,
                                                             const int64_t* __restrict__ len, unsigned long long* handles, unsigned epoch) {
     const int g = blockIdx.y;
     const int64_t b = begin[g], n = len[g];
-    float m = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(flat[b + i]));
-    amax_publish_wave(m, AmaxOut{handles + (int64_t)g * RESEL_AMAX_STRIDE * RESEL_AMAX_SUBSLOTS, epoch});
+    if ((int64_t)blockIdx.x * 256 >= n) return;                        // short segments (biases): one block does it
+    const float* x = flat + b;
+    const int64_t st = (int64_t)gridDim.x * 256;
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;                       // four loads in flight per thread
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * st < n; i += 4 * st) {
+        m0 = fmaxf(m0, fabsf(x[i])); m1 = fmaxf(m1, fabsf(x[i + st])); m2 = fmaxf(m2, fabsf(x[i + 2 * st])); m3 = fmaxf(m3, fabsf(x[i + 3 * st]));
+    }
+    for (; i < n; i += st) m0 = fmaxf(m0, fabsf(x[i]));
+    amax_publish_wave(fmaxf(fmaxf(m0, m1), fmaxf(m2, m3)), AmaxOut{handles + (int64_t)g * RESEL_AMAX_STRIDE * RESEL_AMAX_SUBSLOTS, epoch});
 }
 }  // namespace
 
 extern "C" int resel_amax_segments(const float* flat, const int64_t* begin, const int64_t* len, int nseg, void* handles, unsigned epoch,
                                    resel_stream_t stream) {
     if (!flat || !begin || !len || nseg <= 0 || !handles || (reinterpret_cast<uintptr_t>(handles) & 7u)) return RESEL_EINVAL;
-    hipLaunchKernelGGL(amax_segments_kernel, dim3(8, nseg), dim3(256), 0, (hipStream_t)stream, flat, begin, len, (unsigned long long*)handles, epoch);
+    hipLaunchKernelGGL(amax_segments_kernel, dim3(64, nseg), dim3(256), 0, (hipStream_t)stream, flat, begin, len, (unsigned long long*)handles, epoch);
     return launch_status();
 }
 
