@@ -67,6 +67,8 @@ class FlatParameterStore:
                 views = list(handles.view(len(self.slices), ops.AMAX_WORDS).unbind(0))
             else:
                 handles, begin, length, views = st[0], st[3], st[4], st[5]
+            if torch.cuda.is_current_stream_capturing():
+                handles.zero_()                           # a replay publishes with the epoch baked into the node: start from nothing, not from the last replay's maxima
             ops.amax_segments(self.flat, begin, length, handles)
             st = self._amax = (handles, ops.PARAM_EPOCH[0], vers, begin, length, views)
         return st[5][index]

@@ -1,1 +1,3 @@
-for v in 2FULL 2NOB 3NOB 2NOB 3NOB; do echo "== edition 3 variant $v"; for sh in "66752 2048 384 1 1" "66752 1024 256 1 1" "66752 256 512 1 1" "66752 256 1024 1 0"; do RESEL_HIP_LIBRARY=tools/micro/bin/libresel_ws_D$v.so RESEL_GEMM_EDITION=3 RESEL_AMAX_PREPASS=1 timeout 120 python3 tools/prof_gemm.py $sh 20 2 2>&1 | grep -v amdgpu.ids; done; done
+echo "== eager, default products"; python3 tools/soak.py smamba_s32_c16_b2_nln 300 2>&1 | grep -v amdgpu.ids | tail -4
+echo "== graph, default products"; python3 tools/soak.py smamba_s32_c16_b2_nln 300 graph 2>&1 | grep -v amdgpu.ids | tail -4
+echo "== eager, mode 6"; RESEL_GEMM_SPLIT=6 python3 tools/soak.py smamba_s32_c16_b2_nln 300 2>&1 | grep -v amdgpu.ids | tail -3

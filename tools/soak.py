@@ -1,4 +1,5 @@
-"""Soak run: N consecutive updates of the bench configuration; prints the log scalars every 20 updates and checks they stay finite."""
+"""Soak run: N consecutive updates of the bench configuration; prints the log scalars every 20 updates and checks they stay finite.
+python tools/soak.py [rnn] [updates] [graph]     third argument 'graph': every update through GraphedUpdate.step() (replays)"""
 import sys, os, math
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'recurrent-offpolicy-rl_amd')]
@@ -7,8 +8,13 @@ from bench import build_trainer
 rnn = sys.argv[1] if len(sys.argv) > 1 else 'smamba_s32_c16_b2_nln'
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 120
 alg = build_trainer(rnn, 64, 1024)
+step = alg.train_one_batch
+if len(sys.argv) > 3 and sys.argv[3] == 'graph':
+    from offpolicy_rnn.algorithm.graphed_update import GraphedUpdate
+    gu = GraphedUpdate(alg, warmup=1)
+    step = gu.step
 for i in range(n):
-    log = dict(alg.train_one_batch())
+    log = dict(step())
     alg.grad_num += 1
     vals = {k: (v[0] if isinstance(v, tuple) else v) for k, v in log.items()}
     assert all(math.isfinite(float(v)) for v in vals.values()), (i, vals)
