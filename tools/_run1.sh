@@ -1,5 +1,7 @@
-export RESEL_HIP_LIBRARY=tools/micro/bin/libresel_ws_asm.so
-RESEL_GEMM_EDITION=3 timeout 300 python3 tools/_chk.py 2>&1 | grep -v amdgpu.ids | awk '{ if ($4+0 > 1e-5 || $4=="nan") print "BAD", $0; else n++ } END { print n, "shapes ok" }'
-RESEL_GEMM_EDITION=3 timeout 600 python3 -m pytest tests/test_hip_ops.py -m gpu -x -q -k "gemm" 2>&1 | tail -2
-echo "== edition 3"; RESEL_GEMM_EDITION=3 timeout 300 python3 tools/ab_f16x3.py 2>&1 | grep -v amdgpu.ids | head -6 | cut -c1-110
-echo "== edition 2"; RESEL_GEMM_EDITION=2 python3 tools/ab_f16x3.py 2>&1 | grep -v amdgpu.ids | head -6 | cut -c1-110
+C="--steps 5 --warmup 2 --no-cpu-baseline --no-strict-leg --no-graph-update --no-rccl-leg --no-suite"
+bash tools/profile_bench.sh r04d > /dev/null 2>&1
+bash tools/profile_bench.sh r04d_cgpt $C --rnn cgpt_h8_l6_p0.1_ml1024_rms --algo td3 --rows 32 --horizon 1024 > /dev/null 2>&1
+bash tools/profile_bench.sh r04d_gilr $C --rnn gilr --algo sac --rows 16 --horizon 2000 > /dev/null 2>&1
+bash tools/profile_bench.sh r04d_lru $C --rnn lru --algo sac --rows 16 --horizon 2000 > /dev/null 2>&1
+bash tools/profile_bench.sh r04d_gru $C --rnn gru --algo sac --rows 64 --horizon 1024 > /dev/null 2>&1
+ls gpurun_out/prof_r04d* | grep -c csv
