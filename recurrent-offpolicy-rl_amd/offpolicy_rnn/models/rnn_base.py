@@ -143,6 +143,12 @@ class RNNBase(torch.nn.Module):
         if lid.startswith('cgpt'):
             cfg = parse_cgpt_id(lid)
             return TransformerDecoder(n_in, cfg['nhead'], 4 * n_in, cfg['nlayer'], cfg['pdrop'], cfg['ln']), cfg['maxlength']
+        if lid == 'lstm':
+            # the reference lists `lstm` (rnn_base.py:58) but cannot run it on this path either: ContextualModel.meta_forward asks every
+            # embedding network for its full hidden sequence (contextual_model.py:92-94, 113-115) and RNNHidden refuses to hold one for an
+            # LSTM (RNNHidden.py:23-25: 'It is not supported to store full RNN output of LSTM!!!')
+            raise NotImplementedError("layer id 'lstm': the reference's full-trajectory path rejects it as well (RNNHidden.py:23-25 asserts "
+                                      "when ContextualModel.meta_forward requests the full hidden sequence, contextual_model.py:92-94)")
         if lid.startswith(_UNSUPPORTED_PREFIXES):
             raise NotImplementedError(f'layer id {lid!r} exists in the reference but is outside the MI355X hot path of this build '
                                       f'(supported: fc, efc-<E>, gru, gilr, lru, gilr_lstm, smamba_*, mamba_*, conv1d_*, cgpt_*)')
