@@ -21,11 +21,14 @@
 // Pipeline per K step s (one barrier): MFMAs of k slab 0 | split + LDS stores of step s + 1 (its global loads were issued a step
 // earlier) | fragment reads of slab 1 | global loads of step s + 2 | first half of slab 1's MFMAs | barrier | fragment reads of
 // step s + 1's slab 0 under the second half of slab 1's MFMAs.
+// A third edition for mode 2 (producer / consumer waves, `gemm_ws_kernel` further down) takes the shapes with whole K steps; this one keeps the rest.
 // Blocks are persistent (256 = one per CU) and walk items exactly as in gemm_f32.hip: whole tiles, and K slices for the last
 // partly filled round and for weight gradients, summed by a fix-up kernel in a fixed order (deterministic, no atomics).
 #include "resel_common.h"
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
+#include <type_traits>
 
 namespace {
 using namespace resel;
@@ -163,8 +166,7 @@ __device__ __forceinline__ void split_pair_f16(float x0, float x1, f32x2_t sc, u
     } else {
         const f32x2_t r = {xs.x - (float)h.x, xs.y - (float)h.y};
         p2 = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2_t));
-        const f16x2_t k = {(_Float16)0.00048828125f, (_Float16)0.00048828125f};        // 2^-11
-        p3 = __builtin_bit_cast(uint32_t, h * k);
+        p3 = 0u;                                   // 2^-11 b1 is formed by the consumer of the fragment (mfma_lead_f16)
     }
 }
 template <bool WIDE>
@@ -199,12 +201,15 @@ __device__ __forceinline__ float f16_scale(float amax) {
 template <bool KC, int ROWS>
 struct Src {
     static constexpr int NPC = ROWS / 64;          // KC pieces
+    static constexpr bool is_kc = KC;
     static constexpr int NR = KC ? NPC : (ROWS == 256 ? 4 : 2);
     const char* base;
     const char* base0;                             // the tile's step at k = 0: always a whole, valid K step (K >= 32)
     uint32_t off[NR];
     uint32_t loff[KC ? NPC : 4];                   // LDS byte offsets inside a plane (KC: per piece; !KC: per patch row)
     int64_t step;
+    int64_t pstride;                               // KC: bytes between the pieces of a thread (64 rows); uniform
+    int pvalid;                                    // KC: pieces that start inside the operand's rows; uniform
     int kofs;
     float4 r[NR];
     __device__ __forceinline__ void init(const float* P, int64_t ld, int rows, int r0, int k0, int tid) {
@@ -218,6 +223,8 @@ struct Src {
                 off[i] = (uint32_t)(((r0 + rl < rows ? rl : 0) * ld + kofs) * 4);
             }
             step = BK * 4;
+            pstride = 64 * ld * 4;
+            pvalid = (rows - r0 + 63) / 64;
         } else {
             const int g = ROWS == 256 ? (tid & 7) + 8 * (tid >> 6) : (tid & 7) + 8 * (tid >> 7);
             kofs = ROWS == 256 ? 4 * ((tid >> 3) & 7) : 2 * ((tid >> 3) & 15);
@@ -255,7 +262,12 @@ struct Src {
         for (int i = 0; i < NR; ++i) r[i] = *reinterpret_cast<const float4*>(b + off[i]);
         if (full) base += step;
     }
-    __device__ __forceinline__ void load(int k0, int kend) {
+    __device__ __forceinline__ void load(int k0, int kend) { load_to(r, k0, kend); }
+    __device__ __forceinline__ void load_to(float4 (&r)[NR], int k0, int kend) {
+#ifdef BF3_AB_NOLOAD
+        asm volatile("" : "+v"(r[0].x));
+        return;
+#endif
         if (k0 + BK <= kend) {
 #pragma unroll
             for (int i = 0; i < NR; ++i) r[i] = *reinterpret_cast<const float4*>(base + off[i]);
@@ -268,9 +280,34 @@ struct Src {
         }
         base += step;
     }
+    // third edition (producer waves): one piece of a register set at a time, so that a register is reloaded for two K steps ahead
+    // as soon as its values have been split (KC layouts; the transposed layouts need all NR registers of a patch together)
+    __device__ __forceinline__ void load_piece(float4& v, int i, int k0, int kend) const {
+#ifdef BF3_AB_NOLOAD
+        asm volatile("" : "+v"(v.x));
+        return;
+#endif
+        if (k0 + BK <= kend) {
+            v = *reinterpret_cast<const float4*>(base + off[i]);
+        } else {
+            v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k0 + kofs + (KC ? 0 : i) < kend) v = *reinterpret_cast<const float4*>(base + off[i]);
+        }
+    }
+    __device__ __forceinline__ void advance() { base += step; }
+    template <int PL, int NP, int F16>
+    __device__ __forceinline__ void store_piece(const float4& v, int i, char* pl, f32x2_t sc) const {
+        static_assert(KC, "pieces exist in the [rows][K] layout only");
+        const P3 s = F16 == 1 ? split4_f16<true>(v, sc) : F16 == 2 ? split4_f16<false>(v, sc) : split4<NP>(v);
+        *reinterpret_cast<uint2*>(pl + loff[i]) = s.p1;
+        *reinterpret_cast<uint2*>(pl + PL + loff[i]) = s.p2;
+        if (NP == 3) *reinterpret_cast<uint2*>(pl + 2 * PL + loff[i]) = s.p3;
+    }
     // split the staged values and store the planes of this thread's pieces into the plane set at `pl` (plane stride PL bytes)
     template <int PL, int NP, int F16 = 0>
-    __device__ __forceinline__ void store(char* pl, f32x2_t sc = f32x2_t{1.f, 2048.f}) const {
+    __device__ __forceinline__ void store(char* pl, f32x2_t sc = f32x2_t{1.f, 2048.f}) const { store_from<PL, NP, F16>(r, pl, sc); }
+    template <int PL, int NP, int F16 = 0>
+    __device__ __forceinline__ void store_from(const float4 (&r)[NR], char* pl, f32x2_t sc = f32x2_t{1.f, 2048.f}) const {
         if (KC) {
 #pragma unroll
             for (int i = 0; i < NPC; ++i) {
@@ -370,7 +407,13 @@ __device__ __forceinline__ void mfma_lead(f32x16 (&acc)[2][2], const Frag& f) {
     mfma_term<1, 0>(acc, f); mfma_term<0, 1>(acc, f); mfma_term<0, 0>(acc, f);
 }
 // mode 2: a2 b1s + a1 b2 + a1 b1 (A planes {a1, a2}, B planes {b1, b2, b1s}), small terms first
-__device__ __forceinline__ void mfma_lead_f16(f32x16 (&acc)[2][2], const Frag& f) {
+// the third B "plane" 2^-11 b1 never goes through LDS: four packed fp16 multiplies per fragment (exact unless the product is subnormal -
+// the same values the producer's packed multiply stored before), a fifth less fragment traffic and a plane less to store
+__device__ __forceinline__ void mfma_lead_f16(f32x16 (&acc)[2][2], Frag& f) {
+    const f16x8 k = {(_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f,
+                     (_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f};
+#pragma unroll
+    for (int t = 0; t < 2; ++t) f.b[2][t] = __builtin_bit_cast(bf16x8, __builtin_bit_cast(f16x8, f.b[0][t]) * k);
     mfma_term_f16<1, 2>(acc, f); mfma_term_f16<0, 1>(acc, f); mfma_term_f16<0, 0>(acc, f);
 }
 
@@ -384,7 +427,7 @@ __global__ __launch_bounds__(NTH, 2) void gemm_bf3_kernel(Params p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];           // 2 stages
     constexpr bool F16 = SPLIT == 2;                                     // fp16 planes of the scaled operands (f16x3)
     constexpr int NP = (SPLIT == 3 || SPLIT == 2) ? 2 : 3;               // planes per element of A
-    constexpr int NPB = SPLIT == 3 ? 2 : 3;                              // planes per element of B (mode 2: b1, b2, 2^-11 b1)
+    constexpr int NPB = (SPLIT == 3 || SPLIT == 2) ? 2 : 3;              // planes of B in LDS (mode 2: b1, b2; 2^-11 b1 is formed from b1's fragment)
     f32x2_t scA = {1.f, 2048.f}, scB = {1.f, 2048.f};
     float unscale = 1.f;
     if (F16) {
@@ -495,7 +538,6 @@ __global__ __launch_bounds__(NTH, 2) void gemm_bf3_kernel(Params p) {
                     if (i < 2 * (NP + NPB)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
                     __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-                    if (F16 && i >= 10) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
                     if (i >= 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 }
             } else {
@@ -617,6 +659,396 @@ __global__ __launch_bounds__(NTH, 2) void gemm_bf3_kernel(Params p) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Third edition (mode 2, whole K steps): the same block tile, planes, LDS image and item walk, with the two jobs of a K step given to
+// different waves.  In the second edition every wave loads, splits, stores planes, reads fragments, issues matrix instructions and stores
+// C in program order - a wave parked on `vmcnt` issues no matrix instruction either - and its parts ADD (profiles/r04_gemm.md: data path
+// 192 us + split 50 + C stores 113 + matrix instructions 158 = 513 against 455 measured at 66 752 x 2048 x 384).  Here, 512 threads:
+//   * waves 0..3 (consumers, 2 x 2 over the 256 x 128 tile, wave tile 128 x 64 = 4 x 2 tiles of 32 x 32, 128 accumulator registers) only
+//     read fragments (12 ds_read_b128 per 16-k slab, two register sets), issue matrix instructions and store C; they never wait for a
+//     load.  2^-11 b1 - the third B "plane" of mode 2 - is formed from b1's fragment with four packed fp16 multiplies (the values
+//     the producer's packed multiply used to store): LDS holds two planes per operand;
+//   * waves 4..7 (producers, one per SIMD) hold two register sets = two K steps of the fp32 tiles; ALL their tile loads are inline
+//     assembly the compiler does not count, and every unit (a piece of a [rows][K] operand, an instance of a transposed one) waits for
+//     ITS loads with a hand-written `s_waitcnt vmcnt(24 - n)` tied to its registers through "+v" operands (24 loads in flight, the
+//     unit's n are the oldest; foreign vector-memory operations only make a wait stricter), splits, stores its planes and reloads its
+//     registers for the step two further on.  Each producer thread does the work of second-edition threads t and t + 256 (same
+//     addresses, same LDS image).  What hipcc does to a fine-grained load / split / store pipeline written in plain C++ - branches
+//     per piece, `vmcnt(0)` after every barrier or in front of every load, whole register sets copied at loop edges (= read while
+//     their loads are in flight) - is in profiles/r04_gemm.md; hence: a SCALAR role test (two separate paths to the waitcnt pass),
+//     native 128-bit vectors as asm operands, ONE path through the steady-state loop, the tail behind a drain;
+//   * one `s_barrier` per K step for all eight waves: stage s + 1 written, stage s read;
+//   * whole C tiles leave through a wave-private 5 KB LDS scratch (the third A plane of the stages, unused in mode 2) as 16-byte
+//     stores of eight whole 128-byte lines: 32 store instructions per wave and tile instead of 128 (a wave may have 63 in flight).
+// 243-245 registers, no scratch, two waves per SIMD, one block per CU, persistent.  Measured against the second edition (same box,
+// us): fwd [T,384] -> 256 77 -> 67, [T,256] -> 256 55 -> 48, [T,256] -> 1024 171 -> 150, [T,384] -> 2048 420 -> 365.
+constexpr int NTH_WS = 512;
+constexpr int WS_LDS = 2 * STAGE;
+#define WS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+template <bool AKC, bool BKC, int SPLIT>
+__global__ __launch_bounds__(NTH_WS, 1) void gemm_ws_kernel(Params p) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];           // 2 stages
+    constexpr bool F16 = SPLIT == 2;
+    constexpr int NP = (SPLIT == 3 || SPLIT == 2) ? 2 : 3;
+    constexpr int NPB = (SPLIT == 3 || SPLIT == 2) ? 2 : 3;
+    const int tid = threadIdx.x;
+    const int total = p.nfull + p.nsplit * p.nsl;
+    const int G = gridDim.x;
+    if ((int)blockIdx.x >= total) return;
+    float sa_ = 1.f, sb_ = 1.f;
+    if (F16) { sa_ = f16_scale(amax_read(p.amaxA)); sb_ = f16_scale(amax_read(p.amaxB)); }
+    asm volatile("" :: "v"(sa_), "v"(sb_));            // the scales have landed HERE: no compiler-counted load is pending inside the producers' loop
+
+    if (__builtin_amdgcn_readfirstlane(tid) >= 256) {                   // a scalar condition: the two roles are separate paths to the compiler too
+        // ------------------------------------------------------------------------------------------------ producers
+        const int pt = tid - 256;
+        const f32x2_t scA = {sa_, 2048.f * sa_}, scB = {sb_, 2048.f * sb_};
+        typedef Src<AKC, BM> SA;
+        typedef Src<BKC, BN> SB;
+        SA a0, a1;
+        SB b0, b1;
+        a0.init_lds(pt); a1.init_lds(pt + 256);
+        b0.init_lds(pt); b1.init_lds(pt + 256);
+        // Register sets as native 128-bit values: they are operands of the inline assembly below.  ALL tile loads of this wave are inline
+        // assembly the compiler does not count, and every unit (a piece of a [rows][K] operand, an instance of a transposed one) waits for
+        // its own loads with a hand-written `s_waitcnt vmcnt(24 - n)` tied to its registers through "+v" operands (24 loads = two register
+        // sets in flight; the n loads of the unit are the oldest), splits, stores its planes and reloads its registers for the step two
+        // further on right away.  Issue order = unit order: a0, a1, b0, b1.  Whole K steps only (the host sends other shapes to edition 2).
+        typedef float f32x4a __attribute__((ext_vector_type(4)));
+        f32x4a ra[2][2][SA::NR], rb[2][2][SB::NR];                      // [register set][virtual thread]
+        int nsteps = 0;
+        for (int it = blockIdx.x; it < total; it += G) {
+            const Item i = decode(p, it);
+            nsteps += (i.kend - i.kbeg + BK - 1) / BK;
+        }
+        int p_item = blockIdx.x, p_k0 = 0, p_kend = 0;
+        bool p_live = true;
+        auto p_open = [&]() {
+            const Item it = decode(p, p_item);
+            const float* Ab = p.A + (int64_t)it.z * p.sA;
+            const float* Bb = p.B + (int64_t)it.z * p.sB;
+            a0.init(Ab, p.lda, p.M, it.m0, it.kbeg, pt); a1.init(Ab, p.lda, p.M, it.m0, it.kbeg, pt + 256);
+            b0.init(Bb, p.ldb, p.N, it.n0, it.kbeg, pt); b1.init(Bb, p.ldb, p.N, it.n0, it.kbeg, pt + 256);
+            p_k0 = it.kbeg; p_kend = it.kend;
+        };
+        auto advance = [&]() {
+            a0.base += a0.step; a1.base += a1.step; b0.base += b0.step; b1.base += b1.step;
+            p_k0 += BK;
+            if (p_k0 >= p_kend) {
+                p_item += G;
+                if (p_item < total) p_open(); else p_live = false;
+            }
+        };
+        auto aload = [&](f32x4a& r, const char* base, uint32_t off) {
+#ifdef BF3_AB_NOLOAD
+            asm volatile("" : "+v"(r) : "v"(off), "s"(base) : "memory");
+#else
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r) : "v"(off), "s"(base) : "memory");
+#endif
+        };
+        auto issue_set = [&](auto SET) {                                // prologue: a whole step into set S
+            constexpr int S = decltype(SET)::value;
+            auto all = [&](auto& src, auto& regs) {
+                typedef std::remove_reference_t<decltype(src)> ST;
+#pragma unroll
+                for (int i = 0; i < ST::NR; ++i) {
+                    if constexpr (ST::is_kc) aload(regs[i], src.base + src.pstride * (src.pvalid > i ? i : 0), src.off[0]);
+                    else aload(regs[i], src.base, src.off[i]);
+                }
+            };
+            all(a0, ra[S][0]); all(a1, ra[S][1]); all(b0, rb[S][0]); all(b1, rb[S][1]);
+            advance();
+        };
+        constexpr int FA = F16 ? 1 : 0, FB = F16 ? 2 : 0;
+        // MODE 0: steady state - two sets (24 loads) in flight, every unit waits for its own loads and reloads.  MODE 1: everything has
+        // landed (tail): split and store only.  MODE 2: as 1, then reload the set and wait for it (a tail step that still has a successor).
+        auto recycle = [&](auto SET, auto MODEC) {
+            constexpr int S = decltype(SET)::value;
+            constexpr int MODE = decltype(MODEC)::value;
+            constexpr bool LOAD = MODE == 0;
+            uint32_t st_off = S * STAGE;
+            asm volatile("" : "+s"(st_off));               // opaque: the plane addresses are formed per piece (one add), not kept in eight registers across the loop
+            char* st = lds + st_off;
+            auto one = [&](auto& src, auto& regs, char* pl, f32x2_t sc, auto PLc, auto NPc, auto Fc) {
+                constexpr int PL = decltype(PLc)::value, NPP = decltype(NPc)::value, FF = decltype(Fc)::value;
+                typedef std::remove_reference_t<decltype(src)> ST;
+                if constexpr (ST::is_kc) {
+#pragma unroll
+                    for (int i = 0; i < ST::NR; ++i) {
+                        if (LOAD) asm volatile("s_waitcnt vmcnt(23)" : "+v"(regs[i]) :: "memory");
+                        const float4 v = make_float4(regs[i].x, regs[i].y, regs[i].z, regs[i].w);
+                        const P3 sp = FF == 1 ? split4_f16<true>(v, sc) : FF == 2 ? split4_f16<false>(v, sc) : split4<NPP>(v);
+                        char* d = pl + src.loff[0] + 4096 * i;
+                        *reinterpret_cast<uint2*>(d) = sp.p1;
+                        *reinterpret_cast<uint2*>(d + PL) = sp.p2;
+                        if (NPP == 3) *reinterpret_cast<uint2*>(d + 2 * PL) = sp.p3;
+                        if (MODE != 1) aload(regs[i], src.base + src.pstride * (src.pvalid > i ? i : 0), src.off[0]);
+                    }
+                } else {
+                    float4 t[ST::NR];
+                    if constexpr (ST::NR == 4) { if (LOAD) asm volatile("s_waitcnt vmcnt(20)" : "+v"(regs[0]), "+v"(regs[1]), "+v"(regs[2]), "+v"(regs[3]) :: "memory"); }
+                    else { if (LOAD) asm volatile("s_waitcnt vmcnt(22)" : "+v"(regs[0]), "+v"(regs[1]) :: "memory"); }
+#pragma unroll
+                    for (int i = 0; i < ST::NR; ++i) t[i] = make_float4(regs[i].x, regs[i].y, regs[i].z, regs[i].w);
+                    src.template store_from<PL, NPP, FF>(t, pl, sc);
+                    if (MODE != 1) {
+#pragma unroll
+                        for (int i = 0; i < ST::NR; ++i) aload(regs[i], src.base, src.off[i]);
+                    }
+                }
+            };
+            using IA = std::integral_constant<int, PLA>;
+            using IB = std::integral_constant<int, PLB>;
+            one(a0, ra[S][0], st, scA, IA{}, std::integral_constant<int, NP>{}, std::integral_constant<int, FA>{});
+            one(a1, ra[S][1], st, scA, IA{}, std::integral_constant<int, NP>{}, std::integral_constant<int, FA>{});
+            one(b0, rb[S][0], st + 3 * PLA, scB, IB{}, std::integral_constant<int, NPB>{}, std::integral_constant<int, FB>{});
+            one(b1, rb[S][1], st + 3 * PLA, scB, IB{}, std::integral_constant<int, NPB>{}, std::integral_constant<int, FB>{});
+            if (MODE != 1) advance();
+        };
+        auto landed = [&]() {                            // every load issued so far has landed, in every register of both sets
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+#pragma unroll
+                    for (int i = 0; i < SA::NR; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[q][v][i]) :: "memory");
+#pragma unroll
+                    for (int i = 0; i < SB::NR; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rb[q][v][i]) :: "memory");
+                }
+        };
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+        using M0 = std::integral_constant<int, 0>;
+        using M1 = std::integral_constant<int, 1>;
+        using M2 = std::integral_constant<int, 2>;
+        p_open();
+        issue_set(S0{});                                // step 0
+        if (nsteps > 1) issue_set(S1{});                // step 1
+        int j = 0;
+        // ONE path through the steady state (pairs of steps that both reload): the loop-carried registers keep their places - with
+        // the tail's variants inside this loop hipcc copied whole register sets at the loop edges, i.e. read registers still in flight
+        for (; j + 3 < nsteps; j += 2) {                // step j -> stage j & 1 from set j & 1, one K step ahead of the consumers
+            recycle(S0{}, M0{});
+            WS_BARRIER();
+            recycle(S1{}, M0{});
+            WS_BARRIER();
+        }
+        landed();
+        for (; j < nsteps; ++j) {                       // at most three steps: synchronous
+            const bool more = j + 2 < nsteps;
+            if (j & 1) { if (more) recycle(S1{}, M2{}); else recycle(S1{}, M1{}); }
+            else { if (more) recycle(S0{}, M2{}); else recycle(S0{}, M1{}); }
+            if (more) landed();
+            WS_BARRIER();
+        }
+        WS_BARRIER();
+        return;
+    }
+
+    // ---------------------------------------------------------------------------------------------------- consumers
+    // wave w: rows 128 (w >> 1) .. + 127, columns 64 (w & 1) .. + 63 of the 256 x 128 block tile = 4 x 2 tiles of 32 x 32 = 128 accumulator
+    // registers; fragments of a 16-k slab: A 2 planes x 4 tiles + B 2 planes x 2 tiles = 12 ds_read_b128 (48 registers), two sets
+    static_assert(SPLIT == 2, "the 4 + 4 wave form exists for mode 2");
+    const float unscale = (1.f / sa_) * (1.f / sb_);
+    const int lane = tid & 63, w = tid >> 6;
+    const int wm = (w >> 1) * 128, wn = (w & 1) * 64;
+    const int li = lane & 31, lh = lane >> 5;
+    const char* fa[2];
+    const char* fb[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        fa[s] = lds + wm * ROWB + plane_off(li, 2 * s + lh);
+        fb[s] = lds + 3 * PLA + wn * ROWB + plane_off(li, 2 * s + lh);
+    }
+    struct F4 { f16x8 a[2][4], b[2][2]; };
+    auto rd = [&](F4& f, const char* pa, const char* pb) {
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) f.a[pi][t] = *reinterpret_cast<const f16x8*>(pa + pi * PLA + t * 32 * ROWB);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) f.b[pi][t] = *reinterpret_cast<const f16x8*>(pb + pi * PLB + t * 32 * ROWB);
+        }
+    };
+    f32x16 acc[4][2];
+    auto mm = [&](const F4& f) {                    // a2 (2^-11 b1) + a1 b2 + a1 b1, the small terms first
+        const f16x8 k = {(_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f,
+                         (_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f};
+        const f16x8 bs0 = f.b[0][0] * k, bs1 = f.b[0][1] * k;
+#ifdef BF3_AB_NOMFMA
+#pragma unroll
+        for (int a = 0; a < 4; ++a) asm volatile("" :: "v"(f.a[0][a]), "v"(f.a[1][a]), "v"(bs0), "v"(bs1), "v"(f.b[0][0]), "v"(f.b[0][1]), "v"(f.b[1][0]), "v"(f.b[1][1]));
+        return;
+#endif
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[1][a], bs0, acc[a][0], 0, 0, 0);
+            acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[1][a], bs1, acc[a][1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 1; q >= 0; --q)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[0][a], f.b[q][0], acc[a][0], 0, 0, 0);
+                acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[0][a], f.b[q][1], acc[a][1], 0, 0, 0);
+            }
+    };
+    float cmax = 0.f;
+    F4 f0, f1;
+    WS_BARRIER();
+    rd(f0, fa[0], fb[0]);
+    int cur_st = 0;
+    for (int c_item = blockIdx.x; c_item < total; c_item += G) {
+        const Item cur = decode(p, c_item);
+        float zero = 0.f;
+        asm volatile("" : "+v"(zero));
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[a][b][e] = zero;
+        float bv[2] = {0.f, 0.f};
+        for (int c_k0 = cur.kbeg; c_k0 < cur.kend; c_k0 += BK) {
+            const int so = cur_st * STAGE, sn = (cur_st ^ 1) * STAGE;
+            if (c_k0 + BK >= cur.kend && p.bias && !cur.split) {
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int n = cur.n0 + wn + 32 * b + li;
+                    bv[b] = p.bias[(int64_t)cur.z * p.sBias + (n < p.N ? n : 0)];
+                }
+            }
+            BF3_FENCE();
+            rd(f1, fa[1] + so, fb[1] + so);
+            mm(f0);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {              // one fragment read behind each of the first matrix instructions
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            BF3_FENCE();
+            WS_BARRIER();
+            BF3_FENCE();
+            rd(f0, fa[0] + sn, fb[0] + sn);
+            mm(f1);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            BF3_FENCE();
+            cur_st ^= 1;
+        }
+#ifdef BF3_AB_NOEPI
+        if (lane == 0) p.C[(int64_t)cur.m0 * p.ldc + cur.n0 + w] = acc[0][0][0] + acc[1][1][1] + acc[2][0][2] + acc[3][1][3];
+        continue;
+#endif
+        // epilogue (as the second edition's, four row tiles)
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[a][b][e] *= unscale;
+        if (cur.split) {
+            float* o = p.slab + (int64_t)(cur.split - 1) * TILE + (wm + 4 * lh) * BN + wn + li;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) o[(32 * a + (e & 3) + 8 * (e >> 2)) * BN + 32 * b] = acc[a][b][e];
+            continue;
+        }
+        float* C = p.C + (int64_t)cur.z * p.sC;
+        const bool full_m = cur.m0 + BM <= p.M;
+        if (full_m && cur.n0 + BN <= p.N && p.act != 2) {
+            // whole tiles: every 32 x 32 tile is turned through a wave-private 5 KB LDS scratch (rows of 40 words: the two half-waves of a
+            // dword write hit disjoint banks) and leaves as FOUR 16-byte-per-lane stores of eight whole 128-byte lines each - 32 store
+            // instructions per wave and tile instead of 128: a wave may have 63 vector-memory operations in flight, and with four
+            // consumer waves 128 dword stores each stalled on that limit (160 of 415 us at 66 752 x 2048 x 384).
+            // Scratch: the third A plane of the stages, which mode 2 does not use (waves 0, 1 in stage 0's, 2, 3 in stage 1's).
+            char* sc = lds + (w >> 1) * STAGE + 2 * PLA + (w & 1) * 5120;
+            float* wr = reinterpret_cast<float*>(sc) + (4 * lh) * 40 + li;
+            const float4* rdp = reinterpret_cast<const float4*>(sc + (lane >> 3) * 160 + (lane & 7) * 16);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    float v[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) v[e] = acc[a][b][e] + bv[b];
+                    if (p.act == 1) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) v[e] = elu1(v[e]);
+                    }
+                    if (p.act == 3) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) v[e] = softplus_nb(v[e]);
+                    }
+                    if (p.amaxC.slot) {
+#pragma unroll
+                        for (int e = 0; e < 16; e += 2) cmax = fmaxf(cmax, fmaxf(__builtin_fabsf(v[e]), __builtin_fabsf(v[e + 1])));
+                    }
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) wr[((e & 3) + 8 * (e >> 2)) * 40] = v[e];
+                    float* q = C + (int64_t)(cur.m0 + wm + 32 * a + (lane >> 3)) * p.ldc + cur.n0 + wn + 32 * b + 4 * (lane & 7);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 t = rdp[g * 8 * 10];                   // rows 8 g + (lane >> 3): 8 rows x 160 bytes = 80 float4
+                        *reinterpret_cast<float4*>(q + (int64_t)(8 * g) * p.ldc) = t;
+                    }
+                }
+            }
+            continue;
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int n = cur.n0 + wn + 32 * b + li;
+            if (n >= p.N) continue;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                float v[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[e] = acc[a][b][e] + bv[b];
+                if (p.act == 1) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) v[e] = elu1(v[e]);
+                }
+                if (p.act == 3) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) v[e] = softplus_nb(v[e]);
+                }
+                const int mb = cur.m0 + wm + 32 * a + 4 * lh;
+                float* crow = C + (int64_t)mb * p.ldc + n;
+                if (p.act == 2) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int dm = (e & 3) + 8 * (e >> 2);
+                        if (mb + dm < p.M) v[e] += crow[(int64_t)dm * p.ldc];
+                    }
+                }
+                if (full_m) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) crow[(int64_t)((e & 3) + 8 * (e >> 2)) * p.ldc] = v[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int dm = (e & 3) + 8 * (e >> 2);
+                        if (mb + dm < p.M) crow[(int64_t)dm * p.ldc] = v[e];
+                    }
+                }
+                if (p.amaxC.slot) {
+#pragma unroll
+                    for (int e = 0; e < 16; e += 2) cmax = fmaxf(cmax, fmaxf(__builtin_fabsf(v[e]), __builtin_fabsf(v[e + 1])));
+                }
+            }
+        }
+    }
+    amax_publish_wave(cmax, p.amaxC);
+}
+
 // C tile = epi(sum over the K slices of a split tile), fixed summation order: as gemm_fixup_kernel of gemm_f32.hip for 256 x 128 tiles
 __global__ __launch_bounds__(256) void gemm_bf3_fixup_kernel(Params p) {
     __shared__ float4 part[3][64];
@@ -690,6 +1122,23 @@ int launch_one(const Params& p, dim3 grid, hipStream_t s) {
     return RESEL_OK;
 }
 
+template <bool AKC, bool BKC, int SP>
+int launch_ws(const Params& p, dim3 grid, hipStream_t s) {
+    static std::atomic<bool> attr_set[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return RESEL_ELAUNCH;
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
+        if (hipFuncSetAttribute((const void*)gemm_ws_kernel<AKC, BKC, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS) != hipSuccess)
+            return RESEL_ELAUNCH;
+        attr_set[dev].store(true, std::memory_order_release);
+    }
+    launch_timed(RESEL_PROF_GEMM, gemm_ws_kernel<AKC, BKC, SP>, grid, dim3(NTH_WS), (size_t)WS_LDS, s, p);
+    return RESEL_OK;
+}
+
+// edition of the split GEMM: 3 = producer / consumer waves (gemm_ws_kernel), 2 = every wave does everything (gemm_bf3_kernel)
+int g_edition = [] { const char* e = getenv("RESEL_GEMM_EDITION"); return e ? atoi(e) : 3; }();
+
 }  // namespace
 
 #ifdef BF3_AB_CLOCK
@@ -723,7 +1172,16 @@ int gemm_bf3_launch(const float* A, int64_t lda, int64_t strideA, int a_kcontig,
          else if (a_kcontig) rc = launch_one<true, false, SP>(p, grid, s); \
          else if (b_kcontig) rc = launch_one<false, true, SP>(p, grid, s); \
          else rc = launch_one<false, false, SP>(p, grid, s); } while (0)
-    if (split == 9) BF3_LAUNCH(9); else if (split == 3) BF3_LAUNCH(3); else if (split == 2) BF3_LAUNCH(2); else BF3_LAUNCH(6);
+#define WS_LAUNCH(SP) \
+    do { if (a_kcontig && b_kcontig) rc = launch_ws<true, true, SP>(p, grid, s); \
+         else if (a_kcontig) rc = launch_ws<true, false, SP>(p, grid, s); \
+         else if (b_kcontig) rc = launch_ws<false, true, SP>(p, grid, s); \
+         else rc = launch_ws<false, false, SP>(p, grid, s); } while (0)
+    // third edition: mode 2, whole K steps (also per K slice), [rows][K] operands with whole 64-row pieces
+    const bool ws = g_edition == 3 && split == 2 && K % BK == 0 && pl.kslice % BK == 0 && (!a_kcontig || M % 64 == 0) && (!b_kcontig || N % 64 == 0);
+    if (ws) WS_LAUNCH(2);
+    else if (split == 9) BF3_LAUNCH(9); else if (split == 3) BF3_LAUNCH(3); else if (split == 2) BF3_LAUNCH(2); else BF3_LAUNCH(6);
+#undef WS_LAUNCH
 #undef BF3_LAUNCH
     if (rc != RESEL_OK) return rc;
     if (pl.nsplit) hipLaunchKernelGGL(gemm_bf3_fixup_kernel, dim3(TILE / 4 / 64, pl.nsplit), dim3(64, 4), 0, s, p);

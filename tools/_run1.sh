@@ -1,1 +1,4 @@
-for v in base x4 base x4; do echo "== $v"; for sh in "66752 2048 384" "66752 1024 256"; do RESEL_HIP_LIBRARY=tools/micro/bin/libresel_ws_$v.so RESEL_GEMM_EDITION=3 python3 tools/prof_gemm.py $sh 1 1 20 2 2>&1 | grep -v amdgpu.ids; done; done
+RESEL_GEMM_EDITION=3 python3 tools/gemm_census.py 2>/dev/null | sed -n '/by shape/,$p' | head -28 > gpurun_out/c3.txt
+RESEL_GEMM_EDITION=2 python3 tools/gemm_census.py 2>/dev/null | sed -n '/by shape/,$p' | head -28 > gpurun_out/c2.txt
+paste -d'|' <(cut -c1-17 gpurun_out/c3.txt) <(cut -c1-110 gpurun_out/c2.txt) | head -30
+tail -1 gpurun_out/c3.txt; RESEL_GEMM_EDITION=3 python3 tools/gemm_census.py 2>/dev/null | grep "sum of floors"; RESEL_GEMM_EDITION=2 python3 tools/gemm_census.py 2>/dev/null | grep "sum of floors"

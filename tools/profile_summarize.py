@@ -29,7 +29,7 @@ def pmc(name):
                            ('attn_fwd_kernel', 'attn_q_kernel<32, 0'), ('attn_dq_kernel', 'attn_q_kernel<32, 1'), ('attn_dkv_kernel', 'attn_dkv_kernel'),
                            ('linrec_real_fwd_kernel', 'linrec_real_fwd'), ('linrec_real_bwd_kernel', 'linrec_real_bwd'),
                            ('linrec_complex_fwd_kernel', 'linrec_complex_fwd'), ('linrec_complex_bwd_kernel', 'linrec_complex_bwd'),
-                           ('gemm_f32_kernel', 'gemm_f32_kernel'), ('gemm_f32_kernel', 'gemm_bf3_kernel'), ('gru_fwd_kernel', 'gru_fwd'),
+                           ('gemm_f32_kernel', 'gemm_f32_kernel'), ('gemm_f32_kernel', 'gemm_bf3_kernel'), ('gemm_f32_kernel', 'gemm_ws_kernel'), ('gru_fwd_kernel', 'gru_fwd'),
                            ('gru_bwd_kernel', 'gru_bwd')):
             if pat in k:
                 agg[short].append(float(r['Counter_Value']))
@@ -65,7 +65,7 @@ json.dump({'source': f'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over `python3 ben
 rows = list(csv.DictReader(open(os.path.join(src, f'{tag}_kernel_stats.csv'))))
 tot = sum(float(r['TotalDurationNs']) for r in rows)
 gemm = sum(float(r['TotalDurationNs']) for r in rows if r['Name'].startswith('Cijk'))
-own = sum(float(r['TotalDurationNs']) for r in rows if any(k in r['Name'] for k in ('gemm_f32_kernel', 'gemm_bf3_kernel', 'gemm_bf16_kernel', 'gemm_fixup', 'gemm_bf3_fixup', 'gemm_bf16_fixup')))
+own = sum(float(r['TotalDurationNs']) for r in rows if any(k in r['Name'] for k in ('gemm_f32_kernel', 'gemm_bf3_kernel', 'gemm_ws_kernel', 'gemm_bf16_kernel', 'gemm_fixup', 'gemm_bf3_fixup', 'gemm_bf16_fixup')))
 with open(os.path.join(dst, f'{tag}_summary.md'), 'w') as fh:
     fh.write(f'# {tag}: rocprofv3 --kernel-trace --stats over `python3 bench.py` ({n_upd} updates incl. warm-up)\n\n')
     fh.write(f'bench line: {bench["value"]:.0f} {bench["unit"]}, {bench["ms_per_step"]:.2f} ms/update; GPU kernel time {tot / n_upd / 1e6:.2f} ms/update, '
