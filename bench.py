@@ -400,7 +400,7 @@ def suite_legs(args):
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
             line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
-            out[name] = {k: line.get(k) for k in ('value', 'unit', 'ms_per_step', 'steps', 'dtype', 'config', 'roofline', 'roofline_other', 'graph_update_leg')}
+            out[name] = {k: line.get(k) for k in ('value', 'unit', 'ms_per_step', 'eager_ms_per_step', 'launch', 'steps', 'dtype', 'config', 'roofline', 'roofline_other', 'graph_update_leg')}
         except Exception as e:
             out[name] = {'failed': repr(e)[:200]}
     return out

@@ -53,6 +53,7 @@ struct Params {
     int nfull, nsplit, nsl, kslice;
     const float *amaxA, *amaxB;                  // mode 2: device scalars >= max |A|, max |B| (resel_amax); nullptr otherwise
     AmaxOut amaxC;                               // optional: publish max |C| (the values stored, after bias / activation / accumulate)
+    int ntst;                                    // third edition: non-temporal C stores
 };
 
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : fast_exp(x) - 1.f; }
@@ -208,8 +209,8 @@ struct Src {
     uint32_t off[NR];
     uint32_t loff[KC ? NPC : 4];                   // LDS byte offsets inside a plane (KC: per piece; !KC: per patch row)
     int64_t step;
-    int64_t pstride;                               // KC: bytes between the pieces of a thread (64 rows); uniform
-    int pvalid;                                    // KC: pieces that start inside the operand's rows; uniform
+    int rl0, rlim, ld4, kofs4;                     // KC, third edition: this thread's row in piece 0, the last valid row of the tile (uniform),
+                                                   // the row stride and this thread's k offset in bytes: offset of piece i = min(rl0 + 64 i, rlim) ld4 + kofs4
     int kofs;
     float4 r[NR];
     __device__ __forceinline__ void init(const float* P, int64_t ld, int rows, int r0, int k0, int tid) {
@@ -223,8 +224,10 @@ struct Src {
                 off[i] = (uint32_t)(((r0 + rl < rows ? rl : 0) * ld + kofs) * 4);
             }
             step = BK * 4;
-            pstride = 64 * ld * 4;
-            pvalid = (rows - r0 + 63) / 64;
+            rl0 = tid >> 3;
+            rlim = min(rows - 1 - r0, ROWS - 1);         // rows past the operand read its last row (their products are never stored)
+            ld4 = (int)(ld * 4);
+            kofs4 = kofs * 4;
         } else {
             const int g = ROWS == 256 ? (tid & 7) + 8 * (tid >> 6) : (tid & 7) + 8 * (tid >> 7);
             kofs = ROWS == 256 ? 4 * ((tid >> 3) & 7) : 2 * ((tid >> 3) & 15);
@@ -295,6 +298,9 @@ struct Src {
         }
     }
     __device__ __forceinline__ void advance() { base += step; }
+    __device__ __forceinline__ uint32_t piece_off(int i) const {        // two vector instructions per piece instead of a register per piece
+        return __umul24((uint32_t)min(rl0 + 64 * i, rlim), (uint32_t)ld4) + (uint32_t)kofs4;
+    }
     template <int PL, int NP, int F16>
     __device__ __forceinline__ void store_piece(const float4& v, int i, char* pl, f32x2_t sc) const {
         static_assert(KC, "pieces exist in the [rows][K] layout only");
@@ -753,7 +759,7 @@ __global__ __launch_bounds__(NTH_WS, 1) void gemm_ws_kernel(Params p) {
                 typedef std::remove_reference_t<decltype(src)> ST;
 #pragma unroll
                 for (int i = 0; i < ST::NR; ++i) {
-                    if constexpr (ST::is_kc) aload(regs[i], src.base + src.pstride * (src.pvalid > i ? i : 0), src.off[0]);
+                    if constexpr (ST::is_kc) aload(regs[i], src.base, src.piece_off(i));
                     else aload(regs[i], src.base, src.off[i]);
                 }
             };
@@ -783,7 +789,7 @@ __global__ __launch_bounds__(NTH_WS, 1) void gemm_ws_kernel(Params p) {
                         *reinterpret_cast<uint2*>(d) = sp.p1;
                         *reinterpret_cast<uint2*>(d + PL) = sp.p2;
                         if (NPP == 3) *reinterpret_cast<uint2*>(d + 2 * PL) = sp.p3;
-                        if (MODE != 1) aload(regs[i], src.base + src.pstride * (src.pvalid > i ? i : 0), src.off[0]);
+                        if (MODE != 1) aload(regs[i], src.base, src.piece_off(i));
                     }
                 } else {
                     float4 t[ST::NR];
@@ -997,7 +1003,12 @@ __global__ __launch_bounds__(NTH_WS, 1) void gemm_ws_kernel(Params p) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const float4 t = rdp[g * 8 * 10];                   // rows 8 g + (lane >> 3): 8 rows x 160 bytes = 80 float4
-                        *reinterpret_cast<float4*>(q + (int64_t)(8 * g) * p.ldc) = t;
+                        if (p.ntst) {                                       // streaming stores (RESEL_GEMM_NT): -4 % on the kernel alone at N = 2048
+                            typedef float f4v __attribute__((ext_vector_type(4)));
+                            __builtin_nontemporal_store(f4v{t.x, t.y, t.z, t.w}, reinterpret_cast<f4v*>(q + (int64_t)(8 * g) * p.ldc));
+                        } else {
+                            *reinterpret_cast<float4*>(q + (int64_t)(8 * g) * p.ldc) = t;
+                        }
                     }
                 }
             }
@@ -1137,6 +1148,7 @@ int launch_ws(const Params& p, dim3 grid, hipStream_t s) {
 }
 
 // edition of the split GEMM: 3 = producer / consumer waves (gemm_ws_kernel), 2 = every wave does everything (gemm_bf3_kernel)
+int g_nt = [] { const char* e = getenv("RESEL_GEMM_NT"); return e ? atoi(e) : 1; }();   // default on: 23.43 -> 23.30 ms per update, same box
 int g_edition = [] { const char* e = getenv("RESEL_GEMM_EDITION"); return e ? atoi(e) : 3; }();
 
 }  // namespace
@@ -1163,7 +1175,7 @@ int gemm_bf3_launch(const float* A, int64_t lda, int64_t strideA, int a_kcontig,
     const Plan pl = make_plan(M, N, K, batch);
     if (pl.nsplit && (!workspace || !aligned16(workspace))) return RESEL_EINVAL;
     Params p{A, B, bias, C, (float*)workspace, lda, ldb, ldc, strideA, strideB, strideC, strideBias, M, N, K, act,
-             (M + BM - 1) / BM, (N + BN - 1) / BN, pl.nfull, pl.nsplit, pl.nsl, pl.kslice, amaxA, amaxB, AmaxOut{amax_c, amax_epoch}};
+             (M + BM - 1) / BM, (N + BN - 1) / BN, pl.nfull, pl.nsplit, pl.nsl, pl.kslice, amaxA, amaxB, AmaxOut{amax_c, amax_epoch}, g_nt};
     const int64_t total = (int64_t)pl.nfull + (int64_t)pl.nsplit * pl.nsl;
     dim3 grid((unsigned)std::min<int64_t>(total, GRID));
     int rc;
@@ -1177,8 +1189,8 @@ int gemm_bf3_launch(const float* A, int64_t lda, int64_t strideA, int a_kcontig,
          else if (a_kcontig) rc = launch_ws<true, false, SP>(p, grid, s); \
          else if (b_kcontig) rc = launch_ws<false, true, SP>(p, grid, s); \
          else rc = launch_ws<false, false, SP>(p, grid, s); } while (0)
-    // third edition: mode 2, whole K steps (also per K slice), [rows][K] operands with whole 64-row pieces
-    const bool ws = g_edition == 3 && split == 2 && K % BK == 0 && pl.kslice % BK == 0 && (!a_kcontig || M % 64 == 0) && (!b_kcontig || N % 64 == 0);
+    // third edition: mode 2, whole K steps (also per K slice); row strides within the 24-bit multiply of the piece offsets
+    const bool ws = g_edition == 3 && split == 2 && K % BK == 0 && pl.kslice % BK == 0 && lda < (1 << 22) && ldb < (1 << 22);
     if (ws) WS_LAUNCH(2);
     else if (split == 9) BF3_LAUNCH(9); else if (split == 3) BF3_LAUNCH(3); else if (split == 2) BF3_LAUNCH(2); else BF3_LAUNCH(6);
 #undef WS_LAUNCH

@@ -32,6 +32,11 @@ for (Mo, No) in ((256, 384), (1024, 256), (2048, 384), (128, 256)):
     for T in (4096, 66752):
         check('wgrad', r(T, Mo), r(T, No), False, False)
         check('a-transposed', r(T, Mo), r(No, T) / T ** 0.5, False, True)
+for M in (32800, 32016, 1000):                          # row counts that are no multiple of 64 (cgpt's shifted pass, gilr / lru at T = 2000)
+    for N in (80, 256, 200):
+        check('ragged fwd', r(M, 256), r(N, 256) / 16, True, True, r(N))
+        check('ragged dgrad', r(M, 256), r(256, N) / 16, True, False)
+        check('ragged wgrad', r(M, 256), r(M, N), False, False)
 check('efc-8 fwd', r(8, 66752, 256), r(8, 256, 256) / 16, True, False, r(8, 256), 'elu')
 check('efc-8 fwd kc', r(8, 66752, 256), r(8, 256, 256) / 16, True, True, r(8, 256))
 check('efc-8 wgrad', r(8, 66752, 256), r(8, 66752, 256), False, False)
