@@ -35,13 +35,15 @@ class FlatAdamW:
         self._bc_host = torch.empty(2, dtype=torch.float32, pin_memory=True)
         self._bc_dev = torch.zeros(2, dtype=torch.float32, device=dev)
 
-    def prepare_step(self):
-        """Host side of one captured step: count it and send (1 - beta1^t, sqrt(1 - beta2^t)) to the device (stream-ordered copy)."""
+    def prepare_step(self, stage=None):
+        """Host side of one captured step: count it and send (1 - beta1^t, sqrt(1 - beta2^t)) to the device (stream-ordered copy).
+        `stage`: a pinned 2-float block that no queued copy reads any more (a caller that runs ahead of the device hands out its own)."""
         self.step_count += 1
         t = float(self.step_count)
-        self._bc_host[0] = 1.0 - self.betas[0] ** t
-        self._bc_host[1] = (1.0 - self.betas[1] ** t) ** 0.5
-        self._bc_dev.copy_(self._bc_host, non_blocking=True)
+        host = self._bc_host if stage is None else stage
+        host[0] = 1.0 - self.betas[0] ** t
+        host[1] = (1.0 - self.betas[1] ** t) ** 0.5
+        self._bc_dev.copy_(host, non_blocking=True)
 
     def step(self, grad_scale: torch.Tensor = None):
         """grad_scale: optional 1-element device tensor multiplied into the gradient (e.g. 1 / global valid count)."""

@@ -7,7 +7,11 @@ What varies from update to update is moved OUT of the captured region into stati
   * the REDQ critic subset - drawn on the host from the same numpy stream as the eager update, copied into static index tensors;
   * the step-dependent AdamW factors - `FlatAdamW.prepare_step()` (device-resident bias corrections), torch's `capturable` AdamW for
     the entropy coefficient;
-  * the log scalars - a D2H node into a static pinned buffer, read on demand like `DeferredLog`.
+  * the log scalars - packed into a static device buffer by the graph, copied to pinned memory behind the replay, read on demand like
+    `DeferredLog`.
+Every host -> device refresh and the log's read-back go through a RING of pinned staging slots and run as ordinary stream-ordered
+copies around the replay (not as nodes of it): `step()` never waits for the update it has just launched - the host prepares update
+i + 1 (sampling plan, tables, graph launch) while update i runs; a slot is reused three updates later, after its event.
 Actor noise comes from torch's CUDA generator, which torch.cuda.graph registers: every replay draws fresh numbers.
 
 A graph is valid for ONE batch shape (rows, row length, number of plan segments, longest segment) - synthetic benches, fixed-length
@@ -40,7 +44,8 @@ class _StaticLog(DeferredLog):
 
 
 class GraphedUpdate:
-    PLAN_CAPACITY = 16384                             # plan segments the static buffers hold (64 KB of pinned memory)
+    PLAN_CAPACITY = 16384                             # plan segments the static buffers hold (64 KB of pinned memory per slot)
+    RING = 3                                          # pinned staging slots: the host may be this many updates ahead of the device
 
     def __init__(self, alg, warmup=3, max_graphs=4):
         why = self.refusal(alg)
@@ -67,7 +72,6 @@ class GraphedUpdate:
         self.subset_np = np.ascontiguousarray(first, dtype=np.int32)
         self.subset_i32 = torch.from_numpy(self.subset_np.copy()).to(self.device)
         self.subset_i64 = self.subset_i32.long()
-        self._sub_host = torch.empty(self.subset_np.size, dtype=torch.int32, pin_memory=True)
         for opt in (alg.optimizer_value, alg.optimizer_policy):
             opt.enable_device_factors()
         oa = alg.optimizer_alpha                                             # torch AdamW over the entropy coefficient: capturable form
@@ -76,11 +80,15 @@ class GraphedUpdate:
         for st in oa.state.values():
             if torch.is_tensor(st.get('step')):
                 st['step'] = st['step'].to(self.device)
-        self._plan_host = torch.empty((self.PLAN_CAPACITY, 4), dtype=torch.int32, pin_memory=True)
         self._plan_dev = torch.empty((self.PLAN_CAPACITY, 4), dtype=torch.int32, device=self.device)
-        self._evt = torch.cuda.Event()
-        self._log_host = torch.empty(64, dtype=torch.float32, pin_memory=True)      # static target of the log's D2H node
-        self._last_log = None
+        self._log_dev = torch.zeros(64, dtype=torch.float32, device=self.device)    # static target of the graph's log node
+        self._ring = [dict(plan=torch.empty((self.PLAN_CAPACITY, 4), dtype=torch.int32, pin_memory=True),
+                           sub=torch.empty(self.subset_np.size, dtype=torch.int32, pin_memory=True),
+                           bc=torch.empty(4, dtype=torch.float32, pin_memory=True),
+                           log=torch.empty(64, dtype=torch.float32, pin_memory=True),
+                           evt=torch.cuda.Event(), used=False, handed=None) for _ in range(self.RING)]
+        self._turn = 0
+        self._slot = self._ring[0]
         # attention layers: static sequence tables (two descriptions per batch: the batch and its one-slot shift) and the dropout base
         self._seq = None
         self._drop_base = None
@@ -107,9 +115,10 @@ class GraphedUpdate:
         if sq is None or sq['cap_idx'] < n_idx or sq['cap_cu'] < n_cu:
             ci, cc = max(2 * n_idx, 1024), max(2 * n_cu, 64)
             self.graphs.clear()
+            torch.cuda.synchronize(self.device)       # queued copies may still read the old blocks
             sq = self._seq = dict(cap_idx=ci, cap_cu=cc,
-                                  idx_host=[torch.empty(ci, dtype=torch.int64, pin_memory=True) for _ in range(2)],
-                                  cu_host=[torch.empty(cc, dtype=torch.int32, pin_memory=True) for _ in range(2)],
+                                  idx_host=[[torch.empty(ci, dtype=torch.int64, pin_memory=True) for _ in range(2)] for _ in range(self.RING)],
+                                  cu_host=[[torch.empty(cc, dtype=torch.int32, pin_memory=True) for _ in range(2)] for _ in range(self.RING)],
                                   idx_dev=[torch.empty(ci, dtype=torch.int64, device=self.device) for _ in range(2)],
                                   cu_dev=[torch.empty(cc, dtype=torch.int32, device=self.device) for _ in range(2)])
         return sq
@@ -126,20 +135,21 @@ class GraphedUpdate:
     def _prepare_seqs(self, built):
         """Both descriptions into the pinned buffers (the previous replay has read them); returns their part of the shape key."""
         sq = self._seq_buffers(max(b[0].size for b in built), max(b[1].size for b in built))
+        k = self._turn % self.RING
         for i, (idx, cu, mx, tb) in enumerate(built):
-            sq['idx_host'][i][:idx.size].copy_(torch.from_numpy(idx))
-            sq['cu_host'][i][:cu.size].copy_(torch.from_numpy(cu))
+            sq['idx_host'][k][i][:idx.size].copy_(torch.from_numpy(idx))
+            sq['cu_host'][k][i][:cu.size].copy_(torch.from_numpy(cu))
+            sq['idx_dev'][i][:idx.size].copy_(sq['idx_host'][k][i][:idx.size], non_blocking=True)      # stream-ordered, outside the graph
+            sq['cu_dev'][i][:cu.size].copy_(sq['cu_host'][k][i][:cu.size], non_blocking=True)
         self._seq_now = [(b[0].size, b[1].size, b[2], b[3]) for b in built]
         return tuple(x for b in built for x in (b[0].size, b[1].size, b[2]))
 
     def packed_seqs(self):
-        """Called by the trainer's `_batch_views` while this object drives the update: copy nodes + static device views."""
-        sq, out = self._seq, []
-        for i, (n_idx, n_cu, mx, tb) in enumerate(self._seq_now):
-            sq['idx_dev'][i][:n_idx].copy_(sq['idx_host'][i][:n_idx], non_blocking=True)
-            sq['cu_dev'][i][:n_cu].copy_(sq['cu_host'][i][:n_cu], non_blocking=True)
-            out.append(PackedSeqs.from_static(sq['idx_dev'][i][:n_idx], sq['cu_dev'][i][:n_cu], mx, tb))
-        return out
+        """Called by the trainer's `_batch_views` while this object drives the update: views of the static device tables (refreshed by
+        `_prepare_seqs` before the replay)."""
+        sq = self._seq
+        return [PackedSeqs.from_static(sq['idx_dev'][i][:n_idx], sq['cu_dev'][i][:n_cu], mx, tb)
+                for i, (n_idx, n_cu, mx, tb) in enumerate(self._seq_now)]
 
     @staticmethod
     def refusal(alg):
@@ -165,13 +175,12 @@ class GraphedUpdate:
     def gather(self):
         pl = self._plan
         n = pl['seg'].shape[0]
-        self._plan_dev[:n].copy_(self._plan_host[:n], non_blocking=True)    # memcpy node: re-reads the pinned plan at every replay
         dev = self.alg.replay_buffer.gather_planned(self.device, self._plan_dev[:n], pl['max_len'], pl['nrow'], pl['longest'])
         return dev, pl['total_size'], pl['table']
 
     def log_node(self, keys, packed, host, items):
         self._log_keys = keys
-        self._log_host[:packed.numel()].copy_(packed, non_blocking=True)
+        self._log_dev[:packed.numel()].copy_(packed)                         # a node of the graph; the read-back follows the replay (_finish)
         self._log_items = dict(host, **items)
         return None
 
@@ -186,17 +195,25 @@ class GraphedUpdate:
             raise RuntimeError(f'GraphedUpdate: {n} plan segments exceed the static plan buffer ({self.PLAN_CAPACITY})')
         key = (pl['nrow'], pl['longest'], pl['max_len'], n)
         built = self._build_seqs(pl) if self._drop_base is not None else None
-        self._evt.synchronize()                                              # the previous update has read the pinned plan
+        # staging slot of this update: its copies of three updates ago have long run; the log handed out then is read out before its block is reused
+        slot = self._slot = self._ring[self._turn % self.RING]
+        if slot['handed'] is not None:
+            slot['handed'].resolve()
+            slot['handed'] = None
+        if slot['used']:
+            slot['evt'].synchronize()
         if built is not None:
             key = key + self._prepare_seqs(built)
-        self._plan_host[:n].copy_(torch.from_numpy(pl['seg']))
+        slot['plan'][:n].copy_(torch.from_numpy(pl['seg']))
+        self._plan_dev[:n].copy_(slot['plan'][:n], non_blocking=True)        # stream-ordered: behind the previous update's gather
         self._plan = pl
         sub = np.ascontiguousarray(np.asarray(self._draw(self.E)), dtype=np.int32)
-        self._sub_host.copy_(torch.from_numpy(sub))
-        self.subset_i32.copy_(self._sub_host, non_blocking=True)
+        slot['sub'].copy_(torch.from_numpy(sub))
+        self.subset_i32.copy_(slot['sub'], non_blocking=True)
         self.subset_i64.copy_(self.subset_i32)
-        for opt in (alg.optimizer_value, alg.optimizer_policy):
-            opt.prepare_step()
+        for i, opt in enumerate((alg.optimizer_value, alg.optimizer_policy)):
+            opt.prepare_step(slot['bc'][2 * i:2 * i + 2])
+        self._turn += 1
         return key
 
     def _body(self):
@@ -220,19 +237,20 @@ class GraphedUpdate:
                 opt.device_factors_active = False
 
     def _finish(self):
-        self._evt.record()
         n = len(self._log_keys)
+        slot = self._slot
+        slot['log'][:n].copy_(self._log_dev[:n], non_blocking=True)          # behind the update on the stream
+        slot['evt'].record()
+        slot['used'] = True
         items = dict(self._log_items)
         pl = self._plan                               # the host entries of THIS update (the captured dict holds the recorded update's)
         items.update(real_batch_size=pl['total_size'], real_batch_traj_num=pl['nrow'],
                      average_traj_len=self.alg.replay_buffer.size / len(self.alg.replay_buffer))
-        self._last_log = _StaticLog(list(self._log_keys), self._log_host[:n], self._evt, items)
-        return self._last_log
+        slot['handed'] = _StaticLog(list(self._log_keys), slot['log'][:n], slot['evt'], items)
+        return slot['handed']
 
     def step(self):
         """Exactly one update: eager while warming up or while the batch shape has no graph, a replay otherwise."""
-        if self._last_log is not None:
-            self._last_log.resolve()                  # its pinned buffer is about to be rewritten
         key = self._prepare()
         g = self.graphs.get(key)
         if g is None:
