@@ -1,2 +1,1 @@
-timeout 2000 python3 -m pytest tests -m gpu -x -q 2>&1 | tail -3
-python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_default.json 2>gpurun_out/err.txt; tail -1 gpurun_out/err.txt
+for ed in 3 2; do echo "== edition $ed"; RESEL_GEMM_EDITION=$ed bash tools/pmc_gemm.sh 66752 2048 384 1 1 5 2 2>&1 | grep -v "amdgpu.ids\|rocprofv3\|simple_timer"; done
