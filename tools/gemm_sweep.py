@@ -10,11 +10,11 @@ g = torch.Generator(device='cuda').manual_seed(0)
 bad = n = 0
 
 
-def check(tag, A, B, akc, bkc, bias=None, act=None):
+def check(tag, A, B, akc, bkc, bias=None, act=None, out0=None):
     global bad, n
     aa, ab = ops.amax(A.reshape(-1, A.shape[-1])), ops.amax(B.reshape(-1, B.shape[-1]))
-    out = ops.gemm_f32(A, B, akc, bkc, bias, act, split=2, amax_a=aa, amax_b=ab)
-    ref = ops.gemm_f32(A, B, akc, bkc, bias, act, split=6)
+    out = ops.gemm_f32(A, B, akc, bkc, bias, act, out=None if out0 is None else out0.clone(), split=2, amax_a=aa, amax_b=ab)
+    ref = ops.gemm_f32(A, B, akc, bkc, bias, act, out=None if out0 is None else out0.clone(), split=6)
     err = (out - ref).abs().max().item() / max(ref.abs().max().item(), 1e-30)
     n += 1
     if not err < 1e-5:
@@ -37,6 +37,9 @@ for M in (32800, 32016, 1000):                          # row counts that are no
         check('ragged fwd', r(M, 256), r(N, 256) / 16, True, True, r(N))
         check('ragged dgrad', r(M, 256), r(256, N) / 16, True, False)
         check('ragged wgrad', r(M, 256), r(M, N), False, False)
+check('accumulate', r(66752, 128), r(128, 512) / 11, True, False, None, ops.GEMM_ACCUMULATE, r(66752, 512))
+check('accumulate ragged', r(32800, 256), r(200, 256) / 16, True, True, None, ops.GEMM_ACCUMULATE, r(32800, 200))
+check('softplus', r(66752, 64), r(512, 64) / 8, True, True, r(512), ops.GEMM_SOFTPLUS)
 check('efc-8 fwd', r(8, 66752, 256), r(8, 256, 256) / 16, True, False, r(8, 256), 'elu')
 check('efc-8 fwd kc', r(8, 66752, 256), r(8, 256, 256) / 16, True, True, r(8, 256))
 check('efc-8 wgrad', r(8, 66752, 256), r(8, 66752, 256), False, False)
