@@ -157,8 +157,10 @@ class GraphedUpdate:
         if alg.device.type != 'cuda':
             return 'needs a GPU'
         if getattr(alg, 'overlap_value_embedding', False):
-            # tried in round 4: with the refusal lifted the capture of the gru trainer (target pass and prefetched value embeddings on
-            # side streams, forked / joined with events) ends in a segmentation fault inside capture_end on this ROCm build
+            # tried in round 4 (twice; the second time without the tensors' record_stream calls): with the refusal lifted the capture of
+            # the gru trainer (target pass and prefetched value embeddings on side streams, forked / joined with events, the same side
+            # stream forked more than once per update) ends in a segmentation fault inside capture_end (hipStreamEndCapture) on this ROCm
+            # build.  Captured on ONE stream the recurrences (3 us per step, latency-bound) would run back to back: slower than eager.
             return 'side-stream overlap (gru) is not captured'
         if getattr(alg, 'grad_sync', None) is None or alg.grad_sync.active:
             return 'data-parallel groups are not captured (or not a full-trajectory trainer)'
