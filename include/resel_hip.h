@@ -367,7 +367,11 @@ int resel_gemm_f32(const float* A, int64_t lda, int64_t strideA, int a_kcontig,
  * tests/test_hip_ops.py::test_gemm_f32_f16x3_mode_error_against_fp64).  amax_a / amax_b: magnitude HANDLES (below) holding an upper bound of
  * max |A| / max |B| over the whole operand (all batch members) - resel_amax, or what the producer of the operand published; a
  * bound 2^k too large costs k bits of those ranges, one too small overflows fp16 (inf in C).  Other modes ignore the two pointers
- * (may be NULL).  M <= 128 and K < 32 fall back to modes 6 / 0. */
+ * (may be NULL).  M <= 128 and K < 32 fall back to modes 6 / 0.
+ * Two kernels serve mode 2 (same results to rounding of the same three plane products; b1s is formed from b1 next to the matrix
+ * instruction in both): the producer / consumer edition for K and K slices that are multiples of 32 and row strides < 2^22
+ * (csrc/gemm_bf3.hip `gemm_ws_kernel`), the one-role edition for the rest.  Environment, read once at load: RESEL_GEMM_EDITION=2 sends
+ * everything to the one-role edition, RESEL_GEMM_NT=0 turns the producer / consumer edition's non-temporal C stores off. */
 int resel_gemm_f32x(const float* A, int64_t lda, int64_t strideA, int a_kcontig,
                     const float* B, int64_t ldb, int64_t strideB, int b_kcontig,
                     const float* bias, int64_t strideBias, int act,
