@@ -591,8 +591,8 @@ def main():
                           9: 'exact 3-way bf16 operand split, all 9 plane products, fp32 accumulate',
                           3: 'two bf16 planes per operand, 3 leading plane products, fp32 accumulate (bf16x3)',
                           2: 'fp16 planes of the scaled operands (2 + 3 planes), 3 plane products, fp32 accumulate (f16x3)'}[mode],
-             'ms_per_step_with_fp32_mfma_products': strict_ms,
-             'ms_per_step_with_matmul_precision_high_bf16x3': high_ms,
+             'ms_per_step_fp32_mfma': strict_ms,
+             'ms_per_step_bf16x3_high': high_ms,
              'note': 'all fc / efc-E / projection GEMMs of the update, fp32 in / out (DESIGN.md 4)'}
         ranked.append((t * 1e6, o))
     ranked.sort(key=lambda x: -x[0])
@@ -612,7 +612,8 @@ def main():
                 ss.update({f'{tag}_gbs': round(sc[name]['achieved'], 1), f'{tag}_frac': round(sc[name]['frac'], 4), f'{tag}_us': round(sc[name]['avg_us'], 1),
                            f'{tag}_traffic_mb': (round(sc[name]['traffic'] / 1e6, 1) if sc[name].get('traffic') else None)})
         out['sscan'] = ss
-        out['roofline']['selective_scan'] = ss
+        # flat scalars: records that keep only the scalar members of `roofline` (the driver's parse) keep the scan metric
+        out['roofline'].update({f'sscan_{k}': v for k, v in ss.items()})
     if len(lines) > 1:
         out['roofline_other'] = lines[1:]
     out['kernels'] = kern

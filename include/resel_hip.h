@@ -389,8 +389,9 @@ int resel_gemm_f32x(const float* A, int64_t lda, int64_t strideA, int a_kcontig,
  * resel_causal_conv1d_fwd (y), resel_causal_conv1d_bwd (dx), resel_gelu_dropout_fwd / _bwd (y / dx). */
 /* Magnitude pre-pass: max |x| over a [batch][rows][cols] box (row stride ld, batch stride `stride`, cols % 4 == 0) written into the
  * magnitude handle `out` with epoch `epoch` (see "magnitude handles" above); one HBM-bound pass, no host synchronisation.
- * `state`: resel_amax_state_bytes() bytes, zero before its first use (left zeroed by every call); calls that share a state buffer
- * must be ordered on one stream. */
+ * The call keeps no state: any number of pre-passes may be in flight on any streams (a maximum is order-independent, every wave raises
+ * the handle with one conditional atomicMax).  `state` is ignored (may be NULL) and resel_amax_state_bytes() returns 0 since ABI 7; both
+ * stay in the signature so that ABI 6 callers keep linking. */
 /* Magnitudes of every tensor of a flat parameter buffer in ONE launch: segment g = flat[begin[g], begin[g] + len[g]) (device int64
  * tables) publishes into the g-th of `nseg` consecutive 1 KiB handles at `handles` under `epoch` (the weights change once per optimizer
  * step / soft update; the GEMMs of the update then find their weight's magnitude without a pre-pass per call). */
@@ -399,6 +400,12 @@ int resel_amax_segments(const float* flat, const int64_t* begin, const int64_t* 
 size_t resel_amax_state_bytes(void);
 int resel_amax(const float* x, int64_t ld, int64_t stride, int rows, int cols, int batch, void* out, unsigned epoch, void* state,
                resel_stream_t stream);
+/* Verify mode (ABI 7): does `handle` hold an upper bound of max |x| over the same box?  Waves whose maximum exceeds it report into the
+ * device words err[0..3] (int32, zero = clean): [0] reporting waves, [1] float bits of the largest violating magnitude, [2] `tag` (!= 0)
+ * of the first report, [3] float bits of the bound it saw.  No host synchronisation; the caller reads `err` when it wants the verdict.
+ * The Python side runs it in front of every mode-2 product when RESEL_AMAX_VERIFY=1 (hip/ops.py `amax_verify_raise`). */
+int resel_amax_check(const float* x, int64_t ld, int64_t stride, int rows, int cols, int batch, const void* handle, int* err, int tag,
+                     resel_stream_t stream);
 
 /* ---- mixed-precision GEMM for the bf16 attention projections (cgpt) ------------------------------------------------------
  * C[m][n] = sum_k bf16(A(m, k)) bf16(B(n, k)) + bf16(bias[n]): operands rounded to bf16 (round to nearest even) on their way

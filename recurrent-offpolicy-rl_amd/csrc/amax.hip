@@ -1,8 +1,10 @@
 // Largest magnitude of a GEMM operand, on the device, written into a magnitude handle (resel_common.h): the scale source of
-// resel_gemm_f32x's mode 2 (fp16 planes of the SCALED operand) for operands whose producer published nothing.  HBM-bound single pass: float4 loads along the contiguous axis, one partial per block, and the block whose
-// ticket is the last one folds the partials in a fixed order and resets the ticket - the result does not depend on block
-// timing, needs no pre-zeroed output and no host synchronisation; `state` ([0] ticket, [1..] partials) must be zero before
-// its first use and is left zeroed.  NaNs in the operand are ignored here (fmaxf); they reach the product through the planes.
+// resel_gemm_f32x's mode 2 (fp16 planes of the SCALED operand) for operands whose producer published nothing.  HBM-bound single pass:
+// float4 loads along the contiguous axis, one maximum per wave, published like every producer publishes - one conditional 64-bit
+// atomicMax of {epoch | float bits} on the sub-slot the block id selects.  A maximum does not depend on the order of its operands, so the
+// result is independent of block timing; the call keeps NO state between launches (the first version folded per-block partials behind a
+// ticket in a shared state buffer: two pre-passes in flight on different streams then mixed their partials - ADVICE r04).  NaNs in the
+// operand are ignored here (fmaxf); they reach the product through the planes.
 #include "resel_common.h"
 #include <algorithm>
 
@@ -16,13 +18,9 @@ struct AmaxParams {
     int rows, cols, batch;
     unsigned long long* out;
     unsigned epoch;
-    unsigned* ticket;
-    float* partial;
 };
 
 __global__ __launch_bounds__(256) void amax_kernel(AmaxParams p) {
-    __shared__ float s_m[4];
-    __shared__ int s_last;
     const int c4 = p.cols >> 2;                                  // float4 per row (cols % 4 == 0)
     const int64_t per_b = (int64_t)p.rows * c4, total = per_b * p.batch;
     float m0 = 0.f, m1 = 0.f;
@@ -32,34 +30,7 @@ __global__ __launch_bounds__(256) void amax_kernel(AmaxParams p) {
         m0 = fmaxf(m0, fmaxf(fabsf(v.x), fabsf(v.y)));
         m1 = fmaxf(m1, fmaxf(fabsf(v.z), fabsf(v.w)));
     }
-    float m = fmaxf(m0, m1);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        m = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
-        __hip_atomic_store(&p.partial[blockIdx.x], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned t = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (t == gridDim.x - 1);
-    }
-    __syncthreads();
-    if (!s_last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    m = 0.f;
-    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) m = fmaxf(m, __hip_atomic_load(&p.partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        // sub-slot 0 of the handle, stamped with this call's epoch (the other seven keep older epochs: readers ignore them)
-        p.out[0] = ((unsigned long long)p.epoch << 32) | __float_as_uint(fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3])));
-        __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    amax_publish_wave(fmaxf(m0, m1), AmaxOut{p.out, p.epoch});
 }
 }  // namespace
 
@@ -91,16 +62,56 @@ extern "C" int resel_amax_segments(const float* flat, const int64_t* begin, cons
     return launch_status();
 }
 
-extern "C" size_t resel_amax_state_bytes(void) { return (size_t)(AMAX_BLOCKS + 4) * sizeof(float); }
+extern "C" size_t resel_amax_state_bytes(void) { return 0; }     // ABI 7: resel_amax keeps no state (the argument is ignored)
 
 extern "C" int resel_amax(const float* x, int64_t ld, int64_t stride, int rows, int cols, int batch, void* out, unsigned epoch, void* state,
                           resel_stream_t stream) {
-    if (!x || !out || !state || rows <= 0 || cols <= 0 || batch <= 0 || (cols & 3) || (ld & 3) || (stride & 3) || !aligned16(x) || !aligned16(state)
+    (void)state;
+    if (!x || !out || rows <= 0 || cols <= 0 || batch <= 0 || (cols & 3) || (ld & 3) || (stride & 3) || !aligned16(x)
         || (reinterpret_cast<uintptr_t>(out) & 7u))
         return RESEL_EINVAL;
     const int64_t total = (int64_t)rows * (cols >> 2) * batch;
     const int blocks = (int)std::min<int64_t>(AMAX_BLOCKS, (total + 1023) / 1024 > 0 ? (total + 1023) / 1024 : 1);
-    AmaxParams p{x, ld, stride, rows, cols, batch, (unsigned long long*)out, epoch, (unsigned*)state, (float*)state + 4};
+    AmaxParams p{x, ld, stride, rows, cols, batch, (unsigned long long*)out, epoch};
     hipLaunchKernelGGL(amax_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    return launch_status();
+}
+
+// ---- verify mode (RESEL_AMAX_VERIFY=1 on the Python side): is the magnitude a handle holds really an upper bound of max |x|?  One pass
+// over the operand box of resel_amax; a wave whose maximum exceeds the handle's value reports into `err` (int32 [4], zero = clean):
+// [0] number of reporting waves (atomicAdd), [1] float bits of the largest violating magnitude (atomicMax), [2] `tag` of the first
+// report (atomicCAS from 0; the caller numbers its GEMM operands from 1), [3] float bits of the bound that first report saw.
+namespace {
+__global__ __launch_bounds__(256) void amax_check_kernel(AmaxParams p, const float* handle, int* err, int tag) {
+    const int c4 = p.cols >> 2;
+    const int64_t per_b = (int64_t)p.rows * c4, total = per_b * p.batch;
+    float m0 = 0.f, m1 = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i / per_b, r = (i - b * per_b) / c4, c = i - b * per_b - r * c4;
+        const float4 v = ld4(p.x + b * p.stride + r * p.ld + 4 * c);
+        m0 = fmaxf(m0, fmaxf(fabsf(v.x), fabsf(v.y)));
+        m1 = fmaxf(m1, fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    float m = fmaxf(m0, m1);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    const float bound = amax_read(handle);
+    if (__lane_id() == 0 && m > bound) {
+        atomicAdd(&err[0], 1);
+        atomicMax(&err[1], (int)__float_as_uint(m));
+        if (atomicCAS(&err[2], 0, tag) == 0) err[3] = (int)__float_as_uint(bound);
+    }
+}
+}  // namespace
+
+extern "C" int resel_amax_check(const float* x, int64_t ld, int64_t stride, int rows, int cols, int batch, const void* handle, int* err, int tag,
+                                resel_stream_t stream) {
+    if (!x || !handle || !err || rows <= 0 || cols <= 0 || batch <= 0 || (cols & 3) || (ld & 3) || (stride & 3) || !aligned16(x)
+        || (reinterpret_cast<uintptr_t>(handle) & 7u) || tag == 0)
+        return RESEL_EINVAL;
+    const int64_t total = (int64_t)rows * (cols >> 2) * batch;
+    const int blocks = (int)std::min<int64_t>(AMAX_BLOCKS, (total + 1023) / 1024 > 0 ? (total + 1023) / 1024 : 1);
+    AmaxParams p{x, ld, stride, rows, cols, batch, nullptr, 0u};
+    hipLaunchKernelGGL(amax_check_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, (const float*)handle, err, tag);
     return launch_status();
 }

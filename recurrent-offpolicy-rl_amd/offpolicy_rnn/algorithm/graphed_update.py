@@ -18,8 +18,10 @@ A graph is valid for ONE batch shape (rows, row length, number of plan segments,
 episodes.  Every `step()` is exactly ONE update (same update-to-data ratio and random streams as the eager loop): the first `warmup`
 calls run eagerly (allocator and lazily initialised kernels warm up), a shape is recorded the SECOND time it occurs (a shape that
 never recurs is not worth two device synchronisations and an activation pool), at most `max_graphs` graphs live at a time in ONE
-shared memory pool (they never replay concurrently), the least recently used one is dropped for a newcomer; any update without a
-graph runs eagerly from the same static inputs.
+shared memory pool (they never replay concurrently), the least recently used one is dropped for a newcomer - but an evicted shape must
+recur RECAPTURE_HITS times before it is recorded again and at most `max_graphs` recordings happen per CAPTURE_WINDOW updates, so a
+workload with more recurring shapes than graphs settles into eager launches for the overflow instead of recording on every update;
+any update without a graph runs eagerly from the same static inputs.
 Attention layers (cgpt): the token index / cu_seqlens tables of the batch are built by `_prepare` into pinned buffers (copy nodes in the
 graph; their sizes and the longest sequence are part of the shape key), and the counter-keyed dropout masks take their offsets from a
 per-update host count (0, 4, 8, ... in program order - baked into the kernel nodes) PLUS a device word that a node of the graph
@@ -46,6 +48,9 @@ class _StaticLog(DeferredLog):
 class GraphedUpdate:
     PLAN_CAPACITY = 16384                             # plan segments the static buffers hold (64 KB of pinned memory per slot)
     RING = 3                                          # pinned staging slots: the host may be this many updates ahead of the device
+    SEEN_CAP = 1024                                   # shape keys remembered (variable-length episodes produce many that never recur)
+    RECAPTURE_HITS = 8                                # occurrences an EVICTED shape needs before it is recorded again
+    CAPTURE_WINDOW = 256                              # at most `max_graphs` recordings per this many updates: more recurring shapes than graphs run eagerly
 
     def __init__(self, alg, warmup=3, max_graphs=4):
         why = self.refusal(alg)
@@ -55,7 +60,10 @@ class GraphedUpdate:
         self.graphs = OrderedDict()                   # batch shape key -> CUDAGraph, least recently used first
         self.warmup, self.max_graphs = warmup, max_graphs
         self._eager_left = warmup                     # updates still to run eagerly before anything is recorded
-        self._seen = {}                               # batch shape key -> occurrences so far
+        self._seen = OrderedDict()                    # batch shape key -> occurrences so far (least recently seen first; pruned to SEEN_CAP)
+        self._captures = []                           # step indices of the most recent recordings (capture-rate limit)
+        self._steps = 0
+        self._amax_generation = ops.AMAX_GENERATION[0]
         self._pool = None                             # memory pool shared by every recorded graph
         self.eager_fallbacks = 0
         E = alg.target_values[0].uni_network.layer_list[-1].num_ensemble
@@ -253,17 +261,32 @@ class GraphedUpdate:
 
     def step(self):
         """Exactly one update: eager while warming up or while the batch shape has no graph, a replay otherwise."""
+        if ops.amax_maintenance() or self._amax_generation != ops.AMAX_GENERATION[0]:
+            self.graphs.clear()                       # the magnitude epochs started over: recorded kernel nodes carry epochs of the old generation
+            self._amax_generation = ops.AMAX_GENERATION[0]
         key = self._prepare()
         g = self.graphs.get(key)
+        self._steps += 1
         if g is None:
             seen = self._seen[key] = self._seen.get(key, 0) + 1
-            if self._eager_left > 0 or seen < 2:      # warm-up updates / a shape on its first visit: the same update, launched eagerly
+            self._seen.move_to_end(key)
+            while len(self._seen) > self.SEEN_CAP:
+                self._seen.popitem(last=False)
+            # a recording costs two device synchronisations and a whole capture pass: with more recurring shapes than `max_graphs` an
+            # evict-and-record-again policy would turn every update into capture + replay.  Hence: an evicted shape has to recur
+            # RECAPTURE_HITS times before it is recorded again, and no more than `max_graphs` recordings per CAPTURE_WINDOW updates -
+            # whatever has no graph runs eagerly (the same update from the same static inputs).
+            self._captures = [t for t in self._captures if self._steps - t < self.CAPTURE_WINDOW]
+            throttled = len(self.graphs) >= self.max_graphs and len(self._captures) >= self.max_graphs
+            if self._eager_left > 0 or seen < 2 or throttled:      # warm-up updates / a shape on its first visit: the same update, launched eagerly
                 self._eager_left = max(0, self._eager_left - 1)
                 self.eager_fallbacks += 1
                 self._body()
                 return self._finish()
             if len(self.graphs) >= self.max_graphs:
-                self.graphs.popitem(last=False)       # least recently used; its activations return to the shared pool
+                old_key, _ = self.graphs.popitem(last=False)       # least recently used; its activations return to the shared pool
+                self._seen[old_key] = 2 - self.RECAPTURE_HITS
+            self._captures.append(self._steps)
             torch.cuda.synchronize(self.device)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=self._pool):
@@ -274,6 +297,8 @@ class GraphedUpdate:
             self.graphs[key] = g
         self.graphs.move_to_end(key)
         g.replay()
+        if ops.AMAX_VERIFY:                           # the recorded update contains the check kernels: read their verdict behind the replay
+            ops.amax_verify_raise(self.device)
         return self._finish()
 
     @property

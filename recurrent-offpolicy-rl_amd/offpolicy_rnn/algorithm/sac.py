@@ -214,15 +214,24 @@ class SAC:
     def train(self):
         self.sample_num += self.warmup()
         self.env_reset()
-        ep_ret, ep_len = 0.0, 0
         update = self.train_one_batch
+        graphed = None
         if os.environ.get('RESEL_GRAPH_UPDATE', '1') != '0':  # default: the whole update as one hipGraph replay per recurring batch shape (graphed_update.py)
             from .graphed_update import GraphedUpdate
             why = GraphedUpdate.refusal(self)
             if why:
                 self.logger(f'updates are launched eagerly ({why})')
             else:
-                update = GraphedUpdate(self).step
+                graphed = GraphedUpdate(self)
+                update = graphed.step
+        try:
+            self._train_loop(update)
+        finally:
+            if graphed is not None:             # detach the process-wide dropout base: later eager trainers of this process draw from torch's generator again
+                graphed.close()
+
+    def _train_loop(self, update):
+        ep_ret, ep_len = 0.0, 0
         for it in range(self.parameter.total_iteration):
             self.policy.train()
             self.policy.to(self.sample_device)

@@ -447,6 +447,8 @@ class SACFullLengthRNNEnsembleQ(SAC):
     # ------------------------------------------------------------------------------------------ the update
     def train_one_batch(self) -> Dict:
         par = self.parameter
+        if self._graph is None and self.device.type == 'cuda':
+            ops.amax_maintenance()                               # update boundary: the magnitude epochs may start over here (hip/ops.py)
         self.policy.to(self.device)
         self.optimizer_policy.to(self.device)
         policy_update_cnt = 0
@@ -589,6 +591,8 @@ class SACFullLengthRNNEnsembleQ(SAC):
             return self._graph.log_node(keys, packed, host, dict(real_batch_size=batch_size, real_batch_traj_num=rows,
                                                                   average_traj_len=self.replay_buffer.size / len(self.replay_buffer),
                                                                   amp_scalar_pi=0, amp_scalar_q=0))
+        if ops.AMAX_VERIFY and self.device.type == 'cuda':       # RESEL_AMAX_VERIFY=1: every mode-2 product of this update had its handles checked
+            ops.amax_verify_raise(self.device)
         log = DeferredLog(keys, packed, pinned=self.device.type == 'cuda')     # ONE device->host copy of all scalars
         log.set_host({k: float(v) for k, v in host.items()})
         log.set_host(dict(real_batch_size=batch_size, real_batch_traj_num=rows,

@@ -9,7 +9,7 @@ from ctypes import c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('RESEL_HIP_LIBRARY') or os.path.join(_HERE, 'libresel_hip.so')      # override: ablation builds (tools/gemm_ablate.sh)
-ABI_VERSION = 6
+ABI_VERSION = 7
 _lib = None
 
 P, I, L, F, S, U = c_void_p, c_int, c_int64, c_float, c_void_p, c_uint64
@@ -80,6 +80,7 @@ SIGNATURES = {
     'resel_amax_segments': (c_int, [P, P, P, I, P, E, S]),
     'resel_amax_state_bytes': (c_size_t, []),
     'resel_amax': (c_int, [P, L, L, I, I, I, P, E, P, S]),
+    'resel_amax_check': (c_int, [P, L, L, I, I, I, P, P, I, S]),
     'resel_gemm_bf16_workspace_bytes': (c_size_t, [I, I, I]),
     'resel_gemm_bf16': (c_int, [P, L, I, I, P, L, I, I, P, P, L, I, P, I, I, I, S]),
     'resel_colsum_bf16_workspace_bytes': (c_size_t, [I, I]),

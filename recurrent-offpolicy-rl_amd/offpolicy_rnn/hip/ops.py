@@ -224,7 +224,7 @@ class MambaInnerFn(torch.autograd.Function):
                                              Bsz, L, Di, N, 2 if fold else 1, SSCAN_TIME_SEGMENTS, p_y, e_y, _stream()), 'selective_scan_fwd')
         tag_amax(y, h_y)
         out = mm_nt(y, out_w)
-        ctx.handles = (ctx.ax, h_xc, h_y)                                  # saved tensors come back untagged
+        ctx.handles = keep_handles(ctx.ax, h_xc, h_y)                      # saved tensors come back untagged
         ctx.save_for_backward(x2, in_w, cw, conv_b, xproj_w, dt_w, dt_b, A, D, out_w, maskf, startf, xz, xc, x_dbl, dt, y, ck)
         ctx.dims = (Bsz, L, Dm, Di, N, R, K, conv_w.shape)
         ctx.fold = fold
@@ -239,7 +239,7 @@ class MambaInnerFn(torch.autograd.Function):
         do2 = dout.reshape(M, -1)
         if not do2.is_contiguous():
             do2 = do2.contiguous()
-        ax, h_xc, h_y = ctx.handles
+        ax, h_xc, h_y = live_handles(ctx.handles)
         d_out_w = wgrad(do2, y, amax_x=h_y)
         dy = mm_nn(do2, out_w)                                             # [M, Di]
         dxz = torch.empty(M, 2 * Di, dtype=torch.float32, device=dev)      # fully written: conv bwd -> [:, :Di], scan bwd -> [:, Di:]
@@ -875,7 +875,7 @@ class LinearAct(torch.autograd.Function):
             weight = torch.nn.functional.pad(weight, (0, ctx.kpad, 0, ctx.npad))
             bias = torch.nn.functional.pad(bias, (0, ctx.npad)) if (bias is not None and ctx.npad) else bias
         y2 = mm_nt(x2, weight, bias, act)
-        ctx.ax = amax_of(x2)                          # the input's magnitude handle, for the weight gradient (saved tensors come back untagged)
+        ctx.ax = keep_handles(amax_of(x2))[0]         # the input's magnitude handle, for the weight gradient (saved tensors come back untagged)
         ctx.save_for_backward(x2, weight, y2)
         ctx.act, ctx.has_bias, ctx.xshape = act, bias is not None, x.shape
         out = y2[:, :n_out] if ctx.npad else y2
@@ -897,7 +897,7 @@ class LinearAct(torch.autograd.Function):
         else:
             gy, db = bias_act_bwd(g2, y2, y2.shape[0], ctx.act, need_db)
         dx = mm_nn(gy, weight) if ctx.needs_input_grad[0] else None
-        dw = wgrad(gy, x2, amax_x=ctx.ax) if ctx.needs_input_grad[1] else None
+        dw = wgrad(gy, x2, amax_x=handle_alive(ctx.ax)) if ctx.needs_input_grad[1] else None
         if ctx.kpad or ctx.npad:                      # drop the padding rows / columns again
             k = x2.shape[1] - ctx.kpad
             dx = None if dx is None else dx[:, :k]
@@ -1104,12 +1104,22 @@ AMAX_WORDS = 128              # int64 words per handle
 AMAX_PREPASS_FRACTION = float(os.environ.get('RESEL_AMAX_PREPASS_FRACTION', 0.16))   # of the estimated GEMM time one may spend on reading an untagged operand
 _AMAX_ARENA = {}              # device -> [int64 tensor [AMAX_SLOTS], next index]
 _AMAX_EPOCH = [0]
-_AMAX_STATE = {}              # device -> zero-initialised ticket / partial buffer of resel_amax (calls are ordered on the launch stream)
 LAST_AMAX = None              # handle of the magnitude published by the most recent producer call (wrappers tag Function outputs with it)
 LAST_SPLIT = [None]
 
 
-_AMAX_SERIAL = [0]            # handles handed out so far: a tag older than one lap of the arena points at a recycled handle
+_AMAX_SERIAL = [0]            # handles handed out so far; every arena handle object carries the serial of its current tenant (`_resel_serial`)
+AMAX_GENERATION = [0]         # bumped by `amax_maintenance` when the epoch counter starts over: captured updates hold epochs of the old generation
+_EPOCH_RESET_AT = 0x60000000  # epochs are 31-bit device words; start over at an update boundary long before they run out
+_STORES = None                # weak set of FlatParameterStores (their weight handles carry epochs too); filled by `register_store`
+
+
+def register_store(store):
+    global _STORES
+    if _STORES is None:
+        import weakref
+        _STORES = weakref.WeakSet()
+    _STORES.add(store)
 
 
 def amax_slot(device):
@@ -1119,14 +1129,33 @@ def amax_slot(device):
     if ar is None:
         buf = torch.zeros(AMAX_SLOTS * AMAX_WORDS, dtype=torch.int64, device=device)
         ar = _AMAX_ARENA[device] = [buf, 0, list(buf.view(AMAX_SLOTS, AMAX_WORDS).unbind(0))]     # handle views made once (this sits on the launch path)
-    if _AMAX_EPOCH[0] >= 0x7fffffff:                 # epochs exhausted (days of training): start over on zeroed arenas
-        _AMAX_EPOCH[0] = 0
-        for a in _AMAX_ARENA.values():
-            a[0].zero_()
+    if _AMAX_EPOCH[0] >= 0x7ffffff0:
+        raise RuntimeError('RESeL-HIP: magnitude epochs exhausted inside one update - call ops.amax_maintenance() at update boundaries')
     _AMAX_EPOCH[0] += 1
     i = ar[1]
     ar[1] = (i + 1) % AMAX_SLOTS
-    return ar[2][i], _AMAX_EPOCH[0]
+    h = ar[2][i]
+    h._resel_serial = _AMAX_SERIAL[0]               # whoever kept this handle for its previous tenant sees the change (`handle_alive`)
+    return h, _AMAX_EPOCH[0]
+
+
+def amax_maintenance(force=False):
+    """Call at an UPDATE BOUNDARY (the trainers do, eager and graphed).  Epochs are 31 bits on the device: long before they run out
+    everything that carries one starts over together - arenas zeroed, every arena handle evicted (tags and kept handles become void),
+    the weight handles of every FlatParameterStore dropped (re-published on next use), and `AMAX_GENERATION` bumped so that holders of
+    captured updates (epochs baked into kernel nodes) drop their graphs.  Returns True when it reset."""
+    if not force and _AMAX_EPOCH[0] < _EPOCH_RESET_AT:
+        return False
+    _AMAX_EPOCH[0] = 0
+    AMAX_GENERATION[0] += 1
+    PARAM_EPOCH[0] += 1
+    for ar in _AMAX_ARENA.values():
+        ar[0].zero_()
+        for h in ar[2]:
+            h._resel_serial = None
+    for st in (list(_STORES) if _STORES is not None else []):
+        st._amax = None
+    return True
 
 
 def amax_arena_zero(device):
@@ -1135,6 +1164,22 @@ def amax_arena_zero(device):
     ar = _AMAX_ARENA.get(device)
     if ar is not None:
         ar[0].zero_()
+
+
+def keep_handles(*hs):
+    """For `ctx`: (handle, tenant serial) pairs - saved tensors come back untagged, and between a layer's forward and its backward a
+    deep model may hand out more handles than the arena holds, so a kept handle is only used while its slot still has the same tenant."""
+    return tuple((h, getattr(h, '_resel_serial', None)) for h in hs)
+
+
+def handle_alive(kept):
+    """The handle of a `keep_handles` pair, or None once the arena has given its slot to another tensor."""
+    h, serial = kept
+    return h if h is not None and getattr(h, '_resel_serial', None) == serial else None
+
+
+def live_handles(kept):
+    return tuple(handle_alive(k) for k in kept)
 
 
 def _taggable(t):
@@ -1146,25 +1191,71 @@ def _taggable(t):
 
 def tag_amax(t, handle, whole=False):
     """whole: t covers ALL of the tensor it is a view of (a reshape of a fresh output) - tag that base too, so that other views of it
-    (the [M, C] form of a [B, L, C] activation) find the magnitude.  A tag = (handle, tensor version, handle serial)."""
+    (the [M, C] form of a [B, L, C] activation) find the magnitude.  A tag = (handle, tensor version, tenant serial of the handle)."""
     if t is not None:
         ok = handle is not None and _taggable(t)
-        t._resel_amax = (handle, t._version, _AMAX_SERIAL[0]) if ok else None
+        serial = getattr(handle, '_resel_serial', None) if ok else None
+        t._resel_amax = (handle, t._version, serial) if ok else None
         base = getattr(t, '_base', None)
         if whole and base is not None:
-            base._resel_amax = (handle, base._version, _AMAX_SERIAL[0]) if (ok and _taggable(base)) else None
+            base._resel_amax = (handle, base._version, serial) if (ok and _taggable(base)) else None
     return t
 
 
 def amax_of(t):
     """Handle of a bound on max |t| if one is known (t itself or the tensor t is a view of), else None.  A tag is void once torch has
-    seen an in-place write to its tensor, or once the arena has handed out enough handles since to have recycled this one."""
+    seen an in-place write to its tensor, or once the arena has handed the handle's slot to another tensor."""
     for obj in (t, getattr(t, '_base', None)):
         if obj is not None:
             tg = getattr(obj, '_resel_amax', None)
-            if tg is not None and tg[1] == obj._version and _AMAX_SERIAL[0] - tg[2] < AMAX_SLOTS - 64:
+            if tg is not None and tg[1] == obj._version and getattr(tg[0], '_resel_serial', None) == tg[2]:
                 return tg[0]
     return None
+
+
+# ---- verify mode: RESEL_AMAX_VERIFY=1 checks, in front of EVERY mode-2 product, that the handles it scales with really bound its
+# operands (one extra pass per operand: slow, for tests and debugging).  Violations are collected in a device word block; the trainers
+# read it at the end of each update (`amax_verify_raise`) - also after a replayed update, whose graph then contains the check kernels.
+AMAX_VERIFY = os.environ.get('RESEL_AMAX_VERIFY', '0') == '1'
+_VERIFY_ERR = {}              # device -> int32 [4] (resel_amax_check)
+_VERIFY_CALLS = []            # ring of (tag, description) of the most recent checks
+_VERIFY_TAG = [0]
+
+
+class AmaxBoundError(RuntimeError):
+    pass
+
+
+@torch.no_grad()
+def amax_check(x, handle, what=''):
+    """Queue a device-side check `max |x| <= value(handle)` (x as in `amax`)."""
+    assert x.dtype == torch.float32 and x.stride(-1) == 1 and x.dim() in (2, 3)
+    err = _VERIFY_ERR.get(x.device)
+    if err is None:
+        err = _VERIFY_ERR[x.device] = torch.zeros(4, dtype=torch.int32, device=x.device)
+    _VERIFY_TAG[0] += 1
+    _VERIFY_CALLS.append((_VERIFY_TAG[0], f'{what} {tuple(x.shape)} strides {tuple(x.stride())}'))
+    del _VERIFY_CALLS[:-4096]
+    batch = x.shape[0] if x.dim() == 3 else 1
+    check(lib().resel_amax_check(_p(x), x.stride(-2), x.stride(0) if x.dim() == 3 and batch > 1 else 0, x.shape[-2], x.shape[-1], batch,
+                                 _p(handle), _p(err), _VERIFY_TAG[0], _stream()), 'amax_check')
+
+
+def amax_verify_raise(device=None):
+    """Synchronise and raise AmaxBoundError if any check since the last call found an operand above its handle's bound."""
+    for dev, err in list(_VERIFY_ERR.items()):
+        if device is not None and torch.device(device) != dev:
+            continue
+        e = err.cpu()
+        if int(e[0]) == 0:
+            continue
+        err.zero_()
+        tag = int(e[2])
+        what = dict(_VERIFY_CALLS).get(tag, '?')
+        got = float(e[1:2].view(torch.float32)[0])
+        bound = float(e[3:4].view(torch.float32)[0])
+        raise AmaxBoundError(f'RESeL-HIP: GEMM mode 2 was given a magnitude handle BELOW its operand: max |x| = {got:.6g} > bound {bound:.6g} '
+                             f'(first report: check #{tag}: {what}; {int(e[0])} reporting waves) - the fp16 planes would overflow to inf')
 
 
 @torch.no_grad()
@@ -1173,13 +1264,11 @@ def amax(x):
     handle on the device: one HBM-bound pass, no host synchronisation (include/resel_hip.h `resel_amax`)."""
     _need_cuda('amax', x)
     assert x.dtype == torch.float32 and x.stride(-1) == 1 and x.dim() in (2, 3)
-    st = _AMAX_STATE.get(x.device)
-    if st is None:
-        st = _AMAX_STATE[x.device] = torch.zeros(lib().resel_amax_state_bytes() // 4, dtype=torch.float32, device=x.device)
     out, epoch = amax_slot(x.device)
     batch = x.shape[0] if x.dim() == 3 else 1
+    # stateless since ABI 7: pre-passes on different streams (the trainer's target / side streams) cannot disturb each other
     check(lib().resel_amax(_p(x), x.stride(-2), x.stride(0) if x.dim() == 3 and batch > 1 else 0, x.shape[-2], x.shape[-1], batch,
-                           _p(out), epoch, _p(st), _stream()), 'amax')
+                           _p(out), epoch, None, _stream()), 'amax')
     return out
 
 
@@ -1279,6 +1368,9 @@ def gemm_f32(A, B, a_kcontig=True, b_kcontig=True, bias=None, act=None, out=None
                         tag_amax(B, hb)
                 else:
                     split = 6
+    if AMAX_VERIFY and split == 2:
+        amax_check(A, ha, f'A of gemm M={M} N={N} K={K} batch={batch}')
+        amax_check(B, hb, f'B of gemm M={M} N={N} K={K} batch={batch}')
     # max |C| for whoever multiplies C next (only while mode 2 is the product mode, and only for outputs worth a pass)
     slot, slot_p, epoch = _slot_args(amax_tracking() and act != GEMM_ACCUMULATE and M * N * batch >= (1 << 20), A.device)
     check(L.resel_gemm_f32x(_p(A), A.stride(-2), A.stride(0) if multi else 0, int(a_kcontig), _p(B), B.stride(-2),

@@ -135,6 +135,7 @@ class ContextualModel:
             with torch.no_grad():
                 if tau == 0.0:
                     self.store.flat.copy_(src.store.flat.to(self.store.flat.device))
+                    ops.PARAM_EPOCH[0] += 1             # a raw write into the parameter buffer: weight magnitudes (GEMM mode 2) are refreshed on next use
                 elif tau != 1.0:
                     ops.soft_update_(self.store.flat, src.store.flat, tau)
             return

@@ -37,7 +37,7 @@ class _SharedInput(torch.autograd.Function):
             y2 = torch.mm(x2, w_cat)
             ops.bias_act_(y2, None if bias is None else bias.reshape(1, E * n_out), y2.shape[0], act)
         ctx.save_for_backward(x2, w_cat, y2 if act is not None else None)
-        ctx.ax = ax
+        ctx.ax = ops.keep_handles(ax)[0]
         ctx.dims = (E, n_in, n_out, bias is not None, act)
         ctx.part = None if x_part is None else (col0, x_part.shape[-1], tuple(x_part.shape))
         return y2.view(-1, E, n_out).transpose(0, 1)                              # [E, M, out] view
@@ -58,7 +58,7 @@ class _SharedInput(torch.autograd.Function):
             dx = ops.gemm_f32(g2, w_cat, True, True) if mine else torch.mm(g2, w_cat.t())
         dw = None
         if ctx.needs_input_grad[1]:
-            dw = ops.gemm_f32(x2, g2, False, False, amax_a=ctx.ax) if mine else torch.mm(x2.t(), g2)
+            dw = ops.gemm_f32(x2, g2, False, False, amax_a=ops.handle_alive(ctx.ax)) if mine else torch.mm(x2.t(), g2)
             dw = dw.view(n_in, E, n_out).permute(1, 0, 2)
         dpart = None
         if ctx.part is not None and ctx.needs_input_grad[4]:
@@ -106,7 +106,7 @@ class _PerMember(torch.autograd.Function):
             y = torch.bmm(x3, weight)
             ops.bias_act_(y.view(E * M, -1), None if bias is None else bias.reshape(E, -1), M, act)
         ctx.save_for_backward(x3, weight, y if act is not None else None)
-        ctx.ax = ax
+        ctx.ax = ops.keep_handles(ax)[0]
         ctx.cfg = (bias is not None, act)
         return y
 
@@ -123,7 +123,7 @@ class _PerMember(torch.autograd.Function):
         else:
             gy, db = g, (g.sum(dim=1, keepdim=True) if need_db else None)
         dx = _member_dgrad(gy, weight, x3) if ctx.needs_input_grad[0] else None
-        dw = _member_wgrad(x3, gy, ctx.ax) if ctx.needs_input_grad[1] else None
+        dw = _member_wgrad(x3, gy, ops.handle_alive(ctx.ax)) if ctx.needs_input_grad[1] else None
         return dx, dw, db, None, None
 
 
@@ -142,7 +142,7 @@ class _Head(torch.autograd.Function):
             ax = ax if ax is not None else ops.amax_of(x3)
         else:
             a = torch.bmm(x3, w2)
-        ctx.ax = ax
+        ctx.ax = ops.keep_handles(ax)[0]
         w3v = w3.reshape(E, H)
         q = ops.ensemble_head_fwd_(a, b2.reshape(E, H), w3v, None if b3 is None else b3.reshape(E))
         ctx.save_for_backward(x3, w2, w3v, a)
@@ -156,7 +156,7 @@ class _Head(torch.autograd.Function):
         gq2 = gq.reshape(E, M)
         gy, db2, dw3 = ops.ensemble_head_bwd(gq2, a, w3v)
         dx = _member_dgrad(gy, w2, x3) if ctx.needs_input_grad[0] else None
-        dw2 = _member_wgrad(x3, gy, ctx.ax)
+        dw2 = _member_wgrad(x3, gy, ops.handle_alive(ctx.ax))
         db3 = gq2.sum(dim=1).view(E, 1, 1) if ctx.has_b3 else None
         return dx, dw2, db2.view(E, 1, H), dw3.view(E, H, 1), db3, None
 

@@ -41,6 +41,8 @@ class FlatParameterStore:
                 self.flat[o:o + n].copy_(p.detach().reshape(-1))
         self._amax = None            # per-tensor magnitude handles (GEMM product mode 2): (handles, PARAM_EPOCH at refresh, versions)
         self._repoint()
+        from ..hip import ops
+        ops.register_store(self)     # `ops.amax_maintenance` drops the weight handles of every store when the epoch counter starts over
 
     def _repoint(self):
         for i, (p, o, n) in enumerate(self.slices):

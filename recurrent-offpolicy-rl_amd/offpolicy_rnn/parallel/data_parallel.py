@@ -74,6 +74,9 @@ class GradSync:
         if self.active:
             dist.broadcast(flat, src=src, group=self.group)
             self._count('broadcast', flat)
+            if flat.is_cuda:                         # a raw write into a parameter buffer: the weight magnitudes of GEMM mode 2 are stale now
+                from ..hip import ops
+                ops.PARAM_EPOCH[0] += 1
 
     def all_reduce_max_(self, t: torch.Tensor):
         if self.active:

@@ -3,7 +3,9 @@ product runs the published embedding tower (fc -> sequence layer -> fc, D = 256)
 oracle restates the first two rows; outputs, dx and every parameter gradient of those rows are compared at north_star's fp32
 bar (1e-4, relative to the largest reference magnitude of the compared tensor; the loss ignores the other rows).
 
-  configs[1] / [3]: smamba_s32_c16_b2_nln, T' = 1043 (T = 1024 + skip 18 + 1), d_inner 512, N 32, conv K 16;
+  configs[1] / [3]: smamba_s32_c16_b2_nln, T' = 1043 (T = 1024 + skip 18 + 1), d_inner 512, N 32, conv K 16 - at B = 4 (32 workgroups: the
+    library cuts the rows into time segments) AND at the bench's own B = 64 (512 workgroups: the one-pass forward + 8-step-checkpoint
+    backward that `bench.py` times);
   configs[4]: gilr and lru, T' = 2003 (T = 2000 full episode), B = 16;
   gru at configs[1]'s B, T (T' = 1027, H = 256: 1026 sequential steps) and at configs[0]'s shape (B = 8, T = 128 -> T' = 130).
 Flags as the trainer builds them: the pre-step slots of a row are `start`, validity covers the trajectory, one mid-row reset."""
@@ -32,7 +34,7 @@ def _close_elementwise(got, ref, rtol, name, floor=1e-5):
     assert torch.isfinite(got).all() and excess <= 0, f'{name}: worst element at {worst:.2f}x its bound (rtol {rtol}, floor {floor})'
 
 
-@pytest.mark.parametrize('lid,B,L,skip', [('smamba_s32_c16_b2_nln', 4, 1043, 18), ('gilr', 16, 2003, 2), ('lru', 16, 2003, 2),
+@pytest.mark.parametrize('lid,B,L,skip', [('smamba_s32_c16_b2_nln', 4, 1043, 18), ('smamba_s32_c16_b2_nln', 64, 1043, 18), ('gilr', 16, 2003, 2), ('lru', 16, 2003, 2),
                                           ('gru', 4, 1027, 2), ('gru', 8, 130, 2)])
 def test_embedding_tower_at_the_baseline_row_length_vs_oracle(lid, B, L, skip):
     if not torch.cuda.is_available():
