@@ -378,6 +378,36 @@ int resel_gemm_f32x(const float* A, int64_t lda, int64_t strideA, int a_kcontig,
                     float* C, int64_t ldc, int64_t strideC, void* workspace,
                     int M, int N, int K, int batch, int split, const float* amax_a, const float* amax_b,
                     void* amax_c, unsigned amax_epoch, resel_stream_t stream);
+/* Fused epilogues of the producer / consumer edition (ABI 7).  Product mode 2 only (magnitude handles required), K a multiple of 32,
+ * M > 128, row strides < 2^22; dact also needs M >= 256 and N a multiple of 128 (rows past the last whole 256-row tile take the plain
+ * product + one small in-place pass inside the call) - resel_gemm_f32_fused_supported(kind, ...) says whether a shape qualifies; operand
+ * layouts as resel_gemm_f32, A in its [rows][K] form.
+ * Both write per-wave partial reductions into `workspace` (resel_gemm_f32_fused_workspace_bytes(M, N, K, batch, kind); kind 4 = dact,
+ * 5 = head) and fold them with a second small kernel in a fixed order: deterministic, no atomics.
+ *
+ * resel_gemm_f32_dact - the input gradient of a layer whose input is the ELU output Y of the layer below, with that ELU's derivative and
+ *   that layer's bias gradient in the epilogue (reference: rnn_base.py:461-469 applies the activation module after every fc / efc layer;
+ *   autograd runs elu_backward and the bias sum as separate passes):
+ *     C[b][m][n] = (sum_k A[b](m, k) B[b](n, k)) * (Y[b][m][n] > 0 ? 1 : Y[b][m][n] + 1);   dbias[b][n] = sum_m C[b][m][n]  (dbias may be NULL)
+ *   Y: row stride ldy, batch stride strideY, same [m][n] indexing as C.
+ * resel_gemm_f32_head - the last two layers of an efc-E critic head (reference ensemble_linear_model.py:36-49 via rnn_base.py:421-469:
+ *   efc-E(H) -> ELU -> efc-E(1)) in one GEMM:
+ *     C[b][m][n] = a = elu(sum_k A[b](m, k) B[b](n, k) + bias[b][n]);   q[b][m] = sum_n a[b][m][n] w3[b][n] + b3[b]  (b3 may be NULL)
+ *   (C is kept: the backward needs the hidden activation). */
+int resel_gemm_f32_fused_supported(int kind, int M, int N, int K, int64_t lda, int64_t ldb);
+size_t resel_gemm_f32_fused_workspace_bytes(int M, int N, int K, int batch, int kind);
+int resel_gemm_f32_dact(const float* A, int64_t lda, int64_t strideA, int a_kcontig,
+                        const float* B, int64_t ldb, int64_t strideB, int b_kcontig,
+                        const float* Y, int64_t ldy, int64_t strideY,
+                        float* C, int64_t ldc, int64_t strideC, float* dbias, void* workspace,
+                        int M, int N, int K, int batch, const float* amax_a, const float* amax_b,
+                        void* amax_c, unsigned amax_epoch, resel_stream_t stream);
+int resel_gemm_f32_head(const float* A, int64_t lda, int64_t strideA, int a_kcontig,
+                        const float* B, int64_t ldb, int64_t strideB, int b_kcontig,
+                        const float* bias, int64_t strideBias, const float* w3, int64_t strideW3, const float* b3,
+                        float* C, int64_t ldc, int64_t strideC, float* q, void* workspace,
+                        int M, int N, int K, int batch, const float* amax_a, const float* amax_b,
+                        void* amax_c, unsigned amax_epoch, resel_stream_t stream);
 /* Magnitude handles.  A kernel that writes a tensor which a later GEMM reads can publish max |x| of what it stored, so that mode 2
  * needs no extra pass over the operand.  A handle is 1 KiB (8-byte aligned; NULL = off): eight 8-byte words 128 bytes apart, word j =
  * {float bits : low 32 | epoch : high 32}; a publishing wave raises the word its workgroup id selects with one 64-bit atomicMax

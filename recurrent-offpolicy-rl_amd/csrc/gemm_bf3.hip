@@ -54,6 +54,15 @@ struct Params {
     const float *amaxA, *amaxB;                  // mode 2: device scalars >= max |A|, max |B| (resel_amax); nullptr otherwise
     AmaxOut amaxC;                               // optional: publish max |C| (the values stored, after bias / activation / accumulate)
     int ntst;                                    // third edition: non-temporal C stores
+    // fused epilogues of the third edition (resel_gemm_f32_dact / resel_gemm_f32_head, whole-K items only):
+    //   act 4: C = product * elu'(Y) with Y the OUTPUT of the layer below (y > 0 ? 1 : y + 1); red = per-wave column sums of C
+    //          [batch][2 mt][N] (the bias gradient of that layer, folded by colsum_kernel);
+    //   act 5: C = a = elu(product + bias); red = per-wave row dots sum_n a[m][n] aux[z][n] over the wave's 64 columns [batch][2 nt][M]
+    //          (the width-1 output layer of the critic head, folded by head_fold_kernel)
+    const float* aux;
+    int64_t ldaux, sAux;
+    float* red;
+    int redrows;                                 // act 4: partial rows per batch member in `red` (2 mt + one for the rows the host entry handles apart)
 };
 
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : fast_exp(x) - 1.f; }
@@ -692,7 +701,7 @@ constexpr int NTH_WS = 512;
 constexpr int WS_LDS = 2 * STAGE;
 #define WS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
-template <bool AKC, bool BKC, int SPLIT>
+template <bool AKC, bool BKC, int SPLIT, int EPI = 0>
 __global__ __launch_bounds__(NTH_WS, 1) void gemm_ws_kernel(Params p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];           // 2 stages
     constexpr bool F16 = SPLIT == 2;
@@ -905,8 +914,12 @@ __global__ __launch_bounds__(NTH_WS, 1) void gemm_ws_kernel(Params p) {
     WS_BARRIER();
     rd(f0, fa[0], fb[0]);
     int cur_st = 0;
+    // EPI 4 keeps four tiles of Y in flight through its epilogue (64 registers): the first fragments of the NEXT item are then read behind
+    // the epilogue instead of under the item's last matrix instructions (their stage stays valid until this wave passes the next barrier)
+    constexpr bool DEFER_F0 = EPI == 4;
     for (int c_item = blockIdx.x; c_item < total; c_item += G) {
         const Item cur = decode(p, c_item);
+        if (DEFER_F0 && c_item != (int)blockIdx.x) rd(f0, fa[0] + cur_st * STAGE, fb[0] + cur_st * STAGE);
         float zero = 0.f;
         asm volatile("" : "+v"(zero));
 #pragma unroll
@@ -936,7 +949,7 @@ __global__ __launch_bounds__(NTH_WS, 1) void gemm_ws_kernel(Params p) {
             BF3_FENCE();
             WS_BARRIER();
             BF3_FENCE();
-            rd(f0, fa[0] + sn, fb[0] + sn);
+            if (!(DEFER_F0 && c_k0 + BK >= cur.kend)) rd(f0, fa[0] + sn, fb[0] + sn);
             mm(f1);
 #pragma unroll
             for (int i = 0; i < 12; ++i) {
@@ -967,19 +980,58 @@ __global__ __launch_bounds__(NTH_WS, 1) void gemm_ws_kernel(Params p) {
                     for (int e = 0; e < 16; ++e) o[(32 * a + (e & 3) + 8 * (e >> 2)) * BN + 32 * b] = acc[a][b][e];
             continue;
         }
-        float* C = p.C + (int64_t)cur.z * p.sC;
-        const bool full_m = cur.m0 + BM <= p.M;
-        if (full_m && cur.n0 + BN <= p.N && p.act != 2) {
-            // whole tiles: every 32 x 32 tile is turned through a wave-private 5 KB LDS scratch (rows of 40 words: the two half-waves of a
-            // dword write hit disjoint banks) and leaves as FOUR 16-byte-per-lane stores of eight whole 128-byte lines each - 32 store
-            // instructions per wave and tile instead of 128: a wave may have 63 vector-memory operations in flight, and with four
-            // consumer waves 128 dword stores each stalled on that limit (160 of 415 us at 66 752 x 2048 x 384).
-            // Scratch: the third A plane of the stages, which mode 2 does not use (waves 0, 1 in stage 0's, 2, 3 in stage 1's).
-            char* sc = lds + (w >> 1) * STAGE + 2 * PLA + (w & 1) * 5120;
-            float* wr = reinterpret_cast<float*>(sc) + (4 * lh) * 40 + li;
-            const float4* rdp = reinterpret_cast<const float4*>(sc + (lane >> 3) * 160 + (lane & 7) * 16);
+        if constexpr (EPI == 0) {                                    // the plain epilogue, exactly as before the fused forms existed
+            float* C = p.C + (int64_t)cur.z * p.sC;
+            const bool full_m = cur.m0 + BM <= p.M;
+            if (full_m && cur.n0 + BN <= p.N && p.act != 2) {
+                // whole tiles: every 32 x 32 tile is turned through a wave-private 5 KB LDS scratch (rows of 40 words: the two half-waves of a
+                // dword write hit disjoint banks) and leaves as FOUR 16-byte-per-lane stores of eight whole 128-byte lines each - 32 store
+                // instructions per wave and tile instead of 128: a wave may have 63 vector-memory operations in flight, and with four
+                // consumer waves 128 dword stores each stalled on that limit (160 of 415 us at 66 752 x 2048 x 384).
+                // Scratch: the third A plane of the stages, which mode 2 does not use (waves 0, 1 in stage 0's, 2, 3 in stage 1's).
+                char* sc = lds + (w >> 1) * STAGE + 2 * PLA + (w & 1) * 5120;
+                float* wr = reinterpret_cast<float*>(sc) + (4 * lh) * 40 + li;
+                const float4* rdp = reinterpret_cast<const float4*>(sc + (lane >> 3) * 160 + (lane & 7) * 16);
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        float v[16];
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) v[e] = acc[a][b][e] + bv[b];
+                        if (p.act == 1) {
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) v[e] = elu1(v[e]);
+                        }
+                        if (p.act == 3) {
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) v[e] = softplus_nb(v[e]);
+                        }
+                        if (p.amaxC.slot) {
+#pragma unroll
+                            for (int e = 0; e < 16; e += 2) cmax = fmaxf(cmax, fmaxf(__builtin_fabsf(v[e]), __builtin_fabsf(v[e + 1])));
+                        }
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) wr[((e & 3) + 8 * (e >> 2)) * 40] = v[e];
+                        float* q = C + (int64_t)(cur.m0 + wm + 32 * a + (lane >> 3)) * p.ldc + cur.n0 + wn + 32 * b + 4 * (lane & 7);
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const float4 t = rdp[g * 8 * 10];                   // rows 8 g + (lane >> 3): 8 rows x 160 bytes = 80 float4
+                            if (p.ntst) {                                       // streaming stores (RESEL_GEMM_NT): -4 % on the kernel alone at N = 2048
+                                typedef float f4v __attribute__((ext_vector_type(4)));
+                                __builtin_nontemporal_store(f4v{t.x, t.y, t.z, t.w}, reinterpret_cast<f4v*>(q + (int64_t)(8 * g) * p.ldc));
+                            } else {
+                                *reinterpret_cast<float4*>(q + (int64_t)(8 * g) * p.ldc) = t;
+                            }
+                        }
+                    }
+                }
+                continue;
+            }
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
+                const int n = cur.n0 + wn + 32 * b + li;
+                if (n >= p.N) continue;
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
                     float v[16];
@@ -993,7 +1045,152 @@ __global__ __launch_bounds__(NTH_WS, 1) void gemm_ws_kernel(Params p) {
 #pragma unroll
                         for (int e = 0; e < 16; ++e) v[e] = softplus_nb(v[e]);
                     }
+                    const int mb = cur.m0 + wm + 32 * a + 4 * lh;
+                    float* crow = C + (int64_t)mb * p.ldc + n;
+                    if (p.act == 2) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int dm = (e & 3) + 8 * (e >> 2);
+                            if (mb + dm < p.M) v[e] += crow[(int64_t)dm * p.ldc];
+                        }
+                    }
+                    if (full_m) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) crow[(int64_t)((e & 3) + 8 * (e >> 2)) * p.ldc] = v[e];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int dm = (e & 3) + 8 * (e >> 2);
+                            if (mb + dm < p.M) crow[(int64_t)dm * p.ldc] = v[e];
+                        }
+                    }
                     if (p.amaxC.slot) {
+#pragma unroll
+                        for (int e = 0; e < 16; e += 2) cmax = fmaxf(cmax, fmaxf(__builtin_fabsf(v[e]), __builtin_fabsf(v[e + 1])));
+                    }
+                }
+            }
+        } else {
+            float* C = p.C + (int64_t)cur.z * p.sC;
+            const bool full_m = cur.m0 + BM <= p.M;
+            constexpr bool DACT = EPI == 4, HEAD = EPI == 5;               // fused epilogues: Params::aux / red
+            const int act = EPI ? (HEAD ? 1 : 0) : p.act;
+            if constexpr (DACT) {
+                // Whole tiles only (the host entry sends the rows past the last whole 256-row tile elsewhere).  Two phases:
+                //   A  the Y values are loaded IN THE ACCUMULATOR LAYOUT (column = li of block b, rows 4 lh + (e & 3) + 8 (e >> 2): a dword load
+                //      covers two whole 128-byte lines) and multiplied into the accumulators in place, tile by tile with PF tiles of loads in
+                //      flight; column sums and the magnitude come from the same registers;
+                //   B  the tiles leave exactly as in the plain epilogue (LDS turn, 16-byte full-line non-temporal stores).
+                // No store is issued between the loads of an item: a wait for a load also waits for every OLDER store (one in-order counter
+                // per wave), and with loads and stores interleaved per tile every tile waited for the write acknowledgements of the tiles
+                // before it (measured: 650 us against 305 for the product alone; this form: see profiles/r05_gemm.md).  The loads are inline
+                // assembly with a scalar base + ONE per-lane offset register (the compiler formed a 64-bit address pair per load and spilled
+                // accumulators; every scratch reload is a vmcnt(0)); it does not count them: each tile waits for ITS sixteen loads with a
+                // hand-written vmcnt = the loads issued since (foreign vector-memory operations only make a wait stricter).
+                constexpr int PF = 3;
+                // per-lane constants are formed HERE from the lane id (v_mbcnt) and the wave id in a scalar register: kept across the K loop
+                // they were spilled
+                const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+                const int li = lane & 31, lh = lane >> 5;
+                const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+                const int wm = (w >> 1) * 128, wn = (w & 1) * 64;
+                typedef float f32x4a __attribute__((ext_vector_type(4)));
+                f32x4a yv[8][4];
+                // Y travels as 16-byte loads of whole 128-byte lines (a lane: rows 8 g + (lane >> 3), columns 4 (lane & 7) .. + 3 - the form the C
+                // tiles leave in) and is turned INTO the accumulator layout through the wave's LDS scratch: dword loads in the accumulator
+                // layout cost four times the address work per byte (128 load instructions per item and wave; measured 542 us, this form: r05_gemm.md)
+                char* sc = lds + (w >> 1) * STAGE + 2 * PLA + (w & 1) * 5120;
+                float* wr = reinterpret_cast<float*>(sc) + (4 * lh) * 40 + li;
+                float4* rdp = reinterpret_cast<float4*>(sc + (lane >> 3) * 160 + (lane & 7) * 16);
+                const uint32_t ylane = (uint32_t)(((lane >> 3) * (int)p.ldaux + 4 * (lane & 7)) * 4);
+                const float* ybase = p.aux + (int64_t)cur.z * p.sAux + (int64_t)(cur.m0 + wm) * p.ldaux + cur.n0 + wn;
+                auto yld = [](f32x4a& r, uint32_t off, const float* base) {        // (asm operands inside the generic lambdas below are not captured: a clang quirk)
+                    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r) : "v"(off), "s"(base) : "memory");
+                };
+                auto ywait = [](f32x4a& r0, f32x4a& r1, f32x4a& r2, f32x4a& r3, auto NC) {
+                    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "n"(decltype(NC)::value) : "memory");
+                };
+                auto yload = [&](auto TC) {
+                    constexpr int t = decltype(TC)::value;
+                    if constexpr (t < 8) {
+                        const float* yb = ybase + (int64_t)(32 * (t >> 1)) * p.ldaux + 32 * (t & 1);
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) yld(yv[t][g], ylane, yb + (int64_t)(8 * g) * p.ldaux);
+                    }
+                };
+                float cs[2] = {0.f, 0.f}, cmx = 0.f;
+                auto mul = [&](auto TC) {
+                    constexpr int t = decltype(TC)::value;
+                    constexpr int a = t >> 1, b = t & 1;
+                    yload(std::integral_constant<int, t + PF>{});
+                    ywait(yv[t][0], yv[t][1], yv[t][2], yv[t][3], std::integral_constant<int, 4 * ((t + PF < 7 ? t + PF : 7) - t)>{});
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) rdp[g * 8 * 10] = make_float4(yv[t][g].x, yv[t][g].y, yv[t][g].z, yv[t][g].w);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const float y = wr[((e & 3) + 8 * (e >> 2)) * 40];
+                        const float v = acc[a][b][e] * (y > 0.f ? 1.f : y + 1.f);
+                        acc[a][b][e] = v;
+                        cs[b] += v;
+                        cmx = fmaxf(cmx, __builtin_fabsf(v));
+                    }
+                };
+                yload(std::integral_constant<int, 0>{}); yload(std::integral_constant<int, 1>{}); yload(std::integral_constant<int, 2>{});
+                static_assert(PF == 3, "the prologue issues PF tiles");
+                mul(std::integral_constant<int, 0>{}); mul(std::integral_constant<int, 1>{}); mul(std::integral_constant<int, 2>{});
+                mul(std::integral_constant<int, 3>{}); mul(std::integral_constant<int, 4>{}); mul(std::integral_constant<int, 5>{});
+                mul(std::integral_constant<int, 6>{}); mul(std::integral_constant<int, 7>{});
+                if (p.red) {
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const float c = cs[b] + __shfl_xor(cs[b], 32, 64);       // the two row halves of the accumulator layout
+                        if (lh == 0) p.red[((int64_t)cur.z * p.redrows + 2 * (cur.m0 / BM) + (w >> 1)) * p.N + cur.n0 + wn + 32 * b + li] = c;
+                    }
+                }
+                amax_publish_wave(cmx, p.amaxC);                         // one conditional atomic per wave and item (a maximum carried across the K loops was spilled)
+                // phase B
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) wr[((e & 3) + 8 * (e >> 2)) * 40] = acc[a][b][e];
+                        float* q = C + (int64_t)(cur.m0 + wm + 32 * a + (lane >> 3)) * p.ldc + cur.n0 + wn + 32 * b + 4 * (lane & 7);
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const float4 t = rdp[g * 8 * 10];
+                            typedef float f4v __attribute__((ext_vector_type(4)));
+                            __builtin_nontemporal_store(f4v{t.x, t.y, t.z, t.w}, reinterpret_cast<f4v*>(q + (int64_t)(8 * g) * p.ldc));
+                        }
+                    }
+                }
+                continue;
+            }
+            if (full_m && cur.n0 + BN <= p.N && act != 2) {
+                // whole tiles: every 32 x 32 tile is turned through a wave-private 5 KB LDS scratch (rows of 40 words: the two half-waves of a
+                // dword write hit disjoint banks) and leaves as FOUR 16-byte-per-lane stores of eight whole 128-byte lines each - 32 store
+                // instructions per wave and tile instead of 128: a wave may have 63 vector-memory operations in flight, and with four
+                // consumer waves 128 dword stores each stalled on that limit (160 of 415 us at 66 752 x 2048 x 384).
+                // Scratch: the third A plane of the stages, which mode 2 does not use (waves 0, 1 in stage 0's, 2, 3 in stage 1's).
+                char* sc = lds + (w >> 1) * STAGE + 2 * PLA + (w & 1) * 5120;
+                float* wr = reinterpret_cast<float*>(sc) + (4 * lh) * 40 + li;
+                const float4* rdp = reinterpret_cast<const float4*>(sc + (lane >> 3) * 160 + (lane & 7) * 16);
+                // one 32 x 32 tile (row tile a, column block b).  In the transposed form a lane holds rows 8 g + (lane >> 3), columns 4 (lane & 7) .. + 3.
+                // DACT: yv = the four float4 of Y at those places (requested before the tile is turned), cs += the lane's share of the column sums;
+                // HEAD: w3 = the output layer's weights of the lane's four columns, qr[g] += the lane's share of the row dots
+                auto tile = [&](int a, int b, const float4 (&yv)[4], float4& cs, const float4& w3, float (&qr)[4]) {
+                    float v[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) v[e] = acc[a][b][e] + bv[b];
+                    if (act == 1) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) v[e] = elu1(v[e]);
+                    }
+                    if (act == 3) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) v[e] = softplus_nb(v[e]);
+                    }
+                    if (p.amaxC.slot && !DACT) {
 #pragma unroll
                         for (int e = 0; e < 16; e += 2) cmax = fmaxf(cmax, fmaxf(__builtin_fabsf(v[e]), __builtin_fabsf(v[e + 1])));
                     }
@@ -1002,7 +1199,14 @@ __global__ __launch_bounds__(NTH_WS, 1) void gemm_ws_kernel(Params p) {
                     float* q = C + (int64_t)(cur.m0 + wm + 32 * a + (lane >> 3)) * p.ldc + cur.n0 + wn + 32 * b + 4 * (lane & 7);
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const float4 t = rdp[g * 8 * 10];                   // rows 8 g + (lane >> 3): 8 rows x 160 bytes = 80 float4
+                        float4 t = rdp[g * 8 * 10];                         // rows 8 g + (lane >> 3): 8 rows x 160 bytes = 80 float4
+                        if (DACT) {
+                            t.x *= yv[g].x > 0.f ? 1.f : yv[g].x + 1.f; t.y *= yv[g].y > 0.f ? 1.f : yv[g].y + 1.f;
+                            t.z *= yv[g].z > 0.f ? 1.f : yv[g].z + 1.f; t.w *= yv[g].w > 0.f ? 1.f : yv[g].w + 1.f;
+                            cs.x += t.x; cs.y += t.y; cs.z += t.z; cs.w += t.w;
+                            if (p.amaxC.slot) cmax = amax4(cmax, t);
+                        }
+                        if (HEAD) qr[g] += (t.x * w3.x + t.y * w3.y) + (t.z * w3.z + t.w * w3.w);
                         if (p.ntst) {                                       // streaming stores (RESEL_GEMM_NT): -4 % on the kernel alone at N = 2048
                             typedef float f4v __attribute__((ext_vector_type(4)));
                             __builtin_nontemporal_store(f4v{t.x, t.y, t.z, t.w}, reinterpret_cast<f4v*>(q + (int64_t)(8 * g) * p.ldc));
@@ -1010,49 +1214,124 @@ __global__ __launch_bounds__(NTH_WS, 1) void gemm_ws_kernel(Params p) {
                             *reinterpret_cast<float4*>(q + (int64_t)(8 * g) * p.ldc) = t;
                         }
                     }
-                }
-            }
-            continue;
-        }
+                };
+                if constexpr (EPI == 0) {
+                    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float4 nov[4] = {z4, z4, z4, z4};
+                    float4 ncs = z4;
+                    float nq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int n = cur.n0 + wn + 32 * b + li;
-            if (n >= p.N) continue;
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) tile(a, b, nov, ncs, z4, nq);
+                } else {
+                    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    {
+                        // row tiles outermost: the row dots of a tile's 32 rows complete after its two column blocks (4 registers instead of 16)
+                        const float4 nov[4] = {z4, z4, z4, z4};
+                        float4 ncs = z4, w3[2];
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) w3[b] = ld4(p.aux + (int64_t)cur.z * p.sAux + cur.n0 + wn + 32 * b + 4 * (lane & 7));
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) {
+                            float qr[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int b = 0; b < 2; ++b) tile(a, b, nov, ncs, w3[b], qr);
+                            // fold the eight column groups (lane bits 0..2): lanes with (lane & 7) == 0 hold a row's dot
+                            float* qp = p.red + ((int64_t)cur.z * 2 * p.nt + 2 * (cur.n0 / BN) + (w & 1)) * p.M + cur.m0 + wm + 32 * a + (lane >> 3);
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                float r = qr[g];
+                                r += __shfl_xor(r, 1, 64); r += __shfl_xor(r, 2, 64); r += __shfl_xor(r, 4, 64);
+                                if ((lane & 7) == 0) qp[8 * g] = r;
+                            }
+                        }
+                    }
+                }
+                continue;
+            }
+            // edge tiles (and the accumulating form): the accumulator layout goes out as it is - column n = li of block b, rows 4 lh + (e & 3) + 8 (e >> 2)
+            float cs1[2] = {0.f, 0.f};
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
-                float v[16];
+                float qe[16];
+                if (HEAD) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) v[e] = acc[a][b][e] + bv[b];
-                if (p.act == 1) {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) v[e] = elu1(v[e]);
-                }
-                if (p.act == 3) {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) v[e] = softplus_nb(v[e]);
+                    for (int e = 0; e < 16; ++e) qe[e] = 0.f;
                 }
                 const int mb = cur.m0 + wm + 32 * a + 4 * lh;
-                float* crow = C + (int64_t)mb * p.ldc + n;
-                if (p.act == 2) {
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int dm = (e & 3) + 8 * (e >> 2);
-                        if (mb + dm < p.M) v[e] += crow[(int64_t)dm * p.ldc];
+                for (int b = 0; b < 2; ++b) {
+                    const int n = cur.n0 + wn + 32 * b + li;
+                    if (n >= p.N) continue;
+                    float v[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) v[e] = acc[a][b][e] + bv[b];
+                    if (act == 1) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) v[e] = elu1(v[e]);
+                    }
+                    if (act == 3) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) v[e] = softplus_nb(v[e]);
+                    }
+                    if (DACT) {
+                        const float* yrow = p.aux + (int64_t)cur.z * p.sAux + (int64_t)mb * p.ldaux + n;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int dm = (e & 3) + 8 * (e >> 2);
+                            float y = 0.f;
+                            if (mb + dm < p.M) y = yrow[(int64_t)dm * p.ldaux]; else v[e] = 0.f;      // rows past M hold row 0's products: not part of the column sums
+                            v[e] *= y > 0.f ? 1.f : y + 1.f;
+                            cs1[b] += v[e];
+                        }
+                    }
+                    if (HEAD) {
+                        const float w3 = p.aux[(int64_t)cur.z * p.sAux + n];
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) qe[e] += v[e] * w3;
+                    }
+                    float* crow = C + (int64_t)mb * p.ldc + n;
+                    if (act == 2) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int dm = (e & 3) + 8 * (e >> 2);
+                            if (mb + dm < p.M) v[e] += crow[(int64_t)dm * p.ldc];
+                        }
+                    }
+                    if (full_m) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) crow[(int64_t)((e & 3) + 8 * (e >> 2)) * p.ldc] = v[e];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int dm = (e & 3) + 8 * (e >> 2);
+                            if (mb + dm < p.M) crow[(int64_t)dm * p.ldc] = v[e];
+                        }
+                    }
+                    if (p.amaxC.slot) {
+#pragma unroll
+                        for (int e = 0; e < 16; e += 2) cmax = fmaxf(cmax, fmaxf(__builtin_fabsf(v[e]), __builtin_fabsf(v[e + 1])));
                     }
                 }
-                if (full_m) {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) crow[(int64_t)((e & 3) + 8 * (e >> 2)) * p.ldc] = v[e];
-                } else {
+                if (HEAD) {                                                 // a row's 32 columns of a block sit in the 32 lanes of a half-wave
+                    float* qp = p.red + ((int64_t)cur.z * 2 * p.nt + 2 * (cur.n0 / BN) + (w & 1)) * p.M;
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
-                        const int dm = (e & 3) + 8 * (e >> 2);
-                        if (mb + dm < p.M) crow[(int64_t)dm * p.ldc] = v[e];
+                        float r = qe[e];
+#pragma unroll
+                        for (int o = 1; o < 32; o <<= 1) r += __shfl_xor(r, o, 64);
+                        const int m = mb + (e & 3) + 8 * (e >> 2);
+                        if (li == 0 && m < p.M) qp[m] = r;
                     }
                 }
-                if (p.amaxC.slot) {
+            }
+            if (DACT && p.red) {
 #pragma unroll
-                    for (int e = 0; e < 16; e += 2) cmax = fmaxf(cmax, fmaxf(__builtin_fabsf(v[e]), __builtin_fabsf(v[e + 1])));
+                for (int b = 0; b < 2; ++b) {
+                    const int n = cur.n0 + wn + 32 * b + li;
+                    const float c = cs1[b] + __shfl_xor(cs1[b], 32, 64);     // the two row halves of the accumulator layout
+                    if (lh == 0 && n < p.N) p.red[((int64_t)cur.z * 2 * p.mt + 2 * (cur.m0 / BM) + (w >> 1)) * p.N + n] = c;
                 }
             }
         }
@@ -1133,17 +1412,17 @@ int launch_one(const Params& p, dim3 grid, hipStream_t s) {
     return RESEL_OK;
 }
 
-template <bool AKC, bool BKC, int SP>
+template <bool AKC, bool BKC, int SP, int EPI = 0>
 int launch_ws(const Params& p, dim3 grid, hipStream_t s) {
     static std::atomic<bool> attr_set[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return RESEL_ELAUNCH;
     if (!attr_set[dev].load(std::memory_order_acquire)) {
-        if (hipFuncSetAttribute((const void*)gemm_ws_kernel<AKC, BKC, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)gemm_ws_kernel<AKC, BKC, SP, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS) != hipSuccess)
             return RESEL_ELAUNCH;
         attr_set[dev].store(true, std::memory_order_release);
     }
-    launch_timed(RESEL_PROF_GEMM, gemm_ws_kernel<AKC, BKC, SP>, grid, dim3(NTH_WS), (size_t)WS_LDS, s, p);
+    launch_timed(RESEL_PROF_GEMM, gemm_ws_kernel<AKC, BKC, SP, EPI>, grid, dim3(NTH_WS), (size_t)WS_LDS, s, p);
     return RESEL_OK;
 }
 
@@ -1167,15 +1446,27 @@ size_t gemm_bf3_workspace_bytes(int M, int N, int K, int batch) {
 }
 
 // split in {3, 6, 9}, K >= 32; argument checks are the caller's (resel_gemm_f32)
+// the fused epilogues (act 4 / 5) exist on the producer / consumer edition, for whole-K items: mode 2, K a multiple of 32, M > 128
+bool gemm_bf3_fused_ok(int M, int N, int K, int64_t lda, int64_t ldb) {
+    return g_edition == 3 && M > 128 && N >= 4 && K >= BK && K % BK == 0 && lda < (1 << 22) && ldb < (1 << 22);
+}
+
 int gemm_bf3_launch(const float* A, int64_t lda, int64_t strideA, int a_kcontig, const float* B, int64_t ldb, int64_t strideB, int b_kcontig,
                     const float* bias, int64_t strideBias, int act, float* C, int64_t ldc, int64_t strideC, void* workspace,
                     int M, int N, int K, int batch, int split, hipStream_t s, const float* amaxA, const float* amaxB,
-                    unsigned long long* amax_c, unsigned amax_epoch) {
+                    unsigned long long* amax_c, unsigned amax_epoch, const float* aux, int64_t ldaux, int64_t strideAux, float* red, int redrows) {
     if (split == 2 && (!amaxA || !amaxB)) return RESEL_EINVAL;
-    const Plan pl = make_plan(M, N, K, batch);
+    Plan pl = make_plan(M, N, K, batch);
+    if (act >= 4) {                                  // every tile whole: the epilogue reductions are written per (tile, wave), no K slices
+        if (split != 2 || !gemm_bf3_fused_ok(M, N, K, lda, ldb) || !aux) return RESEL_EINVAL;
+        if (act == 4 && (M % BM || N % BN)) return RESEL_EINVAL;          // the act 4 epilogue has no edge form (resel_gemm_f32_dact splits the rows)
+        const long nbt = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN) * batch;
+        pl = Plan{(int)nbt, 0, 1, (K + BK - 1) / BK * BK};
+    }
     if (pl.nsplit && (!workspace || !aligned16(workspace))) return RESEL_EINVAL;
     Params p{A, B, bias, C, (float*)workspace, lda, ldb, ldc, strideA, strideB, strideC, strideBias, M, N, K, act,
-             (M + BM - 1) / BM, (N + BN - 1) / BN, pl.nfull, pl.nsplit, pl.nsl, pl.kslice, amaxA, amaxB, AmaxOut{amax_c, amax_epoch}, g_nt};
+             (M + BM - 1) / BM, (N + BN - 1) / BN, pl.nfull, pl.nsplit, pl.nsl, pl.kslice, amaxA, amaxB, AmaxOut{amax_c, amax_epoch}, g_nt,
+             aux, ldaux, strideAux, red, redrows};
     const int64_t total = (int64_t)pl.nfull + (int64_t)pl.nsplit * pl.nsl;
     dim3 grid((unsigned)std::min<int64_t>(total, GRID));
     int rc;
@@ -1191,7 +1482,11 @@ int gemm_bf3_launch(const float* A, int64_t lda, int64_t strideA, int a_kcontig,
          else rc = launch_ws<false, false, SP>(p, grid, s); } while (0)
     // third edition: mode 2, whole K steps (also per K slice); row strides within the 24-bit multiply of the piece offsets
     const bool ws = g_edition == 3 && split == 2 && K % BK == 0 && pl.kslice % BK == 0 && lda < (1 << 22) && ldb < (1 << 22);
-    if (ws) WS_LAUNCH(2);
+    if (act >= 4) {                                   // fused epilogues: the layouts the trainer uses - A [rows][K]; B either way
+        if (!a_kcontig) return RESEL_EINVAL;
+        if (act == 4) rc = b_kcontig ? launch_ws<true, true, 2, 4>(p, grid, s) : launch_ws<true, false, 2, 4>(p, grid, s);
+        else rc = b_kcontig ? launch_ws<true, true, 2, 5>(p, grid, s) : launch_ws<true, false, 2, 5>(p, grid, s);
+    } else if (ws) WS_LAUNCH(2);
     else if (split == 9) BF3_LAUNCH(9); else if (split == 3) BF3_LAUNCH(3); else if (split == 2) BF3_LAUNCH(2); else BF3_LAUNCH(6);
 #undef WS_LAUNCH
 #undef BF3_LAUNCH

@@ -42,7 +42,9 @@ size_t gemm_bf3_workspace_bytes(int M, int N, int K, int batch);
 int gemm_bf3_launch(const float* A, int64_t lda, int64_t strideA, int a_kcontig, const float* B, int64_t ldb, int64_t strideB, int b_kcontig,
                     const float* bias, int64_t strideBias, int act, float* C, int64_t ldc, int64_t strideC, void* workspace,
                     int M, int N, int K, int batch, int split, hipStream_t s, const float* amaxA, const float* amaxB,
-                    unsigned long long* amax_c, unsigned amax_epoch);
+                    unsigned long long* amax_c, unsigned amax_epoch, const float* aux = nullptr, int64_t ldaux = 0, int64_t strideAux = 0,
+                    float* red = nullptr, int redrows = 0);
+bool gemm_bf3_fused_ok(int M, int N, int K, int64_t lda, int64_t ldb);
 }
 
 namespace {
@@ -667,5 +669,111 @@ extern "C" int resel_gemm_f32x(const float* A, int64_t lda, int64_t strideA, int
     else RESEL_GEMM_LAUNCH(0);
 #undef RESEL_GEMM_LAUNCH
     if (pl.nsplit) hipLaunchKernelGGL(gemm_fixup_kernel, dim3(TILE / 4 / 64, pl.nsplit), dim3(64, 4), 0, s, p);
+    return launch_status();
+}
+
+// ---- fused epilogues of the producer / consumer edition (ABI 7; product mode 2 only) ----------------------------------------------
+namespace {
+// q[z][m] = b3[z] + sum_{j < parts} part[z][j][m]   (fixed order)
+__global__ __launch_bounds__(256) void head_fold_kernel(const float* __restrict__ part, int parts, int M, const float* __restrict__ b3, float* __restrict__ q) {
+    const int z = blockIdx.y;
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const float* pz = part + (int64_t)z * parts * M + m;
+    float acc = b3 ? b3[z] : 0.f;
+    for (int j = 0; j < parts; ++j) acc += pz[(int64_t)j * M];
+    q[(int64_t)z * M + m] = acc;
+}
+bool fused_args_ok(const float* A, int64_t lda, int64_t strideA, int a_kcontig, const float* B, int64_t ldb, int64_t strideB, int b_kcontig,
+                   const float* C, int64_t ldc, int M, int N, int K, int batch, const float* amax_a, const float* amax_b, const void* amax_c,
+                   const void* workspace) {
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || !amax_a || !amax_b || !workspace || !aligned16(workspace)) return false;
+    if (amax_c && (reinterpret_cast<uintptr_t>(amax_c) & 7u)) return false;
+    if (lda % 4 || ldb % 4 || ldc % 4 || strideA % 4 || strideB % 4 || !aligned16(A) || !aligned16(B) || !aligned16(C)) return false;
+    if ((a_kcontig ? K : M) % 4 || (b_kcontig ? K : N) % 4 || N % 4) return false;
+    if (lda <= 0 || ldb <= 0 || ldc <= 0) return false;
+    return gemm_bf3_fused_ok(M, N, K, lda, ldb);
+}
+}  // namespace
+
+extern "C" int resel_gemm_f32_fused_supported(int kind, int M, int N, int K, int64_t lda, int64_t ldb) {
+    if (kind == 4) return (M >= 256 && N % 128 == 0 && gemm_bf3_fused_ok(M, N, K, lda, ldb)) ? 1 : 0;
+    if (kind == 5) return gemm_bf3_fused_ok(M, N, K, lda, ldb) ? 1 : 0;
+    return 0;
+}
+
+extern "C" size_t resel_gemm_f32_fused_workspace_bytes(int M, int N, int K, int batch, int kind) {
+    if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return 0;
+    const size_t mt = M / 256, nt = (N + 127) / 128;
+    const size_t own = (kind == 5 ? 2 * nt * (size_t)M : (2 * mt + 1) * (size_t)N) * batch * sizeof(float);
+    // kind 4: + the split-K slabs of the plain product over the rows past the last whole 256-row tile
+    return own + (kind == 4 && M % 256 ? resel_gemm_f32_workspace_bytes(M % 256, N, K, batch) + 256 : 0);
+}
+
+namespace {
+// rows past the last whole tile of resel_gemm_f32_dact: C *= elu'(Y) in place, column sums into one partial row.  grid (N / 64, batch), 256 threads
+__global__ __launch_bounds__(256) void dact_tail_kernel(float* __restrict__ C, int64_t ldc, int64_t sC, const float* __restrict__ Y, int64_t ldy, int64_t sY,
+                                                        int rows, int N, float* __restrict__ part, int64_t part_stride, AmaxOut amax) {
+    __shared__ float s_sum[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6, z = blockIdx.y;
+    float acc = 0.f, mx = 0.f;
+    if (c < N) {
+        float* Cz = C + (int64_t)z * sC + c;
+        const float* Yz = Y + (int64_t)z * sY + c;
+        for (int r = rg; r < rows; r += 4) {
+            const float y = Yz[(int64_t)r * ldy];
+            const float v = Cz[(int64_t)r * ldc] * (y > 0.f ? 1.f : y + 1.f);
+            Cz[(int64_t)r * ldc] = v;
+            acc += v;
+            mx = fmaxf(mx, __builtin_fabsf(v));
+        }
+    }
+    s_sum[rg][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (rg == 0 && c < N && part) part[(int64_t)z * part_stride + c] = (s_sum[0][threadIdx.x] + s_sum[1][threadIdx.x]) + (s_sum[2][threadIdx.x] + s_sum[3][threadIdx.x]);
+    amax_publish_wave(mx, amax);
+}
+}  // namespace
+
+extern "C" int resel_gemm_f32_dact(const float* A, int64_t lda, int64_t strideA, int a_kcontig,
+                                   const float* B, int64_t ldb, int64_t strideB, int b_kcontig,
+                                   const float* Y, int64_t ldy, int64_t strideY,
+                                   float* C, int64_t ldc, int64_t strideC, float* dbias, void* workspace,
+                                   int M, int N, int K, int batch, const float* amax_a, const float* amax_b,
+                                   void* amax_c, unsigned amax_epoch, resel_stream_t stream) {
+    if (!fused_args_ok(A, lda, strideA, a_kcontig, B, ldb, strideB, b_kcontig, C, ldc, M, N, K, batch, amax_a, amax_b, amax_c, workspace)) return RESEL_EINVAL;
+    if (!Y || ldy % 4 || strideY % 4 || ldy <= 0 || !aligned16(Y) || !a_kcontig || M < 256 || N % 128) return RESEL_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    // the fused epilogue takes whole 256-row tiles; the (at most 255) rows behind them: plain product, then one small in-place pass
+    const int Mm = M / 256 * 256, tail = M - Mm, rows = 2 * (Mm / 256) + (tail ? 1 : 0);
+    float* part = dbias ? (float*)workspace : nullptr;                     // [batch][rows][N]
+    int rc = gemm_bf3_launch(A, lda, strideA, a_kcontig, B, ldb, strideB, b_kcontig, nullptr, 0, 4, C, ldc, strideC, nullptr, Mm, N, K, batch, 2,
+                             s, amax_a, amax_b, (unsigned long long*)amax_c, amax_epoch, Y, ldy, strideY, part, rows);
+    if (rc != RESEL_OK) return rc;
+    if (tail) {
+        char* ws2 = (char*)workspace + ((size_t)rows * N * batch * sizeof(float) + 255) / 256 * 256;
+        rc = resel_gemm_f32x(A + (int64_t)Mm * lda, lda, strideA, 1, B, ldb, strideB, b_kcontig, nullptr, 0, 0, C + (int64_t)Mm * ldc, ldc, strideC, ws2,
+                             tail, N, K, batch, 2, amax_a, amax_b, nullptr, 0u, stream);
+        if (rc != RESEL_OK) return rc;
+        hipLaunchKernelGGL(dact_tail_kernel, dim3((N + 63) / 64, batch), dim3(256), 0, s, C + (int64_t)Mm * ldc, ldc, strideC, Y + (int64_t)Mm * ldy, ldy, strideY,
+                           tail, N, part ? part + (int64_t)(rows - 1) * N : nullptr, (int64_t)rows * N, AmaxOut{(unsigned long long*)amax_c, amax_epoch});
+    }
+    if (dbias) launch_colsum(part, N, rows, N, dbias, s, 1, 0, batch);
+    return launch_status();
+}
+
+extern "C" int resel_gemm_f32_head(const float* A, int64_t lda, int64_t strideA, int a_kcontig,
+                                   const float* B, int64_t ldb, int64_t strideB, int b_kcontig,
+                                   const float* bias, int64_t strideBias, const float* w3, int64_t strideW3, const float* b3,
+                                   float* C, int64_t ldc, int64_t strideC, float* q, void* workspace,
+                                   int M, int N, int K, int batch, const float* amax_a, const float* amax_b,
+                                   void* amax_c, unsigned amax_epoch, resel_stream_t stream) {
+    if (!fused_args_ok(A, lda, strideA, a_kcontig, B, ldb, strideB, b_kcontig, C, ldc, M, N, K, batch, amax_a, amax_b, amax_c, workspace)) return RESEL_EINVAL;
+    if (!w3 || !q || strideW3 % 4 || !aligned16(w3)) return RESEL_EINVAL;
+    const int rc = gemm_bf3_launch(A, lda, strideA, a_kcontig, B, ldb, strideB, b_kcontig, bias, strideBias, 5, C, ldc, strideC, nullptr, M, N, K, batch, 2,
+                                   (hipStream_t)stream, amax_a, amax_b, (unsigned long long*)amax_c, amax_epoch, w3, 0, strideW3, (float*)workspace);
+    if (rc != RESEL_OK) return rc;
+    hipLaunchKernelGGL(head_fold_kernel, dim3((M + 255) / 256, batch), dim3(256), 0, (hipStream_t)stream, (const float*)workspace,
+                       2 * ((N + 127) / 128), M, b3, q);
     return launch_status();
 }

@@ -80,6 +80,10 @@ SIGNATURES = {
     'resel_amax_segments': (c_int, [P, P, P, I, P, E, S]),
     'resel_amax_state_bytes': (c_size_t, []),
     'resel_amax': (c_int, [P, L, L, I, I, I, P, E, P, S]),
+    'resel_gemm_f32_fused_supported': (c_int, [I, I, I, I, L, L]),
+    'resel_gemm_f32_fused_workspace_bytes': (c_size_t, [I, I, I, I, I]),
+    'resel_gemm_f32_dact': (c_int, [P, L, L, I, P, L, L, I, P, L, L, P, L, L, P, P, I, I, I, I, P, P, P, E, S]),
+    'resel_gemm_f32_head': (c_int, [P, L, L, I, P, L, L, I, P, L, P, L, P, P, L, L, P, P, I, I, I, I, P, P, P, E, S]),
     'resel_amax_check': (c_int, [P, L, L, I, I, I, P, P, I, S]),
     'resel_gemm_bf16_workspace_bytes': (c_size_t, [I, I, I]),
     'resel_gemm_bf16': (c_int, [P, L, I, I, P, L, I, I, P, P, L, I, P, I, I, I, S]),

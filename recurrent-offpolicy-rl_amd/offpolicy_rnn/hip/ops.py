@@ -1244,8 +1244,10 @@ def amax_check(x, handle, what=''):
 def amax_verify_raise(device=None):
     """Synchronise and raise AmaxBoundError if any check since the last call found an operand above its handle's bound."""
     for dev, err in list(_VERIFY_ERR.items()):
-        if device is not None and torch.device(device) != dev:
-            continue
+        if device is not None:
+            d = torch.device(device)
+            if d.type != dev.type or (d.index is not None and d.index != dev.index):       # 'cuda' names every cuda device
+                continue
         e = err.cpu()
         if int(e[0]) == 0:
             continue
@@ -1381,6 +1383,95 @@ def gemm_f32(A, B, a_kcontig=True, b_kcontig=True, bias=None, act=None, out=None
     LAST_AMAX = slot
     LAST_SPLIT[0] = split                            # tools/gemm_census.py: which product mode the call took
     return out
+
+
+# ---- fused epilogues of the producer / consumer GEMM (include/resel_hip.h `resel_gemm_f32_dact` / `resel_gemm_f32_head`) ----------
+def _forced_handles(A, B, amax_a, amax_b):
+    """Magnitude handles of both operands for a product that exists in mode 2 only: the caller's, a producer's tag, the parameter
+    store's - or one pre-pass (tagged for reuse)."""
+    ha = amax_a if amax_a is not None else amax_of(A)
+    hb = amax_b if amax_b is not None else amax_of(B)
+    ha = weight_amax(A) if ha is None else ha
+    hb = weight_amax(B) if hb is None else hb
+    if ha is None:
+        ha = amax(A)
+        tag_amax(A, ha)
+    if hb is None:
+        hb = amax(B)
+        tag_amax(B, hb)
+    return ha, hb
+
+
+def gemm_fused_ok(kind, M, N, K, *mats):
+    """True when a fused-epilogue form (kind 4: dact, 5: head) may take a product of this shape: product mode 2, a long pass, the
+    producer / consumer edition's shape rules (K a multiple of 32, M > 128; dact: N a multiple of 128), 16-byte aligned rows."""
+    if os.environ.get('RESEL_GEMM_FUSED', '1') == '0' or gemm_split() != 2 or not gemm_f32_ok(M, *mats):
+        return False
+    ld = max(int(t.stride(-2)) for t in mats)
+    return bool(lib().resel_gemm_f32_fused_supported(int(kind), int(M), int(N), int(K), ld, ld))
+
+
+@torch.no_grad()
+def gemm_f32_dact(A, B, b_kcontig, Y, out, need_dbias=True, amax_a=None, amax_b=None):
+    """out[b] = (A[b] (.) B[b]) * elu'(Y[b]) with elu' taken from the ELU OUTPUT Y (y > 0 ? 1 : y + 1), and dbias[b][n] = column sums of
+    out[b]: the input gradient of a layer whose input was the ELU output of the layer below, with that ELU's backward and that layer's
+    bias gradient in the GEMM epilogue.  A [batch, M, K] / [M, K] (K contiguous); B [batch, N, K] (b_kcontig) or [batch, K, N]; Y and out
+    [batch, M, N] with free row / batch strides.  -> (out, dbias [batch, N] or None)."""
+    _need_cuda('gemm_f32_dact', A, B, Y, out)
+    batched = A.dim() == 3
+    batch = A.shape[0] if batched else 1
+    M, K = A.shape[-2], A.shape[-1]
+    N = B.shape[-2] if b_kcontig else B.shape[-1]
+    assert (B.shape[-1] if b_kcontig else B.shape[-2]) == K and Y.shape[-2:] == (M, N) and out.shape[-2:] == (M, N)
+    assert A.stride(-1) == 1 and B.stride(-1) == 1 and Y.stride(-1) == 1 and out.stride(-1) == 1
+    ha, hb = _forced_handles(A, B, amax_a, amax_b)
+    if AMAX_VERIFY:
+        amax_check(A, ha, f'A of gemm_dact M={M} N={N} K={K} batch={batch}')
+        amax_check(B, hb, f'B of gemm_dact M={M} N={N} K={K} batch={batch}')
+    GEMM_FLOPS[0] += 2.0 * M * N * K * batch
+    L = lib()
+    ws = _ws(L.resel_gemm_f32_fused_workspace_bytes(M, N, K, batch, 4), A.device)
+    dbias = torch.empty(batch, N, dtype=torch.float32, device=A.device) if need_dbias else None
+    multi = batched and batch > 1
+    slot, slot_p, epoch = _slot_args(amax_tracking() and M * N * batch >= (1 << 20), A.device)
+    check(L.resel_gemm_f32_dact(_p(A), A.stride(-2), A.stride(0) if multi else 0, 1, _p(B), B.stride(-2), B.stride(0) if multi else 0, int(b_kcontig),
+                                _p(Y), Y.stride(-2), Y.stride(0) if multi else 0, _p(out), out.stride(-2), out.stride(0) if multi else 0,
+                                _p(dbias), _p(ws), M, N, K, batch, _p(ha), _p(hb), slot_p, epoch, _stream()), 'gemm_f32_dact')
+    tag_amax(out, slot)
+    global LAST_AMAX
+    LAST_AMAX = slot
+    LAST_SPLIT[0] = 2
+    return out, dbias
+
+
+@torch.no_grad()
+def gemm_f32_head(A, B, b_kcontig, bias, w3, b3, amax_a=None, amax_b=None):
+    """a[b] = elu(A[b] (.) B[b] + bias[b]) and q[b][m] = sum_n a[b][m][n] w3[b][n] + b3[b]: the hidden layer and the width-1 output layer of
+    an efc-E critic head in one GEMM.  A [batch, M, K]; B [batch, N, K] / [batch, K, N]; bias, w3 [batch, N]; b3 [batch] or None.
+    -> (a [batch, M, N], q [batch, M])."""
+    _need_cuda('gemm_f32_head', A, B, bias, w3)
+    batch, M, K = A.shape
+    N = B.shape[-2] if b_kcontig else B.shape[-1]
+    assert A.stride(-1) == 1 and B.stride(-1) == 1 and w3.shape == (batch, N) and w3.is_contiguous() and bias.shape == (batch, N) and bias.stride(-1) == 1
+    ha, hb = _forced_handles(A, B, amax_a, amax_b)
+    if AMAX_VERIFY:
+        amax_check(A, ha, f'A of gemm_head M={M} N={N} K={K} batch={batch}')
+        amax_check(B, hb, f'B of gemm_head M={M} N={N} K={K} batch={batch}')
+    GEMM_FLOPS[0] += 2.0 * M * N * K * batch
+    L = lib()
+    ws = _ws(L.resel_gemm_f32_fused_workspace_bytes(M, N, K, batch, 5), A.device)
+    a = torch.empty(batch, M, N, dtype=torch.float32, device=A.device)
+    q = torch.empty(batch, M, dtype=torch.float32, device=A.device)
+    multi = batch > 1
+    slot, slot_p, epoch = _slot_args(amax_tracking() and M * N * batch >= (1 << 20), A.device)
+    check(L.resel_gemm_f32_head(_p(A), A.stride(-2), A.stride(0) if multi else 0, 1, _p(B), B.stride(-2), B.stride(0) if multi else 0, int(b_kcontig),
+                                _p(bias), bias.stride(0) if multi else 0, _p(w3), N, _p(b3), _p(a), a.stride(-2), a.stride(0) if multi else 0, _p(q), _p(ws),
+                                M, N, K, batch, _p(ha), _p(hb), slot_p, epoch, _stream()), 'gemm_f32_head')
+    tag_amax(a, slot)
+    global LAST_AMAX
+    LAST_AMAX = slot
+    LAST_SPLIT[0] = 2
+    return a, q
 
 
 # ---- one-token rollout step (T = 1, no autograd) ----------------------------------------------------------------------

@@ -161,6 +161,101 @@ class _Head(torch.autograd.Function):
         return dx, dw2, db2.view(E, 1, H), dw3.view(E, H, 1), db3, None
 
 
+class _CriticMLP(torch.autograd.Function):
+    """The whole efc-E critic head as ONE node: q = efc3(elu(efc2(elu(efc1(x))))) with a shared input x2 [M, in], H1 = efc1's width,
+    H2 = efc2's, efc3 of width 1 (reference: three EnsembleLinear layers with their activation modules, rnn_base.py:461-469 over
+    ensemble_linear_model.py:36-49).  One node instead of `_SharedInput` + `_Head` lets the kernels between the layers fold:
+      forward   GEMM 1 (bias + ELU in the epilogue) -> a1 [M, E H1];  GEMM 2 `resel_gemm_f32_head`: a2 = elu(a1 W2 + b2) AND q = a2 . w3 + b3
+                from the same epilogue (the separate head pass read and rewrote a2: 547 MB each way at config 2);
+      backward  head backward (gy2, db2, dw3); dW2 = a1^T gy2;  `resel_gemm_f32_dact`: g1 = (gy2 W2^T) * elu'(a1) AND db1 = column sums of g1
+                from the epilogue (the separate ELU-backward pass read g and a1 and wrote g1: 3 x 547 MB); dX = g1 W1^T (only the x_part
+                block when the actor differentiates the action encoding alone), dW1 = x2^T g1."""
+
+    @staticmethod
+    def forward(ctx, x2, W1, b1, W2, b2, W3, b3, x_part, col0, ax):
+        E, n_in, H1 = W1.shape
+        H2 = W2.shape[2]
+        M = x2.shape[0]
+        w_cat = W1.permute(1, 0, 2).reshape(n_in, E * H1)                          # [in, E H1] (weights only: tiny copy)
+        y2 = ops.gemm_f32(x2, w_cat, True, False, b1.reshape(E * H1), 'elu', amax_a=ax, amax_b=ops.weight_amax(W1))
+        h_x = ax if ax is not None else ops.amax_of(x2)
+        h_a1 = ops.amax_of(y2)
+        a1 = y2.view(M, E, H1).transpose(0, 1)                                     # [E, M, H1] view of the shared layer's output
+        w3v = W3.reshape(E, H2)
+        a2, q = ops.gemm_f32_head(a1, W2, False, b2.reshape(E, H2), w3v, None if b3 is None else b3.reshape(E), amax_a=h_a1,
+                                  amax_b=ops.weight_amax(W2))
+        ctx.save_for_backward(x2, w_cat, y2, W2, w3v, a2)
+        ctx.handles = ops.keep_handles(h_x, h_a1)
+        ctx.dims = (E, n_in, H1, H2, M, b3 is not None)
+        ctx.part = None if x_part is None else (col0, x_part.shape[-1], tuple(x_part.shape))
+        return q.view(E, M, 1)
+
+    @staticmethod
+    def backward(ctx, gq):
+        x2, w_cat, y2, W2, w3v, a2 = ctx.saved_tensors
+        E, n_in, H1, H2, M, has_b3 = ctx.dims
+        h_x, h_a1 = ops.live_handles(ctx.handles)
+        need = ctx.needs_input_grad
+        gq2 = gq.reshape(E, M)
+        gy2, db2, dw3 = ops.ensemble_head_bwd(gq2, a2, w3v)                        # gy2 [E, M, H2] = gq w3 elu'(a2); tagged with its magnitude
+        a1 = y2.view(M, E, H1).transpose(0, 1)
+        dw2 = _member_wgrad(a1, gy2, h_a1) if need[3] else None
+        db3 = gq2.sum(dim=1).view(E, 1, 1) if (has_b3 and need[6]) else None
+        g1 = torch.empty(M, E, H1, dtype=torch.float32, device=x2.device).transpose(0, 1)      # written in the shared layer's [M, E H1] layout
+        _, db1 = ops.gemm_f32_dact(gy2, W2, True, a1, g1, need_dbias=bool(need[2]), amax_b=ops.weight_amax(W2))
+        g2 = g1.transpose(0, 1).reshape(M, E * H1)                                  # a view
+        ops.tag_amax(g2, ops.amax_of(g1))
+        dx = ops.gemm_f32(g2, w_cat, True, True) if need[0] else None              # sums over the ensemble
+        dw1 = None
+        if need[1]:
+            dw1 = ops.gemm_f32(x2, g2, False, False, amax_a=h_x).view(n_in, E, H1).permute(1, 0, 2)
+        dpart = None
+        if ctx.part is not None and need[7]:
+            col0, k, shape = ctx.part
+            dpart = ops.gemm_f32(g2, w_cat[col0:col0 + k], True, True).view(shape)
+        return (dx, dw1, None if db1 is None else db1.view(E, 1, H1), dw2, db2.view(E, 1, H2) if need[4] else None,
+                dw3.view(E, H2, 1) if need[5] else None, db3, dpart, None, None)
+
+
+def critic_mlp_fusable(l0, act0, l1, act1, l2, act2, x) -> bool:
+    """efc-E (shared input) ELU -> efc-E ELU -> efc-E(1) on a long GPU pass whose GEMMs the fused-epilogue forms take."""
+    if not (isinstance(l0, EnsembleLinear) and isinstance(l1, EnsembleLinear) and isinstance(l2, EnsembleLinear)):
+        return False
+    elu = lambda a: isinstance(a, nn.ELU) and a.alpha == 1.0
+    if not (elu(act0) and elu(act1) and isinstance(act2, nn.Identity) and l0.use_bias and l1.use_bias):
+        return False
+    E = l0.active_members()
+    if l1.active_members() != E or l2.active_members() != E or x.dtype != torch.float32 or not x.is_cuda:
+        return False
+    n_in, H1 = l0.weight.shape[1:]
+    H2 = l1.weight.shape[2]
+    if l1.weight.shape[1] != H1 or l2.weight.shape[1] != H2 or l2.weight.shape[2] != 1 or x.shape[-1] != n_in:
+        return False
+    nd = x.dim()
+    if nd >= 5 or (nd in (3, 4) and (l0.desire_ndim is None or l0.desire_ndim == nd) and x.shape[0] == E):
+        return False                                                               # x already carries the ensemble axis: not the shared-input form
+    if not all(l.desire_ndim is None or l.desire_ndim == nd + 1 for l in (l1, l2)):
+        return False
+    M = x.numel() // n_in
+    x2 = x.reshape(-1, n_in)
+    return (min(n_in, H1, H2) >= 32 and H1 % 32 == 0 and H2 % 32 == 0 and ops.gemm_f32_ok(M, x2)
+            and ops.gemm_fused_ok(5, M, H2, H1, l1.weight) and ops.gemm_fused_ok(4, M, H1, H2, l1.weight))
+
+
+def critic_mlp(l0: 'EnsembleLinear', l1: 'EnsembleLinear', l2: 'EnsembleLinear', x: torch.Tensor, grad_part=None) -> torch.Tensor:
+    W1, b1 = l0.active_params()
+    W2, b2 = l1.active_params()
+    W3, b3 = l2.active_params()
+    E, n_in, _ = W1.shape
+    lead = tuple(x.shape[:-1])
+    ax = ops.amax_of(x)
+    if grad_part is not None:
+        q = _CriticMLP.apply(x.detach().reshape(-1, n_in), W1, b1, W2, b2, W3, b3, grad_part[0], grad_part[1], ax)
+    else:
+        q = _CriticMLP.apply(x.reshape(-1, n_in), W1, b1, W2, b2, W3, b3, None, 0, ax)
+    return q.reshape((E,) + lead + (1,))
+
+
 def ensemble_head(hidden: 'EnsembleLinear', out: 'EnsembleLinear', x: torch.Tensor) -> torch.Tensor:
     """`out(elu(hidden(x)))` for per-member x [E, ..., in] and out.weight [E, H, 1] (RNNBase.forward routes the last two
     layers of an efc-E critic head here)."""

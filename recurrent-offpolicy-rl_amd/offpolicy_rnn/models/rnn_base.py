@@ -14,7 +14,7 @@ import torch
 
 from ..hip import ops
 from .RNNHidden import RNNHidden
-from .ensemble_linear_model import EnsembleLinear, ensemble_head, head_fusable
+from .ensemble_linear_model import EnsembleLinear, critic_mlp, critic_mlp_fusable, ensemble_head, head_fusable
 from .flash_attention.TransformerFlashAttention import InferenceParams, TransformerDecoder
 from .conv1d.conv1d import Conv1d
 from .gilr.gilr import GILRLayer
@@ -243,10 +243,10 @@ class RNNBase(torch.nn.Module):
         full = RNNHidden(self.rnn_num, self.rnn_layer_type, device=x.device, batch_first=True) if require_full_hidden else None
         k = 0
         n_layers = len(self.layer_list)
-        fused_next = False
+        fused_next = 0
         for ind, layer in enumerate(self.layer_list):
-            if fused_next:                          # consumed by the ensemble head below
-                fused_next = False
+            if fused_next:                          # consumed by the ensemble head / critic MLP node below
+                fused_next -= 1
                 continue
             lid = self.layer_type[ind]
             if is_rnn_layer(lid):
@@ -276,10 +276,17 @@ class RNNBase(torch.nn.Module):
                 act = self.activation_list[ind]
             else:
                 act = self.activation_list[ind]
+                # efc-E ELU -> efc-E(H) ELU -> efc-E(1) = the published critic: ONE node whose GEMM epilogues carry the head and the
+                # ELU backward / bias gradient between the layers (ensemble_linear_model._CriticMLP)
+                if ind + 3 == n_layers and critic_mlp_fusable(layer, act, self.layer_list[ind + 1], self.activation_list[ind + 1],
+                                                              self.layer_list[ind + 2], self.activation_list[ind + 2], x):
+                    x = critic_mlp(layer, self.layer_list[ind + 1], self.layer_list[ind + 2], x, grad_part=first_grad_part if ind == 0 else None)
+                    fused_next = 2
+                    continue
                 # efc-E(H) ELU -> efc-E(1) at the end of the stack (the critic head): one fused node
                 if ind + 2 == n_layers and head_fusable(layer, act, self.layer_list[ind + 1], self.activation_list[ind + 1], x):
                     x = ensemble_head(layer, self.layer_list[ind + 1], x)
-                    fused_next = True
+                    fused_next = 1
                     continue
                 # plain ELU behind fc / efc-E: fused into the layer's bias pass (one in-place kernel; backward from the output)
                 if isinstance(act, torch.nn.ELU) and act.alpha == 1.0 and isinstance(layer, (EnsembleLinear, torch.nn.Linear)) \

@@ -634,6 +634,70 @@ def test_ensemble_mlp_fused_tail_vs_torch(ops, R, T, n_in, H):
     assert (ops.GEMM_FLOPS[0] > flops0) == (R * T >= ops.GEMM_F32_MIN_ROWS), 'hand-written GEMM routing'
 
 
+@pytest.mark.parametrize('R,T,n_in,H1,H2,E', [(3, 1500, 128, 128, 128, 4), (4, 1043, 384, 256, 256, 8), (5, 1024, 96, 128, 160, 2)])
+@pytest.mark.parametrize('part', [False, True])
+def test_critic_mlp_one_node_vs_torch(ops, R, T, n_in, H1, H2, E, part):
+    """The whole efc-E critic head as ONE autograd node (`_CriticMLP`: reference contextual_sac_value.py:101-107 -> rnn_base.py:461-469 over
+    ensemble_linear_model.py:36-49): the head (a2 . w3 + b3) leaves the second GEMM's epilogue (`resel_gemm_f32_head`), the ELU backward and
+    bias gradient of the first layer leave the input-gradient GEMM's epilogue (`resel_gemm_f32_dact`) - against plain torch autograd on the
+    CPU: q, dx (or only the differentiated column block: the actor step's form), all six parameter gradients.  Row counts that are not
+    multiples of 256 exercise the edge tiles of both epilogues; the second size is configs[1]'s critic at 4 rows."""
+    from offpolicy_rnn.models.ensemble_linear_model import EnsembleLinear, critic_mlp, critic_mlp_fusable
+    torch.manual_seed(5)
+    l1, l2, l3 = EnsembleLinear(n_in, H1, E), EnsembleLinear(H1, H2, E, desire_ndim=4), EnsembleLinear(H2, 1, E, desire_ndim=4)
+    for l in (l1, l2, l3):
+        torch.nn.init.normal_(l.bias, std=0.3)
+    x = torch.randn(R, T, n_in)
+    w = torch.randn(E, R, T, 1)
+    col0, k = n_in // 2, n_in - n_in // 2
+
+    def ref():
+        xs = x.clone().requires_grad_(True)
+        h = xs
+        for i, l in enumerate((l1, l2, l3)):
+            h = torch.einsum('...ti,eio->e...to', h, l.weight) if i == 0 else torch.einsum('e...ti,eio->e...to', h, l.weight)
+            h = h + l.bias.view(E, 1, 1, -1)
+            if i < 2:
+                h = torch.nn.functional.elu(h)
+        (h * w).sum().backward()
+        out = [h.detach(), xs.grad[..., col0:] if part else xs.grad] + [p.grad.clone() for l in (l1, l2, l3) for p in (l.weight, l.bias)]
+        for l in (l1, l2, l3):
+            l.zero_grad()
+        return out
+
+    expect = ref()
+    for l in (l1, l2, l3):
+        l.cuda()
+    elu, ident = torch.nn.ELU(), torch.nn.Identity()
+    xs = x.cuda().requires_grad_(not part)
+    assert critic_mlp_fusable(l1, elu, l2, elu, l3, ident, xs), 'the fused-epilogue forms must take this shape'
+    calls0 = ops.GEMM_FLOPS[0]
+    xp = None
+    if part:
+        xp = xs[..., col0:].clone().requires_grad_(True)
+        q = critic_mlp(l1, l2, l3, xs, grad_part=(xp, col0))
+    else:
+        q = critic_mlp(l1, l2, l3, xs)
+    assert q.shape == (E, R, T, 1) and ops.GEMM_FLOPS[0] > calls0
+    (q * w.cuda()).sum().backward()
+    got = [q, xp.grad if part else xs.grad] + [p.grad for l in (l1, l2, l3) for p in (l.weight, l.bias)]
+    names = ['q', 'dx', 'dW1', 'db1', 'dW2', 'db2', 'dW3', 'db3']
+    for nm, a, b in zip(names, got, expect):
+        close(a, b, rtol=2e-4, atol_scale=5e-5, name=nm)
+    # and the node equals the layer-by-layer nodes it replaces (same kernels for the products: tight)
+    for l in (l1, l2, l3):
+        l.zero_grad()
+    from offpolicy_rnn.models.ensemble_linear_model import ensemble_head
+    xs2 = x.cuda().requires_grad_(not part)
+    xp2 = xs2[..., col0:].clone().requires_grad_(True) if part else None
+    h1 = l1(xs2, act='elu', grad_part=(xp2, col0) if part else None)
+    q2 = ensemble_head(l2, l3, h1)
+    (q2 * w.cuda()).sum().backward()
+    got2 = [q2, xp2.grad if part else xs2.grad] + [p.grad for l in (l1, l2, l3) for p in (l.weight, l.bias)]
+    for nm, a, b in zip(names, got, got2):
+        close(a, b.detach().cpu(), rtol=2e-5, atol_scale=2e-5, name='vs layer-by-layer: ' + nm)
+
+
 @pytest.mark.parametrize('act', [None, 'elu'])
 @pytest.mark.parametrize('rows,n_in,n_out', [(5000, 128, 256), (5000, 96, 64), (300, 128, 256), (5000, 128, 6)])
 def test_linear_act_fwd_bwd_long_pass_vs_torch(ops, rows, n_in, n_out, act):
