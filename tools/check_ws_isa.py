@@ -28,7 +28,9 @@ for m in re.finditer(r'^(_ZN12_GLOBAL__N_114gemm_ws_kernel\w+):', s, re.M):
         l = body[n].strip()
         mm = re.match(r'v_mov_b64\S* v\[\d+:\d+\], v\[(\d+):\d+\]', l) or re.match(r'v_mov_b32_e32 v\d+, v(\d+)', l)
         if mm and int(mm.group(1)) in regs: copies.append((n, l))
-    pro = [re.search(r'v\[\d+:\d+\]', body[n]).group(0) for n in loads if n < waits[0]]
+    # the prologue = the two register sets (24 loads) issued right in front of the loop; kernels with a fused epilogue also hold hand-placed
+    # loads of the CONSUMER waves (elsewhere in the text: not part of this check)
+    pro = [re.search(r'v\[\d+:\d+\]', body[n]).group(0) for n in [n for n in loads if n < waits[0]][-24:]]
     loop = [re.search(r'v\[\d+:\d+\]', body[n]).group(0) for n in loads if hdr < n < end]
     same = pro[:len(loop)] == loop[:len(pro)] if len(pro) == len(loop) else sorted(set(pro)) == sorted(set(loop))
     ok = not spills and not copies and same
