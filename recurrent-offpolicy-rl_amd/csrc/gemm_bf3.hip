@@ -1383,12 +1383,15 @@ __global__ __launch_bounds__(256) void gemm_bf3_fixup_kernel(Params p) {
 }
 
 struct Plan { int nfull, nsplit, nsl, kslice; };
+// K slices for the tiles of a partly filled last round pay a fix-up launch (~6 us) and the slab round trip: only worth it when a whole
+// tile's K loop is long (RESEL_GEMM_SPLIT_MIN_KSTEPS, default below: measured in profiles/r05_gemm.md)
+static const int g_split_min_ksteps = [] { const char* e = getenv("RESEL_GEMM_SPLIT_MIN_KSTEPS"); return e ? atoi(e) : 4; }();
 inline Plan make_plan(int M, int N, int K, int batch) {
     const long nbt = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN) * batch;
     const int ksteps = (K + BK - 1) / BK;
     Plan pl{(int)nbt, 0, 1, ksteps * BK};
     const int r = (int)(nbt % GRID);
-    if (r == 0 || r > GRID / 2 || ksteps < 4) return pl;
+    if (r == 0 || r > GRID / 2 || ksteps < g_split_min_ksteps) return pl;
     int s = std::min(GRID / r, ksteps / 2);
     const int per = (ksteps + s - 1) / s;
     s = (ksteps + per - 1) / per;

@@ -36,6 +36,7 @@
 // Tile ids are XCD-aware: the n-tiles of one m-tile share an L2.
 #include "resel_common.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace resel {                      // gemm_bf3.hip: the split modes with the operands split once per block (second edition)
 size_t gemm_bf3_workspace_bytes(int M, int N, int K, int batch);
@@ -589,12 +590,15 @@ __global__ __launch_bounds__(256) void gemm_fixup_kernel(GemmParams p) {
 // into K slices so that they fill the slots once more (at least two K steps per slice), also when r is everything (weight
 // gradients: 6 tiles, K = 66 752).  r > 256 tiles are left whole (a split could not even double the blocks).
 struct Plan { int nfull, nsplit, nsl, kslice; };
+// K slices for the tiles of a partly filled last round pay a fix-up launch (~6 us) and the slab round trip: only worth it when a whole
+// tile's K loop is long (RESEL_GEMM_SPLIT_MIN_KSTEPS, default below: measured in profiles/r05_gemm.md)
+static const int g_split_min_ksteps = [] { const char* e = getenv("RESEL_GEMM_SPLIT_MIN_KSTEPS"); return e ? atoi(e) : 4; }();
 inline Plan make_plan(int M, int N, int K, int batch) {
     const long nbt = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN) * batch;
     const int ksteps = (K + BK - 1) / BK;
     Plan pl{(int)nbt, 0, 1, ksteps * BK};
     const int r = (int)(nbt % GRID);
-    if (r == 0 || r > GRID / 2 || ksteps < 4) return pl;
+    if (r == 0 || r > GRID / 2 || ksteps < g_split_min_ksteps) return pl;
     int s = std::min(GRID / r, ksteps / 2);
     const int per = (ksteps + s - 1) / s;           // K steps per slice
     s = (ksteps + per - 1) / per;                   // no empty slices

@@ -250,6 +250,19 @@ class SACFullLengthRNNEnsembleQ(SAC):
         R = self.replay_buffer.name2range
         out = {name: dev[..., R[name][0]:R[name][1]] for name in FIELDS}
         out['valid'], out['total_valid'], out['total_start'] = dev[..., W:W + 1], dev[..., W + 1:W + 2], dev[..., W + 2:W + 3]
+        # the per-token scalars (flags, reward, done ...) as ONE planar [k, rows, T] copy: every kernel that takes them wants a dense
+        # [rows * T] vector, and as column views of the batch array (stride W + 3) each use made its own contiguous copy - 24 small
+        # launches per update
+        ones = [n for n in out if out[n].shape[-1] == 1]
+        if ones and dev.is_cuda:
+            key = (tuple(ones), dev.device)
+            idx = self.__dict__.setdefault('_planar_idx', {}).get(key)
+            if idx is None:
+                cols = [R[n][0] if n in R else {'valid': W, 'total_valid': W + 1, 'total_start': W + 2}[n] for n in ones]
+                idx = self._planar_idx[key] = torch.tensor(cols, dtype=torch.int64, device=dev.device)
+            planar = dev.view(rows * T, W + 3).index_select(1, idx).t().contiguous()          # [k, rows * T]
+            for i, n in enumerate(ones):
+                out[n] = planar[i].view(rows, T, 1)
         # per-row sequence-length tables (reference :358-366) are consumed by attention layers only
         out['attention_mask'] = out['target_attention_mask'] = None
         if self._needs_seq_table and self._graph is not None:

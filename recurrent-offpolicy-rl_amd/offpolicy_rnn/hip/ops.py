@@ -263,7 +263,7 @@ class MambaInnerFn(torch.autograd.Function):
         # [Di, R] with a 66 752-long reduction: hand-written MFMA kernel (the library reaches 7 TFLOP/s on this shape)
         d_dt_w = atb(ddt, x_dbl[:, :R]) if R <= 32 and Di % 4 == 0 and ddt.stride(1) == 1 and ddt.stride(0) % 4 == 0 \
             else torch.mm(ddt.t(), x_dbl[:, :R])
-        dx_dbl[:, :R] = mm_nn(ddt, dt_w)
+        mm_nn(ddt, dt_w, out=dx_dbl[:, :R])                                  # straight into its column block of dx_dbl
         d_xproj_w = wgrad(dx_dbl, xc, amax_x=h_xc)
         # the conv output's gradient = the scan's du (in dxc) + the x_proj input gradient: handed to the conv backward as TWO tensors
         # (summed on load) - the accumulating GEMM epilogue cost 150-214 us per call against 67 for the plain product
@@ -807,19 +807,21 @@ def bias_act_(y2, bias2, rows_per_seg, act):
 def bias_act_bwd(g2, a2, rows_per_seg, act, need_dbias):
     """gy = g2 * act'(.) computed from the forward OUTPUT a2, dbias [nseg, C] = per-segment column sums of gy (or None)."""
     _need_cuda('bias_act_bwd', g2, a2)
-    g2 = g2 if g2.is_contiguous() else g2.contiguous()
+    # a column block of a wider gradient (the halves of a `cat` backward) is read in place through its row stride
+    if not (g2.dim() == 2 and g2.stride(1) == 1 and g2.stride(0) >= g2.shape[1] and g2.stride(0) % 4 == 0 and g2.data_ptr() % 16 == 0):
+        g2 = g2.contiguous()
     rows, C = g2.shape
     aid = ACT_IDS[act]
     if aid == 0 and not need_dbias:
         return g2, None
-    gy = torch.empty_like(g2) if aid else g2
+    gy = torch.empty(rows, C, dtype=torch.float32, device=g2.device) if aid else g2
     nseg = rows // int(rows_per_seg)
     db = torch.empty(nseg, C, dtype=torch.float32, device=g2.device) if need_dbias else None
     ws = _ws(lib().resel_bias_act_bwd_workspace_bytes(rows, C, int(rows_per_seg)), g2.device) if need_dbias else None
     global LAST_AMAX
     slot, slot_p, epoch = _slot_args(amax_tracking() and rows * C >= (1 << 20), g2.device)
-    check(lib().resel_bias_act_bwd(_p(g2), _p(a2) if aid else None, _p(gy), _p(db), _p(ws), rows, C, int(rows_per_seg), aid, slot_p, epoch,
-                                   _stream()), 'bias_act_bwd')
+    check(lib().resel_bias_act_bwd(_p(g2), g2.stride(0), _p(a2) if aid else None, _p(gy) if aid else None, _p(db), _p(ws), rows, C, int(rows_per_seg), aid,
+                                   slot_p, epoch, _stream()), 'bias_act_bwd')
     tag_amax(gy, slot)
     LAST_AMAX = slot
     return gy, db
@@ -961,11 +963,15 @@ def mm_nt(x2, w, bias=None, act=None):
     return bias_act_(y2, None if bias is None else bias.reshape(1, -1).contiguous(), y2.shape[0], act)
 
 
-def mm_nn(g2, w):
-    """g2 [M, N] w[N, K] -> [M, K]: input gradient of such a layer."""
-    if _mine(g2.shape[0], w.shape[1], w.shape[0], g2, w):
-        return gemm_f32(g2, w, True, False)
-    return torch.mm(g2, w)
+def mm_nn(g2, w, out=None):
+    """g2 [M, N] w[N, K] -> [M, K]: input gradient of such a layer.  out: a (possibly row-strided) destination, e.g. a column block of a
+    wider buffer."""
+    if _mine(g2.shape[0], w.shape[1], w.shape[0], g2, w) and (out is None or gemm_f32_ok(g2.shape[0], out)):
+        return gemm_f32(g2, w, True, False, out=out)
+    if out is None:
+        return torch.mm(g2, w)
+    out.copy_(torch.mm(g2, w))
+    return out
 
 
 def wgrad(gy, x2, amax_x=None):
