@@ -72,9 +72,6 @@ int resel_profile_collect(int kernel_id, double* total_us, int* launches);
  *   split, k > 1 = k segments; workspace: resel_selective_scan_fwd_workspace_bytes(...) for the same arguments (NULL if 0).
  */
 #define RESEL_SSCAN_CKPT 8
-/* A/B switch of the one-pass forward kernel: 3 (default) = third edition (one barrier per 16-step chunk, csrc/selective_scan.hip
- * sscan_fwd3_kernel) where it applies (N = 8, 16, 32), 2 = second edition.  Process-global; tests and tools only. */
-int resel_selective_scan_fwd_edition(int edition);
 size_t resel_selective_scan_ckpt_bytes(int B, int L, int Di, int N);
 size_t resel_selective_scan_fwd_workspace_bytes(int B, int L, int Di, int N, int time_segments);
 int resel_selective_scan_fwd(const float* u, int64_t ld_u, const float* delta, int64_t ld_delta,
@@ -343,14 +340,16 @@ int resel_ensemble_head_bwd(const float* gq, const float* a, const float* w3, fl
  * act: 0 none, 1 ELU, 2 accumulate (C += product + bias: the accumulating form of an input gradient; no activation), 3 softplus (resel_gemm_f32x only).  The contiguous extent of each operand (K or rows) must be a multiple of 4, pointers 16-byte aligned.
  * split selects how the fp32 products are formed (inputs, accumulation and outputs are fp32 in every mode):
  *   0  v_mfma_f32_32x32x2_f32 (fp32 operands, exact products);
- *   9  each operand split EXACTLY into three bf16 planes (8 + 8 + 8 significant bits), all nine plane products - each exact -
- *      accumulated in fp32 by v_mfma_f32_32x32x16_bf16: the product a b is represented exactly, as in mode 0;
- *   6  as 9 without the three smallest terms (each <= 2^-24 |a b|, the size of one fp32 rounding of the product);
+ *   6  each operand split EXACTLY into three bf16 planes (8 + 8 + 8 significant bits), the six leading plane products - each exact -
+ *      accumulated in fp32 by v_mfma_f32_32x32x16_bf16 (the three dropped terms are each <= 2^-24 |a b|, the size of one fp32 rounding
+ *      of the product);
  *   3  "bf16x3": two planes per operand (16 significant bits) and the three leading plane products; every dropped term is
  *      <= 2^-16 |a b|.  The class torch names float32 matmul precision 'high' (TF32 / bf16x3) - NOT the reference's default
- *      ('highest' = modes 0 / 6 / 9); half the matrix instructions of mode 6.  Shapes with M <= 128 run mode 6;
- *   106 / 109  modes 6 / 9 on the first-edition kernel (every wave splits the fragments it reads; kept for A/B measurements).
- * Modes 6 / 9 split each operand element once per block on its way into LDS (csrc/gemm_bf3.hip, 256 x 128 tiles). */
+ *      ('highest' = modes 0 / 2 / 6); half the matrix instructions of mode 6.  Shapes with M <= 128 run mode 6;
+ *   2  see resel_gemm_f32x below.
+ * (Modes 9 - all nine plane products - and 106 / 109 - modes 6 / 9 on the first-edition kernel - were A/B forms of rounds 2-4; removed
+ * in ABI 7.)  Mode 6 splits each operand element once per block on its way into LDS (csrc/gemm_bf3.hip, 256 x 128 tiles); M <= 128
+ * takes the first-edition kernel of csrc/gemm_f32.hip (128 x 128 tiles, every wave splits the fragments it reads). */
 size_t resel_gemm_f32_workspace_bytes(int M, int N, int K, int batch);
 int resel_gemm_f32(const float* A, int64_t lda, int64_t strideA, int a_kcontig,
                    const float* B, int64_t ldb, int64_t strideB, int b_kcontig,
@@ -372,7 +371,7 @@ int resel_gemm_f32(const float* A, int64_t lda, int64_t strideA, int a_kcontig,
  * Two kernels serve mode 2 (same results to rounding of the same three plane products; b1s is formed from b1 next to the matrix
  * instruction in both): the producer / consumer edition for K and K slices that are multiples of 32 and row strides < 2^22
  * (csrc/gemm_bf3.hip `gemm_ws_kernel`), the one-role edition for the rest.  Environment, read once at load: RESEL_GEMM_EDITION=2 sends
- * everything to the one-role edition, RESEL_GEMM_NT=0 turns the producer / consumer edition's non-temporal C stores off. */
+ * everything to the one-role edition. */
 int resel_gemm_f32x(const float* A, int64_t lda, int64_t strideA, int a_kcontig,
                     const float* B, int64_t ldb, int64_t strideB, int b_kcontig,
                     const float* bias, int64_t strideBias, int act,

@@ -1384,8 +1384,8 @@ __global__ __launch_bounds__(256) void gemm_bf3_fixup_kernel(Params p) {
 
 struct Plan { int nfull, nsplit, nsl, kslice; };
 // K slices for the tiles of a partly filled last round pay a fix-up launch (~6 us) and the slab round trip: only worth it when a whole
-// tile's K loop is long (RESEL_GEMM_SPLIT_MIN_KSTEPS, default below: measured in profiles/r05_gemm.md)
-static const int g_split_min_ksteps = [] { const char* e = getenv("RESEL_GEMM_SPLIT_MIN_KSTEPS"); return e ? atoi(e) : 4; }();
+// tile's K loop is long
+constexpr int g_split_min_ksteps = 4;   // thresholds 12 / 20 / 40 measured equal or slower on the whole update (profiles/r05_gemm.md)
 inline Plan make_plan(int M, int N, int K, int batch) {
     const long nbt = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN) * batch;
     const int ksteps = (K + BK - 1) / BK;
@@ -1430,7 +1430,7 @@ int launch_ws(const Params& p, dim3 grid, hipStream_t s) {
 }
 
 // edition of the split GEMM: 3 = producer / consumer waves (gemm_ws_kernel), 2 = every wave does everything (gemm_bf3_kernel)
-int g_nt = [] { const char* e = getenv("RESEL_GEMM_NT"); return e ? atoi(e) : 1; }();   // default on: 23.43 -> 23.30 ms per update, same box
+constexpr int g_nt = 1;               // non-temporal C stores of the third edition: 23.43 -> 23.30 ms per update, same box
 int g_edition = [] { const char* e = getenv("RESEL_GEMM_EDITION"); return e ? atoi(e) : 3; }();
 
 }  // namespace
@@ -1490,7 +1490,7 @@ int gemm_bf3_launch(const float* A, int64_t lda, int64_t strideA, int a_kcontig,
         if (act == 4) rc = b_kcontig ? launch_ws<true, true, 2, 4>(p, grid, s) : launch_ws<true, false, 2, 4>(p, grid, s);
         else rc = b_kcontig ? launch_ws<true, true, 2, 5>(p, grid, s) : launch_ws<true, false, 2, 5>(p, grid, s);
     } else if (ws) WS_LAUNCH(2);
-    else if (split == 9) BF3_LAUNCH(9); else if (split == 3) BF3_LAUNCH(3); else if (split == 2) BF3_LAUNCH(2); else BF3_LAUNCH(6);
+    else if (split == 3) BF3_LAUNCH(3); else if (split == 2) BF3_LAUNCH(2); else BF3_LAUNCH(6);
 #undef WS_LAUNCH
 #undef BF3_LAUNCH
     if (rc != RESEL_OK) return rc;

@@ -591,8 +591,8 @@ __global__ __launch_bounds__(256) void gemm_fixup_kernel(GemmParams p) {
 // gradients: 6 tiles, K = 66 752).  r > 256 tiles are left whole (a split could not even double the blocks).
 struct Plan { int nfull, nsplit, nsl, kslice; };
 // K slices for the tiles of a partly filled last round pay a fix-up launch (~6 us) and the slab round trip: only worth it when a whole
-// tile's K loop is long (RESEL_GEMM_SPLIT_MIN_KSTEPS, default below: measured in profiles/r05_gemm.md)
-static const int g_split_min_ksteps = [] { const char* e = getenv("RESEL_GEMM_SPLIT_MIN_KSTEPS"); return e ? atoi(e) : 4; }();
+// tile's K loop is long
+constexpr int g_split_min_ksteps = 4;   // thresholds 12 / 20 / 40 measured equal or slower on the whole update (profiles/r05_gemm.md)
 inline Plan make_plan(int M, int N, int K, int batch) {
     const long nbt = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN) * batch;
     const int ksteps = (K + BK - 1) / BK;
@@ -638,8 +638,7 @@ extern "C" int resel_gemm_f32x(const float* A, int64_t lda, int64_t strideA, int
                                int M, int N, int K, int batch, int split, const float* amax_a, const float* amax_b,
                                void* amax_c, unsigned amax_epoch, resel_stream_t stream) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || act < 0 || act > 3) return RESEL_EINVAL;
-    // 106 / 109: modes 6 / 9 on the first-edition kernel of this file (every wave splits the fragments it reads), kept for A/B runs
-    if (split != 0 && split != 2 && split != 3 && split != 6 && split != 9 && split != 106 && split != 109) return RESEL_EINVAL;
+    if (split != 0 && split != 2 && split != 3 && split != 6) return RESEL_EINVAL;
     if (split == 2 && (!amax_a || !amax_b)) return RESEL_EINVAL;
     if (amax_c && (reinterpret_cast<uintptr_t>(amax_c) & 7u)) return RESEL_EINVAL;
     if (split == 2 && M <= 128) split = 6;         // narrow shapes stay on the first edition's fp32-accurate bf16 split
@@ -651,10 +650,9 @@ extern "C" int resel_gemm_f32x(const float* A, int64_t lda, int64_t strideA, int
     if (lda <= 0 || ldb <= 0 || ldc <= 0 || lda >= (int64_t)1 << 22 || ldb >= (int64_t)1 << 22) return RESEL_EINVAL;
     // second edition (256 x 128 tiles) unless half of its tile rows would be padding: M <= 128 (narrow weight gradients) runs
     // 1.2-1.4x faster on the first edition's 128 x 128 tiles (66 752-token weight gradients [128, 256]: 48 vs 59 us, [80, 512]: 67 vs 95)
-    if ((split == 2 || split == 3 || split == 6 || split == 9) && M > 128)
+    if ((split == 2 || split == 3 || split == 6) && M > 128)
         return gemm_bf3_launch(A, lda, strideA, a_kcontig, B, ldb, strideB, b_kcontig, bias, strideBias, act, C, ldc, strideC, workspace,
                                M, N, K, batch, split, (hipStream_t)stream, amax_a, amax_b, (unsigned long long*)amax_c, amax_epoch);
-    if (split > 100) split -= 100;                 // here: 6 / 9 = first-edition split kernels, 0 = fp32 MFMA
     if (split == 3) split = 6;                     // the two-plane mode exists on the second-edition kernel only: narrow shapes keep mode 6
     const Plan pl = make_plan(M, N, K, batch);
     if (pl.nsplit && (!workspace || !aligned16(workspace))) return RESEL_EINVAL;
@@ -669,7 +667,6 @@ extern "C" int resel_gemm_f32x(const float* A, int64_t lda, int64_t strideA, int
          else if (b_kcontig) launch_timed(RESEL_PROF_GEMM, gemm_f32_kernel<false, true, SP>, grid, dim3(256), 0, s, p); \
          else launch_timed(RESEL_PROF_GEMM, gemm_f32_kernel<false, false, SP>, grid, dim3(256), 0, s, p); } while (0)
     if (split == 6) RESEL_GEMM_LAUNCH(6);
-    else if (split == 9) RESEL_GEMM_LAUNCH(9);
     else RESEL_GEMM_LAUNCH(0);
 #undef RESEL_GEMM_LAUNCH
     if (pl.nsplit) hipLaunchKernelGGL(gemm_fixup_kernel, dim3(TILE / 4 / 64, pl.nsplit), dim3(64, 4), 0, s, p);

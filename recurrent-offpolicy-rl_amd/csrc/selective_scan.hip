@@ -39,7 +39,6 @@ void launch_maybe_timed(int slot, K kernel, dim3 grid, dim3 block, hipStream_t s
 unsigned long long* g_stamps = nullptr;
 #endif
 
-int g_fwd_edition = 2;                // one-pass forward kernel: 2 = sscan_fwd2_kernel (default), 3 = sscan_fwd3_kernel where it applies (A/B, tests)
 constexpr int TILE_C = 64;            // channels per workgroup
 constexpr int CKS = RESEL_SSCAN_CKPT; // checkpoint stride
 constexpr int SC = 16;                // backward sub-chunk = one checkpoint interval staged in LDS
@@ -434,220 +433,6 @@ __global__ __launch_bounds__(NW * 64) void sscan_fwd2_kernel(FwdParams p) {
         return;
     }
     if (p.last_state != nullptr && d_ok && t_end == p.L) {
-#pragma unroll
-        for (int j = 0; j < NS; ++j)
-            p.last_state[((int64_t)b * p.Di + d) * N + w * NS + j] = (j & 1) ? hp[j / 2].y : hp[j / 2].x;
-    }
-    amax_publish_wave(omax, p.amax_out);
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Forward, third edition (one-pass form, N = NS * NW states).  What the stamps of the second edition show (tools/micro/sscan_lab.hip,
-// B = 64): the two workgroups that share a CU do NOT share its vector pipes evenly - issue is arbitrated by age, the older
-// workgroup's waves run almost as if alone (190 us) and the younger one's take the leftover slots and then finish ALONE (265 us),
-// each SIMD running one wave at half its issue capacity for the last 75 us; and every phase of a chunk ended on a drain (stage |
-// barrier | scan | barrier | output).  This edition therefore
-//   * puts BOTH waves of a SIMD into one workgroup: workgroup = (row b, 128 channels) = 8 waves, wave = (64-channel half, NS-state
-//     group), one workgroup per CU; the chunk barrier keeps the two waves of a SIMD within a chunk of each other, so they finish
-//     together;
-//   * uses ONE barrier per 16-step chunk: all tiles are double-buffered and an iteration is { output tile of chunk i - 1 | scan of
-//     chunk i | stage chunk i + 1 } barrier - the hand-overs have a whole iteration of slack;
-//   * staggers the two halves inside the iteration: the waves of the first channel half run their tile passes around the scan, those
-//     of the second half in the MIDDLE of theirs, so that one wave of a SIMD issues recurrence arithmetic while the other waits for
-//     its tile loads, LDS round trips and transcendental-heavy softplus / SiLU (MI355X_MICROARCH.md, 'two waves that run the same
-//     program with one barrier per block: try a stagger');
-//   * reads the step operands of a lane as ONE 8-byte LDS word {delta, delta * u} and feeds the packed multiplies their broadcast
-//     operand from the low / high half of that register pair through op_sel (hipcc builds a splat pair with two v_mov per step);
-//   * parks what the output tile needs besides the partial sums - silu(z), D * u - in LDS when the chunk is staged (the staging
-//     thread's own slots: thread-private, no hazard) and sends checkpoints (every 16 steps = a chunk end) straight from the state
-//     registers as 256-byte rows.
-constexpr int F3_CW = 128;            // channels per workgroup of the third edition
-
-template <int NS, int NW>
-__global__ __launch_bounds__(2 * NW * 64) void sscan_fwd3_kernel(FwdParams p) {
-    constexpr int TC = 16;
-    constexpr int CW = F3_CW;
-    constexpr int NT = 2 * NW * 64;
-    constexpr int N = NS * NW;
-    constexpr int NP = NS / 2;
-    static_assert(NT == 512 && NS % 2 == 0 && TC == 2 * CKS && TC * N / 4 <= 128, "tile passes: one float4 per thread and tile");
-    __shared__ __attribute__((aligned(16))) float s_p[2][TC][CW][2];           // {softplus(delta + bias) (+inf at a reset), that * u}
-    __shared__ __attribute__((aligned(16))) float s_g[2][TC][CW][2];           // {silu(z) (1 without a gate), D * u}
-    __shared__ __attribute__((aligned(16))) float s_y[2][NW][TC][CW];          // per-wave partial sums over its states
-    __shared__ __attribute__((aligned(16))) float s_B[2][TC][N];
-    __shared__ __attribute__((aligned(16))) float s_C[2][TC][N];
-
-    const int nd2 = (p.Di + CW - 1) / CW;
-    int b, dt;
-    if (!decode_block(blockIdx.x, nd2, p.B, b, dt)) return;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int w = wv & (NW - 1);                    // state group
-    const int half = wv / NW;                       // 64-channel half of the tile (waves w and w + NW share a SIMD)
-    const int d0 = dt * CW;
-    const int cl = half * 64 + lane;                // channel inside the tile
-    const int d = d0 + cl;
-    const bool d_ok = d < p.Di;
-    const int64_t tok0 = (int64_t)b * p.L;
-    const int L = p.L;
-
-    f2 A2p[NP], hp[NP];
-#pragma unroll
-    for (int k = 0; k < NP; ++k) {
-        float a[2];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) a[e] = d_ok ? fminf(p.A[(int64_t)d * N + w * NS + 2 * k + e] * RESEL_LOG2E, -1e-30f) : -1.f;
-        A2p[k] = f2{a[0], a[1]};
-        hp[k] = f2{0.f, 0.f};
-    }
-    // tile mapping: thread = (row r of the chunk, 4 channels)
-    const int tc4 = (tid & 31) * 4;
-    const int r = tid >> 5;
-    const bool c_ok = (d0 + tc4) < p.Di;
-    float4 Dv = make_float4(0.f, 0.f, 0.f, 0.f), bv = Dv;
-    if (c_ok) {
-        if (p.D) Dv = ld4(p.D + d0 + tc4);
-        if (p.delta_bias) bv = ld4(p.delta_bias + d0 + tc4);
-    }
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool has_z = p.z != nullptr;
-    // B / C tile: threads 0..127 fetch B, 128..255 fetch C, one float4 each (row = item / (N / 4))
-    const int bc_it = tid & 127;
-    const bool bc_on = tid < 256 && bc_it < TC * N / 4;
-    const int bc_row = bc_it / (N / 4), bc_col = (bc_it % (N / 4)) * 4;
-    const float* bc_src = tid < 128 ? p.Bm : p.Cm;
-    const int64_t bc_ld = tid < 128 ? p.ld_b : p.ld_c;
-    float* const bc_dst0 = (tid < 128 ? &s_B[0][0][0] : &s_C[0][0][0]) + bc_it * 4;
-    constexpr int BC_BUF = TC * N;                 // floats per buffer of s_B / s_C
-    // running pointers of this thread's tile element (row r of the current load chunk)
-    const float* gu = p.u + (tok0 + r) * p.ld_u + d0 + tc4;
-    const float* gd = p.delta + (tok0 + r) * p.ld_delta + d0 + tc4;
-    const float* gz = has_z ? p.z + (tok0 + r) * p.ld_z + d0 + tc4 : nullptr;
-    const float* gs = p.start ? p.start + tok0 + r : nullptr;
-    const float* gbc = bc_src + (tok0 + bc_row) * bc_ld + bc_col;
-    float* go = p.out + (tok0 + r) * p.ld_out + d0 + tc4;
-    float omax = 0.f;                                // max |out| of this thread's stores
-
-    float4 lu, ldl, lz, lbc;
-    float lst;
-    auto issue_loads = [&](int c0) {               // chunk starting at step c0 (past the end: every load is guarded off)
-        lu = zero4; ldl = zero4; lz = zero4; lbc = zero4; lst = 0.f;
-        if (c0 + r < L) {
-            if (c_ok) {
-                lu = ld4(gu);
-                ldl = ld4(gd);
-                if (has_z) lz = ld4(gz);
-            }
-            if (gs) lst = *gs;
-        }
-        if (bc_on && c0 + bc_row < L) lbc = p.bc_vec ? ld4(gbc) : make_float4(gbc[0], gbc[1], gbc[2], gbc[3]);
-        gu += TC * p.ld_u; gd += TC * p.ld_delta; gbc += TC * bc_ld;
-        if (has_z) gz += TC * p.ld_z;
-        if (gs) gs += TC;
-    };
-    auto stage = [&](int c0, int buf) {            // the loaded registers -> LDS tiles of buffer `buf`
-        float4 dv = ldl;
-        dv.x += bv.x; dv.y += bv.y; dv.z += bv.z; dv.w += bv.w;
-        if (p.softplus == 1) { dv.x = softplus_nb(dv.x); dv.y = softplus_nb(dv.y); dv.z = softplus_nb(dv.z); dv.w = softplus_nb(dv.w); }
-        float4 du4 = make_float4(dv.x * lu.x, dv.y * lu.y, dv.z * lu.z, dv.w * lu.w);
-        if (c0 + TC > L) {                                                      // last chunk(s) only (uniform branch)
-            if (c0 + r >= L) { dv = zero4; du4 = zero4; }                      // identity step past the end of the row
-        }
-        if (lst != 0.f) {                                                       // reset: exp2(-inf * |A|) = 0 wipes the carried state
-            const float inf = __builtin_inff();
-            dv = make_float4(inf, inf, inf, inf);
-        }
-        float* sp = &s_p[buf][r][tc4][0];
-        st4(sp, make_float4(dv.x, du4.x, dv.y, du4.y));
-        st4(sp + 4, make_float4(dv.z, du4.z, dv.w, du4.w));
-        float4 g = make_float4(1.f, 1.f, 1.f, 1.f);
-        if (has_z) g = make_float4(silu_nb(lz.x), silu_nb(lz.y), silu_nb(lz.z), silu_nb(lz.w));
-        float* sg = &s_g[buf][r][tc4][0];
-        st4(sg, make_float4(g.x, Dv.x * lu.x, g.y, Dv.y * lu.y));
-        st4(sg + 4, make_float4(g.z, Dv.z * lu.z, g.w, Dv.w * lu.w));
-        if (bc_on) st4(bc_dst0 + buf * BC_BUF, lbc);
-    };
-    auto output = [&](int c0, int buf) {           // out rows of the chunk that started at c0 (its partial sums are complete)
-        if (c0 + r < L && c_ok) {
-            float4 y = ld4(&s_y[buf][0][r][tc4]);
-#pragma unroll
-            for (int ww = 1; ww < NW; ++ww) {
-                const float4 q = ld4(&s_y[buf][ww][r][tc4]);
-                y.x += q.x; y.y += q.y; y.z += q.z; y.w += q.w;
-            }
-            const float* sg = &s_g[buf][r][tc4][0];
-            const float4 g0 = ld4(sg), g1 = ld4(sg + 4);
-            y.x = (y.x + g0.y) * g0.x; y.y = (y.y + g0.w) * g0.z;
-            y.z = (y.z + g1.y) * g1.x; y.w = (y.w + g1.w) * g1.z;
-            omax = amax4(omax, y);
-            st4(go, y);
-        }
-        go += TC * p.ld_out;
-    };
-    // steps [T0, T1) of the chunk in buffer `buf`; the operand sets of a step are fetched one step ahead
-    f2v P[2];
-    f2 Bq[2][NP], Cq[2][NP];
-    auto scan_fetch = [&](int buf, int t) {
-        P[t & 1] = *reinterpret_cast<const f2v*>(&s_p[buf][t][cl][0]);
-        lds_coef2<NS>(&s_B[buf][t][w * NS], Bq[t & 1]);
-        lds_coef2<NS>(&s_C[buf][t][w * NS], Cq[t & 1]);
-    };
-    float* ck_mid = nullptr;                        // where the state after the chunk's first CKS steps goes (set per chunk; nullptr: not stored)
-    auto scan_steps = [&](int buf, auto T0c, auto T1c) {
-        constexpr int T0 = decltype(T0c)::value, T1 = decltype(T1c)::value;
-#pragma unroll
-        for (int t = T0; t < T1; ++t) {
-            if (t + 1 < TC) scan_fetch(buf, t + 1);
-            const f2v Pt = P[t & 1];
-            f2 yacc;
-#pragma unroll
-            for (int k = 0; k < NP; ++k) {
-                const f2v arg = pk_mul_lo(Pt, A2p[k]);
-                f2 dA;
-                dA.x = fast_exp2(arg.x);
-                dA.y = fast_exp2(arg.y);
-                const f2v x = pk_mul_hi(Pt, Bq[t & 1][k]);
-                hp[k] = __builtin_elementwise_fma(dA, hp[k], (f2)x);
-                yacc = k == 0 ? Cq[t & 1][k] * hp[k] : __builtin_elementwise_fma(Cq[t & 1][k], hp[k], yacc);
-            }
-            s_y[buf][w][t][cl] = yacc.x + yacc.y;
-            if (t + 1 == CKS && ck_mid != nullptr) store_ckpt<NS>(ck_mid, hp);   // mid-chunk checkpoint, straight from the state registers
-        }
-    };
-    using I0 = std::integral_constant<int, 0>;
-    using IH = std::integral_constant<int, TC / 2>;
-    using I1 = std::integral_constant<int, TC>;
-
-    const int nchunk = (L + TC - 1) / TC;
-    issue_loads(0);
-    stage(0, 0);
-    issue_loads(TC);
-    __syncthreads();
-    const bool ck_on = p.ckpt != nullptr;
-    float* ck_ptr = p.ckpt + (((int64_t)b * p.nck * NW + w) * p.Di + d) * NS;   // checkpoint 0, this wave's state group, this lane's channel
-    for (int i = 0; i < nchunk; ++i) {
-        const int c0 = i * TC, buf = i & 1;
-        ck_mid = (ck_on && c0 + CKS < L && d_ok) ? ck_ptr + (int64_t)(2 * i) * N * p.Di : nullptr;     // checkpoint 2 i: the state after c0 + CKS steps
-        scan_fetch(buf, 0);
-        if (half == 0) {                            // tile passes around the scan
-            if (i > 0) output(c0 - TC, buf ^ 1);
-            scan_steps(buf, I0{}, I1{});
-            stage(c0 + TC, buf ^ 1);
-        } else {                                    // tile passes in the middle of the scan
-            scan_steps(buf, I0{}, IH{});
-            if (i > 0) output(c0 - TC, buf ^ 1);
-            stage(c0 + TC, buf ^ 1);
-            scan_steps(buf, IH{}, I1{});
-        }
-        if (ck_on && c0 + TC < L && d_ok) {         // the state after step c0 + TC - 1 is checkpoint 2 i + 1
-            store_ckpt<NS>(ck_ptr + (int64_t)(2 * i + 1) * N * p.Di, hp);
-        }
-        issue_loads(c0 + 2 * TC);                   // chunk i + 2: a whole iteration ahead of its staging
-        __syncthreads();
-    }
-    output((nchunk - 1) * TC, (nchunk - 1) & 1);
-    if (p.last_state != nullptr && d_ok) {
 #pragma unroll
         for (int j = 0; j < NS; ++j)
             p.last_state[((int64_t)b * p.Di + d) * N + w * NS + j] = (j & 1) ? hp[j / 2].y : hp[j / 2].x;
@@ -1297,12 +1082,6 @@ int launch_fwd(FwdParams p, int force_seg, void* workspace, hipStream_t s) {
     const int bp = (p.B + 7) / 8 * 8;
     const int nseg = fwd_segments(p.B, p.L, p.nd, TC, force_seg);
     if (nseg <= 1) {
-        if constexpr (NW == 4 && NS % 2 == 0 && 16 * NS * NW / 4 <= 128) {
-            if (g_fwd_edition >= 3) {
-                launch_maybe_timed(RESEL_PROF_SSCAN_FWD, sscan_fwd3_kernel<NS, NW>, dim3(bp * ((p.Di + F3_CW - 1) / F3_CW)), dim3(2 * NW * 64), s, p);
-                return launch_status();
-            }
-        }
         launch_maybe_timed(RESEL_PROF_SSCAN_FWD, sscan_fwd2_kernel<NS, NW, TC, 0>, dim3(bp * p.nd), dim3(NW * 64), s, p);
         return launch_status();
     }
@@ -1351,12 +1130,6 @@ inline BwdWs bwd_ws(int B, int L, int Di, int N, int force_seg) {
 }
 
 }  // namespace
-
-extern "C" int resel_selective_scan_fwd_edition(int edition) {
-    if (edition != 2 && edition != 3) return RESEL_EINVAL;
-    g_fwd_edition = edition;
-    return RESEL_OK;
-}
 
 extern "C" size_t resel_selective_scan_ckpt_bytes(int B, int L, int Di, int N) {
     return (size_t)B * (size_t)(n_ckpt(L) > 0 ? n_ckpt(L) : 0) * (size_t)N * (size_t)Di * sizeof(float);

@@ -30,8 +30,7 @@ from ..parallel.data_parallel import GradSync
 from ..policy_value_models.make_models import make_policy_model
 from ..utility.pinned import PinnedRing
 
-_FL = os.environ.get('RESEL_FUSED_LOSSES', '1')                        # A/B switch: 0 = the masked losses spelt in torch autograd
-FUSED_LOSSES, FUSED_Q, FUSED_A = _FL != '0', _FL in ('1', 'q'), _FL in ('1', 'a')
+FUSED_LOSSES = FUSED_Q = FUSED_A = True      # the masked losses as one forward + one backward kernel each (csrc/losses.hip); CPU tensors keep the torch spelling
 from ..utility.q_value_guard import QValueGuard
 from .sac import SAC
 

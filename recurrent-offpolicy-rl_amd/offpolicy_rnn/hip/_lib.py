@@ -22,7 +22,6 @@ SIGNATURES = {
     'resel_profile_enable': (c_int, [I]),
     'resel_profile_collect': (c_int, [I, P, P]),
     'resel_selective_scan_ckpt_bytes': (c_size_t, [I, I, I, I]),
-    'resel_selective_scan_fwd_edition': (I, [I]),
     'resel_selective_scan_fwd_workspace_bytes': (c_size_t, [I, I, I, I, I]),
     'resel_selective_scan_fwd': (c_int, [P, L, P, L, P, L, P, P, L, P, L, P, P, P, P, L, P, P, P, I, I, I, I, I, I, P, E, S]),
     'resel_selective_scan_bwd_workspace_bytes': (c_size_t, [I, I, I, I, I]),

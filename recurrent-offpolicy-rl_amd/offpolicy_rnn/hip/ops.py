@@ -86,15 +86,6 @@ def profile_collect():
 SSCAN_TIME_SEGMENTS = int(os.environ.get('RESEL_SSCAN_TIME_SEGMENTS', '0'))
 
 
-def sscan_fwd_edition(edition: int):
-    """One-pass forward kernel of the selective scan: 3 (library default) = third edition, 2 = second edition (A/B runs, tests)."""
-    check(lib().resel_selective_scan_fwd_edition(int(edition)), 'selective_scan_fwd_edition')
-
-
-if os.environ.get('RESEL_SSCAN_FWD_EDITION'):
-    sscan_fwd_edition(int(os.environ['RESEL_SSCAN_FWD_EDITION']))
-
-
 class SelectiveScanFn(torch.autograd.Function):
     """Token-major selective scan with start resets.  Interface counterpart of the reference's
     `SelectiveScanFn` (mamba_ssm/ops/selective_scan_interface_new.py:19-84)."""
@@ -174,8 +165,6 @@ def selective_scan_fn(u, delta, A, B, C, start, D=None, z=None, delta_bias=None,
 
 
 # ---------------------------------------------------------------------------------------------- fused Mamba mixer
-CONV_TWO_DY = os.environ.get('RESEL_CONV_TWO_DY', '1') != '0'          # A/B switch: 0 = x_proj input gradient accumulated into the scan's du by the GEMM epilogue
-FOLD_SOFTPLUS = os.environ.get('RESEL_FOLD_SOFTPLUS', '1') != '0'      # A/B switch: 0 = softplus inside the scan kernels (delta_softplus = 1)
 
 
 class MambaInnerFn(torch.autograd.Function):
@@ -206,7 +195,7 @@ class MambaInnerFn(torch.autograd.Function):
               'causal_conv1d_fwd')
         tag_amax(xc, h_xc)
         x_dbl = mm_nt(xc, xproj_w)                                         # [M, R + 2N] = (delta_r | B | C)
-        fold = FOLD_SOFTPLUS and _mine(M, Di, R, x_dbl[:, :R], dt_w)
+        fold = _mine(M, Di, R, x_dbl[:, :R], dt_w)
         if fold:       # delta = softplus(dt_proj(.) + bias) leaves the GEMM epilogue: the scan kernels spend no vector issue on it
             dt = gemm_f32(x_dbl[:, :R], dt_w, True, True, dt_b, GEMM_SOFTPLUS)
         else:
@@ -267,14 +256,7 @@ class MambaInnerFn(torch.autograd.Function):
         d_xproj_w = wgrad(dx_dbl, xc, amax_x=h_xc)
         # the conv output's gradient = the scan's du (in dxc) + the x_proj input gradient: handed to the conv backward as TWO tensors
         # (summed on load) - the accumulating GEMM epilogue cost 150-214 us per call against 67 for the plain product
-        if CONV_TWO_DY:
-            gx = mm_nn(dx_dbl, xproj_w)
-        else:                                          # A/B: the accumulating epilogue
-            gx = None
-            if _mine(dx_dbl.shape[0], xproj_w.shape[1], xproj_w.shape[0], dx_dbl, xproj_w, dxc):
-                gemm_f32(dx_dbl, xproj_w, True, False, None, GEMM_ACCUMULATE, out=dxc)
-            else:
-                dxc.addmm_(dx_dbl, xproj_w)
+        gx = mm_nn(dx_dbl, xproj_w)
         dcw = torch.empty(Di, K, dtype=torch.float32, device=dev)
         dcb = torch.empty(Di, dtype=torch.float32, device=dev) if conv_b is not None else None
         ws2 = _ws(lib().resel_causal_conv1d_bwd_workspace_bytes(Bsz, L, Di, K), dev)
@@ -938,8 +920,8 @@ def gemm_f32_ok(rows, *mats):
         and all(st % 4 == 0 for st in t.stride()[:-1]) and (t.dim() < 2 or t.stride(-2) < (1 << 22)) for t in mats)
 
 
-GEMM_F32_MIN_DIM = int(os.environ.get('RESEL_GEMM_F32_MIN_DIM', 4))        # narrower outputs (dt_proj's rank-16 input gradient, the 6-wide heads) stay with the library (measured equal at 12 / 16 / 32)
-GEMM_F32_MIN_K = int(os.environ.get('RESEL_GEMM_F32_MIN_K', 4))          # reductions of one partial K step run the fp32-MFMA kernel (update 26.07 -> 25.8 ms with dt_proj's K = 16 here)
+GEMM_F32_MIN_DIM = 4        # narrower outputs (dt_proj's rank-16 input gradient, the 6-wide heads) stay with the library (measured equal at 12 / 16 / 32)
+GEMM_F32_MIN_K = 4          # reductions of one partial K step run the fp32-MFMA kernel (update 26.07 -> 25.8 ms with dt_proj's K = 16 here)
 
 
 def _mine(rows, n, k, *mats):
@@ -1107,7 +1089,7 @@ _GEMM_WS_BYTES = {}           # (M, N, K, batch) -> workspace bytes of resel_gem
 # Tags die with an in-place modification that torch sees (`_version`); this module's own in-place kernels re-tag or clear.
 AMAX_SLOTS = 2048             # handles per device arena (1 KiB each: eight 8-byte words, 128 bytes apart)
 AMAX_WORDS = 128              # int64 words per handle
-AMAX_PREPASS_FRACTION = float(os.environ.get('RESEL_AMAX_PREPASS_FRACTION', 0.16))   # of the estimated GEMM time one may spend on reading an untagged operand
+AMAX_PREPASS_FRACTION = 0.16  # of the estimated GEMM time one may spend on reading an untagged operand (measured: profiles/r04_gemm.md)
 _AMAX_ARENA = {}              # device -> [int64 tensor [AMAX_SLOTS], next index]
 _AMAX_EPOCH = [0]
 LAST_AMAX = None              # handle of the magnitude published by the most recent producer call (wrappers tag Function outputs with it)
@@ -1288,7 +1270,6 @@ def amax_value(handle):
     return float(lo.view(torch.float32).max())
 
 
-WEIGHT_AMAX = os.environ.get('RESEL_WEIGHT_AMAX', '1') != '0'        # A/B switch: 0 = a magnitude pre-pass per call for weights
 PARAM_EPOCH = [0]             # bumped by every kernel of this module that rewrites parameters in place (flat AdamW, soft update)
 
 
@@ -1304,7 +1285,7 @@ def weight_amax(p):
     """Magnitude handle of a parameter held in a FlatParameterStore (models/flat_params.py keeps one handle per tensor, refreshed by ONE
     launch after the buffer was rewritten), or None (the caller's GEMM then decides about a pre-pass)."""
     ref = getattr(p, '_resel_store', None)
-    if ref is None or not WEIGHT_AMAX or not amax_tracking():
+    if ref is None or not amax_tracking():
         return None
     return ref[0].amax_handle(ref[1], p)
 

@@ -31,7 +31,7 @@ def _both(alg, seed, **kw):
     buf = alg.replay_buffer
     np.random.seed(seed)
     batch, size_h, valid, table_h = buf.sample_trajs(40, None, equalize_data_of_each_traj=True, **kw)
-    host = alg._upload_batch(batch, valid, table_h)['valid']._base
+    host = alg._upload_batch(batch, valid, table_h)['state']._base        # a wide field: still a view of the batch array (the per-token scalars are a planar copy)
     np.random.seed(seed)
     dev, size_d, table_d = buf.sample_trajs_device(alg.device, 40, None, **kw)
     torch.cuda.synchronize()

@@ -150,29 +150,6 @@ def test_selective_scan_slow_decay_carry_is_load_bearing(ops, monkeypatch):
     assert rel > 1e-2, f'cutting the carry changed the output by only {rel:.2e}'
 
 
-@pytest.mark.parametrize('B,L,Di,N', [(3, 1043, 192, 32), (2, 333, 64, 16), (9, 50, 512, 8), (1, 16, 128, 32), (2, 17, 64, 32)])
-def test_selective_scan_forward_editions_agree(ops, monkeypatch, B, L, Di, N):
-    """The third-edition one-pass forward (8-wave workgroups over 128 channels, one barrier per 16-step chunk, staggered halves)
-    against the second edition: outputs, last state and - through the checkpoints it leaves - every gradient of the backward."""
-    ins, start, w = _slow_decay_case(B, L, Di, N, seed=B + L + N)
-    start[:, ::37] = 1
-    monkeypatch.setattr(ops, 'SSCAN_TIME_SEGMENTS', 1)
-    res = {}
-    try:
-        for ed in (2, 3):
-            ops.sscan_fwd_edition(ed)
-            dev_in = [t.clone().cuda().requires_grad_(True) for t in ins]
-            out, last = ops.selective_scan_tm(*dev_in, start.cuda(), True, return_last_state=True)
-            (out * w.cuda()).sum().backward()
-            res[ed] = (out.detach().cpu(), last.detach().cpu(), [t.grad.cpu() for t in dev_in])
-    finally:
-        ops.sscan_fwd_edition(3)
-    close(res[3][0], res[2][0], rtol=2e-6, atol_scale=1e-6, name='out')
-    close(res[3][1], res[2][1], rtol=2e-6, atol_scale=1e-6, name='last_state')
-    for a, b, nm in zip(res[3][2], res[2][2], ('du', 'ddelta', 'dA', 'dB', 'dC', 'dD', 'dz', 'dbias')):
-        close(a, b, rtol=1e-5, atol_scale=1e-6, name=nm)
-
-
 def test_selective_scan_golden_reference_vectors(ops):
     """The reference's own selective_scan_ref outputs (tests/golden/selective_scan.npz), channel-major signature."""
     gold = load_golden('selective_scan.npz')
@@ -868,7 +845,7 @@ def test_encode_concat_padded_block_diagonal_gemm_vs_separate_linears(ops):
     (1024, 256, 4172, False, False, False, None, 1),    # the same with 12 left
     (1500, 200, 4100, True, True, True, 'elu', 1),      # ragged everything, 4 k in the last step
 ])
-@pytest.mark.parametrize('split', [0, 6, 9, 106])
+@pytest.mark.parametrize('split', [0, 6])
 def test_gemm_f32_vs_fp64_product(ops, M, N, K, akc, bkc, bias, act, batch, split):
     """resel_gemm_f32 against an fp64 product: 1e-5 of the largest output magnitude in every product mode (0: fp32 MFMA, exact
     products; 9 / 6: exact three-way bf16 operand split on the bf16 MFMA, all nine / the six leading plane products, operands
@@ -891,7 +868,7 @@ def test_gemm_f32_vs_fp64_product(ops, M, N, K, akc, bkc, bias, act, batch, spli
     assert torch.equal(out, out2)                       # bitwise reproducible (no atomics)
 
 
-@pytest.mark.parametrize('M,N,K,split', [(66752, 512, 80, 6), (1000, 132, 72, 6), (5000, 256, 64, 0), (66752, 512, 80, 106)])
+@pytest.mark.parametrize('M,N,K,split', [(66752, 512, 80, 6), (1000, 132, 72, 6), (5000, 256, 64, 0)])
 def test_gemm_f32_accumulating_epilogue(ops, M, N, K, split):
     """Epilogue code 2: C += A B (the accumulating form `dxc.addmm_(dx_dbl, x_proj.weight)` of the Mamba mixer's backward), whole
     tiles and K-split tails alike, against the fp64 sum."""
@@ -906,8 +883,8 @@ def test_gemm_f32_accumulating_epilogue(ops, M, N, K, split):
 
 def test_gemm_f32_split_modes_error_against_fp64(ops):
     """The bf16-split product modes are as accurate as the fp32 instruction: mean and maximum error against an fp64 product, on
-    operands with a wide dynamic range (6 decades), K = 4096.  Mode 9 represents every product exactly (as mode 0 does): its
-    error is the accumulation's; mode 6 adds at most one product rounding per term."""
+    operands with a wide dynamic range (6 decades), K = 4096.  Mode 6 adds at most one product rounding per term to the accumulation's
+    error; mode 2: see the next test."""
     g = torch.Generator().manual_seed(5)
     M, N, K = 512, 384, 4096
     A = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, K, generator=g) * 2.0)).cuda()
@@ -915,12 +892,12 @@ def test_gemm_f32_split_modes_error_against_fp64(ops):
     ref = A.double() @ B.double().t()
     scale = (A.double().abs() @ B.double().abs().t())          # sum |a b|: the natural error scale of a dot product
     err = {}
-    for split in (0, 6, 9, 2):
+    for split in (0, 6, 2):
         e = ((ops.gemm_f32(A, B, True, True, split=split).double() - ref).abs() / scale)
         err[split] = (e.mean().item(), e.max().item())
     lib = (((A @ B.t()).double() - ref).abs() / scale)
     print('relative to sum|ab|: mean / max', err, 'library fp32 GEMM', (lib.mean().item(), lib.max().item()))
-    for split in (6, 9, 2):
+    for split in (6, 2):
         assert err[split][0] <= 1.5 * err[0][0] + 1e-9 and err[split][1] <= 2.0 * err[0][1] + 1e-9, err
     assert err[6][1] < 1e-6 and err[2][1] < 1e-6
 
