@@ -60,6 +60,8 @@ int resel_profile_collect(int kernel_id, double* total_us, int* launches);
  *                                                      2: `delta` already IS softplus(raw + bias) - the producing GEMM's epilogue applied
  *                                                      it (resel_gemm_f32x act 3) - the forward uses it as it stands and the backward
  *                                                      returns the gradient with respect to the RAW value: x (1 - exp(-delta)))
+ *                                                      + 4 (ABI 7): `A` holds the parameter A_log; the kernels form A = -exp(A_log)
+ *                                                      themselves (reference smamba/mamba.py:187) and the backward returns dA_log)
  *   h_t    = exp(delta'_t * A) * (1 - start_t) * h_{t-1} + delta'_t * Bm_t * u_t          h: [Di, N]
  *   out_t  = (<Cm_t, h_t> + D * u_t) * silu(z_t)     (gate skipped when z == NULL, skip term when D == NULL)
  * u, delta, z, out: [B*L, Di] (ld_u, ld_delta, ld_z, ld_out; 16-byte aligned); A: [Di, N] dense;

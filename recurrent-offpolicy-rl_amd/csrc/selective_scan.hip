@@ -50,6 +50,7 @@ struct FwdParams {
     float *out, *ckpt, *last_state;
     int64_t ld_u, ld_delta, ld_z, ld_b, ld_c, ld_out;
     int B, L, Di, N, nck, softplus, nd, bc_vec;
+    int a_log;                      // A holds A_log: the kernels form A = -exp(A_log) themselves (delta_softplus bit 2)
     int seg_len, nseg;              // time-parallel form (MODE 1 / 2): steps per segment (multiple of the chunk), segments per row
     float *h_carry, *sdl;           // [B][nseg][N][Di] local end states -> entry states; [B][nseg][Di] delta sums
     AmaxOut amax_out;               // optional: publish max |out| (the out_proj GEMM scales its operand with it)
@@ -70,6 +71,13 @@ template <int NS>
 __device__ __forceinline__ void load_coef(cfloat_p p, float (&dst)[NS]) {
 #pragma unroll
     for (int j = 0; j < NS; ++j) dst[j] = p[j];
+}
+
+// A[i], or -exp(A_log[i]) when the caller passes the parameter itself (reference smamba/mamba.py:187 `A = -torch.exp(self.A_log.float())`:
+// two element-wise launches per mixer call, and a third for dA_log = dA * A in the backward)
+__device__ __forceinline__ float load_A(const float* A, int64_t i, int a_log) {
+    const float a = A[i];
+    return a_log ? -expf(a) : a;
 }
 
 // XCD-aware decode of a 1-D block id into (row b, channel tile dt): ids congruent mod 8 share an XCD.
@@ -207,7 +215,7 @@ __global__ __launch_bounds__(NW * 64) void sscan_fwd2_kernel(FwdParams p) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int j = 2 * k + e;
-            a[e] = (d_ok && j < NS) ? fminf(p.A[(int64_t)d * N + w * NS + j] * RESEL_LOG2E, -1e-30f) : -1.f;
+            a[e] = (d_ok && j < NS) ? fminf(load_A(p.A, (int64_t)d * N + w * NS + j, p.a_log) * RESEL_LOG2E, -1e-30f) : -1.f;
         }
         A2p[k] = f2{a[0], a[1]};
         hp[k] = f2{0.f, 0.f};
@@ -441,11 +449,11 @@ __global__ __launch_bounds__(NW * 64) void sscan_fwd2_kernel(FwdParams p) {
 }
 
 // h_carry[b][s] (local end states on entry) -> states ENTERING segment s; one thread per (row, state, channel)
-__global__ void sscan_carry_kernel(float* __restrict__ h_carry, const float* __restrict__ sdl, const float* __restrict__ A, int B, int nseg, int N, int Di) {
+__global__ void sscan_carry_kernel(float* __restrict__ h_carry, const float* __restrict__ sdl, const float* __restrict__ A, int a_log, int B, int nseg, int N, int Di) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)B * N * Di) return;
     const int d = (int)(i % Di), n = (int)((i / Di) % N), b = (int)(i / ((int64_t)Di * N));
-    const float a2 = fminf(A[(int64_t)d * N + n] * RESEL_LOG2E, -1e-30f);
+    const float a2 = fminf(load_A(A, (int64_t)d * N + n, a_log) * RESEL_LOG2E, -1e-30f);
     float h = 0.f;
     for (int s = 0; s < nseg; ++s) {
         float* q = h_carry + (((int64_t)b * nseg + s) * N + n) * Di + d;
@@ -464,6 +472,7 @@ struct BwdParams {
     float *dB_part, *dC_part, *dA_part, *dD_part, *dbias_part;     // workspace slabs
     int64_t ld_u, ld_delta, ld_z, ld_b, ld_c, ld_dout, ld_du, ld_ddelta, ld_dz;
     int B, L, Di, N, nck, softplus, nd, bc_vec;
+    int a_log;                      // A holds A_log (see FwdParams)
     int seg_len, nseg;              // time-parallel form: steps per segment (multiple of 32), segments per row (1 = whole row)
     float *dh_carry, *sdl;          // [B][nseg][N][Di]: dL/dh flowing INTO the end of each segment; [B][nseg][Di] delta sums
     AmaxOut amax_dz, amax_ddelta;   // optional: publish max |dz|, max |ddelta| (operands of the in_proj / dt_proj gradient GEMMs)
@@ -626,7 +635,7 @@ __global__ __launch_bounds__(NW * 64) void sscan_bwd_kernel(BwdParams p) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int j = 2 * k + e;
-            a[e] = (d_ok && j < NS) ? p.A[(int64_t)d * N + w * NS + j] : -1.f;
+            a[e] = (d_ok && j < NS) ? load_A(p.A, (int64_t)d * N + w * NS + j, p.a_log) : -1.f;
         }
         A2p[k] = f2{fminf(a[0] * RESEL_LOG2E, -1e-30f), fminf(a[1] * RESEL_LOG2E, -1e-30f)};   // A * log2(e)
         dh[k] = f2{0.f, 0.f};
@@ -972,7 +981,7 @@ __global__ __launch_bounds__(NW * 64) void sscan_bwd_local_kernel(BwdParams p) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int j = 2 * k + e;
-            a[e] = (d_ok && j < NS) ? fminf(p.A[(int64_t)d * N + w * NS + j] * RESEL_LOG2E, -1e-30f) : -1.f;
+            a[e] = (d_ok && j < NS) ? fminf(load_A(p.A, (int64_t)d * N + w * NS + j, p.a_log) * RESEL_LOG2E, -1e-30f) : -1.f;
         }
         A2p[k] = f2{a[0], a[1]};
         dh[k] = f2{0.f, 0.f};
@@ -1038,11 +1047,11 @@ __global__ __launch_bounds__(NW * 64) void sscan_bwd_local_kernel(BwdParams p) {
     }
 }
 // dh_carry[b][s] (adjoint at the START of segment s for a zero adjoint at its end) -> adjoint entering the END of segment s
-__global__ void sscan_carry_rev_kernel(float* __restrict__ dh_carry, const float* __restrict__ sdl, const float* __restrict__ A, int B, int nseg, int N, int Di) {
+__global__ void sscan_carry_rev_kernel(float* __restrict__ dh_carry, const float* __restrict__ sdl, const float* __restrict__ A, int a_log, int B, int nseg, int N, int Di) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)B * N * Di) return;
     const int d = (int)(i % Di), n = (int)((i / Di) % N), b = (int)(i / ((int64_t)Di * N));
-    const float a2 = fminf(A[(int64_t)d * N + n] * RESEL_LOG2E, -1e-30f);
+    const float a2 = fminf(load_A(A, (int64_t)d * N + n, a_log) * RESEL_LOG2E, -1e-30f);
     float carry = 0.f;
     for (int s = nseg - 1; s >= 0; --s) {
         float* q = dh_carry + (((int64_t)b * nseg + s) * N + n) * Di + d;
@@ -1053,7 +1062,11 @@ __global__ void sscan_carry_rev_kernel(float* __restrict__ dh_carry, const float
 }
 
 // dB / dC: sum the per-channel-tile slabs; parameter gradients: sum the per-row partials.
-__global__ void sscan_reduce_bc_kernel(const float* __restrict__ part, int nd, int64_t ntok, int N, float* out, int64_t ld) {
+__global__ void sscan_reduce_bc_kernel(const float* __restrict__ partB, const float* __restrict__ partC, int nd, int64_t ntok, int N,
+                                       float* outB, int64_t ldB, float* outC, int64_t ldC) {
+    const float* part = blockIdx.y ? partC : partB;
+    float* out = blockIdx.y ? outC : outB;
+    const int64_t ld = blockIdx.y ? ldC : ldB;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // float4 index over [ntok, N]
     const int n4 = N / 4;
     if (i >= ntok * n4) return;
@@ -1066,6 +1079,42 @@ __global__ void sscan_reduce_bc_kernel(const float* __restrict__ part, int nd, i
     }
     float* o = out + tok * ld + c;
     o[0] = acc.x; o[1] = acc.y; o[2] = acc.z; o[3] = acc.w;
+}
+// dA [Di * N] (blockIdx.y = 0; with A_log: dA_log = dA * A, A = -exp(A_log)), dD [Di] (1), ddelta_bias [Di] (2): column sums of the per-row
+// partial slabs [K][C] in a fixed order - the body of resel_common.h's colsum_kernel, three outputs per launch
+__global__ __launch_bounds__(256) void sscan_param_grads_kernel(const float* __restrict__ pA, const float* __restrict__ pD, const float* __restrict__ pb, int K,
+                                                                int na, int Di, const float* __restrict__ A, int a_log, float* __restrict__ dA,
+                                                                float* __restrict__ dD, float* __restrict__ dbias) {
+    __shared__ float s_acc[16][17];
+    const int which = blockIdx.y;
+    const float* part = which == 0 ? pA : which == 1 ? pD : pb;
+    float* out = which == 0 ? dA : which == 1 ? dD : dbias;
+    const int C = which == 0 ? na : Di;
+    if (out == nullptr || (int)blockIdx.x * 16 >= C) return;
+    const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    float acc = 0.f;
+    if (c < C) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int k = rg;
+        for (; k + 48 < K; k += 64) {
+            a0 += part[(int64_t)k * C + c];
+            a1 += part[(int64_t)(k + 16) * C + c];
+            a2 += part[(int64_t)(k + 32) * C + c];
+            a3 += part[(int64_t)(k + 48) * C + c];
+        }
+        for (; k < K; k += 16) a0 += part[(int64_t)k * C + c];
+        acc = (a0 + a1) + (a2 + a3);
+    }
+    s_acc[rg][cl] = acc;
+    __syncthreads();
+    if (rg == 0 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += s_acc[r][cl];
+        if (which == 0 && a_log) t *= -expf(A[c]);
+        out[c] = t;
+    }
 }
 // Time segments of the forward: one pass while the one-pass grid (B * nd workgroups, two fit a CU) covers ~3/4 of the chip's
 // 512 slots, otherwise enough segments to fill them (each at least two chunks long).  `force` > 0 overrides (tests).
@@ -1092,7 +1141,7 @@ int launch_fwd(FwdParams p, int force_seg, void* workspace, hipStream_t s) {
     p.sdl = p.h_carry + (size_t)p.B * nseg * p.N * p.Di;
     launch_maybe_timed(RESEL_PROF_SSCAN_FWD_LOCAL, sscan_fwd2_kernel<NS, NW, TC, 1>, dim3(bp * p.nd, nseg), dim3(NW * 64), s, p);
     const int64_t n = (int64_t)p.B * p.N * p.Di;
-    hipLaunchKernelGGL(sscan_carry_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p.h_carry, p.sdl, p.A, p.B, nseg, p.N, p.Di);
+    hipLaunchKernelGGL(sscan_carry_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p.h_carry, p.sdl, p.A, p.a_log, p.B, nseg, p.N, p.Di);
     launch_maybe_timed(RESEL_PROF_SSCAN_FWD, sscan_fwd2_kernel<NS, NW, TC, 2>, dim3(bp * p.nd, nseg), dim3(NW * 64), s, p);
     return launch_status();
 }
@@ -1102,7 +1151,7 @@ int launch_bwd(const BwdParams& p, hipStream_t s) {
     if (p.nseg > 1) {                                // time-parallel form: local adjoint pass, carry, then the full pass per segment
         launch_maybe_timed(RESEL_PROF_SSCAN_BWD_LOCAL, sscan_bwd_local_kernel<NS, NW, 32>, dim3(bp * p.nd, p.nseg), dim3(NW * 64), s, p);
         const int64_t n = (int64_t)p.B * p.N * p.Di;
-        hipLaunchKernelGGL(sscan_carry_rev_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p.dh_carry, p.sdl, p.A, p.B, p.nseg, p.N, p.Di);
+        hipLaunchKernelGGL(sscan_carry_rev_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p.dh_carry, p.sdl, p.A, p.a_log, p.B, p.nseg, p.N, p.Di);
     }
     launch_maybe_timed(RESEL_PROF_SSCAN_BWD, sscan_bwd_kernel<NS, NW>, dim3(bp * p.nd, p.nseg), dim3(NW * 64), s, p);
     return launch_status();
@@ -1153,9 +1202,9 @@ extern "C" int resel_selective_scan_fwd(const float* u, int64_t ld_u, const floa
     if (!aligned16(u) || !aligned16(delta) || !aligned16(out) || (z && !aligned16(z))) return RESEL_EINVAL;
     if ((D && !aligned16(D)) || (delta_bias && !aligned16(delta_bias))) return RESEL_EINVAL;
     FwdParams p{u, delta, z, A, Bm, Cm, D, delta_bias, start, out, ckpt, last_state,
-                ld_u, ld_delta, ld_z, ld_b, ld_c, ld_out, B, L, Di, N, n_ckpt(L), delta_softplus,
+                ld_u, ld_delta, ld_z, ld_b, ld_c, ld_out, B, L, Di, N, n_ckpt(L), delta_softplus & 3,
                 (Di + TILE_C - 1) / TILE_C,
-                (ld_b % 4 == 0 && ld_c % 4 == 0 && aligned16(Bm) && aligned16(Cm)) ? 1 : 0, 0, 1, nullptr, nullptr,
+                (ld_b % 4 == 0 && ld_c % 4 == 0 && aligned16(Bm) && aligned16(Cm)) ? 1 : 0, (delta_softplus >> 2) & 1, 0, 1, nullptr, nullptr,
                 AmaxOut{(unsigned long long*)amax_out, amax_epoch}};
 #ifdef SSCAN_STAMP
     p.stamps = g_stamps;
@@ -1203,8 +1252,8 @@ extern "C" int resel_selective_scan_bwd(const float* u, int64_t ld_u, const floa
                 (float*)(base + ws.dB), (float*)(base + ws.dC), (float*)(base + ws.dA), (float*)(base + ws.dD),
                 (float*)(base + ws.dbias),
                 ld_u, ld_delta, ld_z, ld_b, ld_c, ld_dout, ld_du, ld_ddelta, ld_dz,
-                B, L, Di, N, n_ckpt(L), delta_softplus, (Di + TILE_C - 1) / TILE_C,
-                (ld_b % 4 == 0 && ld_c % 4 == 0 && aligned16(Bm) && aligned16(Cm)) ? 1 : 0,
+                B, L, Di, N, n_ckpt(L), delta_softplus & 3, (Di + TILE_C - 1) / TILE_C,
+                (ld_b % 4 == 0 && ld_c % 4 == 0 && aligned16(Bm) && aligned16(Cm)) ? 1 : 0, (delta_softplus >> 2) & 1,
                 ws.nseg > 1 ? ((L + ws.nseg - 1) / ws.nseg + 31) / 32 * 32 : L, ws.nseg,
                 ws.nseg > 1 ? (float*)(base + ws.carry) : nullptr, ws.nseg > 1 ? (float*)(base + ws.sdl) : nullptr,
                 AmaxOut{(unsigned long long*)amax_dz, amax_epoch}, AmaxOut{(unsigned long long*)amax_ddelta, amax_epoch}};
@@ -1221,13 +1270,11 @@ extern "C" int resel_selective_scan_bwd(const float* u, int64_t ld_u, const floa
     if (rc != RESEL_OK) return rc;
     const int64_t ntok = (int64_t)B * L;
     const int64_t n4 = ntok * (N / 4);
-    hipLaunchKernelGGL(sscan_reduce_bc_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s,
-                       p.dB_part, p.nd, ntok, N, dBm, ld_db);
-    hipLaunchKernelGGL(sscan_reduce_bc_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s,
-                       p.dC_part, p.nd, ntok, N, dCm, ld_dc);
+    // two tail launches (were five): dB | dC slabs in one grid, the three parameter-gradient column sums in another
+    hipLaunchKernelGGL(sscan_reduce_bc_kernel, dim3((unsigned)((n4 + 255) / 256), 2), dim3(256), 0, s,
+                       p.dB_part, p.dC_part, p.nd, ntok, N, dBm, ld_db, dCm, ld_dc);
     const int64_t na = (int64_t)Di * N;
-    launch_colsum(p.dA_part, na, B * ws.nseg, (int)na, dA, s);
-    if (dD) launch_colsum(p.dD_part, Di, B * ws.nseg, Di, dD, s);
-    if (ddelta_bias) launch_colsum(p.dbias_part, Di, B * ws.nseg, Di, ddelta_bias, s);
+    hipLaunchKernelGGL(sscan_param_grads_kernel, dim3((unsigned)((na + 15) / 16), 3), dim3(256), 0, s,
+                       p.dA_part, p.dD_part, p.dbias_part, B * ws.nseg, (int)na, Di, A, p.a_log, dA, dD, ddelta_bias);
     return launch_status();
 }

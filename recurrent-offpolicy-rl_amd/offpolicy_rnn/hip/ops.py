@@ -200,7 +200,7 @@ class MambaInnerFn(torch.autograd.Function):
             dt = gemm_f32(x_dbl[:, :R], dt_w, True, True, dt_b, GEMM_SOFTPLUS)
         else:
             dt = mm_nt(x_dbl[:, :R], dt_w)                                  # [M, Di]; bias enters the scan as delta_bias
-        A = -torch.exp(A_log.float())
+        A = A_log.float().contiguous()                                     # the kernels form A = -exp(A_log) themselves (delta_softplus + 4)
         need_grad = any(ctx.needs_input_grad)
         ck = _ws(lib().resel_selective_scan_ckpt_bytes(Bsz, L, Di, N), x.device) if need_grad else None
         y = torch.empty(M, Di, dtype=torch.float32, device=x.device)
@@ -210,7 +210,7 @@ class MambaInnerFn(torch.autograd.Function):
         h_y, p_y, e_y = _slot_args(track, x.device)
         check(lib().resel_selective_scan_fwd(_p(xc), Di, _p(dt), Di, zptr, 2 * Di, _p(A), bptr, R + 2 * N, cptr, R + 2 * N,
                                              _p(D), None if fold else _p(dt_b), _p(startf), _p(y), Di, _p(ck), None, _p(_ws(nb, x.device) if nb else None),
-                                             Bsz, L, Di, N, 2 if fold else 1, SSCAN_TIME_SEGMENTS, p_y, e_y, _stream()), 'selective_scan_fwd')
+                                             Bsz, L, Di, N, 4 + (2 if fold else 1), SSCAN_TIME_SEGMENTS, p_y, e_y, _stream()), 'selective_scan_fwd')
         tag_amax(y, h_y)
         out = mm_nt(y, out_w)
         ctx.handles = keep_handles(ctx.ax, h_xc, h_y)                      # saved tensors come back untagged
@@ -247,7 +247,7 @@ class MambaInnerFn(torch.autograd.Function):
             _p(xc), Di, _p(dt), Di, P(xz, Di), 2 * Di, _p(A), P(x_dbl, R), R + 2 * N, P(x_dbl, R + N), R + 2 * N,
             _p(D), None if ctx.fold else _p(dt_b), _p(startf), _p(dy), Di, _p(ck),
             _p(dxc), Di, _p(ddt), Di, P(dxz, Di), 2 * Di, P(dx_dbl, R), R + 2 * N, P(dx_dbl, R + N), R + 2 * N,
-            _p(dA), _p(dD), _p(ddt_b), _p(ws), Bsz, L, Di, N, 2 if ctx.fold else 1, SSCAN_TIME_SEGMENTS, p_dxz, p_ddt, e_b, _stream()), 'selective_scan_bwd')
+            _p(dA), _p(dD), _p(ddt_b), _p(ws), Bsz, L, Di, N, 4 + (2 if ctx.fold else 1), SSCAN_TIME_SEGMENTS, p_dxz, p_ddt, e_b, _stream()), 'selective_scan_bwd')
         tag_amax(ddt, h_ddt)
         # [Di, R] with a 66 752-long reduction: hand-written MFMA kernel (the library reaches 7 TFLOP/s on this shape)
         d_dt_w = atb(ddt, x_dbl[:, :R]) if R <= 32 and Di % 4 == 0 and ddt.stride(1) == 1 and ddt.stride(0) % 4 == 0 \
@@ -265,7 +265,7 @@ class MambaInnerFn(torch.autograd.Function):
         tag_amax(dxz, h_dxz)
         d_in_w = wgrad(dxz, x2, amax_x=ax)
         dx = mm_nn(dxz, in_w).view(Bsz, L, Dm) if ctx.needs_input_grad[0] else None
-        return (dx, d_in_w, dcw.reshape(cw_shape), dcb, d_xproj_w, d_dt_w, ddt_b, dA * A, dD, d_out_w, None, None)
+        return (dx, d_in_w, dcw.reshape(cw_shape), dcb, d_xproj_w, d_dt_w, ddt_b, dA, dD, d_out_w, None, None)      # dA: already dL/dA_log
 
 
 def mamba_inner_fn(x, in_w, conv_w, conv_b, xproj_w, dt_w, dt_b, A_log, D, out_w, mask=None, start=None):
