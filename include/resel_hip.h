@@ -373,7 +373,8 @@ int resel_gemm_f32(const float* A, int64_t lda, int64_t strideA, int a_kcontig,
  * Two kernels serve mode 2 (same results to rounding of the same three plane products; b1s is formed from b1 next to the matrix
  * instruction in both): the producer / consumer edition for K and K slices that are multiples of 32 and row strides < 2^22
  * (csrc/gemm_bf3.hip `gemm_ws_kernel`), the one-role edition for the rest.  Environment, read once at load: RESEL_GEMM_EDITION=2 sends
- * everything to the one-role edition. */
+ * everything to the one-role edition; =4 sends tall products with A in its [rows][K] form to an experimental 256 x 256 block tile
+ * (`gemm_w8_kernel`; measured equal or slower as a whole, profiles/r05_gemm.md 4b). */
 int resel_gemm_f32x(const float* A, int64_t lda, int64_t strideA, int a_kcontig,
                     const float* B, int64_t ldb, int64_t strideB, int b_kcontig,
                     const float* bias, int64_t strideBias, int act,

@@ -1339,6 +1339,251 @@ __global__ __launch_bounds__(NTH_WS, 1) void gemm_ws_kernel(Params p) {
     amax_publish_wave(cmax, p.amaxC);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Fourth edition (experimental, RESEL_GEMM_EDITION=4; mode 2, A [rows][K], whole K steps, one batch member, no K slices): a 256 x 256
+// BLOCK TILE - a third fewer L2 -> CU bytes per product than 256 x 128 (profiles/r04_gemm.md: the K loop is byte-bound).  The 1 024
+// accumulator registers per lane of such a tile do not fit the producer / consumer form (four consumer waves x 256 + fragments), so
+// every wave does everything again (second edition's structure): 8 waves as 2 x 4, wave tile 128 x 64 = 128 accumulator registers,
+// ONE fragment set (48 registers: the other wave of the SIMD covers the LDS round trips), 32 staging registers (each thread loads,
+// splits and stores 1 / 512 of both tiles: four 16-byte pieces per operand and K step).  LDS: two planes per operand, 64 KB per stage,
+// two stages; the epilogue turns its tiles through the stage that has just been consumed (a barrier per item keeps a fast wave's
+// next plane stores out of a slow wave's scratch).
+constexpr int BN8 = 256;
+constexpr int PLB8 = BN8 * ROWB;
+constexpr int STAGE8 = 2 * PLA + 2 * PLB8;          // 65 536 bytes
+constexpr int W8_LDS = 2 * STAGE8;
+
+__device__ __forceinline__ void tile_origin8(const Params& p, int t, int& m0, int& n0) {
+    const int ntile = p.mt * p.nt;                   // p.nt counts 256-column tiles here
+    const int q = ntile / 8, r = ntile % 8, x = t & 7, j = t >> 3;
+    const int bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+    m0 = (bid / p.nt) * BM;
+    n0 = (bid % p.nt) * BN8;
+}
+
+template <bool BKC>
+__global__ __launch_bounds__(512, 1) void gemm_w8_kernel(Params p) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const float sa_ = f16_scale(amax_read(p.amaxA)), sb_ = f16_scale(amax_read(p.amaxB));
+    const f32x2_t scA = {sa_, 2048.f * sa_}, scB = {sb_, 2048.f * sb_};
+    const float unscale = (1.f / sa_) * (1.f / sb_);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = (w >> 2) * 128, wn = (w & 3) * 64;
+    const int li = lane & 31, lh = lane >> 5;
+    const int total = p.nfull, G = gridDim.x;
+    if ((int)blockIdx.x >= total) return;
+
+    Src<true, BM> sa;
+    Src<BKC, BN8> sb;
+    sa.init_lds(tid);
+    sb.init_lds(tid);
+    int p_item = blockIdx.x, p_k0 = 0;
+    bool p_live = true;
+    auto p_open = [&]() {
+        int m0, n0;
+        tile_origin8(p, p_item, m0, n0);
+        sa.init(p.A, p.lda, p.M, m0, 0, tid);
+        sb.init(p.B, p.ldb, p.N, n0, 0, tid);
+        p_k0 = 0;
+    };
+    auto produce = [&]() {                          // global loads of the next K step in program order (also across items)
+        if (!p_live) return;
+        sa.load(p_k0, p.K);
+        sb.load(p_k0, p.K);
+        p_k0 += BK;
+        if (p_k0 >= p.K) {
+            p_item += G;
+            if (p_item < total) p_open(); else p_live = false;
+        }
+    };
+    auto stage_store = [&](int st) {
+        sa.template store<PLA, 2, 1>(lds + st * STAGE8, scA);
+        sb.template store<PLB8, 2, 2>(lds + st * STAGE8 + 2 * PLA, scB);
+    };
+    const char* fa[2];
+    const char* fb[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        fa[s] = lds + wm * ROWB + plane_off(li, 2 * s + lh);
+        fb[s] = lds + 2 * PLA + wn * ROWB + plane_off(li, 2 * s + lh);
+    }
+    struct F4 { f16x8 a[2][4], b[2][2]; };
+    auto rd = [&](F4& f, const char* pa, const char* pb) {
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) f.a[pi][t] = *reinterpret_cast<const f16x8*>(pa + pi * PLA + t * 32 * ROWB);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) f.b[pi][t] = *reinterpret_cast<const f16x8*>(pb + pi * PLB8 + t * 32 * ROWB);
+        }
+    };
+    f32x16 acc[4][2];
+    auto mm = [&](const F4& f) {                    // a2 (2^-11 b1) + a1 b2 + a1 b1, the small terms first
+        const f16x8 k = {(_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f,
+                         (_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f};
+        const f16x8 bs0 = f.b[0][0] * k, bs1 = f.b[0][1] * k;
+#ifdef BF3_AB_NOMFMA
+#pragma unroll
+        for (int a = 0; a < 4; ++a) asm volatile("" :: "v"(f.a[0][a]), "v"(f.a[1][a]), "v"(bs0), "v"(bs1), "v"(f.b[0][0]), "v"(f.b[0][1]), "v"(f.b[1][0]), "v"(f.b[1][1]));
+        return;
+#endif
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[1][a], bs0, acc[a][0], 0, 0, 0);
+            acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[1][a], bs1, acc[a][1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 1; q >= 0; --q)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[0][a], f.b[q][0], acc[a][0], 0, 0, 0);
+                acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[0][a], f.b[q][1], acc[a][1], 0, 0, 0);
+            }
+    };
+    float cmax = 0.f;
+    F4 f;
+    p_open();
+    produce();
+    stage_store(0);
+    produce();
+    __syncthreads();
+    int cur_st = 0;
+    for (int c_item = blockIdx.x; c_item < total; c_item += G) {
+        int m0, n0;
+        tile_origin8(p, c_item, m0, n0);
+        float zero = 0.f;
+        asm volatile("" : "+v"(zero));
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[a][b][e] = zero;
+        float bv[2] = {0.f, 0.f};
+        for (int c_k0 = 0; c_k0 < p.K; c_k0 += BK) {
+            const int so = cur_st * STAGE8;
+            const bool fast = p_live && p_k0 + BK <= p.K;
+            if (c_k0 + BK >= p.K && p.bias) {
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int n = n0 + wn + 32 * b + li;
+                    bv[b] = p.bias[n < p.N ? n : 0];
+                }
+            }
+            BF3_FENCE();
+            rd(f, fa[0] + so, fb[0] + so);
+            mm(f);
+            stage_store(cur_st ^ 1);                 // the tile of step s + 1 (its loads were issued a step ago)
+            BF3_FENCE();
+            rd(f, fa[1] + so, fb[1] + so);
+            mm(f);
+            sa.load_sched(fast);                     // the tile of step s + 2 into the registers the split has released
+            sb.load_sched(fast);
+            BF3_FENCE();
+#ifdef BF3_AB_NOBAR
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // stage s + 1 is complete; every wave has read stage s
+#endif
+            BF3_FENCE();
+            if (fast) {
+                p_k0 += BK;
+                if (p_k0 >= p.K) {
+                    p_item += G;
+                    if (p_item < total) p_open(); else p_live = false;
+                }
+            } else {
+                produce();
+            }
+            BF3_FENCE();
+            cur_st ^= 1;
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[a][b][e] *= unscale;
+        float* C = p.C;
+#ifdef BF3_AB_NOEPI
+        if (lane == 0) C[(int64_t)m0 * p.ldc + n0 + w] = acc[0][0][0] + acc[1][1][1] + acc[2][0][2] + acc[3][1][3];
+        __syncthreads();
+        continue;
+#endif
+        const bool full_m = m0 + BM <= p.M;
+        if (full_m && n0 + BN8 <= p.N) {
+            // whole tiles leave through a wave-private 5 KB scratch in the stage that has just been consumed (cur_st now names the OTHER one,
+            // which already holds the next item's first tile)
+            char* sc = lds + (cur_st ^ 1) * STAGE8 + w * 5120;
+            float* wr = reinterpret_cast<float*>(sc) + (4 * lh) * 40 + li;
+            const float4* rdp = reinterpret_cast<const float4*>(sc + (lane >> 3) * 160 + (lane & 7) * 16);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    float v[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) v[e] = acc[a][b][e] + bv[b];
+                    if (p.act == 1) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) v[e] = elu1(v[e]);
+                    }
+                    if (p.act == 3) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) v[e] = softplus_nb(v[e]);
+                    }
+                    if (p.amaxC.slot) {
+#pragma unroll
+                        for (int e = 0; e < 16; e += 2) cmax = fmaxf(cmax, fmaxf(__builtin_fabsf(v[e]), __builtin_fabsf(v[e + 1])));
+                    }
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) wr[((e & 3) + 8 * (e >> 2)) * 40] = v[e];
+                    float* q = C + (int64_t)(m0 + wm + 32 * a + (lane >> 3)) * p.ldc + n0 + wn + 32 * b + 4 * (lane & 7);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 t = rdp[g * 8 * 10];
+                        typedef float f4v __attribute__((ext_vector_type(4)));
+                        __builtin_nontemporal_store(f4v{t.x, t.y, t.z, t.w}, reinterpret_cast<f4v*>(q + (int64_t)(8 * g) * p.ldc));
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int n = n0 + wn + 32 * b + li;
+                if (n >= p.N) continue;
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    float v[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) v[e] = acc[a][b][e] + bv[b];
+                    if (p.act == 1) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) v[e] = elu1(v[e]);
+                    }
+                    if (p.act == 3) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) v[e] = softplus_nb(v[e]);
+                    }
+                    const int mb = m0 + wm + 32 * a + 4 * lh;
+                    float* crow = C + (int64_t)mb * p.ldc + n;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int dm = (e & 3) + 8 * (e >> 2);
+                        if (mb + dm < p.M) crow[(int64_t)dm * p.ldc] = v[e];
+                    }
+                    if (p.amaxC.slot) {
+#pragma unroll
+                        for (int e = 0; e < 16; e += 2) cmax = fmaxf(cmax, fmaxf(__builtin_fabsf(v[e]), __builtin_fabsf(v[e + 1])));
+                    }
+                }
+            }
+        }
+        __syncthreads();                             // the scratch sits in the stage the next item's first step stores into
+    }
+    amax_publish_wave(cmax, p.amaxC);
+}
+
 // C tile = epi(sum over the K slices of a split tile), fixed summation order: as gemm_fixup_kernel of gemm_f32.hip for 256 x 128 tiles
 __global__ __launch_bounds__(256) void gemm_bf3_fixup_kernel(Params p) {
     __shared__ float4 part[3][64];
@@ -1484,7 +1729,28 @@ int gemm_bf3_launch(const float* A, int64_t lda, int64_t strideA, int a_kcontig,
          else if (b_kcontig) rc = launch_ws<false, true, SP>(p, grid, s); \
          else rc = launch_ws<false, false, SP>(p, grid, s); } while (0)
     // third edition: mode 2, whole K steps (also per K slice); row strides within the 24-bit multiply of the piece offsets
-    const bool ws = g_edition == 3 && split == 2 && K % BK == 0 && pl.kslice % BK == 0 && lda < (1 << 22) && ldb < (1 << 22);
+    const bool ws = g_edition >= 3 && split == 2 && K % BK == 0 && pl.kslice % BK == 0 && lda < (1 << 22) && ldb < (1 << 22);
+    // fourth edition (RESEL_GEMM_EDITION=4): tall products with A [rows][K], whole K steps, a whole number of 256-column tiles or a last
+    // one that is more than half full, no bias stride (one batch member), epilogues 0 / 1 / 3
+    if (g_edition == 4 && split == 2 && act != 2 && act < 4 && a_kcontig && batch == 1 && K % BK == 0 && K >= 2 * BK && M >= 2048 && N >= 192 &&
+        ((N + BN8 - 1) / BN8 * BN8 - N) < 128 && lda < (1 << 22) && ldb < (1 << 22)) {
+        Params q = p;
+        q.nt = (N + BN8 - 1) / BN8;
+        q.nfull = q.mt * q.nt;
+        q.nsplit = 0;
+        dim3 g8((unsigned)std::min<int64_t>(q.nfull, GRID));
+        static std::atomic<bool> attr8[2][64];
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return RESEL_ELAUNCH;
+        if (!attr8[b_kcontig ? 1 : 0][dev].load(std::memory_order_acquire)) {
+            const void* fn = b_kcontig ? (const void*)gemm_w8_kernel<true> : (const void*)gemm_w8_kernel<false>;
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS) != hipSuccess) return RESEL_ELAUNCH;
+            attr8[b_kcontig ? 1 : 0][dev].store(true, std::memory_order_release);
+        }
+        if (b_kcontig) launch_timed(RESEL_PROF_GEMM, gemm_w8_kernel<true>, g8, dim3(512), (size_t)W8_LDS, s, q);
+        else launch_timed(RESEL_PROF_GEMM, gemm_w8_kernel<false>, g8, dim3(512), (size_t)W8_LDS, s, q);
+        return launch_status();
+    }
     if (act >= 4) {                                   // fused epilogues: the layouts the trainer uses - A [rows][K]; B either way
         if (!a_kcontig) return RESEL_EINVAL;
         if (act == 4) rc = b_kcontig ? launch_ws<true, true, 2, 4>(p, grid, s) : launch_ws<true, false, 2, 4>(p, grid, s);

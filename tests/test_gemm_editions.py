@@ -28,10 +28,13 @@ def test_producer_loop_isa(tmp_path):
 
 
 @pytest.mark.gpu
-def test_large_grids_against_mode6():
+@pytest.mark.parametrize('edition', ['3', '4'])
+def test_large_grids_against_mode6(edition):
+    """edition 4 = the experimental 256 x 256 block tile (`gemm_w8_kernel`: takes the tall A-[rows][K] shapes of the sweep, the rest falls
+    through to edition 3); off by default, kept selectable for the A/B in profiles/r05_gemm.md."""
     if not torch.cuda.is_available():
         pytest.skip('needs a GPU')
-    env = dict(os.environ, RESEL_GEMM_EDITION='3')
+    env = dict(os.environ, RESEL_GEMM_EDITION=edition)
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'gemm_sweep.py')], capture_output=True, text=True, env=env, timeout=900)
     print(r.stdout[-2000:])
     assert r.returncode == 0 and 'cases ok' in r.stdout and 'BAD' not in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
