@@ -458,6 +458,11 @@ class SACFullLengthRNNEnsembleQ(SAC):
 
     # ------------------------------------------------------------------------------------------ the update
     def train_one_batch(self) -> Dict:
+        from ..models.rnn_base import training_pass
+        with training_pass():                                    # no pass of an update reads the per-layer output sequences (rnn_base.py)
+            return self._train_one_batch()
+
+    def _train_one_batch(self) -> Dict:
         par = self.parameter
         if self._graph is None and self.device.type == 'cuda':
             ops.amax_maintenance()                               # update boundary: the magnitude epochs may start over here (hip/ops.py)

@@ -81,6 +81,22 @@ def parse_cgpt_id(layer_id: str) -> dict:
     return cfg
 
 
+# Set by the trainers around an update (`training_pass()`): nobody reads the per-layer output sequences (`full_rnn_memory`) of a training
+# pass, so a sequence layer may hand back its output with the following plain ELU already applied by its last GEMM's epilogue (the
+# reference's full hidden holds the PRE-activation sequence, rnn_base.py:456-460: outside a training pass nothing changes).  The entry of
+# such a layer in the returned `full` RNNHidden is None.
+_TRAINING_PASS = [0]
+
+
+class training_pass:
+    def __enter__(self):
+        _TRAINING_PASS[0] += 1
+
+    def __exit__(self, *exc):
+        _TRAINING_PASS[0] -= 1
+        return False
+
+
 def is_rnn_layer(layer_id: str) -> bool:
     return layer_id != 'fc' and not layer_id.startswith('efc')
 
@@ -255,7 +271,16 @@ class RNNBase(torch.nn.Module):
                 elif lid == 'lru':
                     x, h = layer(x, hidden_state[k], hidden_state.rnn_start, hidden_state.grad_detach)
                 elif lid.startswith('smamba'):
-                    x, h = layer(x, hidden_state[k], hidden_state.rnn_start, hidden_state.mask)
+                    act_mod = self.activation_list[ind]
+                    fuse_act = (_TRAINING_PASS[0] > 0 and isinstance(act_mod, torch.nn.ELU) and act_mod.alpha == 1.0 and x.is_cuda
+                                and x.dtype == torch.float32 and x.dim() == 3 and x.shape[-2] > 1 and not layer.use_ff)
+                    x, h = layer(x, hidden_state[k], hidden_state.rnn_start, hidden_state.mask, out_act='elu' if fuse_act else None)
+                    if fuse_act:                       # the activation rode in the layer's last GEMM: skip the module below
+                        k += 1
+                        out_state.append(h)
+                        if require_full_hidden:
+                            full.append(None)
+                        continue
                 elif lid.startswith('mamba'):
                     x, h = layer(x, hidden_state[k], hidden_state.rnn_start, hidden_state.mask, hidden_state.grad_detach)
                 elif lid.startswith('conv1d'):

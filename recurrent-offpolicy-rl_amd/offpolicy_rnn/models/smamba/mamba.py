@@ -155,7 +155,8 @@ class BlockList(nn.Module):
             self.norm_f = norm_cls(dim)
         self.apply(partial(_init_weights, n_layer=block_num))
 
-    def forward(self, x, hidden=None, rnn_start=None, mask=None):
+    def forward(self, x, hidden=None, rnn_start=None, mask=None, out_act=None):
+        """out_act = 'elu': the caller's plain ELU behind this layer is applied by the head GEMM's epilogue (training passes, rnn_base.py)."""
         if hidden is None:
             hidden = torch.zeros((1, x.shape[0], self.desired_hidden_dim), device=x.device)
         states = torch.chunk(hidden, self.block_num, dim=-1)
@@ -170,6 +171,10 @@ class BlockList(nn.Module):
         else:
             x = x + residual
         # the bias-free head Linear through ops.linear (hand-written GEMM forward / input gradient / weight gradient on training passes)
-        x = ops.linear(x, self.head.weight, None) if isinstance(self.head, nn.Linear) and x.shape[-2] > 1 else self.head(x)
+        if out_act is not None:
+            assert isinstance(self.head, nn.Linear) and x.shape[-2] > 1
+            x = ops.linear_act(x, self.head.weight, None, out_act)
+        else:
+            x = ops.linear(x, self.head.weight, None) if isinstance(self.head, nn.Linear) and x.shape[-2] > 1 else self.head(x)
         # whole-row passes leave the state placeholders untouched: hand the caller's tensor back instead of re-assembling it (12.6 MB at config 2)
         return x, (hidden if all(o is st for o, st in zip(outs, states)) else torch.cat(outs, dim=-1))
