@@ -44,3 +44,41 @@ def test_layer_fwd_bwd_vs_reference_recording(lid):
             np.testing.assert_allclose(params[name].grad.cpu(), v, rtol=2e-3, atol=3e-4, err_msg=name)
             checked += 1
     assert checked > 0
+
+
+def test_training_pass_fuses_the_elu_behind_smamba_without_changing_values():
+    """Inside `rnn_base.training_pass()` (the trainers' updates) the plain ELU behind a smamba layer is applied by the layer's last GEMM and the
+    layer's entry in the returned full-hidden record is None; outside, the record holds the PRE-activation sequence as in the reference
+    (rnn_base.py:456-460).  Outputs and every gradient agree between the two forms."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from offpolicy_rnn.models.rnn_base import RNNBase, training_pass
+    torch.manual_seed(3)
+    net = RNNBase(96, 64, [256, 256], ['elu', 'elu', 'linear'], ['fc', 'smamba_s16_c4_b1_nln', 'fc']).cuda()
+    B, L = 4, 1100                                              # 4 400 tokens: the hand-written GEMMs (and their ELU epilogue) run
+    x = torch.randn(B, L, 96, device='cuda')
+    start = torch.zeros(B, L, 1, device='cuda')
+    start[:, :5] = 1
+    mask = torch.ones(B, L, 1, device='cuda')
+    w = torch.randn(B, L, 64, device='cuda')
+    res = []
+    for fused in (False, True):
+        net.zero_grad()
+        xs = x.clone().requires_grad_(True)
+        hid = net.make_init_state(B, torch.device('cuda'))
+        hid.set_rnn_start(start)
+        hid.set_mask(mask)
+        if fused:
+            with training_pass():
+                y, _, full = net.meta_forward(xs, hid, require_full_hidden=True)
+        else:
+            y, _, full = net.meta_forward(xs, hid, require_full_hidden=True)
+        (y * w).sum().backward()
+        res.append((y.detach(), xs.grad, [p.grad.clone() for p in net.parameters()], full))
+    (y0, g0, p0, f0), (y1, g1, p1, f1) = res
+    assert f1[0] is None and torch.is_tensor(f0[0]) and f0[0].shape == (B, L, 256)
+    assert (f0[0] < -1.0).any(), 'the unfused record is the pre-activation sequence (an ELU output never goes below -1)'
+    tol = lambda a, b: (a - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-6)
+    assert tol(y1, y0) and tol(g1, g0)
+    for a, b in zip(p1, p0):
+        assert tol(a, b)
