@@ -147,23 +147,27 @@ int resel_add_layernorm_bwd(const float* dy, const float* dres_in, const float* 
  * (CPU specs real_rnn_tie_input_gate_cpu.py:4-14, complex_rnn_cpu.py:4-26) with a time-parallel chunked scan.
  * real:    v' = act ? tanh(v) : v ; f' = (act ? sigmoid(f) : f) * (1 - start) ; h_t = f'_t h_{t-1} + (1 - f'_t) v'_t
  * complex: h_t = lambda (1 - start_t) h_{t-1} + gamma * (vr_t + i vi_t)       (lambda, gamma per channel)
- * v, f, h, vr, vi, hr, hi: dense [B, L, C]; start: [B*L] or NULL; h0*: [B, C] or NULL (zeros).
+ * h, hr, hi, dh*: dense [B, L, C]; start: [B*L] or NULL; h0*: [B, C] or NULL (zeros).
+ * v, f / vr, vi and their gradients may be column blocks of a wider token-major matrix (ABI 8): `ld_u` / `ld_du` = floats between the
+ * rows of consecutive tokens (>= C; C for dense tensors).  The layers hand in the [M, E C] output of their shared-input EnsembleLinear
+ * in place (reference gilr.py:60-62 / lru.py:112-120 slice an [E, B, T, C] tensor) and receive the gradients in the same layout.
  * Backward outputs are gradients w.r.t. the PRE-activation v, f (real) / vr, vi, lambda, gamma (complex;
  * dlam_re, dlam_im, dgamma: [C], reduced over B and L).  No gradient flows into h0 (reference: complex_rnn.py:242).
+ * amax_h / amax_du (optional magnitude handles, see resel_amax): max |h| (complex: over hr and hi) / max over dv and df.
  */
-int resel_linrec_real_fwd(const float* v, const float* f, const float* start, const float* h0, float* h,
-                          int B, int L, int C, int fuse_act, resel_stream_t stream);
-int resel_linrec_real_bwd(const float* v, const float* f, const float* start, const float* h0, const float* h,
-                          const float* dh, float* dv, float* df, int B, int L, int C, int fuse_act,
-                          resel_stream_t stream);
-int resel_linrec_complex_fwd(const float* vr, const float* vi, const float* lam_re, const float* lam_im,
+int resel_linrec_real_fwd(const float* v, const float* f, int64_t ld_u, const float* start, const float* h0, float* h,
+                          int B, int L, int C, int fuse_act, void* amax_h, unsigned amax_epoch, resel_stream_t stream);
+int resel_linrec_real_bwd(const float* v, const float* f, int64_t ld_u, const float* start, const float* h0, const float* h,
+                          const float* dh, float* dv, float* df, int64_t ld_du, int B, int L, int C, int fuse_act,
+                          void* amax_du, unsigned amax_epoch, resel_stream_t stream);
+int resel_linrec_complex_fwd(const float* vr, const float* vi, int64_t ld_u, const float* lam_re, const float* lam_im,
                              const float* gamma, const float* start, const float* h0r, const float* h0i,
-                             float* hr, float* hi, int B, int L, int C, resel_stream_t stream);
+                             float* hr, float* hi, int B, int L, int C, void* amax_h, unsigned amax_epoch, resel_stream_t stream);
 size_t resel_linrec_complex_bwd_workspace_bytes(int B, int L, int C);
-int resel_linrec_complex_bwd(const float* vr, const float* vi, const float* lam_re, const float* lam_im,
+int resel_linrec_complex_bwd(const float* vr, const float* vi, int64_t ld_u, const float* lam_re, const float* lam_im,
                              const float* gamma, const float* start, const float* h0r, const float* h0i,
                              const float* hr, const float* hi, const float* dhr, const float* dhi,
-                             float* dvr, float* dvi, float* dlam_re, float* dlam_im, float* dgamma,
+                             float* dvr, float* dvi, int64_t ld_du, float* dlam_re, float* dlam_im, float* dgamma,
                              void* workspace, int B, int L, int C, resel_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------

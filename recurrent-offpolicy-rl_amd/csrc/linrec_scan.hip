@@ -51,8 +51,8 @@ __device__ __forceinline__ void gilr_gate(float vraw, float fraw, float keep, in
 
 template <bool ACT, int CL>
 __global__ __launch_bounds__(NSEG * 64) void linrec_real_fwd_kernel(const float* __restrict__ v, const float* __restrict__ f,
-                                                                    const float* __restrict__ start, const float* __restrict__ h0,
-                                                                    float* __restrict__ h, int B, int L, int C) {
+                                                                    int64_t ld_u, const float* __restrict__ start, const float* __restrict__ h0,
+                                                                    float* __restrict__ h, int B, int L, int C, AmaxOut amax_h) {
     constexpr int act = ACT ? 1 : 0;
     constexpr int NST = NSEG * 64 / CL;                          // time segments of this workgroup
     __shared__ float s_a[NST][CL], s_c[NST][CL];
@@ -61,14 +61,14 @@ __global__ __launch_bounds__(NSEG * 64) void linrec_real_fwd_kernel(const float*
     const int b = blockIdx.y, c = blockIdx.x * CL + lane;
     stage_keep(s_keep, start, b, L);
     const bool ok = c < C;
-    const int64_t base = (int64_t)b * L * C + c;
+    const int64_t base = (int64_t)b * L * C + c, ubase = (int64_t)b * L * ld_u + c;     // h is dense, (v, f) rows are ld_u apart
     const Seg sg = segment<NST>(w, L);
     float a = 1.f, hl = 0.f;
     if (ok) {
 #pragma unroll 8
         for (int t = sg.t0; t < sg.t1; ++t) {
             float vv, fe;
-            gilr_gate(v[base + (int64_t)t * C], f[base + (int64_t)t * C], s_keep[t], act, vv, fe);
+            gilr_gate(v[ubase + (int64_t)t * ld_u], f[ubase + (int64_t)t * ld_u], s_keep[t], act, vv, fe);
             hl = __builtin_fmaf(fe, hl - vv, vv);                 // f h + (1 - f) v
             a *= fe;
         }
@@ -78,25 +78,28 @@ __global__ __launch_bounds__(NSEG * 64) void linrec_real_fwd_kernel(const float*
     __syncthreads();
     float hin = (h0 && ok) ? h0[(int64_t)b * C + c] : 0.f;
     for (int ww = 0; ww < w; ++ww) hin = __builtin_fmaf(s_a[ww][lane], hin, s_c[ww][lane]);
+    float hmax = 0.f;
     if (ok) {
         float hc = hin;
 #pragma unroll 8
         for (int t = sg.t0; t < sg.t1; ++t) {
             float vv, fe;
-            gilr_gate(v[base + (int64_t)t * C], f[base + (int64_t)t * C], s_keep[t], act, vv, fe);
+            gilr_gate(v[ubase + (int64_t)t * ld_u], f[ubase + (int64_t)t * ld_u], s_keep[t], act, vv, fe);
             hc = __builtin_fmaf(fe, hc - vv, vv);
             h[base + (int64_t)t * C] = hc;
+            hmax = fmaxf(hmax, __builtin_fabsf(hc));
         }
     }
+    amax_publish_wave(hmax, amax_h);
 }
 
 // g_t = dh_t + f_{t+1} g_{t+1} ;  dv_t = g_t (1 - f_t) ;  df_t = g_t (h_{t-1} - v_t)   (then through tanh / sigmoid)
 template <bool ACT, int CL>
 __global__ __launch_bounds__(NSEG * 64) void linrec_real_bwd_kernel(const float* __restrict__ v, const float* __restrict__ f,
-                                                                    const float* __restrict__ start, const float* __restrict__ h0,
+                                                                    int64_t ld_u, const float* __restrict__ start, const float* __restrict__ h0,
                                                                     const float* __restrict__ h, const float* __restrict__ dh,
-                                                                    float* __restrict__ dv, float* __restrict__ df,
-                                                                    int B, int L, int C) {
+                                                                    float* __restrict__ dv, float* __restrict__ df, int64_t ld_du,
+                                                                    int B, int L, int C, AmaxOut amax_du) {
     constexpr int act = ACT ? 1 : 0;
     constexpr int NST = NSEG * 64 / CL;                          // time segments of this workgroup
     __shared__ float s_a[NST][CL], s_c[NST][CL];
@@ -105,10 +108,10 @@ __global__ __launch_bounds__(NSEG * 64) void linrec_real_bwd_kernel(const float*
     const int b = blockIdx.y, c = blockIdx.x * CL + lane;
     stage_keep(s_keep, start, b, L);
     const bool ok = c < C;
-    const int64_t base = (int64_t)b * L * C + c;
+    const int64_t base = (int64_t)b * L * C + c, ubase = (int64_t)b * L * ld_u + c, dbase = (int64_t)b * L * ld_du + c;
     const Seg sg = segment<NST>(w, L);
     auto gate_f = [&](int t) -> float {                          // effective gate f_t (0 beyond the row end: keep sentinel)
-        const float fr = f[base + (int64_t)min(t, L - 1) * C];
+        const float fr = f[ubase + (int64_t)min(t, L - 1) * ld_u];
         return (act ? sigmoidf_(fr) : fr) * s_keep[t];
     };
     float a = 1.f, gl = 0.f;
@@ -124,6 +127,7 @@ __global__ __launch_bounds__(NSEG * 64) void linrec_real_bwd_kernel(const float*
     s_a[w][lane] = a;
     s_c[w][lane] = gl;
     __syncthreads();
+    float dmax = 0.f;
     float gin = 0.f;                                              // g just right of this segment
     for (int ww = NST - 1; ww > w; --ww) gin = __builtin_fmaf(s_a[ww][lane], gin, s_c[ww][lane]);
     if (ok && sg.t1 > sg.t0) {
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(NSEG * 64) void linrec_real_bwd_kernel(const float*
         for (int t = sg.t1 - 1; t >= sg.t0; --t) {
             g = __builtin_fmaf(fnext, g, dh[base + (int64_t)t * C]);
             const float keep = s_keep[t];
-            const float vraw = v[base + (int64_t)t * C], fraw = f[base + (int64_t)t * C];
+            const float vraw = v[ubase + (int64_t)t * ld_u], fraw = f[ubase + (int64_t)t * ld_u];
             const float vv = act ? tanhf_(vraw) : vraw;
             const float sg_ = act ? sigmoidf_(fraw) : fraw;
             const float fe = sg_ * keep;
@@ -146,11 +150,13 @@ __global__ __launch_bounds__(NSEG * 64) void linrec_real_bwd_kernel(const float*
                 gv *= (1.f - vv * vv);
                 gf *= sg_ * (1.f - sg_);
             }
-            dv[base + (int64_t)t * C] = gv;
-            df[base + (int64_t)t * C] = gf;
+            dv[dbase + (int64_t)t * ld_du] = gv;
+            df[dbase + (int64_t)t * ld_du] = gf;
+            dmax = fmaxf(dmax, fmaxf(__builtin_fabsf(gv), __builtin_fabsf(gf)));
             fnext = fe;
         }
     }
+    amax_publish_wave(dmax, amax_du);
 }
 
 // --------------------------------------------------------------------------------------- complex (lru)
@@ -159,7 +165,8 @@ __global__ __launch_bounds__(NSEG * 64) void linrec_complex_fwd_kernel(const flo
                                                                        const float* __restrict__ lam_re, const float* __restrict__ lam_im,
                                                                        const float* __restrict__ gamma, const float* __restrict__ start,
                                                                        const float* __restrict__ h0r, const float* __restrict__ h0i,
-                                                                       float* __restrict__ hr, float* __restrict__ hi, int B, int L, int C) {
+                                                                       float* __restrict__ hr, float* __restrict__ hi, int B, int L, int C,
+                                                                       int64_t ld_u, AmaxOut amax_h) {
     constexpr int NST = NSEG * 64 / CL;
     __shared__ float s_ar[NST][CL], s_ai[NST][CL], s_cr[NST][CL], s_ci[NST][CL];
     extern __shared__ float s_keep[];
@@ -167,7 +174,7 @@ __global__ __launch_bounds__(NSEG * 64) void linrec_complex_fwd_kernel(const flo
     const int b = blockIdx.y, c = blockIdx.x * CL + lane;
     stage_keep(s_keep, start, b, L);
     const bool ok = c < C;
-    const int64_t base = (int64_t)b * L * C + c;
+    const int64_t base = (int64_t)b * L * C + c, ubase = (int64_t)b * L * ld_u + c;
     const Seg sg = segment<NST>(w, L);
     const float lr = ok ? lam_re[c] : 0.f, li = ok ? lam_im[c] : 0.f, gm = (ok && gamma) ? gamma[c] : 1.f;
     float ar = 1.f, ai = 0.f, cr = 0.f, ci = 0.f;
@@ -176,7 +183,7 @@ __global__ __launch_bounds__(NSEG * 64) void linrec_complex_fwd_kernel(const flo
         for (int t = sg.t0; t < sg.t1; ++t) {
             const float keep = s_keep[t];
             const float fr = lr * keep, fi = li * keep;
-            const float xr = gm * vr[base + (int64_t)t * C], xi = gm * vi[base + (int64_t)t * C];
+            const float xr = gm * vr[ubase + (int64_t)t * ld_u], xi = gm * vi[ubase + (int64_t)t * ld_u];
             const float nr = cr * fr - ci * fi + xr, ni = cr * fi + ci * fr + xi;
             cr = nr; ci = ni;
             const float pr = ar * fr - ai * fi, pi = ar * fi + ai * fr;
@@ -191,19 +198,22 @@ __global__ __launch_bounds__(NSEG * 64) void linrec_complex_fwd_kernel(const flo
         const float nr = pr * xr0 - pi * xi0 + s_cr[ww][lane], ni = pr * xi0 + pi * xr0 + s_ci[ww][lane];
         xr0 = nr; xi0 = ni;
     }
+    float hmax = 0.f;
     if (ok) {
         float cr2 = xr0, ci2 = xi0;
 #pragma unroll 8
         for (int t = sg.t0; t < sg.t1; ++t) {
             const float keep = s_keep[t];
             const float fr = lr * keep, fi = li * keep;
-            const float xr = gm * vr[base + (int64_t)t * C], xi = gm * vi[base + (int64_t)t * C];
+            const float xr = gm * vr[ubase + (int64_t)t * ld_u], xi = gm * vi[ubase + (int64_t)t * ld_u];
             const float nr = cr2 * fr - ci2 * fi + xr, ni = cr2 * fi + ci2 * fr + xi;
             cr2 = nr; ci2 = ni;
             hr[base + (int64_t)t * C] = cr2;
             hi[base + (int64_t)t * C] = ci2;
+            hmax = fmaxf(hmax, fmaxf(__builtin_fabsf(cr2), __builtin_fabsf(ci2)));
         }
     }
+    amax_publish_wave(hmax, amax_h);
 }
 
 // g_t = dh_t + conj(f_{t+1}) g_{t+1} ; dv = gamma g ; dgamma += Re(g conj(v_raw)) ; dlambda += (1 - s_t) g conj(h_{t-1})
@@ -215,7 +225,7 @@ __global__ __launch_bounds__(NSEG * 64) void linrec_complex_bwd_kernel(const flo
                                                                        const float* __restrict__ hr, const float* __restrict__ hi,
                                                                        const float* __restrict__ dhr, const float* __restrict__ dhi,
                                                                        float* __restrict__ dvr, float* __restrict__ dvi,
-                                                                       float* __restrict__ part, int B, int L, int C) {
+                                                                       float* __restrict__ part, int B, int L, int C, int64_t ld_u, int64_t ld_du) {
     constexpr int NST = NSEG * 64 / CL;
     __shared__ float s_ar[NST][CL], s_ai[NST][CL], s_cr[NST][CL], s_ci[NST][CL];
     extern __shared__ float s_keep[];
@@ -223,7 +233,7 @@ __global__ __launch_bounds__(NSEG * 64) void linrec_complex_bwd_kernel(const flo
     const int b = blockIdx.y, c = blockIdx.x * CL + lane;
     stage_keep(s_keep, start, b, L);
     const bool ok = c < C;
-    const int64_t base = (int64_t)b * L * C + c;
+    const int64_t base = (int64_t)b * L * C + c, ubase = (int64_t)b * L * ld_u + c, dbase = (int64_t)b * L * ld_du + c;
     const Seg sg = segment<NST>(w, L);
     const float lr = ok ? lam_re[c] : 0.f, li = ok ? lam_im[c] : 0.f, gm = (ok && gamma) ? gamma[c] : 1.f;
     auto keep_at = [&](int t) -> float { return s_keep[t]; };          // sentinel slot L holds 0
@@ -263,9 +273,9 @@ __global__ __launch_bounds__(NSEG * 64) void linrec_complex_bwd_kernel(const flo
             const float pr = t > 0 ? plr : h0r_, pi = t > 0 ? pli : h0i_;
             dlr += kt * (g_r * pr + g_i * pi);                      // d/d lam_re : g . h_prev
             dli += kt * (g_i * pr - g_r * pi);                      // d/d lam_im
-            dgm += g_r * vr[base + (int64_t)t * C] + g_i * vi[base + (int64_t)t * C];
-            dvr[base + (int64_t)t * C] = gm * g_r;
-            dvi[base + (int64_t)t * C] = gm * g_i;
+            dgm += g_r * vr[ubase + (int64_t)t * ld_u] + g_i * vi[ubase + (int64_t)t * ld_u];
+            dvr[dbase + (int64_t)t * ld_du] = gm * g_r;
+            dvi[dbase + (int64_t)t * ld_du] = gm * g_i;
             kn = kt;
         }
     }
@@ -287,38 +297,46 @@ inline int pick_cl(int B, int C) {
 
 }  // namespace
 
-extern "C" int resel_linrec_real_fwd(const float* v, const float* f, const float* start, const float* h0, float* h,
-                                     int B, int L, int C, int fuse_act, resel_stream_t stream) {
-    if (!v || !f || !h || B <= 0 || L <= 0 || C <= 0) return RESEL_EINVAL;
+// (v, f) / (vr, vi) and their gradients may be column blocks of a wider token-major matrix - the [M, E C] output of a shared-input
+// EnsembleLinear, whose [E, B, T, C] view the layers slice: ld_u / ld_du = floats between consecutive tokens (>= C, multiples of 4 not needed:
+// every access is a 4-byte lane access).  h / dh are dense [B, L, C].
+inline bool amax_arg_ok(const void* a) { return !a || !(reinterpret_cast<uintptr_t>(a) & 7u); }
+
+extern "C" int resel_linrec_real_fwd(const float* v, const float* f, int64_t ld_u, const float* start, const float* h0, float* h,
+                                     int B, int L, int C, int fuse_act, void* amax_h, unsigned amax_epoch, resel_stream_t stream) {
+    if (!v || !f || !h || B <= 0 || L <= 0 || C <= 0 || ld_u < C || !amax_arg_ok(amax_h)) return RESEL_EINVAL;
     const int cl = pick_cl(B, C);
     const dim3 grid((C + cl - 1) / cl, B), blk(NSEG * 64);
     const size_t lds = (size_t)(L + 1) * sizeof(float);          // keep table (dynamic LDS)
     hipStream_t s = (hipStream_t)stream;
-    if (fuse_act) LINREC_DISPATCH(cl, (launch_timed(RESEL_PROF_LINREC_REAL_FWD, linrec_real_fwd_kernel<true, CL>, grid, blk, lds, s, v, f, start, h0, h, B, L, C)));
-    else LINREC_DISPATCH(cl, (launch_timed(RESEL_PROF_LINREC_REAL_FWD, linrec_real_fwd_kernel<false, CL>, grid, blk, lds, s, v, f, start, h0, h, B, L, C)));
+    const AmaxOut ao{(unsigned long long*)amax_h, amax_epoch};
+    if (fuse_act) LINREC_DISPATCH(cl, (launch_timed(RESEL_PROF_LINREC_REAL_FWD, linrec_real_fwd_kernel<true, CL>, grid, blk, lds, s, v, f, ld_u, start, h0, h, B, L, C, ao)));
+    else LINREC_DISPATCH(cl, (launch_timed(RESEL_PROF_LINREC_REAL_FWD, linrec_real_fwd_kernel<false, CL>, grid, blk, lds, s, v, f, ld_u, start, h0, h, B, L, C, ao)));
     return launch_status();
 }
 
-extern "C" int resel_linrec_real_bwd(const float* v, const float* f, const float* start, const float* h0, const float* h,
-                                     const float* dh, float* dv, float* df, int B, int L, int C, int fuse_act,
-                                     resel_stream_t stream) {
-    if (!v || !f || !h || !dh || !dv || !df || B <= 0 || L <= 0 || C <= 0) return RESEL_EINVAL;
+extern "C" int resel_linrec_real_bwd(const float* v, const float* f, int64_t ld_u, const float* start, const float* h0, const float* h,
+                                     const float* dh, float* dv, float* df, int64_t ld_du, int B, int L, int C, int fuse_act,
+                                     void* amax_du, unsigned amax_epoch, resel_stream_t stream) {
+    if (!v || !f || !h || !dh || !dv || !df || B <= 0 || L <= 0 || C <= 0 || ld_u < C || ld_du < C || !amax_arg_ok(amax_du)) return RESEL_EINVAL;
     const int cl = pick_cl(B, C);
     const dim3 grid((C + cl - 1) / cl, B), blk(NSEG * 64);
     const size_t lds = (size_t)(L + 1) * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
-    if (fuse_act) LINREC_DISPATCH(cl, (launch_timed(RESEL_PROF_LINREC_REAL_BWD, linrec_real_bwd_kernel<true, CL>, grid, blk, lds, s, v, f, start, h0, h, dh, dv, df, B, L, C)));
-    else LINREC_DISPATCH(cl, (launch_timed(RESEL_PROF_LINREC_REAL_BWD, linrec_real_bwd_kernel<false, CL>, grid, blk, lds, s, v, f, start, h0, h, dh, dv, df, B, L, C)));
+    const AmaxOut ao{(unsigned long long*)amax_du, amax_epoch};
+    if (fuse_act) LINREC_DISPATCH(cl, (launch_timed(RESEL_PROF_LINREC_REAL_BWD, linrec_real_bwd_kernel<true, CL>, grid, blk, lds, s, v, f, ld_u, start, h0, h, dh, dv, df, ld_du, B, L, C, ao)));
+    else LINREC_DISPATCH(cl, (launch_timed(RESEL_PROF_LINREC_REAL_BWD, linrec_real_bwd_kernel<false, CL>, grid, blk, lds, s, v, f, ld_u, start, h0, h, dh, dv, df, ld_du, B, L, C, ao)));
     return launch_status();
 }
 
-extern "C" int resel_linrec_complex_fwd(const float* vr, const float* vi, const float* lam_re, const float* lam_im,
+extern "C" int resel_linrec_complex_fwd(const float* vr, const float* vi, int64_t ld_u, const float* lam_re, const float* lam_im,
                                         const float* gamma, const float* start, const float* h0r, const float* h0i,
-                                        float* hr, float* hi, int B, int L, int C, resel_stream_t stream) {
-    if (!vr || !vi || !lam_re || !lam_im || !hr || !hi || B <= 0 || L <= 0 || C <= 0) return RESEL_EINVAL;
+                                        float* hr, float* hi, int B, int L, int C, void* amax_h, unsigned amax_epoch, resel_stream_t stream) {
+    if (!vr || !vi || !lam_re || !lam_im || !hr || !hi || B <= 0 || L <= 0 || C <= 0 || ld_u < C || !amax_arg_ok(amax_h)) return RESEL_EINVAL;
     const int cl = pick_cl(B, C);
+    const AmaxOut ao{(unsigned long long*)amax_h, amax_epoch};
     LINREC_DISPATCH(cl, (launch_timed(RESEL_PROF_LINREC_COMPLEX_FWD, linrec_complex_fwd_kernel<CL>, dim3((C + cl - 1) / cl, B), dim3(NSEG * 64),
-                                      (size_t)(L + 1) * sizeof(float), (hipStream_t)stream, vr, vi, lam_re, lam_im, gamma, start, h0r, h0i, hr, hi, B, L, C)));
+                                      (size_t)(L + 1) * sizeof(float), (hipStream_t)stream, vr, vi, lam_re, lam_im, gamma, start, h0r, h0i, hr, hi, B, L, C, ld_u, ao)));
     return launch_status();
 }
 
@@ -327,19 +345,19 @@ extern "C" size_t resel_linrec_complex_bwd_workspace_bytes(int B, int L, int C) 
     return (size_t)B * (NSEG * 4) * 3 * C * sizeof(float);      // up to 64 time segments per row (CL = 16)
 }
 
-extern "C" int resel_linrec_complex_bwd(const float* vr, const float* vi, const float* lam_re, const float* lam_im,
+extern "C" int resel_linrec_complex_bwd(const float* vr, const float* vi, int64_t ld_u, const float* lam_re, const float* lam_im,
                                         const float* gamma, const float* start, const float* h0r, const float* h0i,
                                         const float* hr, const float* hi, const float* dhr, const float* dhi,
-                                        float* dvr, float* dvi, float* dlam_re, float* dlam_im, float* dgamma,
+                                        float* dvr, float* dvi, int64_t ld_du, float* dlam_re, float* dlam_im, float* dgamma,
                                         void* workspace, int B, int L, int C, resel_stream_t stream) {
     if (!vr || !vi || !lam_re || !lam_im || !hr || !hi || !dhr || !dhi || !dvr || !dvi || !dlam_re || !dlam_im || !workspace ||
-        B <= 0 || L <= 0 || C <= 0)
+        B <= 0 || L <= 0 || C <= 0 || ld_u < C || ld_du < C)
         return RESEL_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const int cl = pick_cl(B, C), nst = NSEG * 64 / cl;
     LINREC_DISPATCH(cl, (launch_timed(RESEL_PROF_LINREC_COMPLEX_BWD, linrec_complex_bwd_kernel<CL>, dim3((C + cl - 1) / cl, B), dim3(NSEG * 64),
                                       (size_t)(L + 1) * sizeof(float), s, vr, vi, lam_re, lam_im, gamma, start, h0r, h0i, hr, hi, dhr, dhi, dvr, dvi,
-                                      (float*)workspace, B, L, C)));
+                                      (float*)workspace, B, L, C, ld_u, ld_du)));
     // per-(row, segment) partials [B * nst][3][C] -> d lambda_re, d lambda_im, d gamma (fixed summation order)
     const float* part = (const float*)workspace;
     launch_colsum(part, 3 * (int64_t)C, B * nst, C, dlam_re, s);

@@ -2,7 +2,7 @@
 #include "resel_common.h"
 #include <cstdint>
 
-extern "C" int resel_abi_version(void) { return 7; }
+extern "C" int resel_abi_version(void) { return 8; }
 
 // ---- dropout offset base: a device word that every counter-keyed mask kernel (resel_dropout, resel_gelu_dropout_*, resel_attn_varlen_*
 // with p_drop > 0) adds to its `offset` argument when it RUNS.  A captured update bakes the host-drawn offsets into its kernel nodes; with

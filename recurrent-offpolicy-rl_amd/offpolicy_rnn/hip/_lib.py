@@ -9,7 +9,7 @@ from ctypes import c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('RESEL_HIP_LIBRARY') or os.path.join(_HERE, 'libresel_hip.so')      # override: ablation builds (tools/gemm_ablate.sh)
-ABI_VERSION = 7
+ABI_VERSION = 8
 _lib = None
 
 P, I, L, F, S, U = c_void_p, c_int, c_int64, c_float, c_void_p, c_uint64
@@ -34,11 +34,11 @@ SIGNATURES = {
     'resel_add_layernorm_fwd': (c_int, [P, P, P, P, P, P, P, I, I, F, I, P, E, S]),
     'resel_add_layernorm_bwd_workspace_bytes': (c_size_t, [I, I]),
     'resel_add_layernorm_bwd': (c_int, [P, P, P, P, P, P, P, P, P, I, I, I, I, P, E, S]),
-    'resel_linrec_real_fwd': (c_int, [P, P, P, P, P, I, I, I, I, S]),
-    'resel_linrec_real_bwd': (c_int, [P, P, P, P, P, P, P, P, I, I, I, I, S]),
-    'resel_linrec_complex_fwd': (c_int, [P, P, P, P, P, P, P, P, P, P, I, I, I, S]),
+    'resel_linrec_real_fwd': (c_int, [P, P, L, P, P, P, I, I, I, I, P, E, S]),
+    'resel_linrec_real_bwd': (c_int, [P, P, L, P, P, P, P, P, P, L, I, I, I, I, P, E, S]),
+    'resel_linrec_complex_fwd': (c_int, [P, P, L, P, P, P, P, P, P, P, P, I, I, I, P, E, S]),
     'resel_linrec_complex_bwd_workspace_bytes': (c_size_t, [I, I, I]),
-    'resel_linrec_complex_bwd': (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, S]),
+    'resel_linrec_complex_bwd': (c_int, [P, P, L, P, P, P, P, P, P, P, P, P, P, P, P, L, P, P, P, P, I, I, I, S]),
     'resel_gru_workspace_bytes': (c_size_t, [I, I, I]),
     'resel_gru_seq_fwd': (c_int, [P, P, P, P, P, P, P, I, I, I, S]),
     'resel_gru_seq_bwd': (c_int, [P, P, P, P, P, P, P, P, I, I, I, S]),

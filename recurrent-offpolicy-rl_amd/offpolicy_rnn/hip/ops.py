@@ -375,19 +375,52 @@ def rms_norm_fn(x, weight, bias, residual=None, eps=1e-6, prenorm=False, residua
 
 
 # ---------------------------------------------------------------------------------------------- linear recurrences
+def _token_rows(*ts):
+    """[B, L, C] fp32 operands of a scan -> (operands usable in place, ld): their (b, t) axes collapse to token rows `ld` floats apart with unit
+    column stride (dense tensors, or column blocks of one wider token-major matrix); anything else is copied to dense."""
+    t0 = ts[0]
+    ld = t0.stride(1)
+    if all(t.dtype == torch.float32 and t.dim() == 3 and t.stride(2) == 1 and t.stride(1) == ld and t.stride(0) == t.shape[1] * ld and ld >= t.shape[2]
+           for t in ts):
+        return ts, ld
+    return tuple(t.float().contiguous() for t in ts), t0.shape[2]
+
+
+def _member_rows(u):
+    """u [E, B, L, C]: the members as token-row operands (see `_token_rows`) - the [E, B, T, C] view of a shared-input EnsembleLinear's
+    [M, E C] output qualifies as it is (ld = E C), so does a dense tensor (ld = C).  Returns (u or a dense copy, ld)."""
+    E, Bsz, L, C = u.shape
+    if not (u.dtype == torch.float32 and u.stride(3) == 1 and u.stride(1) == L * u.stride(2) and u.stride(2) >= C):
+        u = u.float().contiguous()
+    return u, u.stride(2)
+
+
+def _like_members(u):
+    """Uninitialised tensor with u's shape AND memory layout (gradients of the members go back in the layout the producer reads)."""
+    return torch.empty_strided(u.shape, u.stride(), dtype=torch.float32, device=u.device)
+
+
+def _real_fwd(v, f, ld, start, h0, fuse_act):
+    Bsz, L, C = v.shape
+    h = torch.empty(Bsz, L, C, dtype=torch.float32, device=v.device)
+    slot, slot_p, epoch = _slot_args(amax_tracking() and h.numel() >= (1 << 20), v.device)
+    check(lib().resel_linrec_real_fwd(_p(v), _p(f), ld, _p(start), _p(h0), _p(h), Bsz, L, C, int(bool(fuse_act)), slot_p, epoch, _stream()),
+          'linrec_real_fwd')
+    return h, slot
+
+
 class GilrScanFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, v, f, start, h0, fuse_act):
         _need_cuda('linrec_real', v, f)
-        v, f = v.float().contiguous(), f.float().contiguous()
+        (v, f), ld = _token_rows(v, f)
         Bsz, L, C = v.shape
         start = _flags(start, Bsz, L)
         h0 = None if h0 is None else h0.float().reshape(Bsz, C).contiguous()
-        h = torch.empty_like(v)
-        check(lib().resel_linrec_real_fwd(_p(v), _p(f), _p(start), _p(h0), _p(h), Bsz, L, C, int(bool(fuse_act)), _stream()),
-              'linrec_real_fwd')
+        global LAST_AMAX
+        h, LAST_AMAX = _real_fwd(v, f, ld, start, h0, fuse_act)
         ctx.save_for_backward(v, f, start, h0, h)
-        ctx.act = bool(fuse_act)
+        ctx.act, ctx.ld = bool(fuse_act), ld
         return h
 
     @staticmethod
@@ -395,15 +428,56 @@ class GilrScanFn(torch.autograd.Function):
         v, f, start, h0, h = ctx.saved_tensors
         Bsz, L, C = v.shape
         dh = dh.float().contiguous()
-        dv, df = torch.empty_like(v), torch.empty_like(f)
-        check(lib().resel_linrec_real_bwd(_p(v), _p(f), _p(start), _p(h0), _p(h), _p(dh), _p(dv), _p(df), Bsz, L, C,
-                                          int(ctx.act), _stream()), 'linrec_real_bwd')
+        dv = torch.empty(Bsz, L, C, dtype=torch.float32, device=v.device)
+        df = torch.empty_like(dv)
+        check(lib().resel_linrec_real_bwd(_p(v), _p(f), ctx.ld, _p(start), _p(h0), _p(h), _p(dh), _p(dv), _p(df), C, Bsz, L, C,
+                                          int(ctx.act), None, 0, _stream()), 'linrec_real_bwd')
         return dv, df, None, None, None
+
+
+class GilrMembersFn(torch.autograd.Function):
+    """The gilr recurrence on u = (v | f) [2, B, T, C] as its producer left it (reference gilr.py:60-62 slices u[0], u[1]): the kernels
+    read the two members through their row stride and write both gradients into ONE tensor of u's layout - no dense copies of the
+    members going in (2 x 2 per call), no zero-filled [2, B, T, C] per member plus an add coming back (autograd's select_backward)."""
+
+    @staticmethod
+    def forward(ctx, u, start, h0, fuse_act):
+        _need_cuda('linrec_real', u)
+        assert u.dim() == 4 and u.shape[0] == 2
+        u, ld = _member_rows(u)
+        _, Bsz, L, C = u.shape
+        start = _flags(start, Bsz, L)
+        h0 = None if h0 is None else h0.float().reshape(Bsz, C).contiguous()
+        global LAST_AMAX
+        h, LAST_AMAX = _real_fwd(u[0], u[1], ld, start, h0, fuse_act)
+        ctx.save_for_backward(u, start, h0, h)
+        ctx.act, ctx.ld = bool(fuse_act), ld
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        u, start, h0, h = ctx.saved_tensors
+        _, Bsz, L, C = u.shape
+        dh = dh.float().contiguous()
+        du = _like_members(u)
+        slot, slot_p, epoch = _slot_args(amax_tracking() and du.numel() >= (1 << 20), u.device)
+        check(lib().resel_linrec_real_bwd(_p(u[0]), _p(u[1]), ctx.ld, _p(start), _p(h0), _p(h), _p(dh), _p(du[0]), _p(du[1]), du.stride(2),
+                                          Bsz, L, C, int(ctx.act), slot_p, epoch, _stream()), 'linrec_real_bwd')
+        return tag_amax(du, slot), None, None, None
 
 
 def gilr_scan(v, f, start=None, h0=None, fuse_act=True):
     """h_t = f'_t h_{t-1} + (1 - f'_t) v'_t with v' = tanh(v), f' = sigmoid(f) (1 - start) when fuse_act."""
-    return GilrScanFn.apply(v, f, start, h0, fuse_act)
+    global LAST_AMAX
+    LAST_AMAX = None
+    return tag_amax(GilrScanFn.apply(v, f, start, h0, fuse_act), LAST_AMAX)
+
+
+def gilr_scan_members(u, start=None, h0=None, fuse_act=True):
+    """`gilr_scan(u[0], u[1], ...)` for u [2, B, T, C], reading the members in place (see `GilrMembersFn`)."""
+    global LAST_AMAX
+    LAST_AMAX = None
+    return tag_amax(GilrMembersFn.apply(u, start, h0, fuse_act), LAST_AMAX)
 
 
 def real_scan_tie_input_gate(v, f):
@@ -411,41 +485,124 @@ def real_scan_tie_input_gate(v, f):
     return GilrScanFn.apply(v, f, None, None, False)
 
 
+def _complex_fwd(vr, vi, ld, lam_re, lam_im, gamma, start, h0r, h0i):
+    """-> h2 [2, B, L, C] = (Re h | Im h) stacked (the layer's next product wants exactly that), its magnitude handle."""
+    Bsz, L, C = vr.shape
+    h2 = torch.empty(2, Bsz, L, C, dtype=torch.float32, device=vr.device)
+    slot, slot_p, epoch = _slot_args(amax_tracking() and h2.numel() >= (1 << 20), vr.device)
+    check(lib().resel_linrec_complex_fwd(_p(vr), _p(vi), ld, _p(lam_re), _p(lam_im), _p(gamma), _p(start), _p(h0r), _p(h0i),
+                                         _p(h2[0]), _p(h2[1]), Bsz, L, C, slot_p, epoch, _stream()), 'linrec_complex_fwd')
+    return h2, slot
+
+
+def _complex_args(lam_re, lam_im, gamma, start, h0r, h0i, Bsz, L, C):
+    lam_re, lam_im = lam_re.float().contiguous(), lam_im.float().contiguous()
+    gamma = None if gamma is None else gamma.float().contiguous()
+    start = _flags(start, Bsz, L)
+    h0r = None if h0r is None else h0r.float().reshape(Bsz, C).contiguous()
+    h0i = None if h0i is None else h0i.float().reshape(Bsz, C).contiguous()
+    return lam_re, lam_im, gamma, start, h0r, h0i
+
+
+def _complex_bwd(vr, vi, ld, lam_re, lam_im, gamma, start, h0r, h0i, h2, dh2, dvr, dvi, ld_du):
+    Bsz, L, C = vr.shape
+    dlr, dli = torch.empty_like(lam_re), torch.empty_like(lam_im)
+    dg = torch.empty_like(lam_re) if gamma is not None else None
+    ws = _ws(lib().resel_linrec_complex_bwd_workspace_bytes(Bsz, L, C), vr.device)
+    check(lib().resel_linrec_complex_bwd(_p(vr), _p(vi), ld, _p(lam_re), _p(lam_im), _p(gamma), _p(start), _p(h0r), _p(h0i),
+                                         _p(h2[0]), _p(h2[1]), _p(dh2[0]), _p(dh2[1]), _p(dvr), _p(dvi), ld_du, _p(dlr), _p(dli), _p(dg),
+                                         _p(ws), Bsz, L, C, _stream()), 'linrec_complex_bwd')
+    return dlr, dli, dg
+
+
 class LruScanFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, vr, vi, lam_re, lam_im, gamma, start, h0r, h0i):
         _need_cuda('linrec_complex', vr, vi, lam_re, lam_im)
-        vr, vi = vr.float().contiguous(), vi.float().contiguous()
+        (vr, vi), ld = _token_rows(vr, vi)
         Bsz, L, C = vr.shape
-        lam_re, lam_im = lam_re.float().contiguous(), lam_im.float().contiguous()
-        gamma = None if gamma is None else gamma.float().contiguous()
-        start = _flags(start, Bsz, L)
-        h0r = None if h0r is None else h0r.float().reshape(Bsz, C).contiguous()
-        h0i = None if h0i is None else h0i.float().reshape(Bsz, C).contiguous()
-        hr, hi = torch.empty_like(vr), torch.empty_like(vi)
-        check(lib().resel_linrec_complex_fwd(_p(vr), _p(vi), _p(lam_re), _p(lam_im), _p(gamma), _p(start), _p(h0r), _p(h0i),
-                                             _p(hr), _p(hi), Bsz, L, C, _stream()), 'linrec_complex_fwd')
-        ctx.save_for_backward(vr, vi, lam_re, lam_im, gamma, start, h0r, h0i, hr, hi)
-        return hr, hi
+        lam_re, lam_im, gamma, start, h0r, h0i = _complex_args(lam_re, lam_im, gamma, start, h0r, h0i, Bsz, L, C)
+        h2, _ = _complex_fwd(vr, vi, ld, lam_re, lam_im, gamma, start, h0r, h0i)
+        ctx.save_for_backward(vr, vi, lam_re, lam_im, gamma, start, h0r, h0i, h2)
+        ctx.ld = ld
+        return h2[0], h2[1]
 
     @staticmethod
     def backward(ctx, dhr, dhi):
-        vr, vi, lam_re, lam_im, gamma, start, h0r, h0i, hr, hi = ctx.saved_tensors
+        vr, vi, lam_re, lam_im, gamma, start, h0r, h0i, h2 = ctx.saved_tensors
         Bsz, L, C = vr.shape
-        dhr, dhi = dhr.float().contiguous(), dhi.float().contiguous()
-        dvr, dvi = torch.empty_like(vr), torch.empty_like(vi)
-        dlr, dli = torch.empty_like(lam_re), torch.empty_like(lam_im)
-        dg = torch.empty_like(lam_re) if gamma is not None else None
-        ws = _ws(lib().resel_linrec_complex_bwd_workspace_bytes(Bsz, L, C), vr.device)
-        check(lib().resel_linrec_complex_bwd(_p(vr), _p(vi), _p(lam_re), _p(lam_im), _p(gamma), _p(start), _p(h0r), _p(h0i),
-                                             _p(hr), _p(hi), _p(dhr), _p(dhi), _p(dvr), _p(dvi), _p(dlr), _p(dli), _p(dg),
-                                             _p(ws), Bsz, L, C, _stream()), 'linrec_complex_bwd')
+        dh2 = (dhr.float().contiguous(), dhi.float().contiguous())
+        dvr = torch.empty(Bsz, L, C, dtype=torch.float32, device=vr.device)
+        dvi = torch.empty_like(dvr)
+        dlr, dli, dg = _complex_bwd(vr, vi, ctx.ld, lam_re, lam_im, gamma, start, h0r, h0i, h2, dh2, dvr, dvi, C)
         return dvr, dvi, dlr, dli, dg, None, None, None
+
+
+class LruMembersFn(torch.autograd.Function):
+    """The lru recurrence on u [E >= 2, B, T, C] as its producer left it (reference lru.py:112-120: members 0 / 1 are Re / Im of the
+    input, member 2 the skip term): reads the members through their row stride, returns h2 = (Re h | Im h) stacked [2, B, T, C] (what
+    `middle_proj` multiplies - no `torch.stack` copy) and, for E = 3, member 2 as a pass-through output so that ALL of u's gradient
+    comes back through this node as one tensor of u's layout (blocks 0 / 1 written by the kernel, block 2 one copy)."""
+
+    @staticmethod
+    def forward(ctx, u, lam_re, lam_im, gamma, start, h0r, h0i):
+        _need_cuda('linrec_complex', u, lam_re, lam_im)
+        assert u.dim() == 4 and u.shape[0] in (2, 3)
+        u, ld = _member_rows(u)
+        E, Bsz, L, C = u.shape
+        lam_re, lam_im, gamma, start, h0r, h0i = _complex_args(lam_re, lam_im, gamma, start, h0r, h0i, Bsz, L, C)
+        global LAST_AMAX
+        h2, LAST_AMAX = _complex_fwd(u[0], u[1], ld, lam_re, lam_im, gamma, start, h0r, h0i)
+        ctx.save_for_backward(u, lam_re, lam_im, gamma, start, h0r, h0i, h2)
+        ctx.ld = ld
+        return (h2, u[2]) if E == 3 else (h2, None)
+
+    @staticmethod
+    def backward(ctx, dh2, du2):
+        u, lam_re, lam_im, gamma, start, h0r, h0i, h2 = ctx.saved_tensors
+        E = u.shape[0]
+        dh2 = dh2.float().contiguous()
+        du = _like_members(u)
+        dlr, dli, dg = _complex_bwd(u[0], u[1], ctx.ld, lam_re, lam_im, gamma, start, h0r, h0i, h2, dh2, du[0], du[1], du.stride(2))
+        if E == 3:
+            if du2 is None:
+                du[2].zero_()
+            else:
+                du[2].copy_(du2)
+        return du, dlr, dli, dg, None, None, None
 
 
 def complex_scan(vr, vi, lam_re, lam_im, gamma=None, start=None, h0r=None, h0i=None):
     """h_t = lambda (1 - start_t) h_{t-1} + gamma (vr_t + i vi_t); lambda, gamma per channel [C]."""
     return LruScanFn.apply(vr, vi, lam_re, lam_im, gamma, start, h0r, h0i)
+
+
+def complex_scan_members(u, lam_re, lam_im, gamma=None, start=None, h0r=None, h0i=None):
+    """`complex_scan(u[0], u[1], ...)` for u [2 or 3, B, T, C] read in place -> (h2 [2, B, T, C] = (Re h | Im h), u[2] or None); see `LruMembersFn`."""
+    global LAST_AMAX
+    LAST_AMAX = None
+    h2, u2 = LruMembersFn.apply(u, lam_re, lam_im, gamma, start, h0r, h0i)
+    return tag_amax(h2, LAST_AMAX), u2
+
+
+class SubAddMembers(torch.autograd.Function):
+    """m [2, ...] , r [...] -> m[0] - m[1] + r (lru.py:120 `mid[0] - mid[1] + u[2]`); the backward writes (g | -g) into ONE tensor of m's
+    shape (autograd: a negation pass, two zero-filled [2, ...] tensors with one member copied in, and their sum)."""
+
+    @staticmethod
+    def forward(ctx, m, r):
+        out = torch.sub(m[0], m[1])
+        if r is not None:
+            out.add_(r)
+        ctx.has_r = r is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        dm = torch.empty((2,) + tuple(g.shape), dtype=g.dtype, device=g.device)
+        dm[0].copy_(g)
+        torch.neg(g, out=dm[1])
+        return dm, (g if ctx.has_r else None)
 
 
 # ---------------------------------------------------------------------------------------------- GRU

@@ -44,7 +44,7 @@ class GILRLayer(nn.Module):
     def forward(self, x, hidden=None, rnn_start=None):
         u = self.in_proj(x)                                         # [2, B, T, C]
         h0 = None if hidden is None else hidden[0]
-        h = ops.gilr_scan(u[0], u[1], rnn_start, h0, True)
+        h = ops.gilr_scan_members(u, rnn_start, h0, True)           # the two members read in place, one gradient tensor back
         out = ops.linear(h, self.out_proj.weight, self.out_proj.bias)
         if self.use_ff:
             out = self.ff(out)

@@ -48,9 +48,10 @@ class LRULayer(nn.Module):
         h0r = h0i = None
         if hidden is not None:
             h0r, h0i = hidden[0].chunk(2, dim=-1)
-        hr, hi = ops.complex_scan(u[0], u[1], lam_re, lam_im, gamma, rnn_start, h0r, h0i)
-        mid = self.middle_proj(torch.stack((hr, hi), dim=0))
-        out = mid[0] - mid[1] + u[2]
+        # members of u read in place, (Re h | Im h) produced stacked, u[2] handed through: one gradient tensor in u's layout comes back
+        h2, u2 = ops.complex_scan_members(u, lam_re, lam_im, gamma, rnn_start, h0r, h0i)
+        hr, hi = h2[0], h2[1]
+        out = ops.SubAddMembers.apply(self.middle_proj(h2), u2)
         if self.use_ff:
             out = self.ff(out)
         hidden = torch.cat((hr[:, -1:, :], hi[:, -1:, :]), dim=-1).transpose(0, 1)

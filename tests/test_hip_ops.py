@@ -292,6 +292,61 @@ def test_lru_scan_fwd_bwd(ops, B, L, C):
         close(a, b, rtol=3e-4, atol_scale=1e-4, name=nm)
 
 
+@pytest.mark.parametrize('B,L,C', [(2, 33, 64), (16, 301, 256), (3, 50, 96)])
+@pytest.mark.parametrize('layout', ['shared', 'dense'])
+def test_linrec_members_in_place_equal_the_dense_forms(ops, B, L, C, layout):
+    """`gilr_scan_members` / `complex_scan_members` read the members of u [E, B, T, C] through their row stride - u being the [E, B, T, C]
+    view of a shared-input EnsembleLinear's [M, E C] output (reference gilr.py:60-62, lru.py:112-120) - and hand back ONE gradient tensor in
+    u's layout: same bits as the dense per-member calls, against the oracle like them."""
+    g = torch.Generator().manual_seed(B * L + C)
+    start = make_start(B, L, g).cuda()
+
+    def members(E):
+        y2 = rnd(B * L, E * C, g=g).cuda()
+        if layout == 'shared':
+            return y2.view(B * L, E, C).transpose(0, 1).reshape(E, B, L, C)        # strides (C, L E C, E C, 1): a view
+        return y2.view(B * L, E, C).transpose(0, 1).contiguous().view(E, B, L, C)
+
+    # ---- real (gilr)
+    u = members(2).requires_grad_(True)
+    h0, dh = rnd(B, C, g=g).cuda(), rnd(B, L, C, g=g).cuda()
+    h = ops.gilr_scan_members(u, start, h0, True)
+    (du,) = torch.autograd.grad(h, u, dh)
+    assert du.stride() == u.stride()
+    vd, fd = u.detach()[0].contiguous().requires_grad_(True), u.detach()[1].contiguous().requires_grad_(True)
+    hd = ops.gilr_scan(vd, fd, start, h0, True)
+    dv, df = torch.autograd.grad(hd, (vd, fd), dh)
+    assert torch.equal(h, hd) and torch.equal(du[0], dv) and torch.equal(du[1], df)
+    assert ops.amax_of(h) is not None or h.numel() < (1 << 20)
+    if h.numel() >= (1 << 20):
+        assert ops.amax_value(ops.amax_of(h)) == float(h.detach().abs().max()) and ops.amax_value(ops.amax_of(du)) == float(du.abs().max())
+    vs, fs = u.detach()[0], u.detach()[1]                                          # the strided members given separately: read in place as well
+    assert torch.equal(ops.gilr_scan(vs, fs, start, h0, True), hd)
+    h_ref = K.linrec_real_ref(vd.detach().cpu(), fd.detach().cpu(), start.cpu(), h0.cpu(), True)[0]
+    close_fwd(h.cpu(), h_ref, name='h')
+
+    # ---- complex (lru), E = 3 with the pass-through member and the (Re | Im) combination
+    mag, th = 0.9 + 0.099 * torch.rand(C, generator=g), 6.28 * torch.rand(C, generator=g)
+    lr, li, gm = (mag * torch.cos(th)).cuda(), (mag * torch.sin(th)).cuda(), torch.sqrt(1 - mag ** 2).cuda()
+    u = members(3).requires_grad_(True)
+    dh2, dout = rnd(2, B, L, C, g=g).cuda(), rnd(B, L, C, g=g).cuda()
+    pars = [t.clone().requires_grad_(True) for t in (lr, li, gm)]
+    h2, u2 = ops.complex_scan_members(u, *pars, start)
+    out = ops.SubAddMembers.apply(h2, u2)
+    grads = torch.autograd.grad((h2 * dh2).sum() + (out * dout).sum(), [u] + pars)
+    assert grads[0].stride() == u.stride()
+    ud = [u.detach()[e].contiguous().requires_grad_(True) for e in range(3)]
+    pars_d = [t.clone().requires_grad_(True) for t in (lr, li, gm)]
+    hr, hi = ops.complex_scan(ud[0], ud[1], *pars_d, start)
+    out_d = hr - hi + ud[2]
+    grads_d = torch.autograd.grad((hr * dh2[0]).sum() + (hi * dh2[1]).sum() + (out_d * dout).sum(), ud + pars_d)
+    assert torch.equal(h2[0], hr) and torch.equal(h2[1], hi) and torch.equal(out, out_d)
+    for e in range(3):
+        close(grads[0][e], grads_d[e].cpu(), rtol=1e-6, atol_scale=1e-6, name=f'du{e}')      # (dh2 + dout) is summed in another order
+    for a, b in zip(grads[1:], grads_d[3:]):
+        close(a, b.cpu(), rtol=1e-5, atol_scale=1e-5, name='dparam')
+
+
 # ------------------------------------------------------------------------------------------------ GRU
 @pytest.mark.parametrize('B,L,H', [(3, 20, 64), (18, 40, 256), (2, 130, 32), (5, 9, 80), (2, 6, 384), (68, 6, 256)])
 def test_gru_seq_fwd_bwd_vs_aten(ops, B, L, H):

@@ -8,7 +8,8 @@ from collections import Counter
 from torch.utils._python_dispatch import TorchDispatchMode
 from bench import build_trainer
 rnn = sys.argv[1] if len(sys.argv) > 1 else 'smamba_s32_c16_b2_nln'
-alg = build_trainer(rnn, 64, 1024)
+rows, horizon = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (64, 1024)
+alg = build_trainer(rnn, rows, horizon)
 for _ in range(3):
     alg.train_one_batch(); alg.grad_num += 1
 torch.cuda.synchronize()
