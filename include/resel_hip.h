@@ -170,6 +170,12 @@ int resel_linrec_complex_bwd(const float* vr, const float* vi, int64_t ld_u, con
                              float* dvr, float* dvi, int64_t ld_du, float* dlam_re, float* dlam_im, float* dgamma,
                              void* workspace, int B, int L, int C, resel_stream_t stream);
 
+/* lru's per-channel parameters in one launch each way (reference offpolicy_rnn/models/lru/lru.py:104-110: exp / cos / sin / mul on [C]
+ * tensors).  params_log [3, C] = (nu_log | theta_log | gamma_log) -> out [3, C] = (lam_re | lam_im | gamma) with
+ * lambda = exp(-exp(nu_log)) (cos, sin)(exp(theta_log)), gamma = exp(gamma_log); bwd: dout [3, C] -> dparams_log [3, C].  (ABI 8) */
+int resel_lru_params_fwd(const float* params_log, float* out, int C, resel_stream_t stream);
+int resel_lru_params_bwd(const float* params_log, const float* dout, float* dparams_log, int C, resel_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * GRU recurrence on a hoisted input projection.  Replaces cuDNN/MIOpen GRU reached through
  * torch.nn.GRU(batch_first=True) (offpolicy_rnn/models/rnn_base.py:59,247; called at :453-454).

@@ -286,6 +286,29 @@ __global__ __launch_bounds__(NSEG * 64) void linrec_complex_bwd_kernel(const flo
     }
 }
 
+// lru's per-channel parameters (reference lru.py:104-110): rows of p_log = (nu_log, theta_log, gamma_log) ->
+//   lambda = exp(-exp(nu_log)) (cos, sin)(exp(theta_log)), gamma = exp(gamma_log)            out rows = (lam_re, lam_im, gamma)
+// One launch each way instead of ~10 element-wise launches on 256-element tensors forward and ~15 backward.
+__global__ void lru_params_fwd_kernel(const float* __restrict__ p_log, float* __restrict__ out, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float nu = expf(p_log[c]), th = expf(p_log[C + c]), gm = expf(p_log[2 * C + c]);
+    const float mag = expf(-nu);
+    out[c] = mag * cosf(th);
+    out[C + c] = mag * sinf(th);
+    out[2 * C + c] = gm;
+}
+__global__ void lru_params_bwd_kernel(const float* __restrict__ p_log, const float* __restrict__ dout, float* __restrict__ dp, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float nu = expf(p_log[c]), th = expf(p_log[C + c]), gm = expf(p_log[2 * C + c]);
+    const float mag = expf(-nu), cs = cosf(th), sn = sinf(th);
+    const float dlr = dout[c], dli = dout[C + c], dg = dout[2 * C + c];
+    dp[c] = -(dlr * cs + dli * sn) * mag * nu;                   // d mag / d nu = -mag, d nu / d nu_log = nu
+    dp[C + c] = (dli * cs - dlr * sn) * mag * th;                // d theta / d theta_log = theta
+    dp[2 * C + c] = dg * gm;
+}
+
 // channels per wave: the widest split whose grid still fills the chip
 inline int pick_cl(int B, int C) {
     if ((int64_t)((C + 63) / 64) * B >= 256) return 64;
@@ -363,5 +386,17 @@ extern "C" int resel_linrec_complex_bwd(const float* vr, const float* vi, int64_
     launch_colsum(part, 3 * (int64_t)C, B * nst, C, dlam_re, s);
     launch_colsum(part + C, 3 * (int64_t)C, B * nst, C, dlam_im, s);
     if (dgamma) launch_colsum(part + 2 * (int64_t)C, 3 * (int64_t)C, B * nst, C, dgamma, s);
+    return launch_status();
+}
+
+extern "C" int resel_lru_params_fwd(const float* params_log, float* out, int C, resel_stream_t stream) {
+    if (!params_log || !out || C <= 0) return RESEL_EINVAL;
+    hipLaunchKernelGGL(lru_params_fwd_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, params_log, out, C);
+    return launch_status();
+}
+
+extern "C" int resel_lru_params_bwd(const float* params_log, const float* dout, float* dparams_log, int C, resel_stream_t stream) {
+    if (!params_log || !dout || !dparams_log || C <= 0) return RESEL_EINVAL;
+    hipLaunchKernelGGL(lru_params_bwd_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, params_log, dout, dparams_log, C);
     return launch_status();
 }

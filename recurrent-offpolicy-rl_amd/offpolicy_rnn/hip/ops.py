@@ -538,38 +538,70 @@ class LruScanFn(torch.autograd.Function):
         return dvr, dvi, dlr, dli, dg, None, None, None
 
 
+class LruParamsFn(torch.autograd.Function):
+    """params_log [3, C] = (nu_log | theta_log | gamma_log) -> lam3 [3, C] = (lam_re | lam_im | gamma), lambda = exp(-exp(nu_log)) e^{i exp(theta_log)},
+    gamma = exp(gamma_log) (reference lru.py:104-110): one launch each way instead of ~25 element-wise launches on [C] tensors per layer call."""
+
+    @staticmethod
+    def forward(ctx, params_log):
+        _need_cuda('lru_params', params_log)
+        p = params_log.float().contiguous()
+        out = torch.empty_like(p)
+        check(lib().resel_lru_params_fwd(_p(p), _p(out), p.shape[1], _stream()), 'lru_params_fwd')
+        ctx.save_for_backward(p)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (p,) = ctx.saved_tensors
+        dout = dout.float().contiguous()
+        dp = torch.empty_like(p)
+        check(lib().resel_lru_params_bwd(_p(p), _p(dout), _p(dp), p.shape[1], _stream()), 'lru_params_bwd')
+        return dp
+
+
+def lru_params(params_log):
+    return LruParamsFn.apply(params_log)
+
+
 class LruMembersFn(torch.autograd.Function):
     """The lru recurrence on u [E >= 2, B, T, C] as its producer left it (reference lru.py:112-120: members 0 / 1 are Re / Im of the
     input, member 2 the skip term): reads the members through their row stride, returns h2 = (Re h | Im h) stacked [2, B, T, C] (what
     `middle_proj` multiplies - no `torch.stack` copy) and, for E = 3, member 2 as a pass-through output so that ALL of u's gradient
-    comes back through this node as one tensor of u's layout (blocks 0 / 1 written by the kernel, block 2 one copy)."""
+    comes back through this node as one tensor of u's layout (blocks 0 / 1 written by the kernel, block 2 one copy).
+    lam3 [3, C] = (lam_re | lam_im | gamma) (`lru_params`); its gradient comes back as one [3, C] tensor too."""
 
     @staticmethod
-    def forward(ctx, u, lam_re, lam_im, gamma, start, h0r, h0i):
-        _need_cuda('linrec_complex', u, lam_re, lam_im)
-        assert u.dim() == 4 and u.shape[0] in (2, 3)
+    def forward(ctx, u, lam3, start, h0r, h0i):
+        _need_cuda('linrec_complex', u, lam3)
+        assert u.dim() == 4 and u.shape[0] in (2, 3) and lam3.shape == (3, u.shape[3])
         u, ld = _member_rows(u)
         E, Bsz, L, C = u.shape
-        lam_re, lam_im, gamma, start, h0r, h0i = _complex_args(lam_re, lam_im, gamma, start, h0r, h0i, Bsz, L, C)
+        lam3 = lam3.float().contiguous()
+        _, _, _, start, h0r, h0i = _complex_args(lam3[0], lam3[1], lam3[2], start, h0r, h0i, Bsz, L, C)
         global LAST_AMAX
-        h2, LAST_AMAX = _complex_fwd(u[0], u[1], ld, lam_re, lam_im, gamma, start, h0r, h0i)
-        ctx.save_for_backward(u, lam_re, lam_im, gamma, start, h0r, h0i, h2)
+        h2, LAST_AMAX = _complex_fwd(u[0], u[1], ld, lam3[0], lam3[1], lam3[2], start, h0r, h0i)
+        ctx.save_for_backward(u, lam3, start, h0r, h0i, h2)
         ctx.ld = ld
         return (h2, u[2]) if E == 3 else (h2, None)
 
     @staticmethod
     def backward(ctx, dh2, du2):
-        u, lam_re, lam_im, gamma, start, h0r, h0i, h2 = ctx.saved_tensors
-        E = u.shape[0]
+        u, lam3, start, h0r, h0i, h2 = ctx.saved_tensors
+        E, Bsz, L, C = u.shape
         dh2 = dh2.float().contiguous()
         du = _like_members(u)
-        dlr, dli, dg = _complex_bwd(u[0], u[1], ctx.ld, lam_re, lam_im, gamma, start, h0r, h0i, h2, dh2, du[0], du[1], du.stride(2))
+        dlam3 = torch.empty_like(lam3)
+        ws = _ws(lib().resel_linrec_complex_bwd_workspace_bytes(Bsz, L, C), u.device)
+        check(lib().resel_linrec_complex_bwd(_p(u[0]), _p(u[1]), ctx.ld, _p(lam3[0]), _p(lam3[1]), _p(lam3[2]), _p(start), _p(h0r), _p(h0i),
+                                             _p(h2[0]), _p(h2[1]), _p(dh2[0]), _p(dh2[1]), _p(du[0]), _p(du[1]), du.stride(2),
+                                             _p(dlam3[0]), _p(dlam3[1]), _p(dlam3[2]), _p(ws), Bsz, L, C, _stream()), 'linrec_complex_bwd')
         if E == 3:
             if du2 is None:
                 du[2].zero_()
             else:
                 du[2].copy_(du2)
-        return du, dlr, dli, dg, None, None, None
+        return du, dlam3, None, None, None
 
 
 def complex_scan(vr, vi, lam_re, lam_im, gamma=None, start=None, h0r=None, h0i=None):
@@ -577,11 +609,12 @@ def complex_scan(vr, vi, lam_re, lam_im, gamma=None, start=None, h0r=None, h0i=N
     return LruScanFn.apply(vr, vi, lam_re, lam_im, gamma, start, h0r, h0i)
 
 
-def complex_scan_members(u, lam_re, lam_im, gamma=None, start=None, h0r=None, h0i=None):
-    """`complex_scan(u[0], u[1], ...)` for u [2 or 3, B, T, C] read in place -> (h2 [2, B, T, C] = (Re h | Im h), u[2] or None); see `LruMembersFn`."""
+def complex_scan_members(u, lam3, start=None, h0r=None, h0i=None):
+    """`complex_scan(u[0], u[1], lam3[0], lam3[1], lam3[2], ...)` for u [2 or 3, B, T, C] read in place and lam3 = `lru_params(params_log)`
+    -> (h2 [2, B, T, C] = (Re h | Im h), u[2] or None); see `LruMembersFn`."""
     global LAST_AMAX
     LAST_AMAX = None
-    h2, u2 = LruMembersFn.apply(u, lam_re, lam_im, gamma, start, h0r, h0i)
+    h2, u2 = LruMembersFn.apply(u, lam3, start, h0r, h0i)
     return tag_amax(h2, LAST_AMAX), u2
 
 

@@ -42,14 +42,12 @@ class LRULayer(nn.Module):
         u = self.in_proj(x)                                         # [3, B, T, C]
         if self.squash_inproj:
             u = torch.tanh(u)
-        nu, theta, gamma = torch.exp(self.params_log)
-        mag = torch.exp(-nu)
-        lam_re, lam_im = mag * torch.cos(theta), mag * torch.sin(theta)
         h0r = h0i = None
         if hidden is not None:
             h0r, h0i = hidden[0].chunk(2, dim=-1)
-        # members of u read in place, (Re h | Im h) produced stacked, u[2] handed through: one gradient tensor in u's layout comes back
-        h2, u2 = ops.complex_scan_members(u, lam_re, lam_im, gamma, rnn_start, h0r, h0i)
+        # lambda = exp(-exp(nu_log)) e^{i exp(theta_log)}, gamma = exp(gamma_log): one launch (`ops.lru_params`); the members of u are read in
+        # place, (Re h | Im h) comes out stacked, u[2] is handed through: one gradient tensor in u's layout comes back
+        h2, u2 = ops.complex_scan_members(u, ops.lru_params(self.params_log), rnn_start, h0r, h0i)
         hr, hi = h2[0], h2[1]
         out = ops.SubAddMembers.apply(self.middle_proj(h2), u2)
         if self.use_ff:

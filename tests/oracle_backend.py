@@ -89,8 +89,14 @@ def gilr_scan_members(u, start=None, h0=None, fuse_act=True):
     return gilr_scan(u[0], u[1], start, h0, fuse_act)
 
 
-def complex_scan_members(u, lam_re, lam_im, gamma=None, start=None, h0r=None, h0i=None):
-    hr, hi = complex_scan(u[0], u[1], lam_re, lam_im, gamma, start, h0r, h0i)
+def lru_params(params_log):
+    nu, theta, gamma = torch.exp(params_log)
+    mag = torch.exp(-nu)
+    return torch.stack((mag * torch.cos(theta), mag * torch.sin(theta), gamma))
+
+
+def complex_scan_members(u, lam3, start=None, h0r=None, h0i=None):
+    hr, hi = complex_scan(u[0], u[1], lam3[0], lam3[1], lam3[2], start, h0r, h0i)
     return torch.stack((hr, hi), dim=0), (u[2] if u.shape[0] == 3 else None)
 
 
@@ -205,7 +211,7 @@ def sumsq(x, out=None):
 def install(monkeypatch):
     from offpolicy_rnn.hip import ops
     table = dict(ensemble_head_fwd_=ensemble_head_fwd_, ensemble_head_bwd=ensemble_head_bwd, bias_act_=bias_act_, bias_act_bwd=bias_act_bwd, linear_act=linear_act, mamba_inner_fn=mamba_inner_fn, selective_scan_tm=selective_scan_tm, causal_conv1d_fn=causal_conv1d_fn, layer_norm_fn=_norm(False),
-                 rms_norm_fn=_norm(True), gilr_scan=gilr_scan, complex_scan=complex_scan, gilr_scan_members=gilr_scan_members, complex_scan_members=complex_scan_members, SubAddMembers=SubAddMembers, gru_seq=gru_seq, tanh_gaussian=tanh_gaussian, attn_varlen=attn_varlen, dropout_counter=dropout_counter, counter_dropout=counter_dropout,
+                 rms_norm_fn=_norm(True), gilr_scan=gilr_scan, complex_scan=complex_scan, gilr_scan_members=gilr_scan_members, complex_scan_members=complex_scan_members, lru_params=lru_params, SubAddMembers=SubAddMembers, gru_seq=gru_seq, tanh_gaussian=tanh_gaussian, attn_varlen=attn_varlen, dropout_counter=dropout_counter, counter_dropout=counter_dropout,
                  sac_target=sac_target, guard_apply_slots=guard_apply_slots, soft_update_=soft_update_, adamw_flat_=adamw_flat_, sumsq=sumsq)
     for k, fn in table.items():
         monkeypatch.setattr(ops, k, fn)

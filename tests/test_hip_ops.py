@@ -330,10 +330,10 @@ def test_linrec_members_in_place_equal_the_dense_forms(ops, B, L, C, layout):
     lr, li, gm = (mag * torch.cos(th)).cuda(), (mag * torch.sin(th)).cuda(), torch.sqrt(1 - mag ** 2).cuda()
     u = members(3).requires_grad_(True)
     dh2, dout = rnd(2, B, L, C, g=g).cuda(), rnd(B, L, C, g=g).cuda()
-    pars = [t.clone().requires_grad_(True) for t in (lr, li, gm)]
-    h2, u2 = ops.complex_scan_members(u, *pars, start)
+    lam3 = torch.stack((lr, li, gm)).requires_grad_(True)
+    h2, u2 = ops.complex_scan_members(u, lam3, start)
     out = ops.SubAddMembers.apply(h2, u2)
-    grads = torch.autograd.grad((h2 * dh2).sum() + (out * dout).sum(), [u] + pars)
+    grads = torch.autograd.grad((h2 * dh2).sum() + (out * dout).sum(), [u, lam3])
     assert grads[0].stride() == u.stride()
     ud = [u.detach()[e].contiguous().requires_grad_(True) for e in range(3)]
     pars_d = [t.clone().requires_grad_(True) for t in (lr, li, gm)]
@@ -343,8 +343,26 @@ def test_linrec_members_in_place_equal_the_dense_forms(ops, B, L, C, layout):
     assert torch.equal(h2[0], hr) and torch.equal(h2[1], hi) and torch.equal(out, out_d)
     for e in range(3):
         close(grads[0][e], grads_d[e].cpu(), rtol=1e-6, atol_scale=1e-6, name=f'du{e}')      # (dh2 + dout) is summed in another order
-    for a, b in zip(grads[1:], grads_d[3:]):
-        close(a, b.cpu(), rtol=1e-5, atol_scale=1e-5, name='dparam')
+    for i, b in enumerate(grads_d[3:]):
+        close(grads[1][i], b.cpu(), rtol=1e-5, atol_scale=1e-5, name='dparam')
+
+
+def test_lru_params_one_launch_vs_torch(ops):
+    """lam3 = (lam_re | lam_im | gamma) from params_log (reference lru.py:104-110) and its gradient against the same formula in torch."""
+    g = torch.Generator().manual_seed(5)
+    for C in (256, 96, 1000):
+        p = (torch.randn(3, C, generator=g) * 0.5 - 1.0)
+        d = torch.randn(3, C, generator=g)
+        pr = p.clone().requires_grad_(True)
+        nu, theta, gamma = torch.exp(pr)
+        mag = torch.exp(-nu)
+        ref = torch.stack((mag * torch.cos(theta), mag * torch.sin(theta), gamma))
+        (gref,) = torch.autograd.grad(ref, pr, d)
+        pg = p.cuda().requires_grad_(True)
+        out = ops.lru_params(pg)
+        (gg,) = torch.autograd.grad(out, pg, d.cuda())
+        close(out, ref, rtol=2e-6, atol_scale=1e-6, name='lam3')
+        close(gg, gref, rtol=5e-6, atol_scale=2e-6, name='dparams_log')
 
 
 # ------------------------------------------------------------------------------------------------ GRU
