@@ -131,14 +131,17 @@ int resel_causal_conv1d_bwd2(const float* x, int64_t ld_x, const float* w, const
  * residual / res_out / bias may be NULL.  stats: [M, 2] (mean, rstd) saved for the backward.
  * Backward: dres_in (optional, [M, C]) is the gradient arriving at res_out from downstream; dx receives the
  * gradient w.r.t. x (== w.r.t. residual).  dw, db: [C]; workspace resel_add_layernorm_bwd_workspace_bytes().
+ * act (ABI 8): 1 = y = elu(.) of the above (the plain ELU that follows a gilr / lru layer, reference rnn_base.py:456-469, applied where the
+ * layer's closing add + LayerNorm stores its output); the backward then takes the bias `b` and forms elu' from the recomputed
+ * pre-activation (no extra tensor saved).  0 = none.
  */
 int resel_add_layernorm_fwd(const float* x, const float* residual, const float* w, const float* b,
-                            float* y, float* res_out, float* stats, int M, int C, float eps, int rms,
+                            float* y, float* res_out, float* stats, int M, int C, float eps, int rms, int act,
                             void* amax_y, unsigned amax_epoch, resel_stream_t stream);
 size_t resel_add_layernorm_bwd_workspace_bytes(int M, int C);
-int resel_add_layernorm_bwd(const float* dy, const float* dres_in, const float* res, const float* w,
+int resel_add_layernorm_bwd(const float* dy, const float* dres_in, const float* res, const float* w, const float* b,
                             const float* stats, float* dx, float* dw, float* db, void* workspace,
-                            int M, int C, int rms, int has_bias, void* amax_dx, unsigned amax_epoch, resel_stream_t stream);
+                            int M, int C, int rms, int has_bias, int act, void* amax_dx, unsigned amax_epoch, resel_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Linear-recurrence scans (gilr, lru).  Replace the Triton kernels

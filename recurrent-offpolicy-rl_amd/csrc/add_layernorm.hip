@@ -10,6 +10,9 @@
 namespace {
 using namespace resel;
 
+__device__ __forceinline__ float elu1(float y) { return y > 0.f ? y : expm1f(y); }         // ELU, alpha = 1 (torch's expm1 form)
+__device__ __forceinline__ float delu1(float y) { return y > 0.f ? 1.f : expf(y); }         // its derivative from the pre-activation
+
 constexpr int WAVES = 4;            // rows in flight per block
 constexpr int BWD_BLOCKS = 512;     // 2 per CU
 
@@ -17,7 +20,7 @@ template <int VPL>                  // float4 per lane: C <= VPL * 256
 __global__ __launch_bounds__(WAVES * 64) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ residual,
                                                             const float* __restrict__ w, const float* __restrict__ b,
                                                             float* __restrict__ y, float* __restrict__ res_out,
-                                                            float* __restrict__ stats, int M, int C, float eps, int rms, AmaxOut amax) {
+                                                            float* __restrict__ stats, int M, int C, float eps, int rms, int act, AmaxOut amax) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * WAVES + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -59,6 +62,7 @@ __global__ __launch_bounds__(WAVES * 64) void ln_fwd_kernel(const float* __restr
             o.x = (v[i].x - mean) * rstd * wv.x; o.y = (v[i].y - mean) * rstd * wv.y;
             o.z = (v[i].z - mean) * rstd * wv.z; o.w = (v[i].w - mean) * rstd * wv.w;
             if (b) { const float4 bb = reinterpret_cast<const float4*>(b)[c]; o.x += bb.x; o.y += bb.y; o.z += bb.z; o.w += bb.w; }
+            if (act) { o.x = elu1(o.x); o.y = elu1(o.y); o.z = elu1(o.z); o.w = elu1(o.w); }      // |elu(y)| <= |y|: the bound below still holds
             reinterpret_cast<float4*>(y + (int64_t)row * C)[c] = o;
             wmax = amax4(wmax, wv);
         }
@@ -84,19 +88,20 @@ __global__ __launch_bounds__(WAVES * 64) void ln_fwd_kernel(const float* __restr
 template <int VPL>
 __global__ __launch_bounds__(WAVES * 64) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ dres_in,
                                                             const float* __restrict__ res, const float* __restrict__ w,
-                                                            const float* __restrict__ stats, float* __restrict__ dx,
+                                                            const float* __restrict__ b, const float* __restrict__ stats, float* __restrict__ dx,
                                                             float* __restrict__ dw_part, float* __restrict__ db_part,
-                                                            int M, int C, int rms, AmaxOut amax) {
+                                                            int M, int C, int rms, int act, AmaxOut amax) {
     __shared__ __attribute__((aligned(16))) float s_acc[2][WAVES][VPL * 256];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int c4 = C / 4;
-    float4 dwa[VPL], dba[VPL], wreg[VPL];
+    float4 dwa[VPL], dba[VPL], wreg[VPL], breg[VPL];
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
         dwa[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         dba[i] = dwa[i];
         const int c = i * 64 + lane;
         wreg[i] = c < c4 ? reinterpret_cast<const float4*>(w)[c] : dwa[i];
+        breg[i] = (act && b && c < c4) ? reinterpret_cast<const float4*>(b)[c] : dwa[i];
     }
     float dxmax = 0.f;
     for (int row = blockIdx.x * WAVES + wv; row < M; row += gridDim.x * WAVES) {
@@ -110,8 +115,12 @@ __global__ __launch_bounds__(WAVES * 64) void ln_bwd_kernel(const float* __restr
             g[i] = xh[i];
             if (c < c4) {
                 const float4 r = reinterpret_cast<const float4*>(res + (int64_t)row * C)[c];
-                const float4 d = reinterpret_cast<const float4*>(dy + (int64_t)row * C)[c];
+                float4 d = reinterpret_cast<const float4*>(dy + (int64_t)row * C)[c];
                 xh[i].x = (r.x - mean) * rstd; xh[i].y = (r.y - mean) * rstd; xh[i].z = (r.z - mean) * rstd; xh[i].w = (r.w - mean) * rstd;
+                if (act) {          // the forward stored elu(y), y = xh w + b: its derivative from the recomputed y (1 for y > 0, e^y below)
+                    d.x *= delu1(xh[i].x * wreg[i].x + breg[i].x); d.y *= delu1(xh[i].y * wreg[i].y + breg[i].y);
+                    d.z *= delu1(xh[i].z * wreg[i].z + breg[i].z); d.w *= delu1(xh[i].w * wreg[i].w + breg[i].w);
+                }
                 dwa[i].x += d.x * xh[i].x; dwa[i].y += d.y * xh[i].y; dwa[i].z += d.z * xh[i].z; dwa[i].w += d.w * xh[i].w;
                 dba[i].x += d.x; dba[i].y += d.y; dba[i].z += d.z; dba[i].w += d.w;
                 g[i].x = d.x * wreg[i].x; g[i].y = d.y * wreg[i].y; g[i].z = d.z * wreg[i].z; g[i].w = d.w * wreg[i].w;
@@ -159,19 +168,19 @@ inline bool ln_ok(int M, int C) { return M > 0 && C > 0 && C % 4 == 0 && C <= 20
 }  // namespace
 
 extern "C" int resel_add_layernorm_fwd(const float* x, const float* residual, const float* w, const float* b,
-                                       float* y, float* res_out, float* stats, int M, int C, float eps, int rms,
+                                       float* y, float* res_out, float* stats, int M, int C, float eps, int rms, int act,
                                        void* amax_y, unsigned amax_epoch, resel_stream_t stream) {
-    if (!x || !w || !y || !ln_ok(M, C) || (amax_y && (reinterpret_cast<uintptr_t>(amax_y) & 7u))) return RESEL_EINVAL;
+    if (!x || !w || !y || !ln_ok(M, C) || (act != 0 && act != 1) || (amax_y && (reinterpret_cast<uintptr_t>(amax_y) & 7u))) return RESEL_EINVAL;
     const AmaxOut ao{(unsigned long long*)amax_y, amax_epoch};
     if (!aligned16(x) || !aligned16(y) || !aligned16(w) || (residual && !aligned16(residual)) || (b && !aligned16(b)) ||
         (res_out && !aligned16(res_out)))
         return RESEL_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((M + WAVES - 1) / WAVES), blk(WAVES * 64);
-    if (C <= 256) hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, blk, 0, s, x, residual, w, b, y, res_out, stats, M, C, eps, rms, ao);
-    else if (C <= 512) hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, blk, 0, s, x, residual, w, b, y, res_out, stats, M, C, eps, rms, ao);
-    else if (C <= 1024) hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, blk, 0, s, x, residual, w, b, y, res_out, stats, M, C, eps, rms, ao);
-    else hipLaunchKernelGGL(ln_fwd_kernel<8>, grid, blk, 0, s, x, residual, w, b, y, res_out, stats, M, C, eps, rms, ao);
+    if (C <= 256) hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, blk, 0, s, x, residual, w, b, y, res_out, stats, M, C, eps, rms, act, ao);
+    else if (C <= 512) hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, blk, 0, s, x, residual, w, b, y, res_out, stats, M, C, eps, rms, act, ao);
+    else if (C <= 1024) hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, blk, 0, s, x, residual, w, b, y, res_out, stats, M, C, eps, rms, act, ao);
+    else hipLaunchKernelGGL(ln_fwd_kernel<8>, grid, blk, 0, s, x, residual, w, b, y, res_out, stats, M, C, eps, rms, act, ao);
     return launch_status();
 }
 
@@ -179,10 +188,11 @@ extern "C" size_t resel_add_layernorm_bwd_workspace_bytes(int M, int C) {
     return (size_t)2 * bwd_blocks(M) * C * sizeof(float);
 }
 
-extern "C" int resel_add_layernorm_bwd(const float* dy, const float* dres_in, const float* res, const float* w,
+extern "C" int resel_add_layernorm_bwd(const float* dy, const float* dres_in, const float* res, const float* w, const float* b,
                                        const float* stats, float* dx, float* dw, float* db, void* workspace,
-                                       int M, int C, int rms, int has_bias, void* amax_dx, unsigned amax_epoch, resel_stream_t stream) {
+                                       int M, int C, int rms, int has_bias, int act, void* amax_dx, unsigned amax_epoch, resel_stream_t stream) {
     if (!dy || !res || !w || !stats || !dx || !dw || !workspace || !ln_ok(M, C) || (reinterpret_cast<uintptr_t>(amax_dx) & 7u)) return RESEL_EINVAL;
+    if ((act != 0 && act != 1) || (b && !aligned16(b)) || (has_bias && act && !b)) return RESEL_EINVAL;
     const AmaxOut ao{(unsigned long long*)amax_dx, amax_epoch};
     if (!aligned16(dy) || !aligned16(res) || !aligned16(w) || !aligned16(dx) || (dres_in && !aligned16(dres_in)))
         return RESEL_EINVAL;
@@ -191,10 +201,10 @@ extern "C" int resel_add_layernorm_bwd(const float* dy, const float* dres_in, co
     float* dw_part = (float*)workspace;
     float* db_part = dw_part + (size_t)nblk * C;
     dim3 grid(nblk), blk(WAVES * 64);
-    if (C <= 256) hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, blk, 0, s, dy, dres_in, res, w, stats, dx, dw_part, db_part, M, C, rms, ao);
-    else if (C <= 512) hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, blk, 0, s, dy, dres_in, res, w, stats, dx, dw_part, db_part, M, C, rms, ao);
-    else if (C <= 1024) hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, blk, 0, s, dy, dres_in, res, w, stats, dx, dw_part, db_part, M, C, rms, ao);
-    else hipLaunchKernelGGL(ln_bwd_kernel<8>, grid, blk, 0, s, dy, dres_in, res, w, stats, dx, dw_part, db_part, M, C, rms, ao);
+    if (C <= 256) hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, blk, 0, s, dy, dres_in, res, w, b, stats, dx, dw_part, db_part, M, C, rms, act, ao);
+    else if (C <= 512) hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, blk, 0, s, dy, dres_in, res, w, b, stats, dx, dw_part, db_part, M, C, rms, act, ao);
+    else if (C <= 1024) hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, blk, 0, s, dy, dres_in, res, w, b, stats, dx, dw_part, db_part, M, C, rms, act, ao);
+    else hipLaunchKernelGGL(ln_bwd_kernel<8>, grid, blk, 0, s, dy, dres_in, res, w, b, stats, dx, dw_part, db_part, M, C, rms, act, ao);
     launch_colsum(dw_part, C, nblk, C, dw, s);
     if (has_bias && db) launch_colsum(db_part, C, nblk, C, db, s);
     return launch_status();

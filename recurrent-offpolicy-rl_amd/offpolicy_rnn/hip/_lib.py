@@ -31,9 +31,9 @@ SIGNATURES = {
     'resel_causal_conv1d_bwd_workspace_bytes': (c_size_t, [I, I, I, I]),
     'resel_causal_conv1d_bwd': (c_int, [P, L, P, P, P, P, L, P, L, P, P, P, I, I, I, I, I, P, E, S]),
     'resel_causal_conv1d_bwd2': (c_int, [P, L, P, P, P, P, L, P, L, P, L, P, P, P, I, I, I, I, I, P, E, S]),
-    'resel_add_layernorm_fwd': (c_int, [P, P, P, P, P, P, P, I, I, F, I, P, E, S]),
+    'resel_add_layernorm_fwd': (c_int, [P, P, P, P, P, P, P, I, I, F, I, I, P, E, S]),
     'resel_add_layernorm_bwd_workspace_bytes': (c_size_t, [I, I]),
-    'resel_add_layernorm_bwd': (c_int, [P, P, P, P, P, P, P, P, P, I, I, I, I, P, E, S]),
+    'resel_add_layernorm_bwd': (c_int, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P, E, S]),
     'resel_linrec_real_fwd': (c_int, [P, P, L, P, P, P, I, I, I, I, P, E, S]),
     'resel_linrec_real_bwd': (c_int, [P, P, L, P, P, P, P, P, P, L, I, I, I, I, P, E, S]),
     'resel_linrec_complex_fwd': (c_int, [P, P, L, P, P, P, P, P, P, P, P, I, I, I, P, E, S]),

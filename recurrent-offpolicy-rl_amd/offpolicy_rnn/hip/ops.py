@@ -316,8 +316,9 @@ def causal_conv1d_fn(x, weight, bias=None, mask=None, activation=True):
 # ---------------------------------------------------------------------------------------------- add + norm
 class AddNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, residual, weight, bias, eps, rms, prenorm):
+    def forward(ctx, x, residual, weight, bias, eps, rms, prenorm, act=None):
         _need_cuda('add_layernorm', x, weight)
+        assert act in (None, 'elu')
         shape = x.shape
         C = shape[-1]
         x2 = x.float().reshape(-1, C).contiguous()
@@ -332,17 +333,18 @@ class AddNormFn(torch.autograd.Function):
         global LAST_AMAX
         slot, slot_p, epoch = _slot_args(amax_tracking() and M * C >= (1 << 20), x.device)
         check(lib().resel_add_layernorm_fwd(_p(x2), _p(r2), _p(w), _p(b), _p(y), _p(res_out), _p(stats), M, C, float(eps),
-                                            int(bool(rms)), slot_p, epoch, _stream()), 'add_layernorm_fwd')
+                                            int(bool(rms)), int(act == 'elu'), slot_p, epoch, _stream()), 'add_layernorm_fwd')
         LAST_AMAX = slot
-        ctx.save_for_backward(res_out if res_out is not None else x2, w, stats)
+        ctx.save_for_backward(res_out if res_out is not None else x2, w, stats, b if act else None)
         ctx.rms, ctx.has_bias, ctx.has_res, ctx.prenorm, ctx.shape = bool(rms), b is not None, residual is not None, prenorm, shape
+        ctx.act = int(act == 'elu')
         if prenorm:
             return y.reshape(shape), res_out.reshape(shape)
         return y.reshape(shape)
 
     @staticmethod
     def backward(ctx, dy, dres=None):
-        res, w, stats = ctx.saved_tensors
+        res, w, stats, b = ctx.saved_tensors
         M, C = res.shape
         dy2 = dy.float().reshape(M, C).contiguous()
         dr2 = None if (dres is None or not ctx.prenorm) else dres.float().reshape(M, C).contiguous()
@@ -351,23 +353,24 @@ class AddNormFn(torch.autograd.Function):
         db = torch.empty(C, dtype=torch.float32, device=res.device) if ctx.has_bias else None
         ws = _ws(lib().resel_add_layernorm_bwd_workspace_bytes(M, C), res.device)
         slot, slot_p, epoch = _slot_args(amax_tracking() and M * C >= (1 << 20), res.device)
-        check(lib().resel_add_layernorm_bwd(_p(dy2), _p(dr2), _p(res), _p(w), _p(stats), _p(dx), _p(dw), _p(db), _p(ws),
-                                            M, C, int(ctx.rms), int(ctx.has_bias), slot_p, epoch, _stream()), 'add_layernorm_bwd')
+        check(lib().resel_add_layernorm_bwd(_p(dy2), _p(dr2), _p(res), _p(w), _p(b), _p(stats), _p(dx), _p(dw), _p(db), _p(ws),
+                                            M, C, int(ctx.rms), int(ctx.has_bias), ctx.act, slot_p, epoch, _stream()), 'add_layernorm_bwd')
         dx = tag_amax(dx.reshape(ctx.shape), slot, whole=True)      # the gradient the block below multiplies with its out_proj weight
-        return dx, (dx if ctx.has_res else None), dw, db, None, None, None
+        return dx, (dx if ctx.has_res else None), dw, db, None, None, None, None
 
 
-def _add_norm(x, residual, weight, bias, eps, rms, prenorm):
+def _add_norm(x, residual, weight, bias, eps, rms, prenorm, act=None):
     global LAST_AMAX
     LAST_AMAX = None
-    out = AddNormFn.apply(x, residual, weight, bias, eps, rms, prenorm)
+    out = AddNormFn.apply(x, residual, weight, bias, eps, rms, prenorm, act)
     tag_amax(out[0] if prenorm else out, LAST_AMAX, whole=True)    # the normalised output feeds a projection: its magnitude came out of the same pass
     return out
 
 
-def layer_norm_fn(x, weight, bias, residual=None, eps=1e-6, prenorm=False, residual_in_fp32=False):
-    """Signature of the reference's fused add+LayerNorm (mamba_ssm/ops/triton/layernorm.py `layer_norm_fn`)."""
-    return _add_norm(x, residual, weight, bias, eps, False, prenorm)
+def layer_norm_fn(x, weight, bias, residual=None, eps=1e-6, prenorm=False, residual_in_fp32=False, act=None):
+    """Signature of the reference's fused add+LayerNorm (mamba_ssm/ops/triton/layernorm.py `layer_norm_fn`).  act='elu' (this library's
+    addition): the plain ELU that follows the layer, applied where the normalised output is stored."""
+    return _add_norm(x, residual, weight, bias, eps, False, prenorm, act)
 
 
 def rms_norm_fn(x, weight, bias, residual=None, eps=1e-6, prenorm=False, residual_in_fp32=False):

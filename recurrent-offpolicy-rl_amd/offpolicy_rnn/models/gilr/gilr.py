@@ -19,10 +19,11 @@ class PositionWiseFeedForward(nn.Module):
         self.dropout = nn.Dropout(dropout)
         self.layer_norm = nn.LayerNorm(d_model, eps=eps)
 
-    def forward(self, x):
+    def forward(self, x, out_act=None):
+        """out_act='elu': the plain ELU behind the layer rides in the closing add + LayerNorm kernel (RNNBase, training passes)."""
         y = self.dropout(self.activation(ops.linear(x, self.w_1.weight, self.w_1.bias)))
         return ops.layer_norm_fn(self.dropout(ops.linear(y, self.w_2.weight, self.w_2.bias)), self.layer_norm.weight, self.layer_norm.bias, residual=x,
-                                 eps=self.layer_norm.eps)        # fused add + LayerNorm
+                                 eps=self.layer_norm.eps, act=out_act)        # fused add + LayerNorm (+ ELU)
 
 
 class GILRLayer(nn.Module):
@@ -41,11 +42,12 @@ class GILRLayer(nn.Module):
     def rnn_parameters(self):
         return list(self.parameters(True))
 
-    def forward(self, x, hidden=None, rnn_start=None):
+    def forward(self, x, hidden=None, rnn_start=None, out_act=None):
         u = self.in_proj(x)                                         # [2, B, T, C]
         h0 = None if hidden is None else hidden[0]
         h = ops.gilr_scan_members(u, rnn_start, h0, True)           # the two members read in place, one gradient tensor back
+        assert out_act is None or self.use_ff
         out = ops.linear(h, self.out_proj.weight, self.out_proj.bias)
         if self.use_ff:
-            out = self.ff(out)
+            out = self.ff(out, out_act)
         return out, h[:, -1:, :].transpose(0, 1)

@@ -38,7 +38,7 @@ class LRULayer(nn.Module):
     def rnn_parameters(self):
         return self.parameters(recurse=True)
 
-    def forward(self, x, hidden=None, rnn_start=None, grad_detach=None):
+    def forward(self, x, hidden=None, rnn_start=None, grad_detach=None, out_act=None):
         u = self.in_proj(x)                                         # [3, B, T, C]
         if self.squash_inproj:
             u = torch.tanh(u)
@@ -50,7 +50,8 @@ class LRULayer(nn.Module):
         h2, u2 = ops.complex_scan_members(u, ops.lru_params(self.params_log), rnn_start, h0r, h0i)
         hr, hi = h2[0], h2[1]
         out = ops.SubAddMembers.apply(self.middle_proj(h2), u2)
+        assert out_act is None or self.use_ff
         if self.use_ff:
-            out = self.ff(out)
+            out = self.ff(out, out_act)
         hidden = torch.cat((hr[:, -1:, :], hi[:, -1:, :]), dim=-1).transpose(0, 1)
         return out, hidden

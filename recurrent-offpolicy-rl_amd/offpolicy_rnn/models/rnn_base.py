@@ -244,6 +244,13 @@ class RNNBase(torch.nn.Module):
         return self._make_state(batch_size, device, True)
 
     # ------------------------------------------------------------------------------------------ forward
+    def _fuse_out_act(self, ind, x) -> bool:
+        """The activation module behind sequence layer `ind` is a plain ELU and this is a training pass over whole fp32 GPU sequences: the
+        layer may apply it in its last kernel (`out_act='elu'`)."""
+        act_mod = self.activation_list[ind]
+        return (_TRAINING_PASS[0] > 0 and isinstance(act_mod, torch.nn.ELU) and act_mod.alpha == 1.0 and x.is_cuda
+                and x.dtype == torch.float32 and x.dim() == 3 and x.shape[-2] > 1)
+
     def meta_forward(self, x: torch.Tensor, hidden_state: Optional[RNNHidden] = None, require_full_hidden: bool = False,
                      first_grad_part=None) -> Tuple[torch.Tensor, RNNHidden, Optional[RNNHidden]]:
         """first_grad_part = (x_part, col0): the first layer (a shared-input efc layer) differentiates x only through that
@@ -266,14 +273,23 @@ class RNNBase(torch.nn.Module):
                 continue
             lid = self.layer_type[ind]
             if is_rnn_layer(lid):
+                if lid in ('gilr', 'lru') and self._fuse_out_act(ind, x) and layer.use_ff:
+                    # the plain ELU behind the layer rides in its closing add + LayerNorm kernel (training passes only, see _TRAINING_PASS)
+                    if lid == 'gilr':
+                        x, h = layer(x, hidden_state[k], hidden_state.rnn_start, out_act='elu')
+                    else:
+                        x, h = layer(x, hidden_state[k], hidden_state.rnn_start, hidden_state.grad_detach, out_act='elu')
+                    k += 1
+                    out_state.append(h)
+                    if require_full_hidden:
+                        full.append(None)
+                    continue
                 if lid in ('gilr', 'gilr_lstm'):
                     x, h = layer(x, hidden_state[k], hidden_state.rnn_start)
                 elif lid == 'lru':
                     x, h = layer(x, hidden_state[k], hidden_state.rnn_start, hidden_state.grad_detach)
                 elif lid.startswith('smamba'):
-                    act_mod = self.activation_list[ind]
-                    fuse_act = (_TRAINING_PASS[0] > 0 and isinstance(act_mod, torch.nn.ELU) and act_mod.alpha == 1.0 and x.is_cuda
-                                and x.dtype == torch.float32 and x.dim() == 3 and x.shape[-2] > 1 and not layer.use_ff)
+                    fuse_act = self._fuse_out_act(ind, x) and not layer.use_ff
                     x, h = layer(x, hidden_state[k], hidden_state.rnn_start, hidden_state.mask, out_act='elu' if fuse_act else None)
                     if fuse_act:                       # the activation rode in the layer's last GEMM: skip the module below
                         k += 1

@@ -69,8 +69,10 @@ def linear_act(x, weight, bias, act):
 
 
 def _norm(rms):
-    def fn(x, weight, bias, residual=None, eps=1e-6, prenorm=False, residual_in_fp32=False):
+    def fn(x, weight, bias, residual=None, eps=1e-6, prenorm=False, residual_in_fp32=False, act=None):
         y, res = K.add_layernorm_ref(x, residual, weight, bias, eps, rms)
+        if act == 'elu':
+            y = torch.nn.functional.elu(y)
         return (y, res) if prenorm else y
     return fn
 

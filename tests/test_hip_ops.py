@@ -242,6 +242,26 @@ def test_add_layernorm_fwd_bwd(ops, M, C, rms, prenorm):
         close(a, b_, rtol=2e-4, atol_scale=5e-5, name=f'grad{i}')
 
 
+@pytest.mark.parametrize('M,C,bias', [(4100, 256, True), (333, 512, True), (1000, 96, False)])
+def test_add_layernorm_with_the_elu_epilogue_vs_torch(ops, M, C, bias):
+    """act='elu' of the fused add + LayerNorm: elu(LN(x + residual)) and its gradients (elu' re-formed from the recomputed pre-activation)."""
+    g = torch.Generator().manual_seed(M + C)
+    x, r, dy = rnd(M, C, g=g), rnd(M, C, g=g), rnd(M, C, g=g)
+    w, b = 1 + 0.2 * rnd(C, g=g), (0.3 * rnd(C, g=g) if bias else None)
+
+    def run(dev, fn):
+        ts = [t.clone().to(dev).requires_grad_(True) for t in ((x, r, w, b) if bias else (x, r, w))]
+        y = fn(*ts) if bias else fn(ts[0], ts[1], ts[2], None)
+        y.backward(dy.to(dev))
+        return y, [t.grad for t in ts]
+
+    y_ref, g_ref = run('cpu', lambda x_, r_, w_, b_: torch.nn.functional.elu(torch.nn.functional.layer_norm(x_ + r_, (C,), w_, b_, 1e-5)))
+    y_gpu, g_gpu = run('cuda', lambda x_, r_, w_, b_: ops.layer_norm_fn(x_, w_, b_, residual=r_, eps=1e-5, act='elu'))
+    close_fwd(y_gpu, y_ref, name='y')
+    for nm, a, b_ in zip(('dx', 'dres', 'dw', 'db'), g_gpu, g_ref):
+        close(a, b_, rtol=2e-4, atol_scale=5e-5, name=nm)
+
+
 # ------------------------------------------------------------------------------------------------ linear recurrences
 # (64, 40, 256): 64 channels per wave; (16, 45, 512): 32 x 2 time segments; the small batches: 16 channels x 4 segments per wave
 @pytest.mark.parametrize('B,L,C', [(2, 33, 64), (3, 500, 96), (1, 2003, 256), (2, 7, 32), (64, 40, 256), (16, 45, 512)])

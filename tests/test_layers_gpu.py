@@ -46,15 +46,17 @@ def test_layer_fwd_bwd_vs_reference_recording(lid):
     assert checked > 0
 
 
-def test_training_pass_fuses_the_elu_behind_smamba_without_changing_values():
-    """Inside `rnn_base.training_pass()` (the trainers' updates) the plain ELU behind a smamba layer is applied by the layer's last GEMM and the
-    layer's entry in the returned full-hidden record is None; outside, the record holds the PRE-activation sequence as in the reference
-    (rnn_base.py:456-460).  Outputs and every gradient agree between the two forms."""
+@pytest.mark.parametrize('lid', ['smamba_s16_c4_b1_nln', 'gilr', 'lru'])
+def test_training_pass_fuses_the_elu_behind_smamba_without_changing_values(lid):
+    """Inside `rnn_base.training_pass()` (the trainers' updates) the plain ELU behind a smamba / gilr / lru layer is applied by the layer's last
+    kernel (the head GEMM's epilogue; the closing add + LayerNorm of the feed-forward block) and the layer's entry in the returned full-hidden
+    record is None; outside, the record holds the PRE-activation sequence as in the reference (rnn_base.py:456-460).  Outputs and every
+    gradient agree between the two forms."""
     if not torch.cuda.is_available():
         pytest.skip('needs a GPU')
     from offpolicy_rnn.models.rnn_base import RNNBase, training_pass
     torch.manual_seed(3)
-    net = RNNBase(96, 64, [256, 256], ['elu', 'elu', 'linear'], ['fc', 'smamba_s16_c4_b1_nln', 'fc']).cuda()
+    net = RNNBase(96, 64, [256, 256], ['elu', 'elu', 'linear'], ['fc', lid, 'fc']).cuda()
     B, L = 4, 1100                                              # 4 400 tokens: the hand-written GEMMs (and their ELU epilogue) run
     x = torch.randn(B, L, 96, device='cuda')
     start = torch.zeros(B, L, 1, device='cuda')
@@ -74,11 +76,11 @@ def test_training_pass_fuses_the_elu_behind_smamba_without_changing_values():
         else:
             y, _, full = net.meta_forward(xs, hid, require_full_hidden=True)
         (y * w).sum().backward()
-        res.append((y.detach(), xs.grad, [p.grad.clone() for p in net.parameters()], full))
+        res.append((y.detach(), xs.grad, [None if p.grad is None else p.grad.clone() for p in net.parameters()], full))     # gilr holds an unused LayerNorm, as upstream
     (y0, g0, p0, f0), (y1, g1, p1, f1) = res
     assert f1[0] is None and torch.is_tensor(f0[0]) and f0[0].shape == (B, L, 256)
     assert (f0[0] < -1.0).any(), 'the unfused record is the pre-activation sequence (an ELU output never goes below -1)'
     tol = lambda a, b: (a - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-6)
     assert tol(y1, y0) and tol(g1, g0)
     for a, b in zip(p1, p0):
-        assert tol(a, b)
+        assert (a is None) == (b is None) and (a is None or tol(a, b))
