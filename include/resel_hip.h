@@ -424,6 +424,14 @@ int resel_gemm_f32_head(const float* A, int64_t lda, int64_t strideA, int a_kcon
                         float* C, int64_t ldc, int64_t strideC, float* q, void* workspace,
                         int M, int N, int K, int batch, const float* amax_a, const float* amax_b,
                         void* amax_c, unsigned amax_epoch, resel_stream_t stream);
+/* out [rows, cols] (row stride ld_out) = zeros with nblk <= 8 source blocks copied in: block k = src[k] [nr[k], nc[k]] (row stride ld_src[k]) placed
+ * at (r0[k], c0[k]); later blocks win where blocks overlap.  The arrays are HOST arrays of length nblk (read before the call returns).  One launch
+ * for the operands of the merged input-encoder GEMM - the block-diagonal of the encoder weights, their concatenated biases, the concatenated
+ * zero-padded input rows (reference contextual_sac_value.py:90-99 / contextual_sac_policy.py: one nn.Linear per input and a cat of the outputs).
+ * (ABI 8) */
+int resel_place_blocks(float* out, int64_t ld_out, int rows, int cols, int nblk, const float* const* src, const int64_t* ld_src,
+                       const int* r0, const int* nr, const int* c0, const int* nc, resel_stream_t stream);
+
 /* Magnitude handles.  A kernel that writes a tensor which a later GEMM reads can publish max |x| of what it stored, so that mode 2
  * needs no extra pass over the operand.  A handle is 1 KiB (8-byte aligned; NULL = off): eight 8-byte words 128 bytes apart, word j =
  * {float bits : low 32 | epoch : high 32}; a publishing wave raises the word its workgroup id selects with one 64-bit atomicMax

@@ -38,6 +38,7 @@ SIGNATURES = {
     'resel_linrec_real_bwd': (c_int, [P, P, L, P, P, P, P, P, P, L, I, I, I, I, P, E, S]),
     'resel_linrec_complex_fwd': (c_int, [P, P, L, P, P, P, P, P, P, P, P, I, I, I, P, E, S]),
     'resel_linrec_complex_bwd_workspace_bytes': (c_size_t, [I, I, I]),
+    'resel_place_blocks': (c_int, [P, L, I, I, I, P, P, P, P, P, P, S]),
     'resel_lru_params_fwd': (c_int, [P, P, I, S]),
     'resel_lru_params_bwd': (c_int, [P, P, P, I, S]),
     'resel_linrec_complex_bwd': (c_int, [P, P, L, P, P, P, P, P, P, P, P, P, P, P, P, L, P, P, P, P, I, I, I, S]),

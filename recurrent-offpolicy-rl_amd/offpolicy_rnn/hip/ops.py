@@ -1084,6 +1084,40 @@ class LinearAct(torch.autograd.Function):
         return dx, dw, None if db is None else db.reshape(-1), None
 
 
+class PlaceBlocksFn(torch.autograd.Function):
+    """out [rows, cols] = zeros with the source blocks copied in at their (r0, c0) (include/resel_hip.h `resel_place_blocks`): ONE launch for what
+    block_diag / cat / pad assemble in several; the backward hands every source the matching slice of the gradient as a VIEW.
+    srcs: fp32 tensors [..., nc_i]; their leading axes collapse to the nr_i rows of the block."""
+
+    @staticmethod
+    def forward(ctx, rows, cols, origins, *srcs):
+        _need_cuda('place_blocks', *srcs)
+        n = len(srcs)
+        assert 1 <= n <= 8 and len(origins) == n
+        s2 = []
+        for t in srcs:
+            t2 = t.reshape(-1, t.shape[-1])                                    # a view whenever the leading axes collapse
+            s2.append(t2 if (t2.dtype == torch.float32 and t2.stride(1) == 1) else t2.float().contiguous())
+        out = torch.empty(rows, cols, dtype=torch.float32, device=srcs[0].device)
+        VP, LL, II = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int * n
+        check(lib().resel_place_blocks(_p(out), cols, rows, cols, n, VP(*[t.data_ptr() for t in s2]), LL(*[t.stride(0) for t in s2]),
+                                       II(*[o[0] for o in origins]), II(*[t.shape[0] for t in s2]), II(*[o[1] for o in origins]),
+                                       II(*[t.shape[1] for t in s2]), _stream()), 'place_blocks')
+        ctx.meta = [(o[0], o[1], t2.shape[0], t2.shape[1], tuple(t.shape)) for o, t2, t in zip(origins, s2, srcs)]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        outs = []
+        for need, (r0, c0, nr, nc, shape) in zip(ctx.needs_input_grad[3:], ctx.meta):
+            outs.append(g[r0:r0 + nr, c0:c0 + nc].reshape(shape) if need else None)    # a view of g (rows of a block keep g's row stride)
+        return (None, None, None) + tuple(outs)
+
+
+def place_blocks(rows, cols, origins, *srcs):
+    return PlaceBlocksFn.apply(int(rows), int(cols), tuple((int(r), int(c)) for r, c in origins), *srcs)
+
+
 def linear_act(x, weight, bias, act):
     global LAST_AMAX
     LAST_AMAX = None

@@ -46,8 +46,9 @@ def encode_concat(pairs, act_mod=None) -> torch.Tensor:
     """cat([enc_i(x_i)], -1) for Linear encoders as ONE library GEMM: the (narrow) inputs are concatenated instead of the
     (wide) outputs and multiplied by the block-diagonal of the encoder weights with the biases fused (addmm epilogue) -
     per update this removes three skinny GEMMs, three bias-add passes and the 384-wide cat per call.  The zero blocks
-    add exact zeros to every dot product; autograd splits the gradients back through block_diag / cat."""
-    """act_mod: the activation module applied to the result (None: none) - fused into the GEMM when `_fusable`."""
+    add exact zeros to every dot product; autograd splits the gradients back through block_diag / cat (long GPU passes: through
+    `ops.place_blocks`, one launch per operand, gradients as views).
+    act_mod: the activation module applied to the result (None: none) - fused into the GEMM when `_fusable`."""
     mods = [m for m, _ in pairs]
     xs = [x for _, x in pairs]
     fuse = act_mod is not None and _fusable(act_mod, xs[0], mods)
@@ -58,13 +59,25 @@ def encode_concat(pairs, act_mod=None) -> torch.Tensor:
         if fuse and mods[0].weight.shape[0] >= ops.GEMM_F32_MIN_DIM and mods[0].weight.shape[1] >= ops.GEMM_F32_MIN_K:
             return ops.linear_act(xs[0], mods[0].weight, mods[0].bias, 'elu')
         return (act_mod if fuse else post)(ops.linear(xs[0], mods[0].weight, mods[0].bias))
-    w = torch.block_diag(*[m.weight for m in mods])
-    b = torch.cat([m.bias for m in mods])
-    pad = (-w.shape[1]) % 4                  # 17 + 17 + 6 + 1 = 41 input columns: three zero columns make the rows 16-byte multiples,
-    if pad and xs[0].is_cuda:                # which the hand-written GEMM needs (35 us against the library's 97 at 66 752 tokens)
-        xs = xs + [torch.zeros(*xs[0].shape[:-1], pad, dtype=xs[0].dtype, device=xs[0].device)]
-        w = torch.nn.functional.pad(w, (0, pad))
-    x = torch.cat(xs, dim=-1)
+    ks, ns = [m.weight.shape[1] for m in mods], [m.weight.shape[0] for m in mods]
+    kp = sum(ks) + (-sum(ks)) % 4            # 17 + 17 + 6 + 1 = 41 input columns: three zero columns make the rows 16-byte multiples,
+    if xs[0].is_cuda and xs[0].dtype == torch.float32 and xs[0].numel() // xs[0].shape[-1] >= ops.GEMM_F32_MIN_ROWS and len(mods) <= 8:
+        # which the hand-written GEMM needs (35 us against the library's 97 at 66 752 tokens).  Long GPU passes: the three operands are
+        # assembled by ONE launch each (`ops.place_blocks`) and their gradients come back as views
+        c0 = [sum(ks[:i]) for i in range(len(ks))]
+        r0 = [sum(ns[:i]) for i in range(len(ns))]
+        w = ops.place_blocks(sum(ns), kp, list(zip(r0, c0)), *[m.weight for m in mods])
+        b = ops.place_blocks(1, sum(ns), [(0, r) for r in r0], *[m.bias for m in mods]).view(-1)
+        rows = xs[0].numel() // xs[0].shape[-1]
+        x = ops.place_blocks(rows, kp, [(0, c) for c in c0], *xs).view(*xs[0].shape[:-1], kp)
+    else:
+        w = torch.block_diag(*[m.weight for m in mods])
+        b = torch.cat([m.bias for m in mods])
+        pad = (-w.shape[1]) % 4
+        if pad and xs[0].is_cuda:
+            xs = xs + [torch.zeros(*xs[0].shape[:-1], pad, dtype=xs[0].dtype, device=xs[0].device)]
+            w = torch.nn.functional.pad(w, (0, pad))
+        x = torch.cat(xs, dim=-1)
     x2 = x.reshape(-1, x.shape[-1])
     if fuse and w.shape[0] >= ops.GEMM_F32_MIN_DIM and w.shape[1] >= ops.GEMM_F32_MIN_K:
         return ops.linear_act(x2, w, b, 'elu').view(*x.shape[:-1], w.shape[0])

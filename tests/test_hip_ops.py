@@ -262,6 +262,38 @@ def test_add_layernorm_with_the_elu_epilogue_vs_torch(ops, M, C, bias):
         close(a, b_, rtol=2e-4, atol_scale=5e-5, name=nm)
 
 
+def test_place_blocks_vs_block_diag_cat_pad(ops):
+    """`ops.place_blocks` (one launch) against torch.block_diag / cat / pad, values and gradients (the operands of the merged encoder GEMM,
+    policy_value_models/_inputs.py)."""
+    g = torch.Generator().manual_seed(11)
+    ws = [rnd(128, 17, g=g), rnd(128, 17, g=g), rnd(128, 6, g=g), rnd(128, 1, g=g)]
+    bs = [rnd(128, g=g) for _ in ws]
+    batch = rnd(5, 301, 60, g=g).cuda()
+    xs_src = [batch[..., 0:17], batch[..., 20:37], batch[..., 40:46], batch[..., 50:51]]       # column blocks of one packed batch array
+    ks, ns = [17, 17, 6, 1], [128] * 4
+    kp = 44
+    c0 = [0, 17, 34, 40]
+    r0 = [0, 128, 256, 384]
+
+    def leafs(ts):
+        return [t.clone().cuda().requires_grad_(True) for t in ts]
+
+    w1, b1, x1 = leafs(ws), leafs(bs), [t.clone().requires_grad_(True) for t in xs_src]
+    W = ops.place_blocks(512, kp, list(zip(r0, c0)), *w1)
+    Bc = ops.place_blocks(1, 512, [(0, r) for r in r0], *b1).view(-1)
+    X = ops.place_blocks(5 * 301, kp, [(0, c) for c in c0], *[t.detach().clone().requires_grad_(True) if False else t for t in x1]).view(5, 301, kp)
+    w2, b2, x2 = leafs(ws), leafs(bs), [t.clone().requires_grad_(True) for t in xs_src]
+    Wr = torch.nn.functional.pad(torch.block_diag(*w2), (0, kp - 41))
+    Br = torch.cat(b2)
+    Xr = torch.cat(x2 + [torch.zeros(5, 301, kp - 41, device='cuda')], dim=-1)
+    assert torch.equal(W, Wr) and torch.equal(Bc, Br) and torch.equal(X, Xr)
+    gw, gb, gx = rnd(512, kp, g=g).cuda(), rnd(512, g=g).cuda(), rnd(5, 301, kp, g=g).cuda()
+    ((W * gw).sum() + (Bc * gb).sum() + (X * gx).sum()).backward()
+    ((Wr * gw).sum() + (Br * gb).sum() + (Xr * gx).sum()).backward()
+    for a, b in zip(w1 + b1 + x1, w2 + b2 + x2):
+        assert torch.equal(a.grad, b.grad)
+
+
 # ------------------------------------------------------------------------------------------------ linear recurrences
 # (64, 40, 256): 64 channels per wave; (16, 45, 512): 32 x 2 time segments; the small batches: 16 channels x 4 segments per wave
 @pytest.mark.parametrize('B,L,C', [(2, 33, 64), (3, 500, 96), (1, 2003, 256), (2, 7, 32), (64, 40, 256), (16, 45, 512)])
