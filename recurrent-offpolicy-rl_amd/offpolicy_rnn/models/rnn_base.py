@@ -303,11 +303,18 @@ class RNNBase(torch.nn.Module):
                     x, h = layer(x, hidden_state[k], hidden_state.mask)
                 elif lid.startswith('cgpt'):
                     multi = x.dim() == 3 and x.shape[-2] > 1          # whole packed rows (training) vs one rollout step
+                    fuse_act = multi and self._fuse_out_act(ind, x) and x.shape[0] * x.shape[1] >= ops.GEMM_F32_MIN_ROWS
                     x = layer(x, inference_params=None if multi else hidden_state[k],
-                              seqlens=hidden_state.attention_concat_mask if multi else None)
+                              seqlens=hidden_state.attention_concat_mask if multi else None, out_act='elu' if fuse_act else None)
                     h = hidden_state[k]
                     if not multi:
                         h.seqlen_offset += x.shape[-2]        # reference :451-452
+                    if fuse_act:                       # the activation rode in the decoder's output GEMM: skip the module below
+                        k += 1
+                        out_state.append(h)
+                        if require_full_hidden:
+                            full.append(None)
+                        continue
                 else:                                   # gru: no reset / mask handling (reference :453-454)
                     x, h = layer(x, hidden_state[k])
                 k += 1

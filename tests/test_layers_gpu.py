@@ -46,10 +46,10 @@ def test_layer_fwd_bwd_vs_reference_recording(lid):
     assert checked > 0
 
 
-@pytest.mark.parametrize('lid', ['smamba_s16_c4_b1_nln', 'gilr', 'lru'])
+@pytest.mark.parametrize('lid', ['smamba_s16_c4_b1_nln', 'gilr', 'lru', 'cgpt_h8_l2_p0.0_ml1200_rms'])
 def test_training_pass_fuses_the_elu_behind_smamba_without_changing_values(lid):
     """Inside `rnn_base.training_pass()` (the trainers' updates) the plain ELU behind a smamba / gilr / lru layer is applied by the layer's last
-    kernel (the head GEMM's epilogue; the closing add + LayerNorm of the feed-forward block) and the layer's entry in the returned full-hidden
+    kernel (the head GEMM's epilogue; the closing add + LayerNorm of the feed-forward block; cgpt's `output_fc` GEMM) and the layer's entry in the returned full-hidden
     record is None; outside, the record holds the PRE-activation sequence as in the reference (rnn_base.py:456-460).  Outputs and every
     gradient agree between the two forms."""
     if not torch.cuda.is_available():
@@ -80,7 +80,8 @@ def test_training_pass_fuses_the_elu_behind_smamba_without_changing_values(lid):
     (y0, g0, p0, f0), (y1, g1, p1, f1) = res
     assert f1[0] is None and torch.is_tensor(f0[0]) and f0[0].shape == (B, L, 256)
     assert (f0[0] < -1.0).any(), 'the unfused record is the pre-activation sequence (an ELU output never goes below -1)'
-    tol = lambda a, b: (a - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-6)
+    rt = 1e-2 if lid.startswith('cgpt') else 2e-5          # cgpt's backward runs in bf16: a last-bit change of elu' moves roundings
+    tol = lambda a, b: (a - b).abs().max().item() <= rt * max(b.abs().max().item(), 1e-6)
     assert tol(y1, y0) and tol(g1, g0)
     for a, b in zip(p1, p0):
         assert (a is None) == (b is None) and (a is None or tol(a, b))
