@@ -326,11 +326,12 @@ int resel_sumsq(const float* x, int64_t n, float* out, void* workspace, resel_st
  * y [rows, C] contiguous, rows grouped in rows / rows_per_seg segments with one bias row [C] each (bias [nseg, C]).
  * fwd (in place): y <- act(y + bias);  act: 0 = identity, 1 = ELU(alpha = 1).
  * bwd (from the forward OUTPUT a): gy = g * act'(.), dbias[nseg, C] = per-segment column sums of gy (dbias may be NULL).  g has row
- *      stride ldg >= C (a column block of a wider gradient is read in place: ABI 7), a and gy are dense; gy NULL with act == 0 = column
- *      sums only.  workspace: resel_bias_act_bwd_workspace_bytes. */
+ *      stride ldg >= C (a column block of a wider gradient is read in place: ABI 7), a has row stride lda >= C (a block of a row buffer
+ *      that its producing GEMM wrote in place: ABI 8), gy is dense; gy NULL with act == 0 = column sums only.
+ *      workspace: resel_bias_act_bwd_workspace_bytes. */
 int resel_bias_act_fwd(float* y, const float* bias, int64_t rows, int C, int64_t rows_per_seg, int act, resel_stream_t stream);
 size_t resel_bias_act_bwd_workspace_bytes(int64_t rows, int C, int64_t rows_per_seg);
-int resel_bias_act_bwd(const float* g, int64_t ldg, const float* a, float* gy, float* dbias, void* workspace, int64_t rows, int C,
+int resel_bias_act_bwd(const float* g, int64_t ldg, const float* a, int64_t lda, float* gy, float* dbias, void* workspace, int64_t rows, int C,
                        int64_t rows_per_seg, int act, void* amax_gy, unsigned amax_epoch, resel_stream_t stream);
 
 /* ---- ensemble head: last hidden layer's tail + the width-1 output layer of an efc-E MLP ----------------------------

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void bias_act_fwd_kernel(float* __restrict__ y
 }
 
 // grid = (row blocks inside a segment, column blocks of 256 floats, segments); 256 threads = 64 float4 columns x 4 row lanes
-__global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float* __restrict__ g, int64_t ldg, const float* __restrict__ a,
+__global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float* __restrict__ g, int64_t ldg, const float* __restrict__ a, int64_t lda,
                                                            float* __restrict__ gy, float* __restrict__ db_part,
                                                            int C, int64_t rows_per_seg, int act, int nrb, AmaxOut amax) {
     __shared__ __attribute__((aligned(16))) float s_red[4][256];
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float* __restri
             const int64_t o = (seg * rows_per_seg + r) * C + c;
             float4 v = ld4(g + (seg * rows_per_seg + r) * ldg + c);          // g may be a column block of a wider gradient (row stride ldg)
             if (act == 1) {
-                const float4 av = ld4(a + o);
+                const float4 av = ld4(a + (seg * rows_per_seg + r) * lda + c);   // so may the activation (a block of a row buffer)
                 v.x *= av.x > 0.f ? 1.f : av.x + 1.f; v.y *= av.y > 0.f ? 1.f : av.y + 1.f;
                 v.z *= av.z > 0.f ? 1.f : av.z + 1.f; v.w *= av.w > 0.f ? 1.f : av.w + 1.f;
             }
@@ -161,16 +161,17 @@ extern "C" size_t resel_bias_act_bwd_workspace_bytes(int64_t rows, int C, int64_
     return (size_t)(rows / rows_per_seg) * row_blocks(rows_per_seg) * C * sizeof(float);
 }
 
-extern "C" int resel_bias_act_bwd(const float* g, int64_t ldg, const float* a, float* gy, float* dbias, void* workspace, int64_t rows, int C,
+extern "C" int resel_bias_act_bwd(const float* g, int64_t ldg, const float* a, int64_t lda, float* gy, float* dbias, void* workspace, int64_t rows, int C,
                                   int64_t rows_per_seg, int act, void* amax_gy, unsigned amax_epoch, resel_stream_t stream) {
     if (amax_gy && (reinterpret_cast<uintptr_t>(amax_gy) & 7u)) return RESEL_EINVAL;
     if (!g || !shape_ok(rows, C, rows_per_seg) || act < 0 || act > 1 || (act == 1 && (!a || !gy)) || (dbias && !workspace) || ldg < C || (ldg & 3))
         return RESEL_EINVAL;
+    if (a && (lda < C || (lda & 3))) return RESEL_EINVAL;
     if (!aligned16(g) || (gy && !aligned16(gy)) || (a && !aligned16(a)) || (workspace && !aligned16(workspace))) return RESEL_EINVAL;
     const int nseg = (int)(rows / rows_per_seg), nrb = row_blocks(rows_per_seg);
     hipStream_t s = (hipStream_t)stream;
     float* part = dbias ? (float*)workspace : nullptr;
-    hipLaunchKernelGGL(bias_act_bwd_kernel, dim3(nrb, (C + 255) / 256, nseg), dim3(256), 0, s, g, ldg, a, gy, part, C, rows_per_seg, act, nrb,
+    hipLaunchKernelGGL(bias_act_bwd_kernel, dim3(nrb, (C + 255) / 256, nseg), dim3(256), 0, s, g, ldg, a, lda, gy, part, C, rows_per_seg, act, nrb,
                        AmaxOut{(unsigned long long*)amax_gy, amax_epoch});
     if (dbias) launch_colsum(part, C, nrb, C, dbias, s, 1, 0, nseg);      // dbias[sg, :] = sum over the segment's row blocks
     return launch_status();

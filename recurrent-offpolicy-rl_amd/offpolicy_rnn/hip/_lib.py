@@ -72,7 +72,7 @@ SIGNATURES = {
     'resel_sumsq': (c_int, [P, L, P, P, S]),
     'resel_bias_act_fwd': (c_int, [P, P, L, I, L, I, S]),
     'resel_bias_act_bwd_workspace_bytes': (c_size_t, [L, I, L]),
-    'resel_bias_act_bwd': (c_int, [P, L, P, P, P, P, L, I, L, I, P, E, S]),
+    'resel_bias_act_bwd': (c_int, [P, L, P, L, P, P, P, L, I, L, I, P, E, S]),
     'resel_ensemble_head_fwd': (c_int, [P, P, P, P, P, L, I, L, S]),
     'resel_ensemble_head_bwd_workspace_bytes': (c_size_t, [L, I, L]),
     'resel_ensemble_head_bwd': (c_int, [P, P, P, P, P, P, P, L, I, L, P, E, S]),

@@ -989,13 +989,15 @@ def bias_act_bwd(g2, a2, rows_per_seg, act, need_dbias):
     aid = ACT_IDS[act]
     if aid == 0 and not need_dbias:
         return g2, None
+    if aid and not (a2.dim() == 2 and a2.stride(1) == 1 and a2.stride(0) >= C and a2.stride(0) % 4 == 0 and a2.data_ptr() % 16 == 0):
+        a2 = a2.contiguous()                          # (a block of a row buffer qualifies as it is)
     gy = torch.empty(rows, C, dtype=torch.float32, device=g2.device) if aid else g2
     nseg = rows // int(rows_per_seg)
     db = torch.empty(nseg, C, dtype=torch.float32, device=g2.device) if need_dbias else None
     ws = _ws(lib().resel_bias_act_bwd_workspace_bytes(rows, C, int(rows_per_seg)), g2.device) if need_dbias else None
     global LAST_AMAX
     slot, slot_p, epoch = _slot_args(amax_tracking() and rows * C >= (1 << 20), g2.device)
-    check(lib().resel_bias_act_bwd(_p(g2), g2.stride(0), _p(a2) if aid else None, _p(gy) if aid else None, _p(db), _p(ws), rows, C, int(rows_per_seg), aid,
+    check(lib().resel_bias_act_bwd(_p(g2), g2.stride(0), _p(a2) if aid else None, a2.stride(0) if aid else 0, _p(gy) if aid else None, _p(db), _p(ws), rows, C, int(rows_per_seg), aid,
                                    slot_p, epoch, _stream()), 'bias_act_bwd')
     tag_amax(gy, slot)
     LAST_AMAX = slot
@@ -1040,7 +1042,9 @@ class LinearAct(torch.autograd.Function):
     contraction of the update runs on the hand-written GEMM."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, act):
+    def forward(ctx, x, weight, bias, act, dest=None):
+        """dest: a `ColDest` - the column block of a row buffer the output should be written to in place (when the hand-written GEMM runs
+        and nothing is padded; otherwise the output is a fresh tensor and whoever assembles the buffer copies it in)."""
         x2 = x.reshape(-1, x.shape[-1])
         x2 = x2 if x2.stride(-1) == 1 else x2.contiguous()
         long_pass = x2.is_cuda and x2.shape[0] >= GEMM_F32_MIN_ROWS
@@ -1051,7 +1055,11 @@ class LinearAct(torch.autograd.Function):
             x2 = torch.nn.functional.pad(x2, (0, ctx.kpad)) if ctx.kpad else x2
             weight = torch.nn.functional.pad(weight, (0, ctx.kpad, 0, ctx.npad))
             bias = torch.nn.functional.pad(bias, (0, ctx.npad)) if (bias is not None and ctx.npad) else bias
-        y2 = mm_nt(x2, weight, bias, act)
+        if dest is not None and long_pass and not ctx.npad and dest.fits(x2.shape[0], weight.shape[0]):
+            y2 = mm_nt(x2, weight, bias, act, out=dest.view(), amax_out=dest.rb.amax)
+            dest.note(y2)
+        else:
+            y2 = mm_nt(x2, weight, bias, act)
         ctx.ax = keep_handles(amax_of(x2))[0]         # the input's magnitude handle, for the weight gradient (saved tensors come back untagged)
         ctx.save_for_backward(x2, weight, y2)
         ctx.act, ctx.has_bias, ctx.xshape = act, bias is not None, x.shape
@@ -1081,7 +1089,7 @@ class LinearAct(torch.autograd.Function):
             dw = None if dw is None else dw[:n_out, :k]
             db = None if db is None else db.reshape(-1)[:n_out]
         dx = None if dx is None else dx.reshape(ctx.xshape)
-        return dx, dw, None if db is None else db.reshape(-1), None
+        return dx, dw, None if db is None else db.reshape(-1), None, None
 
 
 class PlaceBlocksFn(torch.autograd.Function):
@@ -1118,10 +1126,89 @@ def place_blocks(rows, cols, origins, *srcs):
     return PlaceBlocksFn.apply(int(rows), int(cols), tuple((int(r), int(c)) for r, c in origins), *srcs)
 
 
-def linear_act(x, weight, bias, act):
+def linear_act(x, weight, bias, act, dest=None):
     global LAST_AMAX
     LAST_AMAX = None
-    return tag_amax(LinearAct.apply(x, weight, bias, act), LAST_AMAX, whole=True)
+    # (an output written into a row buffer is a view of it: its magnitude must not be taken for the whole buffer's)
+    return tag_amax(LinearAct.apply(x, weight, bias, act, dest), LAST_AMAX, whole=dest is None)
+
+
+# ---- row buffers: the column blocks of ONE token-major matrix written in place by the GEMMs that produce them -----------------------
+class RowBuffer:
+    """[M, width] fp32 with M = prod(lead): what `torch.cat([...], -1)` of several layer outputs would build, allocated up front so that
+    each producer's GEMM writes its column block directly (`dest=` of `linear_act`; reference contextual_model.py cat of the input
+    encoding and the embedding, contextual_sac_value.py:101-107).  The producers publish into ONE magnitude handle (the buffer's);
+    `cat_into` hands the buffer on - copying in whatever did not land in place - as one autograd node whose backward slices."""
+
+    def __init__(self, lead, width, device):
+        self.lead, self.width = tuple(int(v) for v in lead), int(width)
+        self.rows = 1
+        for v in self.lead:
+            self.rows *= v
+        self.buf = torch.empty(self.rows, self.width, dtype=torch.float32, device=device)
+        self.amax = _slot_args(amax_tracking() and self.rows * self.width >= (1 << 20), self.buf.device)     # (handle, pointer, epoch)
+        self.published = 0                               # columns whose producer published into the handle
+
+    def block(self, col0, n):
+        return ColDest(self, col0, n)
+
+
+class ColDest:
+    def __init__(self, rb, col0, n):
+        self.rb, self.col0, self.n = rb, int(col0), int(n)
+
+    def view(self):
+        return self.rb.buf[:, self.col0:self.col0 + self.n]
+
+    def fits(self, rows, n):
+        return rows == self.rb.rows and n == self.n and self.col0 % 4 == 0 and self.n % 4 == 0
+
+    def holds(self, t):
+        """t (any leading shape) IS this block of the buffer."""
+        if t.shape[-1] != self.n or t.numel() != self.rb.rows * self.n or t.dtype != torch.float32:
+            return False
+        v = self.view()
+        return t.data_ptr() == v.data_ptr() and t.stride(-1) == 1 and (t.dim() < 2 or t.stride(-2) == self.rb.width) and \
+            t.untyped_storage().data_ptr() == v.untyped_storage().data_ptr()
+
+    def note(self, y2):
+        if self.holds(y2):
+            self.rb.published += self.n
+
+
+class CatInto(torch.autograd.Function):
+    """pieces (tensor_i at column col0_i of the row buffer) -> the whole buffer as [lead..., width]; pieces that are already in place cost
+    nothing, the others one strided copy each.  Backward: column slices of the gradient (views)."""
+
+    @staticmethod
+    def forward(ctx, rb, col0s, *pieces):
+        for c0, t in zip(col0s, pieces):
+            d = rb.block(c0, t.shape[-1])
+            if not d.holds(t):
+                # copied by this library's own kernel: an ATen copy_ would bump the version counter the buffer shares with the views that the
+                # in-place producers saved for their backward
+                t2 = t.reshape(rb.rows, t.shape[-1])
+                t2 = t2 if (t2.dtype == torch.float32 and t2.stride(1) == 1) else t2.float().contiguous()
+                _need_cuda('cat_into', t2)
+                check(lib().resel_place_blocks(_p(d.view()), rb.width, rb.rows, d.n, 1, (ctypes.c_void_p * 1)(t2.data_ptr()), (ctypes.c_int64 * 1)(t2.stride(0)),
+                                               (ctypes.c_int * 1)(0), (ctypes.c_int * 1)(rb.rows), (ctypes.c_int * 1)(0), (ctypes.c_int * 1)(d.n), _stream()),
+                      'cat_into')
+        ctx.meta = [(c0, t.shape[-1], tuple(t.shape)) for c0, t in zip(col0s, pieces)]
+        return rb.buf.detach().view(*rb.lead, rb.width)
+
+    @staticmethod
+    def backward(ctx, g):
+        g2 = g.reshape(-1, g.shape[-1])
+        outs = [g2[:, c0:c0 + n].view(shape) if need else None for need, (c0, n, shape) in zip(ctx.needs_input_grad[2:], ctx.meta)]
+        return (None, None) + tuple(outs)
+
+
+def cat_into(rb, pieces):
+    """pieces: [(tensor, col0), ...] covering the buffer's columns."""
+    complete = all(rb.block(c, t.shape[-1]).holds(t) for t, c in pieces) and sum(t.shape[-1] for t, _ in pieces) == rb.width \
+        and rb.published == rb.width
+    out = CatInto.apply(rb, tuple(int(c) for _, c in pieces), *[t for t, _ in pieces])
+    return tag_amax(out, rb.amax[0] if complete else None, whole=True)
 
 
 def linear(x, weight, bias=None):
@@ -1157,10 +1244,14 @@ def _mine(rows, n, k, *mats):
     return n >= GEMM_F32_MIN_DIM and k >= GEMM_F32_MIN_K and gemm_f32_ok(rows, *mats)
 
 
-def mm_nt(x2, w, bias=None, act=None):
+def mm_nt(x2, w, bias=None, act=None, out=None, amax_out=None):
     """act(x2 [M, K] w[N, K]^T + bias): forward of an nn.Linear-shaped layer over the tokens of a pass.  Hand-written GEMM with
-    the bias / ELU in its epilogue when the pass is long enough (`gemm_f32_ok`), else library GEMM (+ one in-place tail pass)."""
+    the bias / ELU in its epilogue when the pass is long enough (`gemm_f32_ok`), else library GEMM (+ one in-place tail pass).
+    out (with amax_out): a column block of a row buffer to write in place - used only when the hand-written GEMM takes the call
+    (the caller checks where the result landed)."""
     if act in ACT_IDS and _mine(x2.shape[0], w.shape[0], w.shape[1], x2, w):
+        if out is not None and gemm_f32_ok(x2.shape[0], out):
+            return gemm_f32(x2, w, True, True, bias, act, out=out, amax_out=amax_out)
         return gemm_f32(x2, w, True, True, bias, act)
     global LAST_AMAX
     LAST_AMAX = None
@@ -1531,7 +1622,7 @@ def amax_tracking():
 
 
 @torch.no_grad()
-def gemm_f32(A, B, a_kcontig=True, b_kcontig=True, bias=None, act=None, out=None, split=None, amax_a=None, amax_b=None):
+def gemm_f32(A, B, a_kcontig=True, b_kcontig=True, bias=None, act=None, out=None, split=None, amax_a=None, amax_b=None, amax_out=None):
     """C[b] = act(A[b] (.) B[b] + bias[b]) on the matrix cores, fp32 in / out (include/resel_hip.h `resel_gemm_f32`).
     A: [M, K] (a_kcontig) or [K, M]; B: [N, K] (b_kcontig) or [K, N]; optionally a leading batch (ensemble) dimension on all of
     A, B, bias [N] / [batch, N], out.  Row stride free (column stride 1); returns C [M, N] / [batch, M, N].
@@ -1588,7 +1679,9 @@ def gemm_f32(A, B, a_kcontig=True, b_kcontig=True, bias=None, act=None, out=None
         amax_check(A, ha, f'A of gemm M={M} N={N} K={K} batch={batch}')
         amax_check(B, hb, f'B of gemm M={M} N={N} K={K} batch={batch}')
     # max |C| for whoever multiplies C next (only while mode 2 is the product mode, and only for outputs worth a pass)
-    slot, slot_p, epoch = _slot_args(amax_tracking() and act != GEMM_ACCUMULATE and M * N * batch >= (1 << 20), A.device)
+    # (amax_out: the (handle, pointer, epoch) of a row buffer this product fills a column block of - its producers share one handle)
+    slot, slot_p, epoch = amax_out if amax_out is not None else \
+        _slot_args(amax_tracking() and act != GEMM_ACCUMULATE and M * N * batch >= (1 << 20), A.device)
     check(L.resel_gemm_f32x(_p(A), A.stride(-2), A.stride(0) if multi else 0, int(a_kcontig), _p(B), B.stride(-2),
                             B.stride(0) if multi else 0, int(b_kcontig), _p(bias), bs, 2 if act == GEMM_ACCUMULATE else 3 if act == GEMM_SOFTPLUS else ACT_IDS[act], _p(out), out.stride(-2),
                             out.stride(0) if multi else 0, _p(ws), M, N, K, batch, split, _p(ha) if split == 2 else None,

@@ -76,10 +76,22 @@ class ContextualModel:
             raise NotImplementedError('the MI355X build keeps parameters in fp32')
 
     # ------------------------------------------------------------------------------------------ forward
-    def meta_forward(self, embedding_input: torch.Tensor, uni_model_input: torch.Tensor, rnn_memory=None, detach_embedding=False,
-                     uni_grad_part=None) -> Tuple[torch.Tensor, RNNHidden, torch.Tensor, RNNHidden]:
+    def head_row_buffer(self, lead, device, dtype):
+        """A row buffer [prod(lead), uni input width + embedding width] for the head input of a long fp32 GPU pass (None otherwise): the
+        GEMMs that produce the input encoding and the embedding write their column blocks in place instead of a `cat` afterwards."""
+        rows = 1
+        for v in lead:
+            rows *= int(v)
+        if torch.device(device).type != 'cuda' or dtype != torch.float32 or rows < ops.GEMM_F32_MIN_ROWS or len(lead) == 0:
+            return None
+        return ops.RowBuffer(lead, self.uni_network.input_size, device)
+
+    def meta_forward(self, embedding_input: torch.Tensor, uni_model_input, rnn_memory=None, detach_embedding=False,
+                     uni_grad_part=None, row_buffer=None) -> Tuple[torch.Tensor, RNNHidden, torch.Tensor, RNNHidden]:
         """uni_grad_part = (x_part, col0): the head input is differentiated only through that column block of
-        `uni_model_input` (which must carry no graph of its own, like the detached embedding beside it)."""
+        `uni_model_input` (which must carry no graph of its own, like the detached embedding beside it).
+        row_buffer (`head_row_buffer`): the caller had the head input's leading columns produced into it; `uni_model_input` may then be a
+        list of (tensor, col0) pieces.  Without one, a buffer is made here when the input mapping network and the embedding can fill it."""
         if rnn_memory is None:
             rnn_memory = self.make_init_state(1 if embedding_input.dim() == 2 else embedding_input.shape[0], embedding_input.device)
         n_emb = self.embedding_network.rnn_num
@@ -93,16 +105,33 @@ class ContextualModel:
             for t in [emb] + [h for h in list(emb_mem._data) + list(emb_full._data) if torch.is_tensor(h)]:
                 t.record_stream(main)
         else:
+            mapped = not isinstance(self.uni_input_mapping_network, torch.nn.Identity)
+            if row_buffer is None and mapped and torch.is_tensor(uni_model_input) and uni_model_input.dim() == embedding_input.dim():
+                row_buffer = self.head_row_buffer(embedding_input.shape[:-1], embedding_input.device, embedding_input.dtype)
+            w_emb = self.embedding_network.output_size
+            dest = None if row_buffer is None else row_buffer.block(row_buffer.width - w_emb, w_emb)
             # a detached embedding is computed without a graph: same values, but no scan checkpoints / saved activations
             with torch.set_grad_enabled(torch.is_grad_enabled() and not detach_embedding):
-                emb, emb_mem, emb_full = self.embedding_network.meta_forward(embedding_input, rnn_memory[:n_emb], require_full_hidden=True)
+                emb, emb_mem, emb_full = self.embedding_network.meta_forward(embedding_input, rnn_memory[:n_emb], require_full_hidden=True,
+                                                                             out_dest=dest)
         if detach_embedding:
             emb = emb.detach()
-        uni_in = self.uni_input_mapping_network(uni_model_input)
-        if emb.dim() - uni_in.dim() == 1:
-            uni_in = uni_in.unsqueeze(0).repeat_interleave(repeats=emb.shape[0], dim=0)
-        out, uni_mem, uni_full = self.uni_network.meta_forward(torch.cat((uni_in, emb), dim=-1), rnn_memory[n_emb:],
-                                                               require_full_hidden=True, first_grad_part=uni_grad_part)
+        if row_buffer is not None and emb.shape[:-1] == row_buffer.lead:
+            w_uni = row_buffer.width - emb.shape[-1]
+            if isinstance(uni_model_input, (list, tuple)):
+                pieces = list(uni_model_input)
+            elif isinstance(self.uni_input_mapping_network, torch.nn.Identity):
+                pieces = [(uni_model_input, 0)]
+            else:
+                pieces = [(self.uni_input_mapping_network(uni_model_input, out_dest=row_buffer.block(0, w_uni)), 0)]
+            head_in = ops.cat_into(row_buffer, pieces + [(emb, w_uni)])
+        else:
+            assert torch.is_tensor(uni_model_input), 'piece lists need the row buffer they were produced into'
+            uni_in = self.uni_input_mapping_network(uni_model_input)
+            if emb.dim() - uni_in.dim() == 1:
+                uni_in = uni_in.unsqueeze(0).repeat_interleave(repeats=emb.shape[0], dim=0)
+            head_in = torch.cat((uni_in, emb), dim=-1)
+        out, uni_mem, uni_full = self.uni_network.meta_forward(head_in, rnn_memory[n_emb:], require_full_hidden=True, first_grad_part=uni_grad_part)
         return out, emb_mem + uni_mem, emb, emb_full + uni_full
 
     def prefetch_embedding(self, embedding_args, rnn_memory, stream) -> None:

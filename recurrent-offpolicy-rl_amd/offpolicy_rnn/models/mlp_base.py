@@ -8,8 +8,8 @@ class MLPBase(RNNBase):
         super().__init__(input_size, output_size, hidden_size_list, activation, ['fc'] * len(activation))
         self.empty_hidden_state = RNNHidden(0, [])
 
-    def meta_forward(self, x, h=None, require_full_hidden=False):
-        return super().meta_forward(x, self.empty_hidden_state, False)[0]
+    def meta_forward(self, x, h=None, require_full_hidden=False, out_dest=None):
+        return super().meta_forward(x, self.empty_hidden_state, False, out_dest=out_dest)[0]
 
-    def forward(self, x):
-        return self.meta_forward(x)
+    def forward(self, x, out_dest=None):
+        return self.meta_forward(x, out_dest=out_dest)

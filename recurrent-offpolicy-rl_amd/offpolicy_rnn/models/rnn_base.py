@@ -116,6 +116,7 @@ class RNNBase(torch.nn.Module):
         self.rnn_hidden_state_input_size, self.rnn_layer_type = [], []
         self.rnn_num = 0
         self.input_size = input_size
+        self.output_size = output_size
         width_in = input_size
         for ind, width in enumerate(list(hidden_size_list) + [output_size]):
             lid = self.layer_type[ind]
@@ -252,9 +253,11 @@ class RNNBase(torch.nn.Module):
                 and x.dtype == torch.float32 and x.dim() == 3 and x.shape[-2] > 1)
 
     def meta_forward(self, x: torch.Tensor, hidden_state: Optional[RNNHidden] = None, require_full_hidden: bool = False,
-                     first_grad_part=None) -> Tuple[torch.Tensor, RNNHidden, Optional[RNNHidden]]:
+                     first_grad_part=None, out_dest=None) -> Tuple[torch.Tensor, RNNHidden, Optional[RNNHidden]]:
         """first_grad_part = (x_part, col0): the first layer (a shared-input efc layer) differentiates x only through that
-        column block (EnsembleLinear.forward); anything else keeps the ordinary path."""
+        column block (EnsembleLinear.forward); anything else keeps the ordinary path.
+        out_dest: an `ops.ColDest` - if the LAST layer is an `fc` on the hand-written GEMM, its output is written straight into that column
+        block of a row buffer (the caller checks with `dest.holds`)."""
         assert x.shape[-1] == self.input_size, f'inputting size does not match!!!! input is {x.shape[-1]}, expected: {self.input_size}'
         if hidden_state is None:
             hidden_state = self.make_init_state(x.shape[0], x.device)
@@ -343,12 +346,12 @@ class RNNBase(torch.nn.Module):
                         x = layer(x, act='elu', grad_part=first_grad_part if ind == 0 else None)
                     else:
                         assert not (ind == 0 and first_grad_part is not None)
-                        x = ops.linear_act(x, layer.weight, layer.bias, 'elu')
+                        x = ops.linear_act(x, layer.weight, layer.bias, 'elu', dest=out_dest if ind == n_layers - 1 else None)
                     continue
                 assert not (ind == 0 and first_grad_part is not None), 'first_grad_part needs an efc first layer with ELU'
 
                 if isinstance(layer, torch.nn.Linear) and x.dim() > 2:    # 2-D call: the bias rides in the GEMM epilogue (addmm)
-                    x = ops.linear_act(x, layer.weight, layer.bias, None) if x.is_cuda and x.dtype == torch.float32 else \
+                    x = ops.linear_act(x, layer.weight, layer.bias, None, dest=out_dest if ind == n_layers - 1 else None) if x.is_cuda and x.dtype == torch.float32 else \
                         torch.nn.functional.linear(x.reshape(-1, x.shape[-1]), layer.weight, layer.bias).view(*x.shape[:-1], -1)
                 else:
                     x = layer(x)

@@ -42,22 +42,25 @@ def _fusable(act_mod, x, mods) -> bool:
             and x.numel() // x.shape[-1] >= ops.GEMM_F32_MIN_ROWS and all(isinstance(m, torch.nn.Linear) and m.bias is not None for m in mods))
 
 
-def encode_concat(pairs, act_mod=None) -> torch.Tensor:
+def encode_concat(pairs, act_mod=None, dest=None) -> torch.Tensor:
     """cat([enc_i(x_i)], -1) for Linear encoders as ONE library GEMM: the (narrow) inputs are concatenated instead of the
     (wide) outputs and multiplied by the block-diagonal of the encoder weights with the biases fused (addmm epilogue) -
     per update this removes three skinny GEMMs, three bias-add passes and the 384-wide cat per call.  The zero blocks
     add exact zeros to every dot product; autograd splits the gradients back through block_diag / cat (long GPU passes: through
     `ops.place_blocks`, one launch per operand, gradients as views).
-    act_mod: the activation module applied to the result (None: none) - fused into the GEMM when `_fusable`."""
+    act_mod: the activation module applied to the result (None: none) - fused into the GEMM when `_fusable`.
+    dest: an `ops.ColDest` the fused GEMM writes its output to in place (a column block of the head's row buffer)."""
     mods = [m for m, _ in pairs]
     xs = [x for _, x in pairs]
     fuse = act_mod is not None and _fusable(act_mod, xs[0], mods)
     post = (lambda t: t) if (act_mod is None or fuse) else act_mod
     if not all(isinstance(m, torch.nn.Linear) and m.bias is not None for m in mods):
         return post(torch.cat([m(x) for m, x in pairs], dim=-1))
+    # no activation behind the encoders (`linear`): the same node without an epilogue, so that `dest` is honoured there too
+    plain = (act_mod is None or isinstance(act_mod, torch.nn.Identity)) and _fusable(torch.nn.ELU(), xs[0], mods)
     if len(pairs) == 1:                       # one encoder alone (the actor step's action encoding): still the hand-written GEMM
-        if fuse and mods[0].weight.shape[0] >= ops.GEMM_F32_MIN_DIM and mods[0].weight.shape[1] >= ops.GEMM_F32_MIN_K:
-            return ops.linear_act(xs[0], mods[0].weight, mods[0].bias, 'elu')
+        if (fuse or plain) and mods[0].weight.shape[0] >= ops.GEMM_F32_MIN_DIM and mods[0].weight.shape[1] >= ops.GEMM_F32_MIN_K:
+            return ops.linear_act(xs[0], mods[0].weight, mods[0].bias, 'elu' if fuse else None, dest=dest)
         return (act_mod if fuse else post)(ops.linear(xs[0], mods[0].weight, mods[0].bias))
     ks, ns = [m.weight.shape[1] for m in mods], [m.weight.shape[0] for m in mods]
     kp = sum(ks) + (-sum(ks)) % 4            # 17 + 17 + 6 + 1 = 41 input columns: three zero columns make the rows 16-byte multiples,
@@ -79,8 +82,8 @@ def encode_concat(pairs, act_mod=None) -> torch.Tensor:
             w = torch.nn.functional.pad(w, (0, pad))
         x = torch.cat(xs, dim=-1)
     x2 = x.reshape(-1, x.shape[-1])
-    if fuse and w.shape[0] >= ops.GEMM_F32_MIN_DIM and w.shape[1] >= ops.GEMM_F32_MIN_K:
-        return ops.linear_act(x2, w, b, 'elu').view(*x.shape[:-1], w.shape[0])
+    if (fuse or plain) and w.shape[0] >= ops.GEMM_F32_MIN_DIM and w.shape[1] >= ops.GEMM_F32_MIN_K:
+        return ops.linear_act(x2, w, b, 'elu' if fuse else None, dest=dest).view(*x.shape[:-1], w.shape[0])
     y = ops.linear(x2, w, b)
     return (act_mod if fuse else post)(y.view(*x.shape[:-1], w.shape[0]))
 

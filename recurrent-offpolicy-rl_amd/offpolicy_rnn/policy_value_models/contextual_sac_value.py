@@ -45,26 +45,31 @@ class ContextualSACValue(ContextualModel):
     def get_embedding_input(self, state, lst_state, lst_action, reward) -> torch.Tensor:
         return _inputs.embedding_input(self, state, lst_state, lst_action, reward)
 
-    def state_action(self, state, action):
+    def state_action(self, state, action, dest=None):
         return _inputs.encode_concat([(self.state_input_encoder, state), (self.action_input_encoder, action)],
-                                     self.uni_model_input_mapping_activation_func if self.separate_encoder else None)
+                                     self.uni_model_input_mapping_activation_func if self.separate_encoder else None, dest=dest)
 
     def forward(self, state, lst_state, lst_action, action, rnn_memory: Optional[RNNHidden], reward, detach_embedding=False
                 ) -> Tuple[torch.Tensor, torch.Tensor, RNNHidden, Optional[RNNHidden]]:
         emb_in = None if getattr(self, '_prefetched', None) is not None else self.get_embedding_input(state, lst_state, lst_action, reward)
         part = None
+        # long GPU passes: the head input [state-action encoding | embedding] is ONE row buffer whose column blocks the producing GEMMs write
+        # in place (no cat of 205 MB per pass at config 2, one shared magnitude handle instead of a pre-pass)
+        rb = self.head_row_buffer(state.shape[:-1], state.device, state.dtype) if self.separate_encoder else None
         if detach_embedding and torch.is_grad_enabled() and action.requires_grad and self._action_only_graph():
             # actor step: frozen critic, detached embedding - the ONLY differentiable input of the head is the action encoding.
             # Encode state and action separately so that the first layer's backward forms just that column block of dX.
             act_fn = self.uni_model_input_mapping_activation_func
+            n_s = self.state_input_encoder.weight.shape[0]
             with torch.no_grad():
-                sa_s = _inputs.encode_concat([(self.state_input_encoder, state)], act_fn)
-            sa_a = _inputs.encode_concat([(self.action_input_encoder, action)], act_fn)
-            sa = torch.cat((sa_s, sa_a.detach()), dim=-1)
+                sa_s = _inputs.encode_concat([(self.state_input_encoder, state)], act_fn, dest=None if rb is None else rb.block(0, n_s))
+            sa_a = _inputs.encode_concat([(self.action_input_encoder, action)], act_fn,
+                                         dest=None if rb is None else rb.block(n_s, self.action_input_encoder.weight.shape[0]))
+            sa = [(sa_s, 0), (sa_a.detach(), n_s)] if rb is not None else torch.cat((sa_s, sa_a.detach()), dim=-1)
             part = (sa_a, sa_s.shape[-1])
         else:
-            sa = self.state_action(state, action)
-        value, rnn_memory, emb, full = self.meta_forward(emb_in, sa, rnn_memory, detach_embedding, uni_grad_part=part)
+            sa = self.state_action(state, action, dest=None if rb is None else rb.block(0, rb.width - self.embedding_network.output_size))
+        value, rnn_memory, emb, full = self.meta_forward(emb_in, sa, rnn_memory, detach_embedding, uni_grad_part=part, row_buffer=rb)
         return value, emb, rnn_memory, full
 
     def _action_only_graph(self) -> bool:

@@ -262,6 +262,41 @@ def test_add_layernorm_with_the_elu_epilogue_vs_torch(ops, M, C, bias):
         close(a, b_, rtol=2e-4, atol_scale=5e-5, name=nm)
 
 
+@pytest.mark.parametrize('second_in_place', [True, False])
+def test_row_buffer_producers_write_in_place_vs_cat(ops, second_in_place):
+    """Two `linear_act` producers (one with ELU: its saved output is a VIEW of the buffer) write the column blocks of an `ops.RowBuffer`;
+    `ops.cat_into` hands the buffer on without a copy, tagged with the shared magnitude handle.  Same values and gradients as producing
+    the two outputs separately and `torch.cat`; a piece that did not land in place is copied in (and the result carries no handle)."""
+    g = torch.Generator().manual_seed(21)
+    B, L = 5, 1000
+    x1, x2 = rnd(B, L, 64, g=g).cuda(), rnd(B, L, 128, g=g).cuda()
+    w1, b1, w2, b2 = rnd(256, 64, g=g).cuda() / 8, rnd(256, g=g).cuda(), rnd(128, 128, g=g).cuda() / 11, rnd(128, g=g).cuda()
+    gout = rnd(B, L, 384, g=g).cuda()
+
+    def leafs():
+        return [t.clone().requires_grad_(True) for t in (x1, w1, b1, x2, w2, b2)]
+
+    a = leafs()
+    rb = ops.RowBuffer((B, L), 384, 'cuda')
+    y1 = ops.linear_act(a[0], a[1], a[2], 'elu', dest=rb.block(0, 256))
+    y2 = ops.linear_act(a[3], a[4], a[5], None, dest=rb.block(256, 128) if second_in_place else None)
+    assert rb.block(0, 256).holds(y1) and rb.block(256, 128).holds(y2) == second_in_place
+    cat = ops.cat_into(rb, [(y1, 0), (y2, 256)])
+    assert cat.shape == (B, L, 384) and cat.data_ptr() == rb.buf.data_ptr()
+    (cat * gout).sum().backward()
+    r = leafs()
+    ref = torch.cat((ops.linear_act(r[0], r[1], r[2], 'elu'), ops.linear_act(r[3], r[4], r[5], None)), dim=-1)
+    (ref * gout).sum().backward()
+    assert torch.equal(cat, ref)
+    for p, q in zip(a, r):
+        assert torch.equal(p.grad, q.grad)
+    h = ops.amax_of(cat)
+    if second_in_place:
+        assert h is not None and ops.amax_value(h) == float(ref.detach().abs().max())
+    else:
+        assert h is None
+
+
 def test_place_blocks_vs_block_diag_cat_pad(ops):
     """`ops.place_blocks` (one launch) against torch.block_diag / cat / pad, values and gradients (the operands of the merged encoder GEMM,
     policy_value_models/_inputs.py)."""
