@@ -145,8 +145,10 @@ class GraphedUpdate:
         sq = self._seq_buffers(max(b[0].size for b in built), max(b[1].size for b in built))
         k = self._turn % self.RING
         for i, (idx, cu, mx, tb) in enumerate(built):
-            sq['idx_host'][k][i][:idx.size].copy_(torch.from_numpy(idx))
-            sq['cu_host'][k][i][:cu.size].copy_(torch.from_numpy(cu))
+            # staged with numpy (a plain memcpy): a torch CPU copy_ of > 32 768 elements opens an intra-op parallel region over all host threads,
+            # which on a loaded host took 10-15 ms per call - longer than the replay it is meant to hide behind
+            sq['idx_host'][k][i].numpy()[:idx.size] = idx
+            sq['cu_host'][k][i].numpy()[:cu.size] = cu
             sq['idx_dev'][i][:idx.size].copy_(sq['idx_host'][k][i][:idx.size], non_blocking=True)      # stream-ordered, outside the graph
             sq['cu_dev'][i][:cu.size].copy_(sq['cu_host'][k][i][:cu.size], non_blocking=True)
         self._seq_now = [(b[0].size, b[1].size, b[2], b[3]) for b in built]
@@ -214,11 +216,11 @@ class GraphedUpdate:
             slot['evt'].synchronize()
         if built is not None:
             key = key + self._prepare_seqs(built)
-        slot['plan'][:n].copy_(torch.from_numpy(pl['seg']))
+        slot['plan'].numpy()[:n] = pl['seg']
         self._plan_dev[:n].copy_(slot['plan'][:n], non_blocking=True)        # stream-ordered: behind the previous update's gather
         self._plan = pl
         sub = np.ascontiguousarray(np.asarray(self._draw(self.E)), dtype=np.int32)
-        slot['sub'].copy_(torch.from_numpy(sub))
+        slot['sub'].numpy()[...] = sub
         self.subset_i32.copy_(slot['sub'], non_blocking=True)
         self.subset_i64.copy_(self.subset_i32)
         for i, opt in enumerate((alg.optimizer_value, alg.optimizer_policy)):
