@@ -13,7 +13,7 @@
 namespace {
 using namespace resel;
 
-constexpr int BWD_ROWS = 128;        // rows per backward block
+constexpr int BWD_ROWS = 128;        // rows per backward block of the head kernel; bias_act_bwd picks 128 / 64 / 32 (block_rows) to fill the chip
 
 __device__ __forceinline__ float elu_(float x) { return x > 0.f ? x : fast_exp(x) - 1.f; }
 
@@ -37,13 +37,13 @@ __global__ __launch_bounds__(256) void bias_act_fwd_kernel(float* __restrict__ y
 // grid = (row blocks inside a segment, column blocks of 256 floats, segments); 256 threads = 64 float4 columns x 4 row lanes
 __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float* __restrict__ g, int64_t ldg, const float* __restrict__ a, int64_t lda,
                                                            float* __restrict__ gy, float* __restrict__ db_part,
-                                                           int C, int64_t rows_per_seg, int act, int nrb, AmaxOut amax) {
+                                                           int C, int64_t rows_per_seg, int act, int nrb, int brows, AmaxOut amax) {
     __shared__ __attribute__((aligned(16))) float s_red[4][256];
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int c = blockIdx.y * 256 + cl * 4;
     const int64_t seg = blockIdx.z;
-    const int64_t r0 = (int64_t)blockIdx.x * BWD_ROWS;
-    const int64_t r1 = r0 + BWD_ROWS < rows_per_seg ? r0 + BWD_ROWS : rows_per_seg;
+    const int64_t r0 = (int64_t)blockIdx.x * brows;
+    const int64_t r1 = r0 + brows < rows_per_seg ? r0 + brows : rows_per_seg;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     float gmax = 0.f;
     if (c < C) {
@@ -140,6 +140,10 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
 }
 
 inline int row_blocks(int64_t rows_per_seg) { return (int)((rows_per_seg + BWD_ROWS - 1) / BWD_ROWS); }
+// rows per block of bias_act_bwd: 128.  (64 / 32 for gradients that give fewer than 4 blocks per CU - 257 blocks at configs[2]'s 32 832 x 256 -
+// measured SLOWER on the whole update: 30.22 against 29.80 ms, same box, three runs each: more partial rows to write and to sum.)
+inline int block_rows(int64_t, int, int64_t) { return BWD_ROWS; }
+inline int row_blocks_of(int64_t rows_per_seg, int brows) { return (int)((rows_per_seg + brows - 1) / brows); }
 inline bool shape_ok(int64_t rows, int C, int64_t rows_per_seg) {
     return rows > 0 && C > 0 && C % 4 == 0 && rows_per_seg > 0 && rows % rows_per_seg == 0;
 }
@@ -158,7 +162,7 @@ extern "C" int resel_bias_act_fwd(float* y, const float* bias, int64_t rows, int
 
 extern "C" size_t resel_bias_act_bwd_workspace_bytes(int64_t rows, int C, int64_t rows_per_seg) {
     if (!shape_ok(rows, C, rows_per_seg)) return 0;
-    return (size_t)(rows / rows_per_seg) * row_blocks(rows_per_seg) * C * sizeof(float);
+    return (size_t)(rows / rows_per_seg) * row_blocks_of(rows_per_seg, block_rows(rows, C, rows_per_seg)) * C * sizeof(float);
 }
 
 extern "C" int resel_bias_act_bwd(const float* g, int64_t ldg, const float* a, int64_t lda, float* gy, float* dbias, void* workspace, int64_t rows, int C,
@@ -168,10 +172,11 @@ extern "C" int resel_bias_act_bwd(const float* g, int64_t ldg, const float* a, i
         return RESEL_EINVAL;
     if (a && (lda < C || (lda & 3))) return RESEL_EINVAL;
     if (!aligned16(g) || (gy && !aligned16(gy)) || (a && !aligned16(a)) || (workspace && !aligned16(workspace))) return RESEL_EINVAL;
-    const int nseg = (int)(rows / rows_per_seg), nrb = row_blocks(rows_per_seg);
+    const int brows = block_rows(rows, C, rows_per_seg);
+    const int nseg = (int)(rows / rows_per_seg), nrb = row_blocks_of(rows_per_seg, brows);
     hipStream_t s = (hipStream_t)stream;
     float* part = dbias ? (float*)workspace : nullptr;
-    hipLaunchKernelGGL(bias_act_bwd_kernel, dim3(nrb, (C + 255) / 256, nseg), dim3(256), 0, s, g, ldg, a, lda, gy, part, C, rows_per_seg, act, nrb,
+    hipLaunchKernelGGL(bias_act_bwd_kernel, dim3(nrb, (C + 255) / 256, nseg), dim3(256), 0, s, g, ldg, a, lda, gy, part, C, rows_per_seg, act, nrb, brows,
                        AmaxOut{(unsigned long long*)amax_gy, amax_epoch});
     if (dbias) launch_colsum(part, C, nrb, C, dbias, s, 1, 0, nseg);      // dbias[sg, :] = sum over the segment's row blocks
     return launch_status();

@@ -367,7 +367,7 @@ extern "C" int resel_gemm_bf16(const void* A, int64_t lda, int a_kcontig, int a_
 // takes 29 us for [32 832, 256..1024] bf16, 10 x the time of the bytes).  A thread owns 8 consecutive columns (one 16-byte load per
 // row), a block a slab of rows; per-block partials are summed in a fixed order by colsum_kernel (no atomics, bitwise reproducible).
 namespace {
-constexpr int CS_ROWS = 256;                       // rows per block
+constexpr int CS_ROWS = 64;                        // rows per block (256: 129 blocks at configs[2], half the chip, 42 us for 50 MB; 64: 513 blocks)
 __global__ __launch_bounds__(256) void colsum_bf16_kernel(const uint16_t* __restrict__ x, int64_t ld, int M, int N, float* __restrict__ part) {
     __shared__ float s_acc[256][9];
     const int tpr = N >> 3;                        // threads per row
@@ -376,6 +376,7 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const uint16_t* __rest
     const int r0 = blockIdx.x * CS_ROWS, r1 = min(M, r0 + CS_ROWS);
     float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (rl < rpi) {
+#pragma unroll 4
         for (int r = r0 + rl; r < r1; r += rpi) {
             const uint4 v = *reinterpret_cast<const uint4*>(x + (int64_t)r * ld + 8 * cg);
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
