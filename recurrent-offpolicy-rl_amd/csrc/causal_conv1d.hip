@@ -67,7 +67,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 // of a wave is one fully used 512-byte row segment; the two waves of a block sit side by side on the channel axis and
 // blockIdx.x (fastest) continues it, so concurrently running blocks stream whole rows.  [The first version staged
 // 64-channel x 64-step tiles in LDS: its 256-byte row pieces at a 4 KB token stride reached only 1.07 TB/s.]
-// Loads run P steps ahead of their use in a small register ring.  The step groups are straight-line code with exactly
+// Loads run P steps ahead of their use in a small register ring (P = min(KT, 16): 16 against 8 ahead measured 66.5 against 69.5 us at K = 16).  The step groups are straight-line code with exactly
 // one load and (after the warm-up group) one store per step: any conditional memory operation inside them would make
 // the compiler fall back to s_waitcnt vmcnt(0) per step and serialise the ring on the load latency - hence the clamped
 // (always valid) load addresses, the mask values pre-loaded for the whole chunk (one lane per step, fetched back with
@@ -77,8 +77,8 @@ constexpr int CONV_TT = 64;          // time steps per chunk (<= 64: one mask re
 template <int KT, int MODE>          // MODE 0: warm-up group (only its last step produces an output), 1: full, 2: guarded tail
 __device__ __forceinline__ void conv_fwd_group(const ConvParams& p, const float* xrow, float* yrow, int tg, int t_end,
                                                int ig, float mlo, float mhi, const f2 (&wr)[KT], f2 (&win)[KT],
-                                               f2 (&pre)[KT < 8 ? KT : 8], f2 bv, float& ymax) {
-    constexpr int P = KT < 8 ? KT : 8;
+                                               f2 (&pre)[KT < 16 ? KT : 16], f2 bv, float& ymax) {
+    constexpr int P = KT < 16 ? KT : 16;
     const float mreg = ig < 64 ? mlo : mhi;          // KT divides 64: a group never straddles the two mask registers
 #pragma unroll
     for (int s = 0; s < KT; ++s) {
@@ -101,7 +101,7 @@ __device__ __forceinline__ void conv_fwd_group(const ConvParams& p, const float*
 
 template <int KT>
 __global__ __launch_bounds__(128) void conv_fwd_kernel(ConvParams p) {
-    constexpr int P = KT < 8 ? KT : 8;
+    constexpr int P = KT < 16 ? KT : 16;
     const int lane = threadIdx.x & 63;
     if ((blockIdx.x * 128 + (threadIdx.x & 64)) * 2 >= p.Di) return;      // whole wave past the last channel (no barriers below)
     // lanes past the last channel of a partly filled wave shadow the last pair (same loads, same stores, same values):
