@@ -316,7 +316,7 @@ def test_place_blocks_vs_block_diag_cat_pad(ops):
     w1, b1, x1 = leafs(ws), leafs(bs), [t.clone().requires_grad_(True) for t in xs_src]
     W = ops.place_blocks(512, kp, list(zip(r0, c0)), *w1)
     Bc = ops.place_blocks(1, 512, [(0, r) for r in r0], *b1).view(-1)
-    X = ops.place_blocks(5 * 301, kp, [(0, c) for c in c0], *[t.detach().clone().requires_grad_(True) if False else t for t in x1]).view(5, 301, kp)
+    X = ops.place_blocks(5 * 301, kp, [(0, c) for c in c0], *x1).view(5, 301, kp)
     w2, b2, x2 = leafs(ws), leafs(bs), [t.clone().requires_grad_(True) for t in xs_src]
     Wr = torch.nn.functional.pad(torch.block_diag(*w2), (0, kp - 41))
     Br = torch.cat(b2)
