@@ -378,7 +378,8 @@ def rccl_one_rank_leg(args):
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
         line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
-        return {k: line[k] for k in ('ms_per_step', 'rccl_ranks', 'backend', 'collectives_per_step', 'collective_bytes_per_step')}
+        return {k: line.get(k) for k in ('ms_per_step', 'eager_ms_per_step', 'launch', 'graph_update', 'rccl_ranks', 'backend', 'collectives_per_step',
+                                         'collective_bytes_per_step')}
     except Exception as e:
         return {'failed': repr(e)[:200]}
 
@@ -467,7 +468,8 @@ def main():
             torch.cuda.synchronize()
 
     # The update is launched the way the product launches it (algorithm/sac.py `train`): ONE hipGraph replay per update where the
-    # trainer allows it (one process, device-resident replay ring, no host-side clipping: GraphedUpdate.refusal), eagerly otherwise.
+    # trainer allows it (device-resident replay ring, utd = 1: GraphedUpdate.refusal; data-parallel groups: three graphs per update, cut at
+    # the two gradient exchanges, which are issued eagerly between the replays), eagerly otherwise.
     from offpolicy_rnn.algorithm.graphed_update import GraphedUpdate
     why_eager = 'requested (--no-graph-update)' if args.no_graph_update else GraphedUpdate.refusal(alg)
     args.graph_update = why_eager is None
@@ -557,12 +559,14 @@ def main():
     out = {
         'metric': 'env-steps/sec trained', 'value': trained / dt, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'strong' if args.global_rows else 'weak', 'vs_baseline': None,
+        'schema': 3,   # 3: `roofline` key order (contract keys, sscan_fwd_* / sscan_bwd_*, numeric detail), strings in `roofline_notes`; 2 (round 5): flat sscan_* scalars, ms_per_step_fp32_mfma / _bf16x3_high
         'dtype': 'f32', 'dtype_note': ('inputs, accumulators and outputs of every kernel are fp32; GEMM products: ' + {0: 'fp32 MFMA instruction', 6: 'exact 3-way bf16 split of both fp32 operands, 6 leading plane products on the bf16 MFMA (as accurate vs fp64 as the fp32 instruction: DESIGN.md 4)', 9: 'exact 3-way bf16 split of both fp32 operands, all 9 plane products on the bf16 MFMA', 3: 'two bf16 planes per fp32 operand, 3 leading plane products on the bf16 MFMA (bf16x3: float32 matmul precision "high", NOT fp32-accurate)', 2: 'fp16 planes of the scaled fp32 operands (22 significant bits), 3 plane products on the f16 MFMA where the operand magnitudes are known, mode 6 elsewhere (as accurate vs fp64 as the fp32 instruction: DESIGN.md 4)'}[gemm_mode]), 'data': 'synthetic',
         'config': {'workload': f'{args.rnn} {args.algo.upper()}-REDQ update, B={Bsz}/GPU, T={args.horizon}, D=256 ({baseline_config(args)})',
                    'row_length': Tp, 'obs': OBS, 'act': ACT, 'critic': 'efc-8',
                    'global_rows': Bsz * world, 'parallelism': f'dp{world}'},
         # collectives the timed updates ISSUED (counted where they are called, parallel/data_parallel.py), per update
-        'launch': 'one hipGraph replay per update (algorithm/graphed_update.py)' if args.graph_update else f'eager ({why_eager})',
+        'launch': (('one hipGraph replay per update' if not alg.grad_sync.active else 'hipGraph replays cut at the two gradient exchanges (three graphs per update)')
+                   + ' (algorithm/graphed_update.py)') if args.graph_update else f'eager ({why_eager})',
         'graph_update': bool(args.graph_update), 'graph_update_leg': graph_leg, 'eager_ms_per_step': eager_ms if args.graph_update else 1e3 * dt / args.steps,
         'rccl_ranks': alg.grad_sync.world if alg.grad_sync.active else 0, 'backend': alg.grad_sync.backend,
         'collectives_per_step': coll, 'collective_bytes_per_step': coll_bytes, 'parameter_broadcasts': bcast,
@@ -601,7 +605,7 @@ def main():
         o['measured_over'] = ('HIP event pair per dispatch, the same update launched eagerly right behind the timed graph replays'
                               if args.graph_update else 'HIP event pair per dispatch, timed region')
     if lines:
-        out['roofline'] = lines[0]                       # the hand-written kernel with the largest total time in the timed region
+        out['roofline'] = dict(lines[0])                 # the hand-written kernel with the largest total time in the timed region
     # BASELINE.json's second metric ("selective_scan HBM GB/s"): algorithmic GB/s and fraction of the 8 TB/s roof of both scan
     # kernels, in short keys at the top level AND inside `roofline` (records that keep only the contract's keys keep it there)
     sc = {o['kernel']: o for o in lines if o['kernel'].startswith('sscan')}
@@ -614,6 +618,17 @@ def main():
         out['sscan'] = ss
         # flat scalars: records that keep only the scalar members of `roofline` (the driver's parse) keep the scan metric
         out['roofline'].update({f'sscan_{k}': v for k, v in ss.items()})
+    if lines:
+        # key order of `roofline` (schema 3): the contract's keys, then BOTH scan kernels' scalars, then the numeric detail - a record
+        # that keeps only the first N scalar members (round 5's driver parse kept 24 and lost every sscan_bwd_* key) keeps the metric.
+        # Descriptive strings live in the sibling object `roofline_notes`.
+        r = out['roofline']
+        notes = {k: r.pop(k) for k in ('peak_note', 'products', 'note', 'mfma', 'measured_over') if k in r}
+        head = ['kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic']
+        scan = [f'sscan_{t}_{k}' for t in ('fwd', 'bwd') for k in ('frac', 'gbs', 'us', 'traffic_mb')]
+        order = [k for k in head + scan if k in r]
+        out['roofline'] = {**{k: r[k] for k in order}, **{k: v for k, v in r.items() if k not in order}}
+        out['roofline_notes'] = notes
     if len(lines) > 1:
         out['roofline_other'] = lines[1:]
     out['kernels'] = kern

@@ -27,7 +27,14 @@ graph; their sizes and the longest sequence are part of the shape key), and the 
 per-update host count (0, 4, 8, ... in program order - baked into the kernel nodes) PLUS a device word that a node of the graph
 advances (`ops.dropout_offset_base`): every replay draws fresh masks, forward and backward kernels of one replay agree, and an eager
 fallback through `step()` draws exactly what a replay would.
-Refused at construction (use the eager `train_one_batch`): side-stream overlap (gru), gradient clipping, data-parallel groups."""
+`policy_update_per` > 1 (every published launch script of the reference sets 2, gen_tmuxp_mamba_pomdp.py:81): whether the actor step is due
+(reference :450-452) is part of the graph key - an update with and an update without the actor step are two recordings that alternate.
+Gradient clipping (reference :239-250, 274-287) stays on the device: norm -> coefficient -> the scale word the flat AdamW kernel reads.
+Data-parallel groups: the recording is CUT at each gradient exchange (`cut`) - an update is then three graphs replayed back to back with
+the two all-reduces issued eagerly between them on the same stream (works with every backend; nothing waits on the host).
+Refused at construction (use the eager `train_one_batch`): side-stream overlap (gru), utd != 1, randomised masks / truncation, the
+three-phase Q-guard exchange (RESEL_DP_GUARD=allreduce)."""
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -66,6 +73,9 @@ class GraphedUpdate:
         self._amax_generation = ops.AMAX_GENERATION[0]
         self._pool = None                             # memory pool shared by every recorded graph
         self.eager_fallbacks = 0
+        self._rec = None                              # while recording: dict(segs=[(graph, exchange or None), ...], g=<graph being captured>)
+        if alg.grad_sync.active:                      # every rank's Q-guard extrema ride behind the gradients: size the buffer before anything is recorded
+            alg.values[0].store.ensure_grad_extra(4 + 4 * alg.grad_sync.world)
         E = alg.target_values[0].uni_network.layer_list[-1].num_ensemble
         self.E = E
         self._draw = type(alg)._select_target_ensemble.__get__(alg)         # the trainer's own host draw
@@ -172,13 +182,12 @@ class GraphedUpdate:
             # stream forked more than once per update) ends in a segmentation fault inside capture_end (hipStreamEndCapture) on this ROCm
             # build.  Captured on ONE stream the recurrences (3 us per step, latency-bound) would run back to back: slower than eager.
             return 'side-stream overlap (gru) is not captured'
-        if getattr(alg, 'grad_sync', None) is None or alg.grad_sync.active:
-            return 'data-parallel groups are not captured (or not a full-trajectory trainer)'
-        if any(getattr(par, k, None) is not None for k in ('value_max_gradnorm', 'value_embedding_max_gradnorm', 'policy_max_gradnorm',
-                                                           'policy_embedding_max_gradnorm')):
-            return 'gradient clipping reads norms on the host'
-        if par.utd != 1 or par.policy_update_per != 1 or par.randomize_mask or par.random_trunc_traj:
-            return 'utd / policy_update_per != 1 or randomised masks change the launch sequence from update to update'
+        if getattr(alg, 'grad_sync', None) is None:
+            return 'not a full-trajectory trainer'
+        if alg.grad_sync.active and os.environ.get('RESEL_DP_GUARD', 'bucket') == 'allreduce':
+            return 'the three-phase Q-guard exchange (RESEL_DP_GUARD=allreduce) issues collectives inside the target computation'
+        if par.utd != 1 or par.randomize_mask or par.random_trunc_traj:
+            return 'utd != 1 or randomised masks / truncation change the launch sequence from update to update'
         if not (getattr(alg, 'device_replay', False) and alg.replay_buffer.device_supported(randomize_mask=par.randomize_mask)):
             return 'needs the device-resident replay ring'
         return None
@@ -189,6 +198,44 @@ class GraphedUpdate:
         n = pl['seg'].shape[0]
         dev = self.alg.replay_buffer.gather_planned(self.device, self._plan_dev[:n], pl['max_len'], pl['nrow'], pl['longest'])
         return dev, pl['total_size'], pl['table']
+
+    def cut(self, exchange):
+        """Called by the trainer where ranks exchange gradients (`_finish_step`).  Recording: the graph being captured ends here, the
+        exchange is remembered behind it and a new graph begins (same pool, same stream) - the exchange is NOT issued while recording
+        (nothing has run yet).  Otherwise (eager launch through `step()`): issue it now."""
+        rec = self._rec
+        if rec is None:
+            exchange()
+            return
+        rec['g'].capture_end()
+        rec['segs'].append((rec['g'], exchange))
+        rec['g'] = torch.cuda.CUDAGraph()
+        rec['g'].capture_begin(pool=self._pool)
+
+    def _record(self):
+        """Record one update as a list of (graph, exchange) segments; one segment unless the trainer cuts (data parallel)."""
+        torch.cuda.synchronize(self.device)
+        torch.cuda.empty_cache()
+        side = self.__dict__.setdefault('_capture_stream', torch.cuda.Stream(device=self.device))
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        rec = self._rec = dict(segs=[], g=torch.cuda.CUDAGraph())
+        try:
+            with torch.cuda.stream(side):
+                if self._pool is None:
+                    rec['g'].capture_begin()
+                    self._pool = rec['g'].pool()
+                else:
+                    rec['g'].capture_begin(pool=self._pool)
+                try:
+                    self._body()                      # recorded, not run: the prepared inputs are consumed by the replay that follows
+                finally:
+                    rec['g'].capture_end()
+                rec['segs'].append((rec['g'], None))
+        finally:
+            self._rec = None
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        return dict(segs=rec['segs'], log_keys=self._log_keys, log_items=self._log_items)
 
     def log_node(self, keys, packed, host, items):
         self._log_keys = keys
@@ -223,10 +270,13 @@ class GraphedUpdate:
         slot['sub'].numpy()[...] = sub
         self.subset_i32.copy_(slot['sub'], non_blocking=True)
         self.subset_i64.copy_(self.subset_i32)
+        # is the actor step due in this update (reference :450-452 with utd = 1)?  Part of the key: the two launch sequences are two graphs
+        actor_due = alg.grad_num % par.policy_update_per == 0 and par.policy_utd > 0
         for i, opt in enumerate((alg.optimizer_value, alg.optimizer_policy)):
-            opt.prepare_step(slot['bc'][2 * i:2 * i + 2])
+            if i == 0 or actor_due:
+                opt.prepare_step(slot['bc'][2 * i:2 * i + 2])
         self._turn += 1
-        return key
+        return key + (bool(actor_due),)
 
     def _body(self):
         alg = self.alg
@@ -289,20 +339,17 @@ class GraphedUpdate:
                 old_key, _ = self.graphs.popitem(last=False)       # least recently used; its activations return to the shared pool
                 self._seen[old_key] = 2 - self.RECAPTURE_HITS
             self._captures.append(self._steps)
-            torch.cuda.synchronize(self.device)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=self._pool):
-                self._body()                          # recorded, not run: the prepared inputs are consumed by the replay below
-            if self._pool is None:
-                self._pool = g.pool()
-            torch.cuda.synchronize(self.device)
-            self.graphs[key] = g
+            g = self.graphs[key] = self._record()
         self.graphs.move_to_end(key)
-        g.replay()
+        self._log_keys, self._log_items = g['log_keys'], g['log_items']      # of THIS launch sequence (with / without the actor step)
+        for seg, exchange in g['segs']:
+            seg.replay()
+            if exchange is not None:
+                exchange()                            # the gradient all-reduce, eagerly between two replays on the same stream
         if ops.AMAX_VERIFY:                           # the recorded update contains the check kernels: read their verdict behind the replay
             ops.amax_verify_raise(self.device)
         return self._finish()
 
     @property
-    def graph(self):                                  # the most recently recorded graph (tests)
-        return next(reversed(self.graphs.values()), None) if self.graphs else None
+    def graph(self):                                  # the most recently recorded graph (tests): its first segment
+        return next(reversed(self.graphs.values()))['segs'][0][0] if self.graphs else None

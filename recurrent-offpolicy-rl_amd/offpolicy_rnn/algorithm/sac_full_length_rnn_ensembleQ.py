@@ -417,10 +417,17 @@ class SACFullLengthRNNEnsembleQ(SAC):
         return alpha * logp - q_pi                                   # (TD3 trainers drop the entropy term)
 
     def _clip(self, store, model, max_norm, emb_max, scale):
-        """Optional gradient clipping on the *normalised* gradient (reference :239-250, 274-287)."""
+        """Optional gradient clipping on the *normalised* gradient (reference :239-250, 274-287).  Nothing here reads a device value on
+        the host: the norm stays a device scalar (it joins the log's packed scalars), so a clipped update is capturable."""
         gnorm = 0.0
         if max_norm is None and emb_max is None:
             return gnorm
+        if emb_max is None and store.grad.is_cuda:
+            # norm clipping alone rewrites nothing: ||g / count|| = scale * sqrt(sum g^2) from ONE read of the flat buffer, and the
+            # coefficient min(1, max_norm / (norm + 1e-6)) (torch.nn.utils.clip_grad_norm_) is folded into the scale word AdamW reads
+            gnorm = ops.sumsq(store.grad[:store.numel]).sqrt_().mul_(scale)
+            scale.mul_((max_norm / (gnorm + 1e-6)).clamp_(max=1.0))
+            return gnorm[0]
         store.grad[:store.numel].mul_(scale)
         scale.fill_(1.0)
         if max_norm is not None:
@@ -447,10 +454,17 @@ class SACFullLengthRNNEnsembleQ(SAC):
             o = store.numel + 4 + 4 * gs.rank
             store.grad[o:o + 4] = self._guard_ext
         store.grad[store.numel] = local_count
-        gs.all_reduce_async_(store.grad)
-        if overlap is not None:
-            overlap()
-        gs.wait()
+        if gs.active and self._graph is not None:
+            # captured update: the recording is CUT here - the exchange runs eagerly between two graph replays (any backend, gloo included)
+            if overlap is not None:
+                overlap()
+            grad = store.grad
+            self._graph.cut(lambda: gs.all_reduce_(grad))
+        else:
+            gs.all_reduce_async_(store.grad)
+            if overlap is not None:
+                overlap()
+            gs.wait()
         if guard_slots:                                # every rank's extrema are here: initialise / update the guard from the global batch
             ops.guard_apply_slots(store.grad[store.numel + 4:store.numel + 4 + 4 * gs.world], gs.world, self.Q_guard.state)
             self._guard_ext_fresh = False

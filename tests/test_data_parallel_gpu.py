@@ -48,26 +48,38 @@ def _build(rnn, keep=None, batch=30, quiet=False, patcher=None):
     return alg
 
 
-def _run(alg, steps=2):
+def _run(alg, steps=2, graph=False):
+    step = alg.train_one_batch
+    if graph:                                        # every update through GraphedUpdate.step(): eager warm-up, then recorded + replayed
+        from offpolicy_rnn.algorithm.graphed_update import GraphedUpdate
+        assert GraphedUpdate.refusal(alg) is None, GraphedUpdate.refusal(alg)
+        gu = GraphedUpdate(alg, warmup=1)
+        step = gu.step
     for _ in range(steps):
-        log = alg.train_one_batch()
+        log = step()
         alg.grad_num += 1
     torch.cuda.synchronize()
+    if graph:
+        assert len(gu.graphs) >= 1 and gu.eager_fallbacks < steps, (len(gu.graphs), gu.eager_fallbacks)
+        if alg.grad_sync.active:                     # cut at the two gradient exchanges: three graphs per update with an actor step
+            assert max(len(g['segs']) for g in gu.graphs.values()) == 3
+        gu.close()
     return dict(policy=alg.policy.store.flat[:alg.policy.store.numel].detach().cpu(),
                 value=alg.values[0].store.flat[:alg.values[0].store.numel].detach().cpu(),
                 alpha=alg.log_sac_alpha.detach().cpu(), critic_loss=log['critic_loss'], guard=alg.Q_guard.state.detach().cpu())
 
 
-def _worker(rank, world, port, rnn, out_dir, union=False, backend='gloo'):
+def _worker(rank, world, port, rnn, out_dir, union=False, backend='gloo', graph=False, steps=2, per=1):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     torch.cuda.set_device(rank if backend == 'nccl' else 0)
     dist.init_process_group(backend, rank=rank, world_size=world)
     alg = _build(rnn, keep=SPLIT[rank], batch=sum(LENS[i] for i in SPLIT[rank]), quiet=True) if union else _build(rnn)
     alg._subset_rng = None                             # product default under world > 1: the shared stream
+    alg.parameter.policy_update_per = per
     alg.grad_sync.__init__()
     assert alg.grad_sync.world == world and alg.device.type == 'cuda' and alg.grad_sync.backend == backend
-    res = _run(alg)
+    res = _run(alg, steps, graph)
     res['calls'] = dict(alg.grad_sync.calls)
     res['guard'] = alg.Q_guard.state.detach().cpu()
     torch.save(res, os.path.join(out_dir, f'rank{rank}.pt'))
@@ -126,6 +138,29 @@ def test_two_ranks_over_rccl_reproduce_the_union_batch_update(tmp_path, monkeypa
         np.testing.assert_allclose(r0[k].numpy(), ref[k].numpy(), rtol=2e-4, atol=2e-6, err_msg=k)
 
 
+@pytest.mark.parametrize('rnn,per', [('smamba_s8_c4_b1_nln', 1), ('gilr', 2)])
+def test_two_ranks_graphed_update_reproduces_the_union_batch_update(tmp_path, rnn, per, monkeypatch):
+    """Data parallelism WITH the update graph: each rank drives its updates through GraphedUpdate.step() - the recording is cut at the
+    two gradient exchanges, so an update is three graph replays with the all-reduces (gloo here: two ranks share cuda:0) issued
+    eagerly between them.  Five updates (eager warm-up, then recorded and replayed; per = 2: the graphs with and without the actor
+    step alternate) of two ranks with disjoint rows against the single-process EAGER update over the union batch."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from test_data_parallel import _free_port
+    steps = 5 if per == 1 else 8
+    mp.spawn(_worker, args=(2, _free_port(), rnn, str(tmp_path), True, 'gloo', True, steps, per), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(tmp_path, f'rank{i}.pt')) for i in range(2))
+    for k in ('policy', 'value', 'alpha', 'guard'):
+        assert torch.equal(r0[k], r1[k]), f'{k} diverged across ranks'
+    n_actor = (steps + per - 1) // per
+    assert r0['calls']['all_reduce_sum'] == steps + n_actor and r0['calls']['all_reduce_max'] == 0, r0['calls']
+    one = _build(rnn, batch=sum(LENS), quiet=True, patcher=monkeypatch)
+    one.parameter.policy_update_per = per
+    ref = _run(one, steps)
+    for k in ('policy', 'value', 'alpha', 'guard'):
+        np.testing.assert_allclose(r0[k].numpy(), ref[k].numpy(), rtol=5e-4, atol=5e-6, err_msg=k)
+
+
 def _one_rank_bench(launcher, extra_env=None):
     import json
     import subprocess
@@ -142,6 +177,7 @@ def _one_rank_bench(launcher, extra_env=None):
 def _assert_collectives_ran(line):
     assert line['n_gpus'] == 1 and np.isfinite(line['value']) and line['value'] > 0
     assert line['backend'] == 'nccl' and line['rccl_ranks'] == 1
+    assert line['graph_update'] is True, line['launch']     # data-parallel groups run the update graph too (cut at the exchanges)
     # per update: critic step + actor step = 2 flat-gradient all-reduces; the target's Q-guard = 2 MAX all-reduces
     assert line['collectives_per_step']['all_reduce_sum'] == 2 and line['collectives_per_step']['all_reduce_max'] == 0, line['collectives_per_step']
     assert line['parameter_broadcasts'] >= 3 and line['collective_bytes_per_step']['all_reduce_sum'] > 1e6

@@ -106,6 +106,50 @@ def test_train_one_batch_gpu_vs_oracle_more_layer_ids(rnn):
                 np.testing.assert_allclose(sd[mod][k].detach().cpu(), v.detach(), rtol=1e-3, atol=2e-5, err_msg=f'{mod}.{k}')
 
 
+@pytest.mark.parametrize('rnn', ['smamba_s8_c4_b1_nln', 'gilr'])
+def test_clipped_updates_with_policy_update_per_2_vs_oracle(rnn):
+    """The reference's published cadence (policy_update_per = 2, gen_tmuxp_mamba_pomdp.py:81) with gradient-norm clipping switched on
+    at bounds the gradients exceed (reference :239-250, 274-287): the product folds the clip coefficient into the scale word of its flat
+    AdamW kernel (no pass over the gradients, no host read); the oracle calls torch.nn.utils.clip_grad_norm_.  Four updates: logged
+    scalars (the pre-clip norms among them) and parameters."""
+    from offpolicy_rnn import alg_init
+    from oracle.trainer import OracleTrainer, default_parameter
+    from test_oracle_golden import _push as opush
+    torch.manual_seed(11)
+    flags = dict(policy_update_per=2, value_max_gradnorm=0.05, policy_max_gradnorm=0.01)
+    alg = alg_init(make_parameter(rnn, sac_batch_size=40, **flags))
+    cpu = lambda sd: {m: {k: v.detach().cpu().clone() for k, v in d.items()} for m, d in sd.items()}
+    par = default_parameter(rnn=rnn, D=32, sac_batch_size=40, policy_embedding_dim=16, value_embedding_dim=16,
+                            policy_uni_model_input_mapping_dim=16, value_uni_model_input_mapping_dim=16, max_buffer_transition_num=5000, **flags)
+    tr = OracleTrainer(par, 5, 3, 12, smamba_semantics='gpu', policy_state=cpu(alg.policy.state_dict()), value_state=cpu(alg.values[0].state_dict()))
+    rs = np.random.RandomState(9)
+    for n in [12, 5, 7, 12, 4, 9, 6]:
+        o, a, r = _synth(rs, n, 5, 3)
+        _push(alg.replay_buffer, o, a, r, early_done=(n != 12))
+        opush(tr.buffer, o, a, r, early_done=(n != 12))
+    logs = []
+    for runner in (alg, tr):
+        torch.manual_seed(200)
+        np.random.seed(200)
+        out = []
+        for _ in range(4):
+            out.append(dict(runner.train_one_batch()))
+            runner.grad_num += 1
+        logs.append(out)
+    for it, (a, b) in enumerate(zip(*logs)):
+        assert ('actor_loss' in a) == (it % 2 == 0) and ('actor_loss' in b) == (it % 2 == 0)
+        for k, v in b.items():
+            got = a[k][0] if isinstance(a[k], tuple) else a[k]
+            want = v[0] if isinstance(v, tuple) else v
+            assert got == pytest.approx(want, rel=2e-3, abs=5e-4), (it, k, got, want)
+    assert logs[0][0]['value_grad_norm'] > 0.05 and logs[0][0]['policy_grad_norm'] > 0.01      # both clips were active
+    for net, ref in ((alg.policy, tr.policy), (alg.values[0], tr.value)):
+        sd = net.state_dict()
+        for mod, d in ref.items():
+            for k, v in d.items():
+                np.testing.assert_allclose(sd[mod][k].detach().cpu(), v.detach(), rtol=1e-3, atol=2e-5, err_msg=f'{mod}.{k}')
+
+
 @pytest.mark.parametrize('name', ['gru_sac_discrete', 'gilr_sac_discrete'])
 def test_discrete_train_one_batch_gpu_vs_reference_logs(name):
     """Discrete-action SAC-REDQ on cuda:0 against the dicts / parameters the reference itself logged (three updates)."""
@@ -356,12 +400,17 @@ def test_cgpt_td3_update_gpu_vs_oracle():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('rnn,ragged,algo', [('smamba_s8_c4_b1_nln', False, 'sac'), ('gilr', False, 'sac'), ('smamba_s8_c4_b1_nln', True, 'sac'),
-                                              ('lru', False, 'td3'), ('cgpt_h1_l2_p0.0_ml64_rms', False, 'td3')])
-def test_graphed_update_equals_the_eager_update(rnn, ragged, algo, monkeypatch):
+@pytest.mark.parametrize('rnn,ragged,algo,per,clip', [
+    ('smamba_s8_c4_b1_nln', False, 'sac', 1, False), ('gilr', False, 'sac', 1, False), ('smamba_s8_c4_b1_nln', True, 'sac', 1, False),
+    ('lru', False, 'td3', 1, False), ('cgpt_h1_l2_p0.0_ml64_rms', False, 'td3', 1, False),
+    # the reference's published flag set (gen_tmuxp_mamba_pomdp.py:81): the actor steps on every second update - two graphs alternate
+    ('smamba_s8_c4_b1_nln', False, 'sac', 2, False), ('gilr', False, 'td3', 2, False), ('smamba_s8_c4_b1_nln', True, 'sac', 2, False),
+    # gradient clipping (reference :239-250, 274-287) at norms the gradients exceed, with and without the alternating actor step
+    ('smamba_s8_c4_b1_nln', False, 'sac', 1, True), ('gilr', False, 'sac', 2, True), ('lru', False, 'sac', 1, 'value')])
+def test_graphed_update_equals_the_eager_update(rnn, ragged, algo, per, clip, monkeypatch):
     """The whole update replayed from ONE hipGraph (algorithm/graphed_update.py: sampling plan, REDQ subset and AdamW step factors in
     static buffers refreshed before each replay) against the eager update: same seeds, actor noise off (the captured generator draws
-    from graph-safe Philox offsets), four updates - logged scalars and every parameter to 2e-5."""
+    from graph-safe Philox offsets), four updates (eight with policy_update_per = 2) - logged scalars and every parameter to 2e-5."""
     if not torch.cuda.is_available():
         pytest.skip('needs a GPU')
     import numpy as np
@@ -374,7 +423,13 @@ def test_graphed_update_equals_the_eager_update(rnn, ragged, algo, monkeypatch):
     def build():
         torch.manual_seed(0)
         np.random.seed(0)
-        alg = alg_init(make_parameter(rnn, algo=algo, sac_batch_size=4 * 12 - 1, cuda_inference=True))
+        extra = dict(policy_update_per=per)
+        if clip == 'value':                                     # element-wise clipping of the embedding gradients (the torch spelling, in place)
+            extra.update(value_embedding_max_gradnorm=1e-3, policy_embedding_max_gradnorm=1e-3)
+        elif clip:
+            extra.update(value_max_gradnorm=0.05, policy_max_gradnorm=0.01)
+        alg = alg_init(make_parameter(rnn, algo=algo, sac_batch_size=4 * 12 - 1, cuda_inference=True, **extra))
+        assert GraphedUpdate.refusal(alg) is None
         rs = np.random.RandomState(3)
         for i in range(8):                                      # equal lengths: one batch shape; ragged: the shape changes between updates
             n = (12, 9, 7, 12, 5, 12, 10, 8)[i] if ragged else 12
@@ -387,7 +442,7 @@ def test_graphed_update_equals_the_eager_update(rnn, ragged, algo, monkeypatch):
         return [alg.policy.store.flat.detach().clone(), alg.values[0].store.flat.detach().clone(), alg.target_values[0].store.flat.detach().clone(),
                 alg.log_sac_alpha.detach().clone()]
 
-    n_upd = 16 if ragged else 4
+    n_upd = (16 if ragged else 4) * per
     rs_new = np.random.RandomState(99)
     fresh = [_synth(rs_new, n, 5, 3) for n in (12, 6)]         # trajectories that enter the ring in the middle of the run
 
@@ -417,8 +472,12 @@ def test_graphed_update_equals_the_eager_update(rnn, ragged, algo, monkeypatch):
     torch.cuda.synchronize()
     print(f'graphs recorded {len(g.graphs)}, eager updates {g.eager_fallbacks} of {n_upd}')
     assert len(g.graphs) <= (2 if ragged else 4) and g.eager_fallbacks >= 1
-    # equal lengths: warm-up + at most one first visit per shape (the ring refill adds one); ragged shapes must recur to be recorded
-    assert ragged or (g.graph is not None and g.eager_fallbacks <= 3)
+    # equal lengths: warm-up + at most one first visit per launch sequence (the ring refill adds one); ragged shapes must recur to be recorded
+    assert ragged or (g.graph is not None and g.eager_fallbacks <= 3 * per)
+    if per == 2 and not ragged:
+        assert {k[-1] for k in g.graphs} == {True, False}, 'one recording with and one without the actor step'
+    if clip is True:                                            # the clip was active: the logged norm (pre-clip, reference :241) exceeds the bound
+        assert logs_g[-2 if per == 2 else -1]['policy_grad_norm'] > 0.01 and logs_g[-1]['value_grad_norm'] > 0.05
     # not bit for bit: the entropy coefficient's torch AdamW runs in its `capturable` form (step count and bias corrections as
     # fp32 device tensors instead of Python floats), and the coefficient enters every loss
     # cgpt: the attention runs in bf16 - an operand that differs in its last fp32 bit (the replayed GEMMs scale their fp16 planes with
