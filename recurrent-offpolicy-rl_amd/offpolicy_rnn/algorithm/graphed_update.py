@@ -71,7 +71,7 @@ class GraphedUpdate:
         self._captures = []                           # step indices of the most recent recordings (capture-rate limit)
         self._steps = 0
         self._amax_generation = ops.AMAX_GENERATION[0]
-        self._pool = None                             # memory pool shared by every recorded graph
+        self._pool = torch.cuda.graph_pool_handle()   # memory pool shared by every recorded graph (and by the segments of one update)
         self.eager_fallbacks = 0
         self._rec = None                              # while recording: dict(segs=[(graph, exchange or None), ...], g=<graph being captured>)
         if alg.grad_sync.active:                      # every rank's Q-guard extrema ride behind the gradients: size the buffer before anything is recorded
@@ -221,11 +221,7 @@ class GraphedUpdate:
         rec = self._rec = dict(segs=[], g=torch.cuda.CUDAGraph())
         try:
             with torch.cuda.stream(side):
-                if self._pool is None:
-                    rec['g'].capture_begin()
-                    self._pool = rec['g'].pool()
-                else:
-                    rec['g'].capture_begin(pool=self._pool)
+                rec['g'].capture_begin(pool=self._pool)
                 try:
                     self._body()                      # recorded, not run: the prepared inputs are consumed by the replay that follows
                 finally:
