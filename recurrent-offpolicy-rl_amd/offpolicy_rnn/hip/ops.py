@@ -1056,7 +1056,7 @@ class LinearAct(torch.autograd.Function):
             weight = torch.nn.functional.pad(weight, (0, ctx.kpad, 0, ctx.npad))
             bias = torch.nn.functional.pad(bias, (0, ctx.npad)) if (bias is not None and ctx.npad) else bias
         if dest is not None and long_pass and not ctx.npad and dest.fits(x2.shape[0], weight.shape[0]):
-            y2 = mm_nt(x2, weight, bias, act, out=dest.view(), amax_out=dest.rb.amax)
+            y2 = mm_nt(x2, weight, bias, act, out=dest.view(), amax_out=dest.rb.amax if dest.rb.handle() is not None else None)
             dest.note(y2)
         else:
             y2 = mm_nt(x2, weight, bias, act)
@@ -1147,7 +1147,15 @@ class RowBuffer:
             self.rows *= v
         self.buf = torch.empty(self.rows, self.width, dtype=torch.float32, device=device)
         self.amax = _slot_args(amax_tracking() and self.rows * self.width >= (1 << 20), self.buf.device)     # (handle, pointer, epoch)
+        # the handle's tenant serial AT ALLOCATION: the arena has 2 048 slots and a deep embedding tower (or RESEL_AMAX_VERIFY) may hand
+        # out more than that between this constructor and `cat_into` - the slot then belongs to another tensor and no tag may name it
+        self.serial = getattr(self.amax[0], '_resel_serial', None)
         self.published = 0                               # columns whose producer published into the handle
+
+    def handle(self):
+        """The buffer's magnitude handle while its arena slot still has the tenant it had at allocation, else None."""
+        h = self.amax[0]
+        return h if h is not None and getattr(h, '_resel_serial', None) == self.serial else None
 
     def block(self, col0, n):
         return ColDest(self, col0, n)
@@ -1208,7 +1216,7 @@ def cat_into(rb, pieces):
     complete = all(rb.block(c, t.shape[-1]).holds(t) for t, c in pieces) and sum(t.shape[-1] for t, _ in pieces) == rb.width \
         and rb.published == rb.width
     out = CatInto.apply(rb, tuple(int(c) for _, c in pieces), *[t for t, _ in pieces])
-    return tag_amax(out, rb.amax[0] if complete else None, whole=True)
+    return tag_amax(out, rb.handle() if complete else None, whole=True)
 
 
 def linear(x, weight, bias=None):
@@ -1435,8 +1443,14 @@ def amax_slot(device):
     if ar is None:
         buf = torch.zeros(AMAX_SLOTS * AMAX_WORDS, dtype=torch.int64, device=device)
         ar = _AMAX_ARENA[device] = [buf, 0, list(buf.view(AMAX_SLOTS, AMAX_WORDS).unbind(0))]     # handle views made once (this sits on the launch path)
+    if _AMAX_EPOCH[0] >= _EPOCH_RESET_AT and not torch.cuda.is_current_stream_capturing():
+        # a long-lived user of this module that never reaches an update boundary (evaluation / inference loops, soak tools): start the
+        # epochs over HERE, long before the 31-bit device word runs out, instead of failing after weeks of uptime.  Safe between two
+        # producer calls: the reset synchronises the device first (see amax_maintenance), so no kernel with an old epoch is in flight.
+        # Handles the caller still holds become void (`handle_alive` / `amax_of` see the changed tenant serial).
+        amax_maintenance(force=True)
     if _AMAX_EPOCH[0] >= 0x7ffffff0:
-        raise RuntimeError('RESeL-HIP: magnitude epochs exhausted inside one update - call ops.amax_maintenance() at update boundaries')
+        raise RuntimeError('RESeL-HIP: magnitude epochs exhausted inside one captured region')
     _AMAX_EPOCH[0] += 1
     i = ar[1]
     ar[1] = (i + 1) % AMAX_SLOTS
@@ -1456,6 +1470,10 @@ def amax_maintenance(force=False):
     AMAX_GENERATION[0] += 1
     PARAM_EPOCH[0] += 1
     for ar in _AMAX_ARENA.values():
+        # every stream of the device must be idle before the words are zeroed: a producer still running on a side / target stream with an
+        # old-generation epoch (>= 0x60000000) that published AFTER the zero would outrank every new small epoch in its slot, and readers
+        # would scale with a stale magnitude.  Once per ~1.6e9 producer calls: the stall does not matter.
+        torch.cuda.synchronize(ar[0].device)
         ar[0].zero_()
         for h in ar[2]:
             h._resel_serial = None
