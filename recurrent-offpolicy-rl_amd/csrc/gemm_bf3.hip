@@ -1760,7 +1760,9 @@ int gemm_bf3_launch(const float* A, int64_t lda, int64_t strideA, int a_kcontig,
 #undef WS_LAUNCH
 #undef BF3_LAUNCH
     if (rc != RESEL_OK) return rc;
+#ifndef BF3_AB_NOFIXUP                  // ablation (wrong results): the K-slice tiles are never summed - what a free fix-up would buy (tools/bf3_ablate.sh)
     if (pl.nsplit) hipLaunchKernelGGL(gemm_bf3_fixup_kernel, dim3(TILE / 4 / 64, pl.nsplit), dim3(64, 4), 0, s, p);
+#endif
     return launch_status();
 }
 

@@ -81,6 +81,8 @@ class GraphedUpdate:
         self._draw = type(alg)._select_target_ensemble.__get__(alg)         # the trainer's own host draw
         # static subset buffers sized WITHOUT consuming a draw: evaluate the draw on a scratch numpy stream and put the stream back
         st_np = np.random.get_state()
+        if hasattr(alg, '_subset_stream'):
+            alg._subset_stream()                      # data-parallel ranks create their shared stream on first use: create it BEFORE its state is saved
         rng_own = getattr(alg, '_subset_rng', None)
         st_own = None if rng_own is None else rng_own.get_state()
         first = np.asarray(self._draw(E))

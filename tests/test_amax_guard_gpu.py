@@ -95,12 +95,18 @@ def test_epoch_rollover_at_an_update_boundary(ops):
     x = torch.randn(8192, 256, generator=g).to(dev)
     ref = (x.double() @ lin.weight.double().t() + lin.bias.double()).float()
     assert not ops.amax_maintenance()                           # far from the limit: nothing happens
-    ops._AMAX_EPOCH[0] = ops._EPOCH_RESET_AT + 5                # as after ~3 million eager updates
-    y0 = ops.linear_act(x, lin.weight, lin.bias, None)         # the store's weight handles now carry epochs near 2^31
-    assert store._amax is not None
+    ops._AMAX_EPOCH[0] = ops._EPOCH_RESET_AT - 40               # as after ~3 million eager updates: the next products carry epochs near 2^31
+    y0 = ops.linear_act(x, lin.weight, lin.bias, None)
+    assert store._amax is not None and ops._AMAX_EPOCH[0] < ops._EPOCH_RESET_AT
+    ops._AMAX_EPOCH[0] = ops._EPOCH_RESET_AT + 5                # past the limit
     gen = ops.AMAX_GENERATION[0]
-    assert ops.amax_maintenance()
+    assert ops.amax_maintenance()                               # the update boundary resets
     assert ops.AMAX_GENERATION[0] == gen + 1 and store._amax is None and ops._AMAX_EPOCH[0] == 0
+    # a long-lived user that never reaches an update boundary (evaluation loops, soak tools) is reset by the next
+    # producer call itself instead of failing when the 31-bit word runs out
+    ops._AMAX_EPOCH[0] = ops._EPOCH_RESET_AT + 5
+    kept = ops.keep_handles(ops.amax_slot(dev)[0])              # this very call starts the epochs over ...
+    assert ops.AMAX_GENERATION[0] == gen + 2 and ops._AMAX_EPOCH[0] == 1 and ops.handle_alive(kept[0]) is not None
     with torch.no_grad():
         lin.weight.mul_(64.0)                                    # the old handle (large epoch) would now be 64x too small
     ref2 = (x.double() @ lin.weight.double().t() + lin.bias.double()).float()
