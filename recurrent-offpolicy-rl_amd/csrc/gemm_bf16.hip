@@ -336,18 +336,27 @@ void launch_layout(const Params& p, dim3 grid, int akc, int bkc, hipStream_t s) 
 extern "C" size_t resel_gemm_bf16_workspace_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     const Plan pl = make_plan(M, N, K);
-    return (size_t)pl.nsplit * pl.nsl * TILE * sizeof(float);
+    return std::max((size_t)pl.nsplit * pl.nsl * TILE * sizeof(float), gemm_any_workspace_bytes(M, N, K, 1));
 }
 
 extern "C" int resel_gemm_bf16(const void* A, int64_t lda, int a_kcontig, int a_bf16, const void* B, int64_t ldb, int b_kcontig, int b_bf16,
                                const float* bias, void* C, int64_t ldc, int c_bf16, void* workspace, int M, int N, int K,
                                resel_stream_t stream) {
-    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return RESEL_EINVAL;
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || lda <= 0 || ldb <= 0 || ldc <= 0) return RESEL_EINVAL;
     // a thread fetches four consecutive elements of an operand's contiguous axis: extents, leading dimensions and base addresses
-    // must keep those 16-byte (fp32) / 8-byte (bf16) pieces aligned
-    if ((a_kcontig ? K : M) % 4 || (b_kcontig ? K : N) % 4 || lda % 4 || ldb % 4) return RESEL_EINVAL;
-    if ((reinterpret_cast<uintptr_t>(A) & (a_bf16 ? 7u : 15u)) || (reinterpret_cast<uintptr_t>(B) & (b_bf16 ? 7u : 15u))) return RESEL_EINVAL;
-    if (lda <= 0 || ldb <= 0 || ldc <= 0 || lda >= (int64_t)1 << 22 || ldb >= (int64_t)1 << 22) return RESEL_EINVAL;
+    // must keep those 16-byte (fp32) / 8-byte (bf16) pieces aligned.  Shapes that do not, and the M <= 8 rows of a decode step against
+    // a whole weight matrix, go to gemm_any.hip with the same rounding points (operands and bias rounded to bf16, fp32 accumulation,
+    // result rounded as `c_bf16` says) - fp32 operands only there, except a bf16 A in the rows form (the attention output of a decode step)
+    const bool mfma_ok = !((a_kcontig ? K : M) % 4 || (b_kcontig ? K : N) % 4 || lda % 4 || ldb % 4 ||
+                           (reinterpret_cast<uintptr_t>(A) & (a_bf16 ? 7u : 15u)) || (reinterpret_cast<uintptr_t>(B) & (b_bf16 ? 7u : 15u)) ||
+                           lda >= (int64_t)1 << 22 || ldb >= (int64_t)1 << 22);
+    const bool rows = !b_bf16 && gemm_any_rows_ok(A, lda, 0, a_kcontig, a_bf16, (const float*)B, ldb, 0, b_kcontig, M, K, 0);
+    if (!mfma_ok || rows) {
+        if (b_bf16 || (a_bf16 && !rows)) return RESEL_EINVAL;
+        const int rnd = (a_bf16 ? 16 : 1) | 2 | (c_bf16 == 1 ? 8 : (c_bf16 == 2 ? 4 : 0));
+        return gemm_any_launch(A, lda, 0, a_kcontig, (const float*)B, ldb, 0, b_kcontig, bias, 0, 0, C, ldc, 0, workspace, M, N, K, 1, rnd, nullptr, 0u,
+                               (hipStream_t)stream);
+    }
     const Plan pl = make_plan(M, N, K);
     if (pl.nsplit && (!workspace || !aligned16(workspace))) return RESEL_EINVAL;
     Params p{A, B, bias, C, (float*)workspace, lda, ldb, ldc, M, N, K, c_bf16 == 2 ? 2 : (c_bf16 ? 1 : 0),

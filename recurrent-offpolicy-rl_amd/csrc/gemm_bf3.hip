@@ -1760,9 +1760,11 @@ int gemm_bf3_launch(const float* A, int64_t lda, int64_t strideA, int a_kcontig,
 #undef WS_LAUNCH
 #undef BF3_LAUNCH
     if (rc != RESEL_OK) return rc;
-#ifndef BF3_AB_NOFIXUP                  // ablation (wrong results): the K-slice tiles are never summed - what a free fix-up would buy (tools/bf3_ablate.sh)
     if (pl.nsplit) hipLaunchKernelGGL(gemm_bf3_fixup_kernel, dim3(TILE / 4 / 64, pl.nsplit), dim3(64, 4), 0, s, p);
-#endif
+#ifdef BF3_AB_FIXUP2                    // ablation (right results): every fix-up launched TWICE - what the 86 fix-up launches of an update cost, measured
+    if (pl.nsplit && act != 2) hipLaunchKernelGGL(gemm_bf3_fixup_kernel, dim3(TILE / 4 / 64, pl.nsplit), dim3(64, 4), 0, s, p);   // with the data left intact
+#endif                                  // (skipping the fix-up instead leaves garbage tiles: the degenerate data lowers the chip's power draw, its clock
+                                        //  rises and EVERY kernel of the update runs 5-13 % faster - profiles/r06_gemm.md)
     return launch_status();
 }
 

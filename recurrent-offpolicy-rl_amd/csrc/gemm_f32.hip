@@ -618,7 +618,8 @@ extern "C" int resel_gemm_debug_stamps(unsigned long long* host_out) {
 extern "C" size_t resel_gemm_f32_workspace_bytes(int M, int N, int K, int batch) {
     if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return 0;
     const Plan pl = make_plan(M, N, K, batch);
-    return std::max((size_t)pl.nsplit * pl.nsl * TILE * sizeof(float), gemm_bf3_workspace_bytes(M, N, K, batch));
+    return std::max(std::max((size_t)pl.nsplit * pl.nsl * TILE * sizeof(float), gemm_bf3_workspace_bytes(M, N, K, batch)),
+                    gemm_any_workspace_bytes(M, N, K, batch));
 }
 
 extern "C" int resel_gemm_f32(const float* A, int64_t lda, int64_t strideA, int a_kcontig,
@@ -643,11 +644,17 @@ extern "C" int resel_gemm_f32x(const float* A, int64_t lda, int64_t strideA, int
     if (amax_c && (reinterpret_cast<uintptr_t>(amax_c) & 7u)) return RESEL_EINVAL;
     if (split == 2 && M <= 128) split = 6;         // narrow shapes stay on the first edition's fp32-accurate bf16 split
     if (K < BK) split = 0;                         // the split kernels' scheduled loads assume one whole K step per item
-    if (lda % 4 || ldb % 4 || strideA % 4 || strideB % 4 || !aligned16(A) || !aligned16(B)) return RESEL_EINVAL;
-    // float4 loads run along the contiguous axis: its extent must be a multiple of 4 (K for [rows][K] operands, rows otherwise)
-    if ((a_kcontig ? K : M) % 4 || (b_kcontig ? K : N) % 4) return RESEL_EINVAL;
-    // a thread's piece offsets inside a tile are 32-bit byte offsets: 128 rows (or 32 k) of the leading dimension must fit
-    if (lda <= 0 || ldb <= 0 || ldc <= 0 || lda >= (int64_t)1 << 22 || ldb >= (int64_t)1 << 22) return RESEL_EINVAL;
+    if (lda <= 0 || ldb <= 0 || ldc <= 0) return RESEL_EINVAL;
+    // What the matrix-core editions need: float4 loads along each operand's contiguous axis (16-byte aligned rows, that extent a
+    // multiple of 4), 32-bit piece offsets inside a tile (128 rows or 32 k of the leading dimension).  Everything else - the 6-wide
+    // heads and their gradients, rank-2 projections, odd action counts - and the M <= 8 rows of a rollout step against a whole weight
+    // matrix go to gemm_any.hip (exact fp32 FMAs, same epilogues, same magnitude publication): no shape is refused, none is left to a
+    // vendor library.
+    const bool mfma_ok = !(lda % 4 || ldb % 4 || strideA % 4 || strideB % 4 || !aligned16(A) || !aligned16(B) || (a_kcontig ? K : M) % 4 ||
+                           (b_kcontig ? K : N) % 4 || lda >= (int64_t)1 << 22 || ldb >= (int64_t)1 << 22);
+    if (!mfma_ok || gemm_any_rows_ok(A, lda, strideA, a_kcontig, 0, B, ldb, strideB, b_kcontig, M, K, act))
+        return gemm_any_launch(A, lda, strideA, a_kcontig, B, ldb, strideB, b_kcontig, bias, strideBias, act, C, ldc, strideC, workspace, M, N, K,
+                               batch, 0, (unsigned long long*)amax_c, amax_epoch, (hipStream_t)stream);
     // second edition (256 x 128 tiles) unless half of its tile rows would be padding: M <= 128 (narrow weight gradients) runs
     // 1.2-1.4x faster on the first edition's 128 x 128 tiles (66 752-token weight gradients [128, 256]: 48 vs 59 us, [80, 512]: 67 vs 95)
     if ((split == 2 || split == 3 || split == 6) && M > 128)

@@ -162,4 +162,13 @@ inline int launch_status() { return hipGetLastError() == hipSuccess ? RESEL_OK :
 const unsigned long long* dropout_offset_base();
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// gemm_any.hip: the shapes the matrix-core GEMM editions do not take (unaligned rows, tiny reductions) and the M <= 8 rollout rows
+// rnd bits: 1 round A to bf16, 2 round B (and the bias) to bf16, 4 round the fp32 result to a bf16 value, 8 store bf16, 16 A is bf16 (rows form)
+size_t gemm_any_workspace_bytes(int M, int N, int K, int batch);
+bool gemm_any_rows_ok(const void* A, int64_t lda, int64_t strideA, int a_kcontig, int a_bf16, const float* B, int64_t ldb, int64_t strideB,
+                      int b_kcontig, int M, int K, int act);
+int gemm_any_launch(const void* A, int64_t lda, int64_t strideA, int a_kcontig, const float* B, int64_t ldb, int64_t strideB, int b_kcontig,
+                    const float* bias, int64_t strideBias, int act, void* C, int64_t ldc, int64_t strideC, void* workspace,
+                    int M, int N, int K, int batch, int rnd, unsigned long long* amax_c, unsigned amax_epoch, hipStream_t s);
+
 }  // namespace resel

@@ -251,7 +251,7 @@ class MambaInnerFn(torch.autograd.Function):
         tag_amax(ddt, h_ddt)
         # [Di, R] with a 66 752-long reduction: hand-written MFMA kernel (the library reaches 7 TFLOP/s on this shape)
         d_dt_w = atb(ddt, x_dbl[:, :R]) if R <= 32 and Di % 4 == 0 and ddt.stride(1) == 1 and ddt.stride(0) % 4 == 0 \
-            else torch.mm(ddt.t(), x_dbl[:, :R])
+            else gemm_f32(ddt, x_dbl[:, :R], False, False)
         mm_nn(ddt, dt_w, out=dx_dbl[:, :R])                                  # straight into its column block of dx_dbl
         d_xproj_w = wgrad(dx_dbl, xc, amax_x=h_xc)
         # the conv output's gradient = the scan's du (in dxc) + the x_proj input gradient: handed to the conv backward as TWO tensors
@@ -1047,7 +1047,7 @@ class LinearAct(torch.autograd.Function):
         and nothing is padded; otherwise the output is a fresh tensor and whoever assembles the buffer copies it in)."""
         x2 = x.reshape(-1, x.shape[-1])
         x2 = x2 if x2.stride(-1) == 1 else x2.contiguous()
-        long_pass = x2.is_cuda and x2.shape[0] >= GEMM_F32_MIN_ROWS
+        long_pass = x2.is_cuda                         # (rounds 2-5: passes of 4 096 tokens and more)
         ctx.kpad = (-x2.shape[1]) % 4 if long_pass else 0
         ctx.npad = (-weight.shape[0]) % 4 if long_pass else 0
         n_out = weight.shape[0]
@@ -1220,74 +1220,54 @@ def cat_into(rb, pieces):
 
 
 def linear(x, weight, bias=None):
-    """x W^T + b for an fp32 nn.Linear over the tokens of a training pass: the `LinearAct` node (hand-written GEMM forward, input
-    and weight gradients) when the pass is long enough to take it, `F.linear` otherwise (rollout steps, CPU, odd output widths).
-    An input width that is not a multiple of 4 (the 17-wide observation / 6-wide action encoders) is zero-padded to 16-byte rows
-    inside the node."""
-    if x.is_cuda and x.dtype == torch.float32 and x.numel() // x.shape[-1] >= GEMM_F32_MIN_ROWS and weight.shape[0] >= GEMM_F32_MIN_DIM \
-            and weight.shape[1] >= GEMM_F32_MIN_K:
-        return linear_act(x, weight, bias, None)
-    return torch.nn.functional.linear(x, weight, bias)
+    """x W^T + b for an fp32 nn.Linear: the `LinearAct` node (hand-written GEMM forward, input and weight gradients) for every pass -
+    the whole trajectories of an update and the single token of a rollout step alike (`resel_gemm_f32x` takes every shape: the matrix-core
+    editions where the layout allows them, csrc/gemm_any.hip for the rest).  An input width that is not a multiple of 4 (the 17-wide
+    observation / 6-wide action encoders) is zero-padded to 16-byte rows inside the node.  There is no library GEMM behind this module
+    (round 5 kept `F.linear` for passes under 4 096 tokens); CPU tensors raise in `gemm_f32`."""
+    return linear_act(x, weight, bias, None)
 
 
-# tokens per pass from which the hand-written GEMM is used (measured at 66 752 and 8 344: tools/bench_gemm_f32.py); the environment
-# variable is the A/B switch of the profiles (a huge value = library GEMMs everywhere)
-GEMM_F32_MIN_ROWS = int(os.environ.get('RESEL_GEMM_F32_MIN_ROWS', 4096))
+# Every CUDA fp32 pass takes the hand-written kernels since round 6 (the constant is what remains of the round 2-5 switch between them
+# and the GEMM library: 4 096 tokens then).  Code that asked "is this a long pass?" now asks "is this a CUDA pass?".
+GEMM_F32_MIN_ROWS = 1
 
 
 def gemm_f32_ok(rows, *mats):
-    """True when `resel_gemm_f32` may take these operands: a long pass on the GPU, fp32, unit column stride, 16-byte aligned rows."""
-    return rows >= GEMM_F32_MIN_ROWS and all(
-        t.is_cuda and t.dtype == torch.float32 and t.stride(-1) == 1 and t.data_ptr() % 16 == 0 and t.shape[-1] % 4 == 0
-        and all(st % 4 == 0 for st in t.stride()[:-1]) and (t.dim() < 2 or t.stride(-2) < (1 << 22)) for t in mats)
+    """True when `resel_gemm_f32` takes these operands as they are: on the GPU, fp32, unit column stride (any row alignment: the C entry
+    routes shapes the matrix-core editions cannot read to csrc/gemm_any.hip)."""
+    return rows >= 1 and all(t.is_cuda and t.dtype == torch.float32 and t.stride(-1) == 1 for t in mats)
 
 
-GEMM_F32_MIN_DIM = 4        # narrower outputs (dt_proj's rank-16 input gradient, the 6-wide heads) stay with the library (measured equal at 12 / 16 / 32)
-GEMM_F32_MIN_K = 4          # reductions of one partial K step run the fp32-MFMA kernel (update 26.07 -> 25.8 ms with dt_proj's K = 16 here)
+GEMM_F32_MIN_DIM = 1        # (rounds 2-5: outputs / reductions narrower than 4 stayed with the library)
+GEMM_F32_MIN_K = 1
 
 
-def _mine(rows, n, k, *mats):
-    """n: the output extent that is not the token count, k: the other extent of the weight (measured at 66 752 tokens,
-    `tools/bench_skinny.py`: 44 -> 384 encoder forward 35 us against the library's 97, its weight gradient 58 against 222)."""
-    return n >= GEMM_F32_MIN_DIM and k >= GEMM_F32_MIN_K and gemm_f32_ok(rows, *mats)
+def _unit(t):
+    """t with unit column stride (what the C entry's row-stride description needs); a copy only for exotic views."""
+    return t if t.stride(-1) == 1 else t.contiguous()
 
 
 def mm_nt(x2, w, bias=None, act=None, out=None, amax_out=None):
-    """act(x2 [M, K] w[N, K]^T + bias): forward of an nn.Linear-shaped layer over the tokens of a pass.  Hand-written GEMM with
-    the bias / ELU in its epilogue when the pass is long enough (`gemm_f32_ok`), else library GEMM (+ one in-place tail pass).
-    out (with amax_out): a column block of a row buffer to write in place - used only when the hand-written GEMM takes the call
-    (the caller checks where the result landed)."""
-    if act in ACT_IDS and _mine(x2.shape[0], w.shape[0], w.shape[1], x2, w):
-        if out is not None and gemm_f32_ok(x2.shape[0], out):
-            return gemm_f32(x2, w, True, True, bias, act, out=out, amax_out=amax_out)
-        return gemm_f32(x2, w, True, True, bias, act)
-    global LAST_AMAX
-    LAST_AMAX = None
-    aid = ACT_IDS[act]                                                 # 0: identity ('linear' / None), 1: ELU; anything else is a KeyError
-    if aid == 0 or w.shape[0] % 4:
-        y2 = torch.addmm(bias, x2, w.t()) if bias is not None else torch.mm(x2, w.t())
-        return y2 if aid == 0 else torch.nn.functional.elu_(y2)
-    y2 = torch.mm(x2, w.t())
-    return bias_act_(y2, None if bias is None else bias.reshape(1, -1).contiguous(), y2.shape[0], act)
+    """act(x2 [M, K] w[N, K]^T + bias): forward of an nn.Linear-shaped layer over the tokens of a pass, bias / ELU in the GEMM epilogue.
+    out (with amax_out): a column block of a row buffer to write in place."""
+    ACT_IDS[act]                                                       # 0: identity ('linear' / None), 1: ELU; anything else is a KeyError
+    x2, w = _unit(x2), _unit(w)
+    if out is not None and out.stride(-1) == 1:
+        return gemm_f32(x2, w, True, True, bias, act, out=out, amax_out=amax_out)
+    return gemm_f32(x2, w, True, True, bias, act)
 
 
 def mm_nn(g2, w, out=None):
     """g2 [M, N] w[N, K] -> [M, K]: input gradient of such a layer.  out: a (possibly row-strided) destination, e.g. a column block of a
     wider buffer."""
-    if _mine(g2.shape[0], w.shape[1], w.shape[0], g2, w) and (out is None or gemm_f32_ok(g2.shape[0], out)):
-        return gemm_f32(g2, w, True, False, out=out)
-    if out is None:
-        return torch.mm(g2, w)
-    out.copy_(torch.mm(g2, w))
-    return out
+    return gemm_f32(_unit(g2), _unit(w), True, False, out=out)
 
 
 def wgrad(gy, x2, amax_x=None):
     """dW [out, in] = gy[M, out]^T x2[M, in] over the M tokens of a pass: the hand-written K-split GEMM (at 66 752 tokens:
     [128, 256] 49 us against the library's 234, [2048, 384] 731 against 1217, [256, 256] 86 against 123; `tools/bench_gemm_f32.py`)."""
-    if _mine(gy.shape[0], gy.shape[1], x2.shape[1], gy, x2):
-        return gemm_f32(gy, x2, False, False, amax_b=amax_x)
-    return torch.mm(gy.t(), x2)
+    return gemm_f32(_unit(gy), _unit(x2), False, False, amax_b=amax_x)
 
 
 @torch.no_grad()
@@ -1341,10 +1321,10 @@ def gemm_bf16(A, B, a_kcontig=True, b_kcontig=True, bias=None, out_dtype=torch.b
 
 
 def gemm_bf16_ok(x, w):
-    """Operands the mixed-precision GEMM takes: packed token rows on the GPU, 8 / 16-byte aligned, extents multiples of 4."""
+    """Operands the mixed-precision GEMM node takes: token rows on the GPU, fp32 master weight (any row count and alignment since round 6:
+    `resel_gemm_bf16` routes what its matrix-core kernel cannot read, and the few rows of a decode step, to csrc/gemm_any.hip)."""
     return (x.is_cuda and x.dim() == 2 and x.stride(-1) == 1 and x.dtype in (torch.float32, torch.bfloat16) and w.dtype == torch.float32
-            and x.shape[0] >= 256 and x.shape[0] % 4 == 0 and x.shape[1] % 4 == 0 and w.shape[0] % 4 == 0 and x.stride(0) % 4 == 0
-            and x.data_ptr() % 16 == 0 and w.is_contiguous() and w.data_ptr() % 16 == 0)
+            and w.is_contiguous())
 
 
 @torch.no_grad()
@@ -1838,7 +1818,7 @@ def mamba_step(hidden, xz, conv_w, conv_b, xproj_w, dt_w, dt_b, A_log, D, d_conv
     hidden [B, Di*K + Di*N] = (conv window | ssm state), xz [B, 2 Di] = in_proj output.  -> (y [B, Di], new hidden)."""
     Di, K = xz.shape[1] // 2, d_conv
     xc, window = conv_step(xz[:, :Di], hidden[:, :Di * K], conv_w, conv_b, K, 'dk', True)
-    x_db = torch.nn.functional.linear(xc, xproj_w)                                   # [B, R + 2N]
+    x_db = gemm_f32(xc, xproj_w, True, True)                                         # [B, R + 2N]: the rows form of resel_gemm_f32x
     y, state = selective_state_update(hidden[:, Di * K:], xc, x_db, dt_w, dt_b, A_log, D, xz[:, Di:])
     return y, torch.cat((window, state), dim=-1)
 

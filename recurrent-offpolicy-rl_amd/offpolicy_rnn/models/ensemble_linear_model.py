@@ -2,17 +2,23 @@
 offpolicy_rnn/models/ensemble_linear_model.py:8-69).  Parameter names / shapes (`weight` [E, in, out], `bias`
 [E, 1, out]) and the shape polymorphism steered by `desire_ndim` follow the reference.
 
-The contractions are plain library GEMMs (hipBLASLt through torch), arranged so that no operand is ever copied:
-  * shared input (every member sees the same rows): ONE GEMM  [M, in] x [in, E*out]  with the bias fused (addmm); the result
+Every contraction is `ops.gemm_f32` (the hand-written GEMMs behind `resel_gemm_f32x`; there is no library GEMM in this file since round 6),
+arranged so that no operand is ever copied:
+  * shared input (every member sees the same rows): ONE GEMM  [M, in] x [in, E*out]  with bias / ELU in its epilogue; the result
     is handed on as an [E, M, out] *view* (strides (out, E*out, 1)) that the next layer's strided-batched GEMM consumes
     directly; the backward is again one GEMM each for dX (which also sums over the ensemble) and dW;
-  * per-member input [E, M, in]: baddbmm with fused bias; dW = X^T G and dX = G W^T as strided-batched GEMMs on views.
+  * per-member input [E, M, in]: one strided-batched GEMM with the epilogue; dW = X^T G and dX = G W^T likewise, on views.
 torch's generic einsum/bmm autograd materialised a transposed [E, in, M] copy of the activations per layer and step
-(547 MB at config 2) plus separate bias-add kernels; this custom Function removes both."""
+(547 MB at config 2) plus separate bias-add kernels; these Functions remove both."""
 import torch
 import torch.nn as nn
 
 from ..hip import ops
+
+
+def _unit(t):
+    """t with unit stride along its last axis (what `ops.gemm_f32` describes by row / member strides); a copy only for exotic views."""
+    return t if t.stride(-1) == 1 else t.contiguous()
 
 
 class _SharedInput(torch.autograd.Function):
@@ -26,16 +32,11 @@ class _SharedInput(torch.autograd.Function):
         E, n_in, n_out = weight.shape
         w_cat = weight.permute(1, 0, 2).reshape(n_in, E * n_out)                 # [in, E*out] (weights only: tiny copy)
         ops.LAST_AMAX = None
-        if min(n_in, E * n_out) >= ops.GEMM_F32_MIN_DIM and ops.gemm_f32_ok(x2.shape[0], x2, w_cat):
-            # hand-written fp32 MFMA GEMM, bias + ELU in its epilogue (837 us against 995 at 66 752 x 384 -> 2048)
-            y2 = ops.gemm_f32(x2, w_cat, True, False, None if bias is None else bias.reshape(E * n_out), act, amax_a=ax,
-                              amax_b=ops.weight_amax(weight))          # w_cat holds the same values as the parameter
-            ax = ax if ax is not None else ops.amax_of(x2)
-        elif act is None:
-            y2 = torch.addmm(bias.reshape(E * n_out), x2, w_cat) if bias is not None else torch.mm(x2, w_cat)
-        else:                               # GEMM, then bias + activation in one in-place pass
-            y2 = torch.mm(x2, w_cat)
-            ops.bias_act_(y2, None if bias is None else bias.reshape(1, E * n_out), y2.shape[0], act)
+        x2 = x2 if x2.stride(-1) == 1 else x2.contiguous()
+        # bias + ELU in the GEMM's epilogue (837 us against the library's 995 at 66 752 x 384 -> 2048)
+        y2 = ops.gemm_f32(x2, w_cat, True, False, None if bias is None else bias.reshape(E * n_out), act, amax_a=ax,
+                          amax_b=ops.weight_amax(weight))              # w_cat holds the same values as the parameter
+        ax = ax if ax is not None else ops.amax_of(x2)
         ctx.save_for_backward(x2, w_cat, y2 if act is not None else None)
         ctx.ax = ops.keep_handles(ax)[0]
         ctx.dims = (E, n_in, n_out, bias is not None, act)
@@ -52,28 +53,26 @@ class _SharedInput(torch.autograd.Function):
             g2, db = ops.bias_act_bwd(g2, y2, g2.shape[0], act, need_db)
         else:
             db = g2.sum(dim=0, keepdim=True) if need_db else None
-        mine = min(n_in, E * n_out) >= ops.GEMM_F32_MIN_DIM and ops.gemm_f32_ok(g2.shape[0], g2, x2, w_cat)
+        g2 = g2 if g2.stride(-1) == 1 else g2.contiguous()
         dx = None
         if ctx.needs_input_grad[0]:                                               # sums over the ensemble
-            dx = ops.gemm_f32(g2, w_cat, True, True) if mine else torch.mm(g2, w_cat.t())
+            dx = ops.gemm_f32(g2, w_cat, True, True)
         dw = None
         if ctx.needs_input_grad[1]:
-            dw = ops.gemm_f32(x2, g2, False, False, amax_a=ops.handle_alive(ctx.ax)) if mine else torch.mm(x2.t(), g2)
+            dw = ops.gemm_f32(x2, g2, False, False, amax_a=ops.handle_alive(ctx.ax))
             dw = dw.view(n_in, E, n_out).permute(1, 0, 2)
         dpart = None
         if ctx.part is not None and ctx.needs_input_grad[4]:
             col0, k, shape = ctx.part
             wp = w_cat[col0:col0 + k]
-            dpart = (ops.gemm_f32(g2, wp, True, True) if mine and k >= ops.GEMM_F32_MIN_DIM else torch.mm(g2, wp.t())).view(shape)
+            dpart = ops.gemm_f32(g2, wp, True, True).view(shape)
         return dx, dw, None if db is None else db.view(E, 1, n_out), None, dpart, None, None
 
 
 def _member_wgrad(x3, gy, ax=None):
     """dW[e] = x3[e]^T gy[e] for the per-member layers: the hand-written K-split fp32 MFMA kernel (676 us against the tuned
     strided-batched library GEMM's 833 us at 8 x 66 752 x 256 x 256, `tools/bench_gemm_f32.py`) when the layout allows."""
-    if min(x3.shape[2], gy.shape[2]) >= ops.GEMM_F32_MIN_DIM and ops.gemm_f32_ok(x3.shape[1], x3, gy):
-        return ops.gemm_f32(x3, gy, False, False, amax_a=ax)
-    return torch.bmm(x3.transpose(1, 2), gy)
+    return ops.gemm_f32(_unit(x3), _unit(gy), False, False, amax_a=ax)
 
 
 def _member_dgrad(gy, weight, like):
@@ -86,9 +85,7 @@ def _member_dgrad(gy, weight, like):
         dx = torch.empty(M, E, n_in, dtype=gy.dtype, device=gy.device).transpose(0, 1)
     else:
         dx = torch.empty(E, M, n_in, dtype=gy.dtype, device=gy.device)
-    if min(n_in, weight.shape[2]) >= ops.GEMM_F32_MIN_DIM and ops.gemm_f32_ok(M, gy, weight, dx):
-        return ops.gemm_f32(gy, weight, True, True, out=dx)
-    return torch.bmm(gy, weight.transpose(1, 2), out=dx)
+    return ops.gemm_f32(_unit(gy), weight, True, True, out=dx)
 
 
 class _PerMember(torch.autograd.Function):
@@ -96,15 +93,10 @@ class _PerMember(torch.autograd.Function):
     def forward(ctx, x3, weight, bias, act, ax=None):
         E, M, _ = x3.shape
         ops.LAST_AMAX = None
-        if min(weight.shape[1:]) >= ops.GEMM_F32_MIN_DIM and act in (None, 'elu') and ops.gemm_f32_ok(M, x3, weight):
-            # bias + ELU in the GEMM epilogue: 583 us against the library's 605 + a 140 us tail pass (8 x 66 752 x 256 x 256)
-            y = ops.gemm_f32(x3, weight, True, False, bias, act, amax_a=ax)
-            ax = ax if ax is not None else ops.amax_of(x3)
-        elif act is None and (bias is None or weight.shape[2] < 4):
-            y = torch.baddbmm(bias, x3, weight) if bias is not None else torch.bmm(x3, weight)
-        else:                               # baddbmm would first materialise the broadcast bias as a full [E, M, out] copy
-            y = torch.bmm(x3, weight)
-            ops.bias_act_(y.view(E * M, -1), None if bias is None else bias.reshape(E, -1), M, act)
+        x3 = _unit(x3)
+        # bias + ELU in the GEMM epilogue: 583 us against the library's 605 + a 140 us tail pass (8 x 66 752 x 256 x 256)
+        y = ops.gemm_f32(x3, weight, True, False, bias, act, amax_a=ax)
+        ax = ax if ax is not None else ops.amax_of(x3)
         ctx.save_for_backward(x3, weight, y if act is not None else None)
         ctx.ax = ops.keep_handles(ax)[0]
         ctx.cfg = (bias is not None, act)
@@ -137,11 +129,9 @@ class _Head(torch.autograd.Function):
     def forward(ctx, x3, w2, b2, w3, b3, ax=None):
         E, M, _ = x3.shape
         H = w2.shape[2]
-        if min(w2.shape[1:]) >= ops.GEMM_F32_MIN_DIM and ops.gemm_f32_ok(M, x3, w2):
-            a = ops.gemm_f32(x3, w2, True, False, amax_a=ax)
-            ax = ax if ax is not None else ops.amax_of(x3)
-        else:
-            a = torch.bmm(x3, w2)
+        x3 = _unit(x3)
+        a = ops.gemm_f32(x3, w2, True, False, amax_a=ax)
+        ax = ax if ax is not None else ops.amax_of(x3)
         ctx.ax = ops.keep_handles(ax)[0]
         w3v = w3.reshape(E, H)
         q = ops.ensemble_head_fwd_(a, b2.reshape(E, H), w3v, None if b3 is None else b3.reshape(E))

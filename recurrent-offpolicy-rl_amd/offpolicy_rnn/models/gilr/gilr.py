@@ -8,13 +8,14 @@ import torch.nn as nn
 
 from ..ensemble_linear_model import EnsembleLinear
 from ...hip import ops
+from ..linear import Linear
 
 
 class PositionWiseFeedForward(nn.Module):
     def __init__(self, d_model, dropout=0.1, eps=1e-5):
         super().__init__()
-        self.w_1 = nn.Linear(d_model, d_model)
-        self.w_2 = nn.Linear(d_model, d_model)
+        self.w_1 = Linear(d_model, d_model)
+        self.w_2 = Linear(d_model, d_model)
         self.activation = nn.GELU()
         self.dropout = nn.Dropout(dropout)
         self.layer_norm = nn.LayerNorm(d_model, eps=eps)
@@ -32,7 +33,7 @@ class GILRLayer(nn.Module):
         assert batch_first
         self.d_model = output_dim
         self.in_proj = EnsembleLinear(input_dim, self.d_model * factor, 2, desire_ndim=4)
-        self.out_proj = nn.Linear(self.d_model * factor, self.d_model * factor)
+        self.out_proj = Linear(self.d_model * factor, self.d_model * factor)
         self.dropout = nn.Dropout(dropout)
         self.layer_norm = nn.LayerNorm(factor * self.d_model)      # constructed (state_dict parity) but unused, as upstream
         self.use_ff = use_ff

@@ -9,6 +9,7 @@ import torch.nn as nn
 
 from ..ensemble_linear_model import EnsembleLinear
 from ...hip import ops
+from ..linear import Linear
 
 
 class GILRLSTMLayer(nn.Module):
@@ -18,7 +19,7 @@ class GILRLSTMLayer(nn.Module):
         self.d_model = output_dim
         self.in_proj = EnsembleLinear(input_dim, self.d_model * factor, 2, desire_ndim=4)
         self.middle_proj = EnsembleLinear(self.d_model * factor, self.d_model * factor, 4, desire_ndim=4)
-        self.out_proj = nn.Linear(self.d_model * factor, self.d_model * factor)
+        self.out_proj = Linear(self.d_model * factor, self.d_model * factor)
         self.layer_norm = nn.LayerNorm(factor * self.d_model)      # constructed (state_dict parity) but unused, as upstream
         self.swish = nn.SiLU()
 

@@ -23,6 +23,7 @@ from .gru import GRU
 from .s6.mamba import MambaResidualBlock
 from .lru.lru import LRULayer
 from .smamba.mamba import BlockList as MambaBlockList
+from .linear import Linear
 
 ACTIVATIONS = {'tanh': torch.nn.Tanh, 'relu': torch.nn.ReLU, 'sigmoid': torch.nn.Sigmoid, 'leaky_relu': torch.nn.LeakyReLU,
                'linear': torch.nn.Identity, 'elu': torch.nn.ELU, 'gelu': torch.nn.GELU}
@@ -133,7 +134,7 @@ class RNNBase(torch.nn.Module):
     @staticmethod
     def _make_layer(lid: str, n_in: int, n_out: int):
         if lid == 'fc':
-            return torch.nn.Linear(n_in, n_out), None
+            return Linear(n_in, n_out), None
         if lid.startswith('efc'):
             return EnsembleLinear(n_in, n_out, int(lid.split('-')[-1])), None
         if lid == 'gru':
@@ -350,9 +351,8 @@ class RNNBase(torch.nn.Module):
                     continue
                 assert not (ind == 0 and first_grad_part is not None), 'first_grad_part needs an efc first layer with ELU'
 
-                if isinstance(layer, torch.nn.Linear) and x.dim() > 2:    # 2-D call: the bias rides in the GEMM epilogue (addmm)
-                    x = ops.linear_act(x, layer.weight, layer.bias, None, dest=out_dest if ind == n_layers - 1 else None) if x.is_cuda and x.dtype == torch.float32 else \
-                        torch.nn.functional.linear(x.reshape(-1, x.shape[-1]), layer.weight, layer.bias).view(*x.shape[:-1], -1)
+                if isinstance(layer, torch.nn.Linear):                    # the bias rides in the GEMM epilogue (every pass: whole trajectories and rollout steps)
+                    x = ops.linear_act(x, layer.weight, layer.bias, None, dest=out_dest if ind == n_layers - 1 else None)
                 else:
                     x = layer(x)
             if isinstance(act, torch.nn.ModuleList):

@@ -16,6 +16,7 @@ import torch.nn.functional as F
 
 from ..gilr.gilr import PositionWiseFeedForward
 from ...hip import ops
+from ..linear import Linear
 
 
 class RMSNorm(nn.Module):
@@ -35,10 +36,10 @@ class MambaBlock(nn.Module):
         self.dt_rank = int(math.ceil(d_model / 16)) if dt_rank == 'auto' else dt_rank
         self.d_conv, self.d_state = d_conv, d_state
         assert d_conv >= 2, 'the conv-free variant (d_conv < 1) of the reference is not built'
-        self.in_proj = nn.Linear(d_model, self.d_inner * 2, bias=bias)
+        self.in_proj = Linear(d_model, self.d_inner * 2, bias=bias)
         self.conv1d = nn.Conv1d(self.d_inner, self.d_inner, kernel_size=d_conv, groups=self.d_inner, padding=0, bias=True)
-        self.x_proj = nn.Linear(self.d_inner, self.dt_rank + d_state * 2, bias=False)
-        self.dt_proj = nn.Linear(self.dt_rank, self.d_inner, bias=True)
+        self.x_proj = Linear(self.d_inner, self.dt_rank + d_state * 2, bias=False)
+        self.dt_proj = Linear(self.dt_rank, self.d_inner, bias=True)
         self._init_dt_proj_weight()
         self.ssm_hidden_dim = self.d_inner * d_state
         self.conv_hidden_dim = self.d_inner * (d_conv - 1)
@@ -47,7 +48,7 @@ class MambaBlock(nn.Module):
         self.A_log._no_weight_decay = True
         self.D = nn.Parameter(torch.ones(self.d_inner))
         self.D._no_weight_decay = True
-        self.out_proj = nn.Linear(self.d_inner, d_model, bias=bias)
+        self.out_proj = Linear(self.d_inner, d_model, bias=bias)
 
     def _init_dt_proj_weight(self, dt_scale=1.0, dt_max=0.1, dt_min=0.001, dt_init_floor=1e-4):
         with torch.no_grad():
@@ -60,24 +61,24 @@ class MambaBlock(nn.Module):
     def forward(self, x, hidden=None, rnn_start=None, mask=None, grad_detach=None):
         B, T, _ = x.shape
         Di, N, K, R = self.d_inner, self.d_state, self.d_conv, self.dt_rank
-        xz = F.linear(x, self.in_proj.weight, self.in_proj.bias)                     # [B, T, 2 Di]
+        xz = ops.linear(x, self.in_proj.weight, self.in_proj.bias)                   # [B, T, 2 Di]
         if T == 1 and hidden is not None and not torch.is_grad_enabled():
             h = hidden.reshape(B, -1)
             xi = xz[:, 0, :Di] if mask is None else xz[:, 0, :Di] * mask[:, 0]
             xc, tail = ops.conv_step(xi, h[:, Di * N:], self.conv1d.weight, self.conv1d.bias, K, 'kd', True)
-            x_db = F.linear(xc, self.x_proj.weight)
+            x_db = ops.linear(xc, self.x_proj.weight)
             y, state = ops.selective_state_update(h[:, :Di * N], xc, x_db, self.dt_proj.weight, self.dt_proj.bias, self.A_log,
                                                   self.D, xz[:, 0, Di:])
-            out = F.linear(y, self.out_proj.weight, self.out_proj.bias).unsqueeze(1)
+            out = ops.linear(y, self.out_proj.weight, self.out_proj.bias).unsqueeze(1)
             return out, torch.cat((state, tail), dim=-1).reshape(B, 1, -1)
         xi = xz[..., :Di] if mask is None else xz[..., :Di] * mask
         xc = ops.causal_conv1d_fn(xi, self.conv1d.weight, self.conv1d.bias, None, True)
-        x_db = F.linear(xc, self.x_proj.weight)
-        dt = F.linear(x_db[..., :R], self.dt_proj.weight)                              # bias enters as delta_bias
+        x_db = ops.linear(xc, self.x_proj.weight)
+        dt = ops.linear(x_db[..., :R], self.dt_proj.weight)                            # bias enters as delta_bias
         A = -torch.exp(self.A_log.float())
         y, last = ops.selective_scan_tm(xc, dt, A, x_db[..., R:R + N], x_db[..., R + N:], self.D.float(), xz[..., Di:],
                                         self.dt_proj.bias.float(), rnn_start, True, True)
-        out = F.linear(y, self.out_proj.weight, self.out_proj.bias)
+        out = ops.linear(y, self.out_proj.weight, self.out_proj.bias)
         tail = xi[:, T - (K - 1):] if T >= K - 1 else torch.cat((xi.new_zeros(B, K - 1 - T, Di), xi), dim=1)
         return out, torch.cat((last.reshape(B, 1, -1), tail.reshape(B, 1, -1)), dim=-1)
 
@@ -94,7 +95,7 @@ class MambaResidualBlock(nn.Module):
         if use_ff:
             self.ff = PositionWiseFeedForward(output_dim, 0.0)
         else:
-            self.ff = nn.Linear(output_dim, output_dim, bias=False)
+            self.ff = Linear(output_dim, output_dim, bias=False)
             self.norm_f = make()
 
     def forward(self, x, hidden=None, rnn_start=None, mask=None, grad_detach=None):

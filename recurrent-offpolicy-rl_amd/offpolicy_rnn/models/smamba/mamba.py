@@ -16,6 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ...hip import ops
+from ..linear import Linear
 
 
 class RMSNorm(nn.Module):
@@ -29,8 +30,8 @@ class RMSNorm(nn.Module):
 class PositionWiseFeedForward(nn.Module):
     def __init__(self, d_model, dropout=0.0, eps=1e-5):
         super().__init__()
-        self.w_1 = nn.Linear(d_model, d_model)
-        self.w_2 = nn.Linear(d_model, d_model)
+        self.w_1 = Linear(d_model, d_model)
+        self.w_2 = Linear(d_model, d_model)
         self.activation = nn.GELU()
         self.dropout = nn.Dropout(dropout)
         self.layer_norm = nn.LayerNorm(d_model, eps=eps)
@@ -51,11 +52,11 @@ class Mamba(nn.Module):
         self.conv_hidden_dim = self.d_inner * d_conv
         self.ssm_hidden_dim = self.d_inner * d_state
         self.desired_hidden_dim = self.conv_hidden_dim + self.ssm_hidden_dim
-        self.in_proj = nn.Linear(d_model, self.d_inner * 2, bias=bias)
+        self.in_proj = Linear(d_model, self.d_inner * 2, bias=bias)
         self.conv1d = nn.Conv1d(self.d_inner, self.d_inner, kernel_size=d_conv, groups=self.d_inner, padding=d_conv - 1,
                                 bias=conv_bias)
-        self.x_proj = nn.Linear(self.d_inner, self.dt_rank + 2 * d_state, bias=False)
-        self.dt_proj = nn.Linear(self.dt_rank, self.d_inner, bias=True)
+        self.x_proj = Linear(self.d_inner, self.dt_rank + 2 * d_state, bias=False)
+        self.dt_proj = Linear(self.dt_rank, self.d_inner, bias=True)
         std = self.dt_rank ** -0.5 * dt_scale
         if dt_init == 'constant':
             nn.init.constant_(self.dt_proj.weight, std)
@@ -70,7 +71,7 @@ class Mamba(nn.Module):
         self.A_log._no_weight_decay = True
         self.D = nn.Parameter(torch.ones(self.d_inner))
         self.D._no_weight_decay = True
-        self.out_proj = nn.Linear(self.d_inner, d_model, bias=bias)
+        self.out_proj = Linear(self.d_inner, d_model, bias=bias)
 
     def forward(self, x, hidden=None, rnn_start=None, mask=None):
         """x [B, T, D].  T > 1: whole packed rows from a zero state (training).  T == 1: stateful rollout step."""
@@ -83,14 +84,14 @@ class Mamba(nn.Module):
                 hidden = torch.zeros((1, x.shape[0], self.desired_hidden_dim), device=x.device)
             return out, hidden
         Di, N, R = self.d_inner, self.d_state, self.dt_rank
-        xz = F.linear(x, self.in_proj.weight, self.in_proj.bias)                       # [B, T, 2 Di]
+        xz = ops.linear(x, self.in_proj.weight, self.in_proj.bias)                     # [B, T, 2 Di]
         xc = ops.causal_conv1d_fn(xz[..., :Di], self.conv1d.weight, self.conv1d.bias, mask, True)
-        x_dbl = F.linear(xc, self.x_proj.weight)                                       # [B, T, R + 2N]
-        dt = F.linear(x_dbl[..., :R], self.dt_proj.weight)                             # bias enters as delta_bias
+        x_dbl = ops.linear(xc, self.x_proj.weight)                                     # [B, T, R + 2N]
+        dt = ops.linear(x_dbl[..., :R], self.dt_proj.weight)                           # bias enters as delta_bias
         A = -torch.exp(self.A_log.float())
         y = ops.selective_scan_tm(xc, dt, A, x_dbl[..., R:R + N], x_dbl[..., R + N:], self.D.float(), xz[..., Di:],
                                   self.dt_proj.bias.float(), rnn_start, True)
-        out = F.linear(y, self.out_proj.weight, self.out_proj.bias)
+        out = ops.linear(y, self.out_proj.weight, self.out_proj.bias)
         if hidden is None:
             hidden = torch.zeros((1, x.shape[0], self.desired_hidden_dim), device=x.device)
         return out, hidden
@@ -101,10 +102,10 @@ class Mamba(nn.Module):
         B = x.shape[0]
         if hidden is None:
             hidden = torch.zeros((1, B, self.desired_hidden_dim), device=x.device)
-        xz = F.linear(x[:, 0], self.in_proj.weight, self.in_proj.bias)
+        xz = ops.linear(x[:, 0], self.in_proj.weight, self.in_proj.bias)    # M = B rows against the whole weight: the rows form of resel_gemm_f32x
         y, new_hidden = ops.mamba_step(hidden[0], xz, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight,
                                        self.dt_proj.weight, self.dt_proj.bias, self.A_log, self.D, self.d_conv, self.d_state)
-        out = F.linear(y, self.out_proj.weight, self.out_proj.bias).unsqueeze(1)
+        out = ops.linear(y, self.out_proj.weight, self.out_proj.bias).unsqueeze(1)
         return out, new_hidden.unsqueeze(0)
 
 
@@ -151,7 +152,7 @@ class BlockList(nn.Module):
         if use_ff:
             self.head = PositionWiseFeedForward(d_model=dim, dropout=0.0, eps=self.norm_epsilon)
         else:
-            self.head = nn.Linear(dim, dim, bias=False)
+            self.head = Linear(dim, dim, bias=False)
             self.norm_f = norm_cls(dim)
         self.apply(partial(_init_weights, n_layer=block_num))
 

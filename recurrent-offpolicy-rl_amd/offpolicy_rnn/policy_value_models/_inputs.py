@@ -3,6 +3,7 @@ through its own Linear(., 128) when `separate_encoder` (reference contextual_sac
 import torch
 
 from ..hip import ops
+from ..models.linear import Linear
 
 BASIC_EMBEDDING_DIM = 128
 
@@ -15,10 +16,10 @@ def build_encoders(owner, state_dim, action_dim, reward_input, last_action_input
     owner.separate_encoder = separate_encoder
     if separate_encoder:
         d = BASIC_EMBEDDING_DIM
-        owner.state_encoder = torch.nn.Linear(state_dim, d)
-        owner.last_act_encoder = torch.nn.Linear(owner.last_act_dim, d) if owner.last_act_dim else None
-        owner.reward_encoder = torch.nn.Linear(owner.reward_dim, d) if owner.reward_dim else None
-        owner.last_obs_encoder = torch.nn.Linear(owner.last_obs_dim, d) if owner.last_obs_dim else None
+        owner.state_encoder = Linear(state_dim, d)
+        owner.last_act_encoder = Linear(owner.last_act_dim, d) if owner.last_act_dim else None
+        owner.reward_encoder = Linear(owner.reward_dim, d) if owner.reward_dim else None
+        owner.last_obs_encoder = Linear(owner.last_obs_dim, d) if owner.last_obs_dim else None
         return d * (1 + sum(e is not None for e in (owner.last_act_encoder, owner.last_obs_encoder, owner.reward_encoder)))
     ident = torch.nn.Identity()
     owner.state_encoder = owner.last_act_encoder = owner.reward_encoder = owner.last_obs_encoder = ident

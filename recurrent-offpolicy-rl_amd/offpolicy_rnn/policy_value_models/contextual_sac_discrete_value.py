@@ -10,6 +10,7 @@ from ..models.contextual_model import ContextualModel
 from ..models.rnn_base import ACTIVATIONS
 from . import _inputs
 from .utils import nearest_power_of_two, nearest_power_of_two_half
+from ..models.linear import Linear
 
 
 class ContextualSACDiscreteValue(ContextualModel):
@@ -25,7 +26,7 @@ class ContextualSACDiscreteValue(ContextualModel):
         uni_in = state_dim
         self.state_input_encoder = torch.nn.Identity()
         if uni_model_input_mapping_dim > 0 and separate_encoder:
-            self.state_input_encoder = torch.nn.Linear(state_dim, uni_model_input_mapping_dim)
+            self.state_input_encoder = Linear(state_dim, uni_model_input_mapping_dim)
             uni_in = uni_model_input_mapping_dim
             uni_model_input_mapping_dim = 0
         super().__init__(embedding_input_size=cum_dim, embedding_size=embedding_size, embedding_hidden=embedding_hidden,

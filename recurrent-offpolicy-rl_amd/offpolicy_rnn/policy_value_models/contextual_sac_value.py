@@ -9,6 +9,7 @@ from ..models.contextual_model import ContextualModel
 from ..models.rnn_base import ACTIVATIONS
 from . import _inputs
 from .utils import nearest_power_of_two, nearest_power_of_two_half
+from ..models.linear import Linear
 
 
 class ContextualSACValue(ContextualModel):
@@ -24,8 +25,8 @@ class ContextualSACValue(ContextualModel):
         uni_in = state_dim + action_dim
         self.state_input_encoder = self.action_input_encoder = torch.nn.Identity()
         if uni_model_input_mapping_dim > 0 and separate_encoder:
-            self.state_input_encoder = torch.nn.Linear(state_dim, uni_model_input_mapping_dim)
-            self.action_input_encoder = torch.nn.Linear(action_dim, uni_model_input_mapping_dim)
+            self.state_input_encoder = Linear(state_dim, uni_model_input_mapping_dim)
+            self.action_input_encoder = Linear(action_dim, uni_model_input_mapping_dim)
             uni_in = uni_model_input_mapping_dim * 2
             uni_model_input_mapping_dim = 0         # the two encoders replace the generic input mapping network
         super().__init__(embedding_input_size=cum_dim, embedding_size=embedding_size, embedding_hidden=embedding_hidden,

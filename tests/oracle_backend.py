@@ -68,6 +68,35 @@ def linear_act(x, weight, bias, act, dest=None):
     return torch.nn.functional.elu(y) if act == 'elu' else y
 
 
+def gemm_f32(A, B, a_kcontig=True, b_kcontig=True, bias=None, act=None, out=None, split=None, amax_a=None, amax_b=None, amax_out=None):
+    """CPU stand-in for the product's one GEMM entry (hip/ops.py `gemm_f32`: A [M, K] or [K, M], B [N, K] or [K, N], optional leading
+    ensemble axis, bias / ELU / accumulate tails)."""
+    a = A if a_kcontig else A.transpose(-1, -2)
+    b = B.transpose(-1, -2) if b_kcontig else B
+    y = torch.matmul(a, b)
+    if bias is not None:
+        y = y + (bias.reshape(y.shape[0], 1, -1) if y.dim() == 3 else bias.reshape(1, -1))
+    if act == 'elu':
+        y = torch.nn.functional.elu(y)
+    elif act == 'softplus':
+        y = torch.nn.functional.softplus(y)
+    elif act == 'accumulate':
+        y = out + y
+    elif act not in (None, 'linear'):
+        raise KeyError(act)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def linear_bf16(x, weight, bias, out_dtype=torch.bfloat16, round_out=False):
+    """The bf16-autocast projection of the cgpt MHA as the reference's autocast graph spells it (casts around F.linear)."""
+    bf = torch.bfloat16
+    y = torch.nn.functional.linear(x.to(bf), weight.to(bf), None if bias is None else bias.to(bf))
+    return y.to(out_dtype)
+
+
 def _norm(rms):
     def fn(x, weight, bias, residual=None, eps=1e-6, prenorm=False, residual_in_fp32=False, act=None):
         y, res = K.add_layernorm_ref(x, residual, weight, bias, eps, rms)
@@ -212,7 +241,7 @@ def sumsq(x, out=None):
 
 def install(monkeypatch):
     from offpolicy_rnn.hip import ops
-    table = dict(ensemble_head_fwd_=ensemble_head_fwd_, ensemble_head_bwd=ensemble_head_bwd, bias_act_=bias_act_, bias_act_bwd=bias_act_bwd, linear_act=linear_act, mamba_inner_fn=mamba_inner_fn, selective_scan_tm=selective_scan_tm, causal_conv1d_fn=causal_conv1d_fn, layer_norm_fn=_norm(False),
+    table = dict(ensemble_head_fwd_=ensemble_head_fwd_, ensemble_head_bwd=ensemble_head_bwd, bias_act_=bias_act_, bias_act_bwd=bias_act_bwd, linear_act=linear_act, gemm_f32=gemm_f32, linear_bf16=linear_bf16, gemm_bf16_ok=lambda x, w: True, mamba_inner_fn=mamba_inner_fn, selective_scan_tm=selective_scan_tm, causal_conv1d_fn=causal_conv1d_fn, layer_norm_fn=_norm(False),
                  rms_norm_fn=_norm(True), gilr_scan=gilr_scan, complex_scan=complex_scan, gilr_scan_members=gilr_scan_members, complex_scan_members=complex_scan_members, lru_params=lru_params, SubAddMembers=SubAddMembers, gru_seq=gru_seq, tanh_gaussian=tanh_gaussian, attn_varlen=attn_varlen, dropout_counter=dropout_counter, counter_dropout=counter_dropout,
                  sac_target=sac_target, guard_apply_slots=guard_apply_slots, soft_update_=soft_update_, adamw_flat_=adamw_flat_, sumsq=sumsq)
     for k, fn in table.items():
