@@ -195,7 +195,7 @@ class MambaInnerFn(torch.autograd.Function):
               'causal_conv1d_fwd')
         tag_amax(xc, h_xc)
         x_dbl = mm_nt(xc, xproj_w)                                         # [M, R + 2N] = (delta_r | B | C)
-        fold = _mine(M, Di, R, x_dbl[:, :R], dt_w)
+        fold = True    # (rounds 4-5: only where the hand-written GEMM took dt_proj; it takes every shape now)
         if fold:       # delta = softplus(dt_proj(.) + bias) leaves the GEMM epilogue: the scan kernels spend no vector issue on it
             dt = gemm_f32(x_dbl[:, :R], dt_w, True, True, dt_b, GEMM_SOFTPLUS)
         else:
@@ -1239,6 +1239,13 @@ def gemm_f32_ok(rows, *mats):
     return rows >= 1 and all(t.is_cuda and t.dtype == torch.float32 and t.stride(-1) == 1 for t in mats)
 
 
+def rows_aligned16(*mats):
+    """Every row of every operand starts on a 16-byte boundary and is a whole number of float4s: what the matrix-core editions (and their
+    fused epilogues, which have no other form) read."""
+    return all(t.data_ptr() % 16 == 0 and t.shape[-1] % 4 == 0 and all(st % 4 == 0 for st in t.stride()[:-1])
+               and (t.dim() < 2 or t.stride(-2) < (1 << 22)) for t in mats)
+
+
 GEMM_F32_MIN_DIM = 1        # (rounds 2-5: outputs / reductions narrower than 4 stayed with the library)
 GEMM_F32_MIN_K = 1
 
@@ -1710,7 +1717,7 @@ def _forced_handles(A, B, amax_a, amax_b):
 def gemm_fused_ok(kind, M, N, K, *mats):
     """True when a fused-epilogue form (kind 4: dact, 5: head) may take a product of this shape: product mode 2, a long pass, the
     producer / consumer edition's shape rules (K a multiple of 32, M > 128; dact: N a multiple of 128), 16-byte aligned rows."""
-    if os.environ.get('RESEL_GEMM_FUSED', '1') == '0' or gemm_split() != 2 or not gemm_f32_ok(M, *mats):
+    if os.environ.get('RESEL_GEMM_FUSED', '1') == '0' or gemm_split() != 2 or not gemm_f32_ok(M, *mats) or not rows_aligned16(*mats):
         return False
     ld = max(int(t.stride(-2)) for t in mats)
     return bool(lib().resel_gemm_f32_fused_supported(int(kind), int(M), int(N), int(K), ld, ld))

@@ -228,7 +228,7 @@ def critic_mlp_fusable(l0, act0, l1, act1, l2, act2, x) -> bool:
         return False
     M = x.numel() // n_in
     x2 = x.reshape(-1, n_in)
-    return (min(n_in, H1, H2) >= 32 and H1 % 32 == 0 and H2 % 32 == 0 and ops.gemm_f32_ok(M, x2)
+    return (min(n_in, H1, H2) >= 32 and H1 % 32 == 0 and H2 % 32 == 0 and ops.gemm_f32_ok(M, x2) and ops.rows_aligned16(x2)
             and ops.gemm_fused_ok(5, M, H2, H1, l1.weight) and ops.gemm_fused_ok(4, M, H1, H2, l1.weight))
 
 
