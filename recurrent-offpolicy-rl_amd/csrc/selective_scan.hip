@@ -179,8 +179,12 @@ __device__ __forceinline__ void store_ckpt(float* q, const f2 (&hp)[(NS + 1) / 2
 //           h_in[s + 1] = exp2(A2 * S[s]) * h_in[s] + h_loc[s]  (the product of a segment's decays is the exp of the sum);
 //   MODE 2  final pass: every segment rescans from its true entry state and produces outputs and checkpoints exactly as MODE 0.
 // ~1.9x the arithmetic of MODE 0 on nseg x the workgroups; chosen by the launcher when the one-pass grid cannot fill the CUs.
-template <int NS, int NW, int TC, int MODE>
-__global__ __launch_bounds__(NW * 64) void sscan_fwd2_kernel(FwdParams p) {
+// OCC: waves per SIMD the register allocation must leave room for (the second argument of HIP's __launch_bounds__).  2 = the shipped form
+// (TC = 32: 216 VGPRs, 56 KB of LDS).  3 with TC = 16 (162 VGPRs, 28 KB): a THIRD workgroup per CU, for grids that have one to give -
+// B x Di / 64 >= 768 workgroups, i.e. B >= 96 rows at Di = 512.  At configs[1] (B = 64: exactly two workgroups per CU, profiles/r06_sscan_pmc.md)
+// it cannot help and the shorter chunks cost two more barriers per 32 steps, so the launcher keeps TC = 32 there.
+template <int NS, int NW, int TC, int MODE, int OCC = 2>
+__global__ __launch_bounds__(NW * 64, OCC) void sscan_fwd2_kernel(FwdParams p) {
     constexpr int NT = NW * 64;
     constexpr int N = NS * NW;
     constexpr int NP = (NS + 1) / 2;
@@ -1126,12 +1130,16 @@ inline int fwd_segments(int B, int L, int nd, int TC, int force) {
     const int seg_len = ((L + nseg - 1) / nseg + TC - 1) / TC * TC;
     return (L + seg_len - 1) / seg_len;
 }
+int g_fwd_big = [] { const char* e = getenv("RESEL_SSCAN_FWD_BIG"); return e ? atoi(e) : 1; }();   // 0: never take the three-workgroup edition (A/B)
 template <int NS, int NW, int TC>
 int launch_fwd(FwdParams p, int force_seg, void* workspace, hipStream_t s) {
     const int bp = (p.B + 7) / 8 * 8;
     const int nseg = fwd_segments(p.B, p.L, p.nd, TC, force_seg);
     if (nseg <= 1) {
-        launch_maybe_timed(RESEL_PROF_SSCAN_FWD, sscan_fwd2_kernel<NS, NW, TC, 0>, dim3(bp * p.nd), dim3(NW * 64), s, p);
+        if (NS == 8 && NW == 4 && TC == 32 && g_fwd_big && (int64_t)bp * p.nd >= 768)      // three workgroups per CU exist: the TC = 16 edition holds them
+            launch_maybe_timed(RESEL_PROF_SSCAN_FWD, sscan_fwd2_kernel<NS, NW, (NS == 8 && NW == 4 ? 16 : TC), 0, 3>, dim3(bp * p.nd), dim3(NW * 64), s, p);
+        else
+            launch_maybe_timed(RESEL_PROF_SSCAN_FWD, sscan_fwd2_kernel<NS, NW, TC, 0>, dim3(bp * p.nd), dim3(NW * 64), s, p);
         return launch_status();
     }
     if (!workspace) return RESEL_EINVAL;

@@ -86,15 +86,22 @@ def parse_cgpt_id(layer_id: str) -> dict:
 # pass, so a sequence layer may hand back its output with the following plain ELU already applied by its last GEMM's epilogue (the
 # reference's full hidden holds the PRE-activation sequence, rnn_base.py:456-460: outside a training pass nothing changes).  The entry of
 # such a layer in the returned `full` RNNHidden is None.
-_TRAINING_PASS = [0]
+# Per THREAD: a rollout / evaluation forward running on another thread while an update is in flight (the reference samples from the policy
+# between updates; a user may do so concurrently) must keep getting the pre-activation sequences.  Autograd's backward threads never read it.
+import threading
+_TRAINING_PASS = threading.local()
+
+
+def _in_training_pass() -> bool:
+    return getattr(_TRAINING_PASS, 'depth', 0) > 0
 
 
 class training_pass:
     def __enter__(self):
-        _TRAINING_PASS[0] += 1
+        _TRAINING_PASS.depth = getattr(_TRAINING_PASS, 'depth', 0) + 1
 
     def __exit__(self, *exc):
-        _TRAINING_PASS[0] -= 1
+        _TRAINING_PASS.depth -= 1
         return False
 
 
@@ -250,7 +257,7 @@ class RNNBase(torch.nn.Module):
         """The activation module behind sequence layer `ind` is a plain ELU and this is a training pass over whole fp32 GPU sequences: the
         layer may apply it in its last kernel (`out_act='elu'`)."""
         act_mod = self.activation_list[ind]
-        return (_TRAINING_PASS[0] > 0 and isinstance(act_mod, torch.nn.ELU) and act_mod.alpha == 1.0 and x.is_cuda
+        return (_in_training_pass() and isinstance(act_mod, torch.nn.ELU) and act_mod.alpha == 1.0 and x.is_cuda
                 and x.dtype == torch.float32 and x.dim() == 3 and x.shape[-2] > 1)
 
     def meta_forward(self, x: torch.Tensor, hidden_state: Optional[RNNHidden] = None, require_full_hidden: bool = False,

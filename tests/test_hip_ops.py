@@ -109,6 +109,31 @@ def _slow_decay_case(B, L, Di, N, seed):
     return (u, delta, A, Bm, Cm, D, z, db), start, w
 
 
+def test_selective_scan_three_workgroup_forward_edition(ops):
+    """Grids of 768 workgroups and more (B >= 96 rows at d_inner 512: configs[3]'s global batch on one GPU) run the TC = 16 forward
+    (`sscan_fwd2_kernel<8, 4, 16, 0, 3>`: 162 VGPRs, 28 KB of LDS, three workgroups per CU) - same arithmetic, same 8-step checkpoints: output
+    and every gradient (the backward replays from those checkpoints) against the oracle."""
+    from oracle import kernels as K
+    g = torch.Generator().manual_seed(5)
+    B, L, Di, N = 96, 41, 512, 32
+    r = lambda *s: torch.randn(*s, generator=g)
+    u, delta, z, Bm, Cm = r(B, L, Di), r(B, L, Di) * 0.5, r(B, L, Di), r(B, L, N), r(B, L, N)
+    A, D, db = -torch.exp(r(Di, N) * 0.3), r(Di), r(Di) * 0.1
+    start = torch.zeros(B, L)
+    start[:, 0] = 1
+    start[::3, 17] = 1
+    cpu = [t.clone().requires_grad_(True) for t in (u, delta, A, Bm, Cm, D, z, db)]
+    ref, _ = K.selective_scan_ref(*cpu, start, True)
+    w = r(B, L, Di)
+    (ref * w).sum().backward()
+    dev = [t.clone().cuda().requires_grad_(True) for t in (u, delta, A, Bm, Cm, D, z, db)]
+    out = ops.selective_scan_tm(*dev, start.cuda(), True)
+    (out * w.cuda()).sum().backward()
+    close(out, ref, name='sscan fwd (TC 16)')
+    for name, a, b in zip(('du', 'ddelta', 'dA', 'dB', 'dC', 'dD', 'dz', 'dbias'), dev, cpu):
+        close(a.grad, b.grad, rtol=2e-4, name=name)
+
+
 @pytest.mark.parametrize('B,L,Di,N,segs', [(2, 1043, 64, 32, 1), (2, 1043, 64, 32, 11), (3, 1043, 64, 32, 0), (1, 1043, 128, 16, 1),
                                             (1, 1043, 128, 16, 5), (2, 300, 64, 64, 1), (2, 300, 64, 8, 3)])
 def test_selective_scan_slow_decay_vs_oracle(ops, monkeypatch, B, L, Di, N, segs):

@@ -482,7 +482,7 @@ def test_graphed_update_equals_the_eager_update(rnn, ragged, algo, per, clip, mo
     # fp32 device tensors instead of Python floats), and the coefficient enters every loss
     # cgpt: the attention runs in bf16 - an operand that differs in its last fp32 bit (the replayed GEMMs scale their fp16 planes with
     # magnitude handles accumulated over replays, the eager ones with fresh ones) can round to the next bf16 value, 4e-3 of an element
-    rtol, atol = (5e-3, 1e-4) if rnn.startswith('cgpt') else (2e-5, 2e-7 if n_upd <= 16 else 1e-6)     # 32 chained updates: last-bit drift of weights near zero
+    rtol, atol = (5e-3, 3e-4) if rnn.startswith('cgpt') else (2e-5, 2e-7 if n_upd <= 16 else 1e-6)     # 32 chained updates: last-bit drift of weights near zero
     for nm, a, b in zip(('policy', 'value', 'target value', 'log alpha'), state(graphed), state(eager)):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=rtol, atol=atol, err_msg=nm)
     for le, lg in zip(logs_e, logs_g):

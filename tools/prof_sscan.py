@@ -3,7 +3,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'recurrent-offpolicy-rl_amd')]
 import torch
 from offpolicy_rnn.hip import ops
-B, L, Di, N = 64, 1043, 512, 32
+B, L, Di, N = int(sys.argv[1]) if len(sys.argv) > 1 else 64, 1043, 512, 32      # prof_sscan.py [rows]; RESEL_SSCAN_FWD_BIG=0 / 1: the TC = 16 three-workgroup forward for rows >= 96
 dev = 'cuda'
 xz = torch.randn(B, L, 2 * Di, device=dev).requires_grad_(True)
 xdbl = torch.randn(B, L, 16 + 2 * N, device=dev).requires_grad_(True)
