@@ -178,7 +178,7 @@ class GraphedUpdate:
         par = alg.parameter
         if alg.device.type != 'cuda':
             return 'needs a GPU'
-        if getattr(alg, 'overlap_value_embedding', False):
+        if getattr(alg, 'overlap_value_embedding', False) and os.environ.get('RESEL_GRU_CAPTURE', '0') != '1':
             # tried in round 4 (twice; the second time without the tensors' record_stream calls): with the refusal lifted the capture of
             # the gru trainer (target pass and prefetched value embeddings on side streams, forked / joined with events, the same side
             # stream forked more than once per update) ends in a segmentation fault inside capture_end (hipStreamEndCapture) on this ROCm

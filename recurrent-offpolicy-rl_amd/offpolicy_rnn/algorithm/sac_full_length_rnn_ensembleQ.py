@@ -165,6 +165,7 @@ class SACFullLengthRNNEnsembleQ(SAC):
         self.overlap_value_embedding = (self.device.type == 'cuda' and os.environ.get('RESEL_OVERLAP_EMBEDDING', '1') != '0'
                                         and not self.discrete_env and any(lid == 'gru' for lid in self.values[0].embedding_network.layer_type))
         self._side_stream = self._target_stream = None
+        self._side_streams, self._fork_idx = [], 0
         self._shared_policy_out = None
         self._share_this_update = False
         self.share_policy_pass = self._policy_pass_shareable()
@@ -289,9 +290,13 @@ class SACFullLengthRNNEnsembleQ(SAC):
     def _prefetch_value_embedding(self, model, args, hidden):
         if not self.overlap_value_embedding:
             return
-        if self._side_stream is None:
-            self._side_stream = torch.cuda.Stream(device=self.device)
-        model.prefetch_embedding(args, hidden, self._side_stream)
+        # one side stream PER FORK of an update (two: the target critic's and the actor step's embedding): a stream that has been forked,
+        # joined and is forked again inside one hipGraph capture ends hipStreamEndCapture with a segmentation fault on this ROCm build
+        k, self._fork_idx = self._fork_idx, self._fork_idx + 1
+        while len(self._side_streams) <= k:
+            self._side_streams.append(torch.cuda.Stream(device=self.device))
+        self._side_stream = self._side_streams[0]
+        model.prefetch_embedding(args, hidden, self._side_streams[k])
 
     target_from_live_policy = True        # (the non-REDQ TD3 trainer evaluates its frozen target policy instead)
 
@@ -478,6 +483,7 @@ class SACFullLengthRNNEnsembleQ(SAC):
 
     def _train_one_batch(self) -> Dict:
         par = self.parameter
+        self._fork_idx = 0
         if self._graph is None and self.device.type == 'cuda':
             ops.amax_maintenance()                               # update boundary: the magnitude epochs may start over here (hip/ops.py)
         self.policy.to(self.device)
