@@ -178,11 +178,12 @@ class GraphedUpdate:
         par = alg.parameter
         if alg.device.type != 'cuda':
             return 'needs a GPU'
-        if getattr(alg, 'overlap_value_embedding', False) and os.environ.get('RESEL_GRU_CAPTURE', '0') != '1':
+        if getattr(alg, 'overlap_value_embedding', False):
             # tried in round 4 (twice; the second time without the tensors' record_stream calls): with the refusal lifted the capture of
             # the gru trainer (target pass and prefetched value embeddings on side streams, forked / joined with events, the same side
             # stream forked more than once per update) ends in a segmentation fault inside capture_end (hipStreamEndCapture) on this ROCm
-            # build.  Captured on ONE stream the recurrences (3 us per step, latency-bound) would run back to back: slower than eager.
+            # build; round 6 gave every fork of an update its own side stream (`_side_streams`): the same fault.  Captured on ONE stream the
+            # recurrences (3 us per step, latency-bound) would run back to back: slower than eager.
             return 'side-stream overlap (gru) is not captured'
         if getattr(alg, 'grad_sync', None) is None:
             return 'not a full-trajectory trainer'
