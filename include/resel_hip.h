@@ -353,7 +353,12 @@ int resel_ensemble_head_bwd(const float* gq, const float* a, const float* w3, fl
  *   dgrad    dx = dy W                 A = dy (1), B = W (0)      EnsembleLinear (models/ensemble_linear_model.py:36-49)
  *   wgrad    dW = dy^T x               A = dy (0), B = x (0)      K = number of tokens: split over blocks, partial tiles summed in
  *                                                                  a fixed order (workspace: resel_gemm_f32_workspace_bytes)
- * act: 0 none, 1 ELU, 2 accumulate (C += product + bias: the accumulating form of an input gradient; no activation), 3 softplus (resel_gemm_f32x only).  The contiguous extent of each operand (K or rows) must be a multiple of 4, pointers 16-byte aligned.
+ * act: 0 none, 1 ELU, 2 accumulate (C += product + bias: the accumulating form of an input gradient; no activation), 3 softplus (resel_gemm_f32x only).
+ * EVERY extent and alignment is taken (round 6; no ABI change): the matrix-core kernels need the contiguous extent of each operand (K or rows) to be a
+ * multiple of 4, 16-byte aligned rows and row strides < 2^22; operands that are not - the 6-wide TD3 / discrete heads and their gradients, a rank-2
+ * dt_proj, odd action counts - and the M <= 8 rows of a rollout step against a whole weight matrix (models/rnn_base.py single-step branch,
+ * smamba/mamba.py:257-305) run csrc/gemm_any.hip: exact fp32 FMAs, the same epilogues, the same magnitude publication, long reductions cut in
+ * K and summed in a fixed order.  No call of this entry is left to a vendor library by the host side (tests/test_no_library_gemm_gpu.py).
  * split selects how the fp32 products are formed (inputs, accumulation and outputs are fp32 in every mode):
  *   0  v_mfma_f32_32x32x2_f32 (fp32 operands, exact products);
  *   6  each operand split EXACTLY into three bf16 planes (8 + 8 + 8 significant bits), the six leading plane products - each exact -
@@ -470,8 +475,9 @@ int resel_amax_check(const float* x, int64_t ld, int64_t stride, int rows, int c
  * F.linear computes under the reference's bf16 autocast (flash-attn MHA, TransformerFlashAttention.py:67-70) without the
  * separate cast passes: forward (A = activations, B = weight [N][K]), input gradient (B = weight as [K][rows]), weight
  * gradient (both operands [K = tokens][rows]; K slices summed in a fixed order, workspace: resel_gemm_bf16_workspace_bytes).
- * The contiguous extent of each operand must be a multiple of 4, leading dimensions multiples of 4, bases 16-byte (fp32) or
- * 8-byte (bf16) aligned. */
+ * The matrix-core kernel needs the contiguous extent of each operand to be a multiple of 4, leading dimensions multiples of 4 and bases 16-byte
+ * (fp32) or 8-byte (bf16) aligned; other fp32 operands, and M <= 8 rows against a [N][K] fp32 weight (the decode step of flash-attn's MHA; A fp32 or
+ * bf16), run csrc/gemm_any.hip with the same rounding points (round 6; no ABI change). */
 size_t resel_gemm_bf16_workspace_bytes(int M, int N, int K);
 int resel_gemm_bf16(const void* A, int64_t lda, int a_kcontig, int a_bf16, const void* B, int64_t ldb, int b_kcontig, int b_bf16,
                     const float* bias, void* C, int64_t ldc, int c_bf16, void* workspace, int M, int N, int K,
