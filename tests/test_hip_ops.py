@@ -1101,6 +1101,29 @@ def test_gemm_f32_takes_every_shape(ops, M, N, K, akc, bkc, bias, act, batch):
     assert float(ops.amax_value(h)) == pytest.approx(float(out3.abs().max()), rel=1e-6)
 
 
+def test_gemm_f32_random_small_shapes(ops):
+    """120 random shapes up to 300 x 300 x 600 in all four operand layouts, with / without bias, ELU and batch: whichever kernel the entry
+    picks (rows form, generic tiles, first edition, one-role / producer-consumer editions), the product matches fp64."""
+    rs = np.random.RandomState(7)
+    g = torch.Generator().manual_seed(7)
+    for it in range(120):
+        M, N, K = (int(rs.choice([1, 2, 3, 5, 8, 9, 17, 47, 64, 129, 131, 300])), int(rs.choice([1, 3, 4, 6, 12, 18, 64, 130, 256, 300])),
+                   int(rs.choice([1, 2, 3, 6, 16, 31, 32, 33, 44, 64, 100, 256, 600])))
+        akc, bkc, batch = bool(rs.randint(2)), bool(rs.randint(2)), int(rs.choice([1, 1, 2, 3]))
+        bias, act = bool(rs.randint(2)), [None, 'elu'][rs.randint(2)]
+        sh = (batch,) if batch > 1 else ()
+        A = torch.randn(*sh, *((M, K) if akc else (K, M)), generator=g)
+        B = torch.randn(*sh, *((N, K) if bkc else (K, N)), generator=g) / K ** 0.5
+        b = torch.randn(*sh, N, generator=g) if bias else None
+        ref = (A.double() if akc else A.double().transpose(-1, -2)) @ (B.double().transpose(-1, -2) if bkc else B.double())
+        if bias:
+            ref = ref + b.double().unsqueeze(-2)
+        if act == 'elu':
+            ref = torch.nn.functional.elu(ref)
+        out = ops.gemm_f32(A.cuda(), B.cuda(), akc, bkc, None if b is None else b.cuda(), act)
+        close(out, ref.float(), rtol=1e-5, atol_scale=2e-6, name=f'gemm_f32 #{it} M{M} N{N} K{K} akc{akc} bkc{bkc} batch{batch} bias{bias} act{act}')
+
+
 @pytest.mark.parametrize('M,N,K,x_bf,out', [(1, 768, 256, False, 'bf16'), (4, 256, 256, True, 'bf16'), (8, 256, 256, True, 'round'),
                                              (2, 256, 1024, False, 'f32'), (47, 96, 32, False, 'bf16'), (5, 12, 6, False, 'round')])
 def test_gemm_bf16_takes_decode_rows_and_odd_shapes(ops, M, N, K, x_bf, out):
