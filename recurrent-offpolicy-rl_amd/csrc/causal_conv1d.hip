@@ -20,24 +20,7 @@ struct ConvParams {
     AmaxOut amax;                    // optional: publish max |y| (forward) / max |dx| (backward)
     const float* dy2 = nullptr;      // backward: optional second gradient of the output, summed with dy on load (the Mamba mixer's conv output
     int64_t ld_dy2 = 0;              // receives the scan's du AND the x_proj input gradient: no accumulating GEMM, no add pass)
-    int nx = 1, nchunk = 1;          // window kernels: channel blocks per row and time chunks per row (the 1-D grid is decoded with them)
 };
-
-// XCD-aware decode of the window kernels' 1-D grid (round 6).  A time chunk re-reads the K - 1 (backward: 2 K) step halo of its left neighbour;
-// with the former (channel block, chunk, row) grid the neighbours' linear ids differed by `nx` = 2, i.e. they ran on DIFFERENT XCDs
-// (workgroups are dealt round-robin over the 8 XCDs by linear id) and every halo came from HBM: 768 MB per backward launch against 547
-// algorithmic (profiles/r05h_summary.md).  Here ids congruent mod 8 - one XCD - walk the chunks of ONE (row, channel block) in order, then the next
-// one's: neighbours in time run next to each other on one L2 and the halo is an L2 hit.  Any placement is correct; this one is cheaper.
-__device__ __forceinline__ bool decode_chunk(const ConvParams& p, int& cx, int& chunk, int& b) {
-    const int id = blockIdx.x, xcd = id & 7, k = id >> 3;
-    const int r = (k / p.nchunk) * 8 + xcd;          // (row, channel block) pair of this workgroup
-    chunk = k - (k / p.nchunk) * p.nchunk;
-    if (r >= p.B * p.nx) return false;
-    b = r / p.nx;
-    cx = r - b * p.nx;
-    return true;
-}
-inline dim3 chunk_grid(int B, int nx, int nchunk) { return dim3((unsigned)(((int64_t)B * nx + 7) / 8 * 8 * nchunk)); }
 
 template <int KT>
 __device__ __forceinline__ void load_taps(const ConvParams& p, int c, bool ok, float4 (&wr)[KT]) {
@@ -120,13 +103,11 @@ template <int KT>
 __global__ __launch_bounds__(128) void conv_fwd_kernel(ConvParams p) {
     constexpr int P = KT < 16 ? KT : 16;
     const int lane = threadIdx.x & 63;
-    int cx, chunk, b;
-    if (!decode_chunk(p, cx, chunk, b)) return;
-    if ((cx * 128 + (threadIdx.x & 64)) * 2 >= p.Di) return;      // whole wave past the last channel (no barriers below)
+    if ((blockIdx.x * 128 + (threadIdx.x & 64)) * 2 >= p.Di) return;      // whole wave past the last channel (no barriers below)
     // lanes past the last channel of a partly filled wave shadow the last pair (same loads, same stores, same values):
     // every lane stays active, which the v_readlane mask fetches and the exact vmcnt accounting rely on
-    const int c = min((int)(cx * 128 + threadIdx.x) * 2, p.Di - 2);
-    const int t0 = chunk * CONV_TT;
+    const int c = min((int)(blockIdx.x * 128 + threadIdx.x) * 2, p.Di - 2);
+    const int b = blockIdx.z, t0 = blockIdx.y * CONV_TT;
     const int t_end = min(p.L, t0 + CONV_TT);
     const int64_t tok0 = (int64_t)b * p.L;
     const float* xrow = p.x + tok0 * p.ld_x + c;
@@ -229,11 +210,10 @@ template <int KT, bool TWO>
 __global__ __launch_bounds__(128) void conv_bwd_win_kernel(ConvParams p, int nchunk) {
     constexpr int P = KT < 4 ? KT : 4;
     const int lane = threadIdx.x & 63;
-    int cx, chunk, b;
-    if (!decode_chunk(p, cx, chunk, b)) return;
-    if ((cx * 128 + (threadIdx.x & 64)) * 2 >= p.Di) return;      // whole wave past the last channel (no barriers below)
-    const int c_raw = (int)(cx * 128 + threadIdx.x) * 2;
+    if ((blockIdx.x * 128 + (threadIdx.x & 64)) * 2 >= p.Di) return;      // whole wave past the last channel (no barriers below)
+    const int c_raw = (int)(blockIdx.x * 128 + threadIdx.x) * 2;
     const int c = min(c_raw, p.Di - 2);             // shadow lanes (see the forward kernel)
+    const int b = blockIdx.z, chunk = blockIdx.y;
     const int t_own0 = chunk * CB_TT;               // first step this chunk accounts for in dw / db
     const int t0 = min(t_own0, p.L - CB_TT);        // the last chunk is shifted back to end at the row end
     const int64_t tok0 = (int64_t)b * p.L;
@@ -398,9 +378,7 @@ extern "C" int resel_causal_conv1d_fwd(const float* x, int64_t ld_x, const float
     ConvParams p{x, w, bias, mask, nullptr, y, nullptr, nullptr, nullptr, ld_x, ld_y, 0, 0, B, L, Di, K, silu,
                  AmaxOut{(unsigned long long*)amax_y, amax_epoch}};
     const int KT = pad_taps(K);
-    p.nx = (Di + 255) / 256;
-    p.nchunk = (L + CONV_TT - 1) / CONV_TT;
-    const dim3 grid = chunk_grid(B, p.nx, p.nchunk);
+    dim3 grid((Di + 255) / 256, (L + CONV_TT - 1) / CONV_TT, B);
     hipStream_t s = (hipStream_t)stream;
     switch (KT) {
         case 4: launch_timed(RESEL_PROF_CONV_FWD, conv_fwd_kernel<4>, grid, dim3(128), 0, s, p); break;
@@ -445,9 +423,7 @@ extern "C" int resel_causal_conv1d_bwd2(const float* x, int64_t ld_x, const floa
     hipStream_t s = (hipStream_t)stream;
     if (bwd_windowed(L, KT)) {
         const int nchunk = (L + CB_TT - 1) / CB_TT;
-        p.nx = (Di + 255) / 256;
-        p.nchunk = nchunk;
-        const dim3 grid = chunk_grid(B, p.nx, nchunk);
+        dim3 grid((Di + 255) / 256, nchunk, B);
 #define CONV_BWD_WIN(KTv) do { if (dy2) launch_timed(RESEL_PROF_CONV_BWD, conv_bwd_win_kernel<KTv, true>, grid, dim3(128), 0, s, p, nchunk); \
                                else launch_timed(RESEL_PROF_CONV_BWD, conv_bwd_win_kernel<KTv, false>, grid, dim3(128), 0, s, p, nchunk); } while (0)
         switch (KT) {
