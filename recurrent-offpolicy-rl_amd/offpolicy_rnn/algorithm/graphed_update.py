@@ -73,6 +73,9 @@ class GraphedUpdate:
         self._amax_generation = ops.AMAX_GENERATION[0]
         self._pool = torch.cuda.graph_pool_handle()   # memory pool shared by every recorded graph (and by the segments of one update)
         self.eager_fallbacks = 0
+        # data-parallel groups: the process group's watchdog thread polls events while this thread records - harmless, but a capture in the
+        # default `global` mode treats such a call from ANOTHER thread as an error and invalidates the recording
+        self._capture_mode = 'thread_local' if alg.grad_sync.active else 'global'
         self._rec = None                              # while recording: dict(segs=[(graph, exchange or None), ...], g=<graph being captured>)
         if alg.grad_sync.active:                      # every rank's Q-guard extrema ride behind the gradients: size the buffer before anything is recorded
             alg.values[0].store.ensure_grad_extra(4 + 4 * alg.grad_sync.world)
@@ -213,7 +216,7 @@ class GraphedUpdate:
         rec['g'].capture_end()
         rec['segs'].append((rec['g'], exchange))
         rec['g'] = torch.cuda.CUDAGraph()
-        rec['g'].capture_begin(pool=self._pool)
+        rec['g'].capture_begin(pool=self._pool, capture_error_mode=self._capture_mode)
 
     def _record(self):
         """Record one update as a list of (graph, exchange) segments; one segment unless the trainer cuts (data parallel)."""
@@ -224,7 +227,7 @@ class GraphedUpdate:
         rec = self._rec = dict(segs=[], g=torch.cuda.CUDAGraph())
         try:
             with torch.cuda.stream(side):
-                rec['g'].capture_begin(pool=self._pool)
+                rec['g'].capture_begin(pool=self._pool, capture_error_mode=self._capture_mode)
                 try:
                     self._body()                      # recorded, not run: the prepared inputs are consumed by the replay that follows
                 finally:
