@@ -59,12 +59,14 @@ class GraphedUpdate:
     RECAPTURE_HITS = 8                                # occurrences an EVICTED shape needs before it is recorded again
     CAPTURE_WINDOW = 256                              # at most `max_graphs` recordings per this many updates: more recurring shapes than graphs run eagerly
 
-    def __init__(self, alg, warmup=3, max_graphs=4):
+    def __init__(self, alg, warmup=3, max_graphs=None):
         why = self.refusal(alg)
         if why:
             raise RuntimeError('GraphedUpdate: ' + why)
         self.alg, self.device = alg, alg.device
         self.graphs = OrderedDict()                   # batch shape key -> CUDAGraph, least recently used first
+        if max_graphs is None:                        # four batch shapes; with policy_update_per > 1 every shape has two launch sequences
+            max_graphs = 4 * (2 if alg.parameter.policy_update_per > 1 else 1)
         self.warmup, self.max_graphs = warmup, max_graphs
         self._eager_left = warmup                     # updates still to run eagerly before anything is recorded
         self._seen = OrderedDict()                    # batch shape key -> occurrences so far (least recently seen first; pruned to SEEN_CAP)
