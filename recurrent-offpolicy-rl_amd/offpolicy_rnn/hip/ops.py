@@ -196,7 +196,13 @@ class MambaInnerFn(torch.autograd.Function):
         tag_amax(xc, h_xc)
         x_dbl = mm_nt(xc, xproj_w)                                         # [M, R + 2N] = (delta_r | B | C)
         fold = True    # (rounds 4-5: only where the hand-written GEMM took dt_proj; it takes every shape now)
-        if fold:       # delta = softplus(dt_proj(.) + bias) leaves the GEMM epilogue: the scan kernels spend no vector issue on it
+        if fold and R < 32 <= R + 2 * N and os.environ.get('RESEL_DT_PAD', '1') != '0' and gemm_split() == 2:
+            # dt_proj has K = dt_rank = 16: one PARTIAL K step, which only the fp32-MFMA first edition takes (58 us for a product whose floor
+            # is its 137 MB of output: 28 us).  Read 32 columns of x_dbl instead - the 16 behind delta_r are B's, finite - against the weight
+            # padded with 16 zero columns (one launch): a whole K step, so the producer / consumer edition with its full-line stores runs it.
+            w32 = place_blocks(Di, 32, [(0, 0)], dt_w.detach())
+            dt = gemm_f32(x_dbl[:, :32], w32, True, True, dt_b, GEMM_SOFTPLUS, amax_a=amax_of(x_dbl), amax_b=weight_amax(dt_w))
+        elif fold:     # delta = softplus(dt_proj(.) + bias) leaves the GEMM epilogue: the scan kernels spend no vector issue on it
             dt = gemm_f32(x_dbl[:, :R], dt_w, True, True, dt_b, GEMM_SOFTPLUS)
         else:
             dt = mm_nt(x_dbl[:, :R], dt_w)                                  # [M, Di]; bias enters the scan as delta_bias
