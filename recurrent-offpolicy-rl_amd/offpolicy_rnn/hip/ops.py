@@ -259,12 +259,7 @@ class MambaInnerFn(torch.autograd.Function):
         d_dt_w = atb(ddt, x_dbl[:, :R]) if R <= 32 and Di % 4 == 0 and ddt.stride(1) == 1 and ddt.stride(0) % 4 == 0 \
             else gemm_f32(ddt, x_dbl[:, :R], False, False)
         mm_nn(ddt, dt_w, out=dx_dbl[:, :R])                                  # straight into its column block of dx_dbl
-        # [R + 2N, Di] with a 66 752-long reduction: the long-reduction kernel of the narrow projections (bound by ONE read of xc) where its shape
-        # rules hold; the general weight-gradient GEMM runs this 80-row output in mode 6 on half-empty 128-row tiles (75 us against ~45)
-        if R + 2 * N <= 96 and Di % 4 == 0 and xc.stride(1) == 1 and xc.stride(0) % 4 == 0 and os.environ.get('RESEL_XPROJ_ATB', '1') != '0':
-            d_xproj_w = atb(xc, dx_dbl, transposed=True)
-        else:
-            d_xproj_w = wgrad(dx_dbl, xc, amax_x=h_xc)
+        d_xproj_w = wgrad(dx_dbl, xc, amax_x=h_xc)
         # the conv output's gradient = the scan's du (in dxc) + the x_proj input gradient: handed to the conv backward as TWO tensors
         # (summed on load) - the accumulating GEMM epilogue cost 150-214 us per call against 67 for the plain product
         gx = mm_nn(dx_dbl, xproj_w)
