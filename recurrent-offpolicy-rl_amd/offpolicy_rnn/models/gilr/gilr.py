@@ -3,8 +3,6 @@
 h_t = f_t h_{t-1} + (1 - f_t) v_t with v = tanh(.), f = sigmoid(.) (1 - rnn_start): the activations, the reset
 folding and the recurrence run in ONE time-parallel HIP kernel (`ops.gilr_scan`); the reference needs three
 element-wise passes plus a sequential Triton scan for the same thing."""
-import os
-
 import torch
 import torch.nn as nn
 
@@ -26,7 +24,7 @@ class PositionWiseFeedForward(nn.Module):
         """out_act='elu': the plain ELU behind the layer rides in the closing add + LayerNorm kernel (RNNBase, training passes)."""
         h1 = ops.linear(x, self.w_1.weight, self.w_1.bias)
         y = self.activation(h1)
-        if y.is_cuda and os.environ.get('RESEL_GELU_TAG', '1') != '0':
+        if y.is_cuda:
             ops.tag_amax(y, ops.amax_of(h1))          # |gelu(v)| = |v| Phi(v) <= |v|: the magnitude the w_1 product published bounds its GELU too, so
         y = self.dropout(y)                           # w_2 (and its weight gradient) run product mode 2 instead of 6 (66 -> 46 us at configs[4])
         return ops.layer_norm_fn(self.dropout(ops.linear(y, self.w_2.weight, self.w_2.bias)), self.layer_norm.weight, self.layer_norm.bias, residual=x,
