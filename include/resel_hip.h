@@ -37,18 +37,6 @@ typedef void* resel_stream_t; /* hipStream_t */
 int resel_abi_version(void);            /* bumps when a signature changes */
 const char* resel_build_info(void);     /* "gfx950 <date> ..." */
 
-/* Stream signals (ABI 9).  A signal is 8 bytes of device memory (hipMallocSignalMemory) holding a 32-bit value; `resel_stream_wait_value` makes
- * every later operation of `stream` wait until *signal >= value, `resel_stream_write_value` stores `value` in stream order.  Unlike an event, the
- * wait may be enqueued BEFORE the write that releases it exists.  Used by the gru trainer (no counterpart in the reference, which runs its three
- * forward passes - algorithm/sac_full_length_rnn_ensembleQ.py:368-393 - one after the other on one stream): the recurrences of the target policy,
- * target critic and critic passes start together once the pre-recurrence GEMMs of all three have run.  `_supported` = 0: the device has no
- * stream-value waits; callers then launch without the rendezvous. */
-int resel_stream_signal_supported(void);
-int resel_stream_signal_alloc(void** out);                 /* zero-initialised; synchronous (hipMemset) */
-int resel_stream_signal_free(void* signal);
-int resel_stream_write_value(void* signal, unsigned value, resel_stream_t stream);
-int resel_stream_wait_value(void* signal, unsigned value, resel_stream_t stream);
-
 /* Diagnostics for bench.py (off by default; the only global state of the library).  While enabled, the sequence-layer
  * kernels are dispatched with a (start, stop) HIP event pair bound to each dispatch on its own stream;
  * resel_profile_collect() synchronises those events, returns their summed duration and count and clears them.

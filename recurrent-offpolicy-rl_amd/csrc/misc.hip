@@ -2,7 +2,7 @@
 #include "resel_common.h"
 #include <cstdint>
 
-extern "C" int resel_abi_version(void) { return 9; }
+extern "C" int resel_abi_version(void) { return 8; }
 
 // ---- dropout offset base: a device word that every counter-keyed mask kernel (resel_dropout, resel_gelu_dropout_*, resel_attn_varlen_*
 // with p_drop > 0) adds to its `offset` argument when it RUNS.  A captured update bakes the host-drawn offsets into its kernel nodes; with
@@ -88,31 +88,4 @@ extern "C" int resel_place_blocks(float* out, int64_t ld_out, int rows, int cols
     const long long total = (long long)rows * cols;
     hipLaunchKernelGGL(place_blocks_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, (long long)ld_out, total, cols, a);
     return resel::launch_status();
-}
-
-// ---- stream signals (ABI 9): a stream waits for a 32-bit value that ANOTHER stream writes - possibly enqueued LATER by the host, which no
-// event can express.  The gru trainer's three forward recurrences meet on them (hip/ops.py `GruRendezvous`): a persistent recurrence kernel
-// holds every CU for milliseconds and the 245-VGPR GEMM workgroups of the other streams' pre-recurrence work cannot become resident next to
-// it, so without the rendezvous the recurrences ran one after the other (profiles/r06_gru.md).
-extern "C" int resel_stream_signal_supported(void) {
-    int dev = 0, can = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, dev) != hipSuccess) return 0;
-    return can ? 1 : 0;
-}
-extern "C" int resel_stream_signal_alloc(void** out) {
-    if (!out) return RESEL_EINVAL;
-    void* p = nullptr;
-    if (hipExtMallocWithFlags(&p, 8, hipMallocSignalMemory) != hipSuccess) return RESEL_ELAUNCH;
-    if (hipMemset(p, 0, 8) != hipSuccess) { (void)hipFree(p); return RESEL_ELAUNCH; }
-    *out = p;
-    return RESEL_OK;
-}
-extern "C" int resel_stream_signal_free(void* p) { return (p && hipFree(p) == hipSuccess) ? RESEL_OK : RESEL_EINVAL; }
-extern "C" int resel_stream_write_value(void* signal, unsigned value, resel_stream_t stream) {
-    if (!signal) return RESEL_EINVAL;
-    return hipStreamWriteValue32((hipStream_t)stream, signal, value, 0) == hipSuccess ? RESEL_OK : RESEL_ELAUNCH;
-}
-extern "C" int resel_stream_wait_value(void* signal, unsigned value, resel_stream_t stream) {      // until *signal >= value
-    if (!signal) return RESEL_EINVAL;
-    return hipStreamWaitValue32((hipStream_t)stream, signal, value, hipStreamWaitValueGte, 0xffffffffu) == hipSuccess ? RESEL_OK : RESEL_ELAUNCH;
 }

@@ -527,28 +527,24 @@ class SACFullLengthRNNEnsembleQ(SAC):
             self._share_this_update = self.share_policy_pass and actor_due
             self.policy.eval()
             target_done = None
-            # gru: the three forward recurrences of this phase (target critic on the side stream, target policy on the target stream, critic on
-            # the main stream) start together once the GEMMs in front of all three have run (ops.GruRendezvous: otherwise they run back to back)
-            phase = ops.GruRendezvous(3, self.device) if self.overlap_value_embedding else contextlib.nullcontext()
-            with phase:
-                if self.overlap_value_embedding:
-                    # latency-bound layers: the whole (graph-free) target computation goes to a second stream, so that the critic's
-                    # forward below (main stream) runs beside the target policy pass and the target critic's embedding pass
-                    main = torch.cuda.current_stream(self.device)
-                    if self._target_stream is None:
-                        self._target_stream = torch.cuda.Stream(device=self.device)
-                    self._target_stream.wait_stream(main)
-                    with torch.cuda.stream(self._target_stream):
-                        target_Q = self.get_target_Q(b, target_policy_hidden, target_hiddens, self._stats)
-                        target_done = torch.cuda.Event()
-                        target_done.record(self._target_stream)
-                else:
+            if self.overlap_value_embedding:
+                # latency-bound layers: the whole (graph-free) target computation goes to a second stream, so that the critic's
+                # forward below (main stream) runs beside the target policy pass and the target critic's embedding pass
+                main = torch.cuda.current_stream(self.device)
+                if self._target_stream is None:
+                    self._target_stream = torch.cuda.Stream(device=self.device)
+                self._target_stream.wait_stream(main)
+                with torch.cuda.stream(self._target_stream):
                     target_Q = self.get_target_Q(b, target_policy_hidden, target_hiddens, self._stats)
-                valid_num = self._stats[1]
+                    target_done = torch.cuda.Event()
+                    target_done.record(self._target_stream)
+            else:
+                target_Q = self.get_target_Q(b, target_policy_hidden, target_hiddens, self._stats)
+            valid_num = self._stats[1]
 
-                # 2. critic step
-                value.train()
-                q = value.forward(b['state'], b['last_state'], b['last_action'], b['action'], value_hiddens[0], b['reward_input'])[0]
+            # 2. critic step
+            value.train()
+            q = value.forward(b['state'], b['last_state'], b['last_action'], b['action'], value_hiddens[0], b['reward_input'])[0]
             if target_done is not None:
                 main.wait_event(target_done)
                 target_Q.record_stream(main)
@@ -573,19 +569,14 @@ class SACFullLengthRNNEnsembleQ(SAC):
 
             # 4. actor (+ alpha) step
             if self.grad_num % par.policy_update_per == 0 and (utd_idx + 1) / par.utd * par.policy_utd > policy_update_cnt:
-                phase = ops.GruRendezvous(2, self.device) if self.overlap_value_embedding else contextlib.nullcontext()
-                phase.__enter__()                                  # (actor's recurrence + the critic's embedding recurrence on the side stream)
                 self._prefetch_value_embedding(value, (b['state'], b['last_state'], b['last_action'], b['reward_input']), value_hiddens[0])
-                try:
-                    if self._shared_policy_out is not None:        # the target pass's head outputs, one slot later
-                        out2 = torch.nn.functional.pad(self._shared_policy_out[:, :-1], (0, 0, 1, 0))
-                        self._shared_policy_out = None
-                        action_mean, act_sample, log_prob = self.policy.process_model_out(out2)
-                    else:
-                        action_mean, _, act_sample, log_prob, _, _ = self.policy.forward(b['state'], b['last_state'], b['last_action'],
-                                                                                        policy_hidden, b['reward_input'])
-                finally:
-                    phase.__exit__(None, None, None)
+                if self._shared_policy_out is not None:            # the target pass's head outputs, one slot later
+                    out2 = torch.nn.functional.pad(self._shared_policy_out[:, :-1], (0, 0, 1, 0))
+                    self._shared_policy_out = None
+                    action_mean, act_sample, log_prob = self.policy.process_model_out(out2)
+                else:
+                    action_mean, _, act_sample, log_prob, _, _ = self.policy.forward(b['state'], b['last_state'], b['last_action'],
+                                                                                    policy_hidden, b['reward_input'])
                 act_in = act_sample if self.base_algorithm == 'sac' else action_mean
                 # the actor objective differentiates Q only w.r.t. the action: the critic's parameters are frozen while its graph
                 # is recorded, so that the backward does not form the critic weight gradients the reference computes and drops

@@ -9,7 +9,7 @@ from ctypes import c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('RESEL_HIP_LIBRARY') or os.path.join(_HERE, 'libresel_hip.so')      # override: ablation builds (tools/gemm_ablate.sh)
-ABI_VERSION = 9
+ABI_VERSION = 8
 _lib = None
 
 P, I, L, F, S, U = c_void_p, c_int, c_int64, c_float, c_void_p, c_uint64
@@ -19,11 +19,6 @@ E = ctypes.c_uint                # epoch of a magnitude slot
 SIGNATURES = {
     'resel_abi_version': (c_int, []),
     'resel_build_info': (ctypes.c_char_p, []),
-    'resel_stream_signal_supported': (c_int, []),
-    'resel_stream_signal_alloc': (c_int, [P]),
-    'resel_stream_signal_free': (c_int, [P]),
-    'resel_stream_write_value': (c_int, [P, ctypes.c_uint, S]),
-    'resel_stream_wait_value': (c_int, [P, ctypes.c_uint, S]),
     'resel_profile_enable': (c_int, [I]),
     'resel_profile_collect': (c_int, [I, P, P]),
     'resel_selective_scan_ckpt_bytes': (c_size_t, [I, I, I, I]),

@@ -648,63 +648,6 @@ class SubAddMembers(torch.autograd.Function):
 
 
 # ---------------------------------------------------------------------------------------------- GRU
-class GruRendezvous:
-    """`with GruRendezvous(n, device):` - the first `n` persistent gru FORWARD recurrences launched inside the block (one per stream) start
-    TOGETHER, once the work queued in front of every one of them has run.
-
-    Why (profiles/r06_gru.md, a kernel trace of the gru update): a persistent recurrence holds one workgroup on every CU for 2.2 ms, and the
-    245-VGPR workgroups of the hand-written GEMM cannot become resident next to it.  The trainer issues the three forward passes of an update on
-    three streams (target critic, target policy, critic) one after the other; the first pass reached its recurrence before the host had even
-    enqueued the second pass's input GEMMs, those GEMMs then waited for the recurrence to END, and the three recurrences ran back to back
-    (8 ms) instead of side by side (3 ms).  Events cannot order "start after work that is not enqueued yet"; stream VALUE waits can
-    (`resel_stream_wait_value` / `_write_value`, include/resel_hip.h): participant i writes flag i in stream order right in front of its
-    recurrence and waits for the other n - 1 flags.  Fewer participants than n (another layer id in one of the networks): the missing flags are
-    written from a stream of their own when the block ends, so a waiter is delayed, never stuck.  No-op where the device has no stream waits."""
-    _state = {}                                      # device -> dict(flags=[ptr] * 3, epoch, release=Stream)
-    active = None
-
-    def __init__(self, n, device):
-        self.n, self.device = int(n), torch.device(device)
-        st = GruRendezvous._state.get(self.device)
-        if st is None and self.device.type == 'cuda' and os.environ.get('RESEL_GRU_RENDEZVOUS', '1') != '0' and lib().resel_stream_signal_supported():
-            flags = []
-            for _ in range(3):
-                ptr = ctypes.c_void_p()
-                check(lib().resel_stream_signal_alloc(ctypes.byref(ptr)), 'stream_signal_alloc')
-                flags.append(ptr.value)
-            st = GruRendezvous._state[self.device] = dict(flags=flags, epoch=0, release=torch.cuda.Stream(device=self.device))
-        self.st = st if (st is not None and self.n <= 3) else None
-
-    def __enter__(self):
-        if self.st is not None:
-            assert GruRendezvous.active is None, 'gru rendezvous blocks do not nest'
-            self.st['epoch'] = (self.st['epoch'] % 0x7fffffff) + 1
-            self.count, self.seen = 0, set()
-            GruRendezvous.active = self
-        return self
-
-    def arrive(self):
-        """Called right in front of a persistent forward launch (GruSeqFn.forward) with the launch stream current."""
-        stream = torch.cuda.current_stream(self.device).cuda_stream
-        if self.count >= self.n or stream in self.seen or torch.cuda.is_current_stream_capturing():
-            return
-        i, self.count = self.count, self.count + 1
-        self.seen.add(stream)
-        flags, epoch = self.st['flags'], self.st['epoch']
-        check(lib().resel_stream_write_value(flags[i], epoch, stream), 'stream_write_value')
-        for j in range(self.n):
-            if j != i:
-                check(lib().resel_stream_wait_value(flags[j], epoch, stream), 'stream_wait_value')
-
-    def __exit__(self, *exc):
-        if self.st is not None:
-            GruRendezvous.active = None
-            rel = self.st['release'].cuda_stream       # a stream that never waits for anything: the release cannot queue up behind a waiter
-            for i in range(self.count, self.n):
-                check(lib().resel_stream_write_value(self.st['flags'][i], self.st['epoch'], rel), 'stream_write_value')
-        return False
-
-
 class GruSeqFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, gi, w_hh, b_hh, h0):
@@ -718,8 +661,6 @@ class GruSeqFn(torch.autograd.Function):
         h_all = torch.empty(Bsz, L, H, dtype=torch.float32, device=gi.device)
         gates = torch.empty(Bsz, L, 4 * H, dtype=torch.float32, device=gi.device) if need_grad else None
         ws = _ws(lib().resel_gru_workspace_bytes(Bsz, L, H), gi.device)
-        if GruRendezvous.active is not None and L > 1:
-            GruRendezvous.active.arrive()             # the recurrences of the passes of one phase start together (see the class)
         check(lib().resel_gru_seq_fwd(_p(gi), _p(w_hh), _p(b_hh), _p(h0), _p(h_all), _p(gates), _p(ws), Bsz, L, H, _stream()),
               'gru_seq_fwd')
         ctx.save_for_backward(w_hh, h0, h_all, gates)
