@@ -171,10 +171,6 @@ class SACFullLengthRNNEnsembleQ(SAC):
         self.share_policy_pass = self._policy_pass_shareable()
         if self.share_policy_pass:              # the shared pass records an autograd graph inside the target computation: keep that on one stream
             self.overlap_value_embedding = False
-        # gru: the embedding passes take the small-footprint GEMM edition, which can run NEXT TO a persistent recurrence (hip/ops.py
-        # `small_footprint_gemms`): the split editions' workgroups cannot, and the recurrences of the three forward passes then run back to back
-        for m in (self.policy, self.values[0], self.target_values[0], self.target_policy):
-            m.small_footprint_embedding = self.overlap_value_embedding and os.environ.get('RESEL_GRU_SMALL_GEMM', '1') != '0'
 
     step = property(lambda self: self.train_one_batch)          # north_star's "algorithm.step()" alias
     device_replay = True        # keep a device mirror of the replay ring and assemble sampled batches on the GPU (CUDA only)

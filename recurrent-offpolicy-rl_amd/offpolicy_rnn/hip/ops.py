@@ -1391,31 +1391,7 @@ def linear_bf16(x, weight, bias, out_dtype=torch.bfloat16, round_out=False):
 GEMM_SPLIT = int(os.environ['RESEL_GEMM_SPLIT']) if os.environ.get('RESEL_GEMM_SPLIT') else None
 
 
-# gru trainers (profiles/r06_gru.md): a persistent recurrence kernel holds one 128-VGPR wave on every SIMD for 2-3 ms, and the 245-VGPR waves of the
-# split GEMM editions (two per SIMD) cannot become resident next to it - the GEMMs in front of the NEXT pass's recurrence waited for the running
-# one to end, so the three forward recurrences of an update ran back to back instead of side by side.  The fp32-MFMA first edition (one 200-VGPR
-# wave per SIMD, 72 KB of LDS) does fit beside up to two recurrences: inside `small_footprint_gemms()` every product takes it (exact fp32
-# products; slower alone, but it RUNS while a recurrence holds the chip).  The trainer wraps the embedding passes of the gru networks in it.
-_SMALL_FOOTPRINT = [0]
-
-
-class small_footprint_gemms:
-    def __init__(self, on=True):
-        self.on = bool(on)
-
-    def __enter__(self):
-        _SMALL_FOOTPRINT[0] += self.on
-
-    def __exit__(self, *exc):
-        _SMALL_FOOTPRINT[0] -= self.on
-        return False
-
-
 def gemm_split():
-    return 0 if _SMALL_FOOTPRINT[0] > 0 else _base_split()
-
-
-def _base_split():
     if GEMM_SPLIT is not None:
         return GEMM_SPLIT
     return 2 if torch.get_float32_matmul_precision() == 'highest' else 3
@@ -1653,7 +1629,7 @@ def _slot_args(want, device):
 
 def amax_tracking():
     """Producers publish magnitudes only while the GEMMs would use them (product mode 2)."""
-    return _base_split() == 2          # (also inside `small_footprint_gemms`: what those products write is read by mode-2 products later)
+    return gemm_split() == 2
 
 
 @torch.no_grad()

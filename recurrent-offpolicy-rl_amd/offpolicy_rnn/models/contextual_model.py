@@ -111,8 +111,7 @@ class ContextualModel:
             w_emb = self.embedding_network.output_size
             dest = None if row_buffer is None else row_buffer.block(row_buffer.width - w_emb, w_emb)
             # a detached embedding is computed without a graph: same values, but no scan checkpoints / saved activations
-            with torch.set_grad_enabled(torch.is_grad_enabled() and not detach_embedding), \
-                    ops.small_footprint_gemms(getattr(self, 'small_footprint_embedding', False)):
+            with torch.set_grad_enabled(torch.is_grad_enabled() and not detach_embedding):
                 emb, emb_mem, emb_full = self.embedding_network.meta_forward(embedding_input, rnn_memory[:n_emb], require_full_hidden=True,
                                                                              out_dest=dest)
         if detach_embedding:
@@ -141,7 +140,7 @@ class ContextualModel:
         batch) this lets an independent pass - the actor's - use the otherwise idle chip at the same time."""
         main = torch.cuda.current_stream(self.device)
         stream.wait_stream(main)
-        with torch.cuda.stream(stream), torch.no_grad(), ops.small_footprint_gemms(getattr(self, 'small_footprint_embedding', False)):
+        with torch.cuda.stream(stream), torch.no_grad():
             emb, mem, full = self.get_embedding(self.get_embedding_input(*embedding_args), rnn_memory)
             event = torch.cuda.Event()
             event.record(stream)

@@ -90,11 +90,6 @@ def encode_concat(pairs, act_mod=None, dest=None) -> torch.Tensor:
 
 
 def embedding_input(owner, state, lst_state, lst_action, reward) -> torch.Tensor:
-    with ops.small_footprint_gemms(getattr(owner, 'small_footprint_embedding', False)):      # gru trainers: see hip/ops.py
-        return _embedding_input(owner, state, lst_state, lst_action, reward)
-
-
-def _embedding_input(owner, state, lst_state, lst_action, reward) -> torch.Tensor:
     pairs = [(owner.state_encoder, state)]
     if owner.last_state_input:
         pairs.append((owner.last_obs_encoder, lst_state))
