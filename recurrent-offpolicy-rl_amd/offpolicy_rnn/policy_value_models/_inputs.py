@@ -1,7 +1,5 @@
 """Input encoders shared by actor and critic: `[state, last_state, last_action, reward]` filtered by flags, each
 through its own Linear(., 128) when `separate_encoder` (reference contextual_sac_value.py:27-48,90-99)."""
-import os
-
 import torch
 
 from ..hip import ops
@@ -67,8 +65,6 @@ def encode_concat(pairs, act_mod=None, dest=None) -> torch.Tensor:
         return (act_mod if fuse else post)(ops.linear(xs[0], mods[0].weight, mods[0].bias))
     ks, ns = [m.weight.shape[1] for m in mods], [m.weight.shape[0] for m in mods]
     kp = sum(ks) + (-sum(ks)) % 4            # 17 + 17 + 6 + 1 = 41 input columns: three zero columns make the rows 16-byte multiples,
-    if os.environ.get('RESEL_ENC_KPAD', '1') != '0' and kp > 32:
-        kp = (kp + 31) // 32 * 32            # ... and whole 32-wide K steps keep the product off the K-tail path of the split editions (zeros are free here)
     if xs[0].is_cuda and xs[0].dtype == torch.float32 and xs[0].numel() // xs[0].shape[-1] >= ops.GEMM_F32_MIN_ROWS and len(mods) <= 8:
         # which the hand-written GEMM needs (35 us against the library's 97 at 66 752 tokens).  Long GPU passes: the three operands are
         # assembled by ONE launch each (`ops.place_blocks`) and their gradients come back as views
