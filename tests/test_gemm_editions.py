@@ -2,7 +2,9 @@
 
 Its producer loop leans on things the compiler must not undo - no scratch access among the hand-counted loads of the steady state (an
 extra vector-memory wait there drains the pipeline), and above all no COPY of a register that a load is still writing (right answers on
-small grids, garbage on large ones).  `test_producer_loop_isa` compiles the file to ISA and checks exactly that (no GPU needed);
+small grids, garbage on large ones).  `test_producer_loop_isa` compiles the file to ISA and checks exactly that (no GPU needed), and the same for
+the hand-counted Y loads of the dact epilogue's consumer waves (no compiler-emitted vector-memory instruction among them, no use of a Y register
+before its wait: advisor r05);
 `test_large_grids_against_mode6` runs every layout on grids that fill the chip, where the unit tests' sizes do not."""
 import os
 import subprocess
