@@ -42,7 +42,7 @@ __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : __builtin_
 
 struct P { const float *A, *B, *bias; float* C; int64_t lda, ldb, ldc; int M, N, K, act; float sa, sb; };
 
-template <int OCC>
+template <int OCC, int V = 0>       // V = 1: loads two K steps ahead (two register sets) + C through LDS as 16-byte full-line stores
 __global__ __launch_bounds__(256, OCC) void gemm_p2_kernel(P p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -66,12 +66,12 @@ __global__ __launch_bounds__(256, OCC) void gemm_p2_kernel(P p) {
         bg[i] = p.B + (int64_t)min(n0 + row, p.N - 1) * p.ldb + 4 * k4;
         loff[i] = plane_off(row, k4 >> 1) + 8 * (k4 & 1);
     }
-    float4 ra[4], rb[4];
-    auto gload = [&](int k0) {
+    float4 RA[2][4], RB[2][4];
+    auto gload_set = [&](float4 (&ra)[4], float4 (&rb)[4], int k0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) { ra[i] = *reinterpret_cast<const float4*>(ag[i] + k0); rb[i] = *reinterpret_cast<const float4*>(bg[i] + k0); }
     };
-    auto stage_store = [&](char* st) {
+    auto stage_store_set = [&](const float4 (&ra)[4], const float4 (&rb)[4], char* st) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             uint2 a1, a2, b1, b2;
@@ -92,13 +92,19 @@ __global__ __launch_bounds__(256, OCC) void gemm_p2_kernel(P p) {
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
     const f16x8 k11 = {(_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f,
                        (_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f};
+    auto gload = [&](int k0) { gload_set(RA[0], RB[0], k0); };
+    auto stage_store = [&](char* st) { stage_store_set(RA[0], RB[0], st); };
+    const int nk = p.K / BK;
     gload(0);
     stage_store(lds);
+    if (V == 1) {
+        if (nk > 1) gload_set(RA[1], RB[1], BK);
+        if (nk > 2) gload_set(RA[0], RB[0], 2 * BK);
+    }
     __syncthreads();
-    const int nk = p.K / BK;
     for (int ks = 0; ks < nk; ++ks) {
         char* st = lds + (ks & 1) * STAGE;
-        if (ks + 1 < nk) gload((ks + 1) * BK);
+        if (V == 0 && ks + 1 < nk) gload((ks + 1) * BK);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             f16x8 fa[2][2], fb[2][2], fs[2];
@@ -122,10 +128,41 @@ __global__ __launch_bounds__(256, OCC) void gemm_p2_kernel(P p) {
 #pragma unroll
                     for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][a], fb[qq][b], acc[a][b], 0, 0, 0);
         }
-        if (ks + 1 < nk) stage_store(lds + ((ks + 1) & 1) * STAGE);
+        if (V == 0) {
+            if (ks + 1 < nk) stage_store(lds + ((ks + 1) & 1) * STAGE);
+        } else if (ks + 1 < nk) {                  // the set of step ks + 1 (loaded two steps ago) goes to LDS, then it is reloaded for step ks + 3
+            if ((ks + 1) & 1) { stage_store_set(RA[1], RB[1], lds + STAGE); if (ks + 3 < nk) gload_set(RA[1], RB[1], (ks + 3) * BK); }
+            else { stage_store_set(RA[0], RB[0], lds); if (ks + 3 < nk) gload_set(RA[0], RB[0], (ks + 3) * BK); }
+        }
         __syncthreads();
     }
     const float unscale = (1.f / p.sa) * (1.f / p.sb);
+    if (V == 1 && m0 + BM <= p.M && n0 + BN <= p.N) {
+        // whole tiles: each wave turns its 64 x 64 tile through 8.7 KB of LDS (the stages are free now: the loop ended with a barrier), 32 rows at a
+        // time, rows of 68 words, and stores 16 bytes per lane - four whole 256-byte row segments per instruction
+        float* sc = reinterpret_cast<float*>(lds) + w * (32 * 68);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const float bv = p.bias ? p.bias[n0 + wn + 32 * b + li] : 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float v = acc[a][b][e] * unscale + bv;
+                    if (p.act == 1) v = elu1(v);
+                    sc[((e & 3) + 8 * (e >> 2) + 4 * lh) * 68 + 32 * b + li] = v;
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const int idx = g * 64 + lane, row = idx >> 4, c4 = (idx & 15) * 4;
+                const float4 t = *reinterpret_cast<const float4*>(sc + row * 68 + c4);
+                typedef float f4v __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store(f4v{t.x, t.y, t.z, t.w}, reinterpret_cast<f4v*>(p.C + (int64_t)(m0 + wm + 32 * a + row) * p.ldc + n0 + wn + c4));
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         const int n = n0 + wn + 32 * b + li;
@@ -183,6 +220,8 @@ int main(int argc, char** argv) {
     CK(hipFuncSetAttribute((const void*)gemm_p2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE));
     CK(hipFuncSetAttribute((const void*)gemm_p2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE + 40960));
     time_it([&]() { hipLaunchKernelGGL(gemm_p2_kernel<2>, grid, dim3(256), 2 * STAGE, 0, p); }, "128 x 128, TWO workgroups per CU (64 KB LDS)");
+    CK(hipFuncSetAttribute((const void*)gemm_p2_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE));
+    time_it([&]() { hipLaunchKernelGGL((gemm_p2_kernel<2, 1>), grid, dim3(256), 2 * STAGE, 0, p); }, "  + loads two steps ahead, C as 16-byte full-line stores");
     // the same kernel with its LDS request padded past half of the CU's 160 KB: ONE workgroup per CU - what co-residency itself buys
     time_it([&]() { hipLaunchKernelGGL(gemm_p2_kernel<1>, grid, dim3(256), 2 * STAGE + 40960, 0, p); }, "128 x 128, ONE workgroup per CU (LDS padded)");
     CK(hipGetLastError());
