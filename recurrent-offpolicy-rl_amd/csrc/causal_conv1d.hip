@@ -150,20 +150,25 @@ __global__ __launch_bounds__(128) void conv_fwd_kernel(ConvParams p) {
 //   g[t]   = dy[t] * silu'(pre[t])                      pre = conv output before the activation (recomputed)
 //   dx[s]  = mask[s] * sum_k w[k] * g[s + (KT-1) - k]   (g = 0 at and beyond the row end)
 //   dw[k]  = sum_t g[t] * xm[t - (KT-1) + k],  db = sum_t g[t]      over the steps t the chunk OWNS
-// Step i of a chunk is time t = t0 - (KT+1) + i: KT steps of input warm-up, KT steps that start the g window, then 64 / KT
+// Step i of a chunk is time t = t0 - (KT+1) + i: KT steps of input warm-up, KT steps that start the g window, then TT / KT
 // groups in which every step also emits dx[t - (KT-1)] - the warm-up length is chosen so that the dx phase starts on a
 // group boundary, which leaves three straight-line group bodies (exact vmcnt accounting, see the forward).  The last
 // chunk of a row is shifted back to end exactly at the row end (it recomputes a few dx of its neighbour, same values) and
 // owns only its own steps.  Per-chunk dw / db partials are summed by colsum_kernel (fixed order, no atomics).
-constexpr int CB_TT = 64;
+// The chunk length TT is one of 64 / 80 / 96 steps, whichever walks the fewest steps over the row (`bwd_chunk`): a chunk walks TT + 2 KT steps
+// to own TT, and the shifted last chunk repeats what it overlaps - L = 1043, KT = 16: 17 x 96 = 1632 steps at 64, 11 x 128 = 1408 at 96
+// (137 -> 117 us per launch; longer chunks leave too few waves for a latency-bound walk: 128 steps 137 us).
+constexpr int CB_NM = 2;                        // mask registers: step i of a chunk walk in lane i % 64 of register i / 64 (TT + 2 KT <= 128)
 
-template <int KT, int MODE, bool TWO>          // MODE 0: inputs only, 1: + g window and dw / db, 2: + dx; TWO: dy + dy2
+template <int KT, int MODE, bool TWO, int CB_TT>          // MODE 0: inputs only, 1: + g window and dw / db, 2: + dx; TWO: dy + dy2
 __device__ __forceinline__ void conv_bwd_group(const ConvParams& p, const float* xrow, const float* dyrow, const float* dy2row, float* dxrow, int tg,
-                                               int ig, int t_own0, float mlo, float mhi, const f2 (&wr)[KT], f2 (&xwin)[KT],
+                                               int ig, int t_own0, const float (&mk)[CB_NM], const f2 (&wr)[KT], f2 (&xwin)[KT],
                                                f2 (&gwin)[KT], f2 (&dwr)[KT], f2& dbr, f2 (&prex)[KT < 4 ? KT : 4],
                                                f2 (&predy)[KT < 4 ? KT : 4], f2 (&predy2)[KT < 4 ? KT : 4], f2 bv, float& dxmax) {
     constexpr int P = KT < 4 ? KT : 4;
-    const float mreg = ig < 64 ? mlo : mhi;
+    float mreg = mk[0];
+#pragma unroll
+    for (int q = 1; q < CB_NM; ++q) mreg = ig >= 64 * q ? mk[q] : mreg;
 #pragma unroll
     for (int s = 0; s < KT; ++s) {
         const int t = tg + s;
@@ -196,9 +201,12 @@ __device__ __forceinline__ void conv_bwd_group(const ConvParams& p, const float*
 #pragma unroll
             for (int kk = 0; kk < KT; ++kk) acc = __builtin_elementwise_fma(wr[kk], gwin[(s - kk + KT) % KT], acc);
             const int im = ig + s - (KT - 1);                                    // step index whose time is t - (KT-1)
-            const float ma = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mlo), im & 63));
-            const float mb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mhi), im & 63));
-            const float mm = im < 64 ? ma : mb;
+            float mm = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mk[0]), im & 63));
+#pragma unroll
+            for (int q = 1; q < CB_NM; ++q) {
+                const float mq = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mk[q]), im & 63));
+                mm = im >= 64 * q ? mq : mm;
+            }
             const f2 dxv = acc * f2{mm, mm};
             *reinterpret_cast<f2*>(dxrow + (int64_t)(t - (KT - 1)) * p.ld_dx) = dxv;
             dxmax = fmaxf(dxmax, fmaxf(__builtin_fabsf(dxv.x), __builtin_fabsf(dxv.y)));
@@ -206,8 +214,9 @@ __device__ __forceinline__ void conv_bwd_group(const ConvParams& p, const float*
     }
 }
 
-template <int KT, bool TWO>
+template <int KT, bool TWO, int CB_TT>
 __global__ __launch_bounds__(128) void conv_bwd_win_kernel(ConvParams p, int nchunk) {
+    static_assert(CB_TT % KT == 0 && CB_TT + 2 * KT <= 64 * CB_NM, "chunk length");
     constexpr int P = KT < 4 ? KT : 4;
     const int lane = threadIdx.x & 63;
     if ((blockIdx.x * 128 + (threadIdx.x & 64)) * 2 >= p.Di) return;      // whole wave past the last channel (no barriers below)
@@ -232,13 +241,12 @@ __global__ __launch_bounds__(128) void conv_bwd_win_kernel(ConvParams p, int nch
     f2 bv = {0.f, 0.f}, dbr = {0.f, 0.f};
     if (p.bias) bv = *reinterpret_cast<const f2*>(p.bias + c);
     const int ts = t0 - (KT + 1);                   // time of step 0
-    float mlo, mhi;                                 // mask of step i in lane i of (mlo, mhi); 0 outside the row
-    {
-        const int ta = ts + lane, tb = ts + 64 + lane;
+    float mk[CB_NM];                                // mask of step i in lane i % 64 of mk[i / 64]; 0 outside the row
+#pragma unroll
+    for (int q = 0; q < CB_NM; ++q) {
+        const int ta = ts + 64 * q + lane;
         const float va = p.mask ? p.mask[tok0 + min(max(ta, 0), p.L - 1)] : 1.f;
-        const float vb = p.mask ? p.mask[tok0 + min(max(tb, 0), p.L - 1)] : 1.f;
-        mlo = (ta >= 0 && ta < p.L) ? va : 0.f;
-        mhi = (tb >= 0 && tb < p.L) ? vb : 0.f;
+        mk[q] = (ta >= 0 && ta < p.L) ? va : 0.f;
     }
     f2 prex[P], predy[P], predy2[P];
 #pragma unroll
@@ -248,10 +256,10 @@ __global__ __launch_bounds__(128) void conv_bwd_win_kernel(ConvParams p, int nch
         predy2[i] = TWO ? *reinterpret_cast<const f2*>(dy2row + (int64_t)min(max(ts + KT + i, 0), p.L - 1) * p.ld_dy2) : f2{0.f, 0.f};
     }
     float dxmax = 0.f;
-    conv_bwd_group<KT, 0, TWO>(p, xrow, dyrow, dy2row, dxrow, ts, 0, t_own0, mlo, mhi, wr, xwin, gwin, dwr, dbr, prex, predy, predy2, bv, dxmax);
-    conv_bwd_group<KT, 1, TWO>(p, xrow, dyrow, dy2row, dxrow, ts + KT, KT, t_own0, mlo, mhi, wr, xwin, gwin, dwr, dbr, prex, predy, predy2, bv, dxmax);
+    conv_bwd_group<KT, 0, TWO, CB_TT>(p, xrow, dyrow, dy2row, dxrow, ts, 0, t_own0, mk, wr, xwin, gwin, dwr, dbr, prex, predy, predy2, bv, dxmax);
+    conv_bwd_group<KT, 1, TWO, CB_TT>(p, xrow, dyrow, dy2row, dxrow, ts + KT, KT, t_own0, mk, wr, xwin, gwin, dwr, dbr, prex, predy, predy2, bv, dxmax);
     for (int ig = 2 * KT; ig < 2 * KT + CB_TT; ig += KT)
-        conv_bwd_group<KT, 2, TWO>(p, xrow, dyrow, dy2row, dxrow, ts + ig, ig, t_own0, mlo, mhi, wr, xwin, gwin, dwr, dbr, prex, predy, predy2, bv, dxmax);
+        conv_bwd_group<KT, 2, TWO, CB_TT>(p, xrow, dyrow, dy2row, dxrow, ts + ig, ig, t_own0, mk, wr, xwin, gwin, dwr, dbr, prex, predy, predy2, bv, dxmax);
     amax_publish_wave(dxmax, p.amax);
     if (c_raw < p.Di) {
         const int64_t row = (int64_t)b * nchunk + chunk;
@@ -389,8 +397,21 @@ extern "C" int resel_causal_conv1d_fwd(const float* x, int64_t ld_x, const float
     return launch_status();
 }
 
-inline bool bwd_windowed(int L, int KT) { return KT <= 16 && L >= CB_TT; }
-inline int bwd_rows(int B, int L, int KT) { return bwd_windowed(L, KT) ? B * ((L + CB_TT - 1) / CB_TT) : B; }
+// chunk length of the windowed backward for rows of L steps: the candidate that walks the fewest steps (ties: the shorter); 0: not windowed
+inline int bwd_chunk(int L, int KT) {
+    if (KT > 16 || L < 64) return 0;
+    int best = 0;
+    long best_steps = 0;
+    for (int tt = 64; tt <= 96 && tt <= L; tt += 16) {
+        const long steps = (long)((L + tt - 1) / tt) * (tt + 2 * KT);
+        if (!best || steps < best_steps) { best = tt; best_steps = steps; }
+    }
+    return best;
+}
+inline int bwd_rows(int B, int L, int KT) {
+    const int tt = bwd_chunk(L, KT);
+    return tt ? B * ((L + tt - 1) / tt) : B;
+}
 
 extern "C" size_t resel_causal_conv1d_bwd_workspace_bytes(int B, int L, int Di, int K) {
     const int KT = pad_taps(K);
@@ -421,17 +442,19 @@ extern "C" int resel_causal_conv1d_bwd2(const float* x, int64_t ld_x, const floa
     ConvParams p{x, w, bias, mask, dy, nullptr, dx, dw_part, db_part, ld_x, 0, ld_dy, ld_dx, B, L, Di, K, silu,
                  AmaxOut{(unsigned long long*)amax_dx, amax_epoch}, dy2, ld_dy2};
     hipStream_t s = (hipStream_t)stream;
-    if (bwd_windowed(L, KT)) {
-        const int nchunk = (L + CB_TT - 1) / CB_TT;
+    if (const int tt = bwd_chunk(L, KT)) {
+        const int nchunk = (L + tt - 1) / tt;
         dim3 grid((Di + 255) / 256, nchunk, B);
-#define CONV_BWD_WIN(KTv) do { if (dy2) launch_timed(RESEL_PROF_CONV_BWD, conv_bwd_win_kernel<KTv, true>, grid, dim3(128), 0, s, p, nchunk); \
-                               else launch_timed(RESEL_PROF_CONV_BWD, conv_bwd_win_kernel<KTv, false>, grid, dim3(128), 0, s, p, nchunk); } while (0)
+#define CONV_BWD_WIN_T(KTv, TTv) do { if (dy2) launch_timed(RESEL_PROF_CONV_BWD, conv_bwd_win_kernel<KTv, true, TTv>, grid, dim3(128), 0, s, p, nchunk); \
+                                      else launch_timed(RESEL_PROF_CONV_BWD, conv_bwd_win_kernel<KTv, false, TTv>, grid, dim3(128), 0, s, p, nchunk); } while (0)
+#define CONV_BWD_WIN(KTv) do { if (tt == 64) CONV_BWD_WIN_T(KTv, 64); else if (tt == 80) CONV_BWD_WIN_T(KTv, 80); else CONV_BWD_WIN_T(KTv, 96); } while (0)
         switch (KT) {
             case 4: CONV_BWD_WIN(4); break;
             case 8: CONV_BWD_WIN(8); break;
             default: CONV_BWD_WIN(16); break;
         }
 #undef CONV_BWD_WIN
+#undef CONV_BWD_WIN_T
     } else {
         dim3 grid(B, (Di + TILE_C - 1) / TILE_C);
         switch (KT) {

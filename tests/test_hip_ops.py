@@ -213,7 +213,8 @@ def test_selective_scan_reset_isolation(ops):
 
 # ------------------------------------------------------------------------------------------------ conv1d
 @pytest.mark.parametrize('B,L,Di,Kw', [(2, 50, 64, 4), (3, 130, 96, 16), (1, 70, 128, 3), (2, 65, 64, 8), (1, 200, 64, 20),
-                                        (2, 64, 72, 8), (1, 300, 520, 16), (3, 129, 256, 2)])
+                                        (2, 64, 72, 8), (1, 300, 520, 16), (3, 129, 256, 2),
+                                        (2, 192, 64, 16), (1, 1043, 128, 16), (2, 96, 64, 4), (2, 175, 64, 8)])       # the backward's 64 / 80 / 96-step chunks
 def test_causal_conv1d_fwd_bwd(ops, B, L, Di, Kw):
     g = torch.Generator().manual_seed(L + Kw)
     xz = rnd(B, L, 2 * Di, g=g)
